@@ -1,0 +1,221 @@
+"""ctypes binding of libdff_amd.so (C ABI: include/dff.h).
+
+The HIP library is the product path: there is NO CPU / PyTorch fallback.  If the shared
+library is missing or fails to load, importing a sampler raises ``DffLibraryError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdff_amd.so")
+DFF_MAX_BEADS = 64
+
+SCHEDULE_NAMES = (
+    "betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+    "sqrt_one_minus_alphas_cumprod", "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod",
+    "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+    "posterior_mean_coef1", "posterior_mean_coef2",
+)
+
+
+class DffLibraryError(RuntimeError):
+    pass
+
+
+class DffConfig(C.Structure):
+    _fields_ = [("n_beads", C.c_int32), ("hidden", C.c_int32), ("n_layers", C.c_int32),
+                ("timesteps", C.c_int32), ("use_intrinsic_coords", C.c_int32),
+                ("use_distances", C.c_int32), ("use_abs_coords", C.c_int32),
+                ("conservative", C.c_int32)]
+
+
+class DffLangevinParams(C.Structure):
+    _fields_ = [("t_norm", C.c_float), ("force_scale", C.c_float), ("dt", C.c_float),
+                ("vscale", C.c_float), ("noisescale", C.c_float), ("beta", C.c_float),
+                ("dtau", C.c_float), ("overdamped", C.c_int32),
+                ("masses", C.c_float * DFF_MAX_BEADS)]
+
+
+# every symbol include/dff.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "dff_weight_count": (C.c_size_t, [C.POINTER(DffConfig)]),
+    "dff_model_create": (C.c_int, [C.POINTER(DffConfig), _P, C.c_size_t, C.c_int, C.POINTER(_P)]),
+    "dff_model_destroy": (None, [_P]),
+    "dff_schedule": (C.c_int, [_P, C.c_int, _P]),
+    "dff_score": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P]),
+    "dff_langevin_run": (C.c_int, [_P, C.POINTER(DffLangevinParams), C.c_int, _P, _P, _P, C.c_uint64,
+                                   C.c_uint64, C.c_uint64, C.c_int, C.c_int, _P, _P, _P]),
+    "dff_ddpm_run": (C.c_int, [_P, C.c_int, _P, _P, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int,
+                               _P, _P]),
+    "dff_set_group": (C.c_int, [_P, C.c_int]),
+    "dff_last_launch": (C.c_int, [_P, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "dff_debug_gemm": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "dff_debug_stash": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_size_t]),
+    "dff_last_error": (C.c_char_p, []),
+    "dff_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """dlopen libdff_amd.so and type every exported entry point; loud failure if absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise DffLibraryError(
+            f"{p} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+            f"or ./build.sh).  There is no CPU fallback.")
+    try:
+        lib = C.CDLL(p)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise DffLibraryError(f"cannot load {p}: {e}") from e
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise DffLibraryError(f"{p} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(lib, rc: int, what: str):
+    if rc != 0:
+        msg = lib.dff_last_error().decode(errors="replace")
+        if rc == 1:
+            raise ValueError(f"{what}: {msg}")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class Model:
+    """Owner of one ``dff_model`` handle (packed weights + scratch on one GPU)."""
+
+    def __init__(self, n_beads: int, hidden: int, n_layers: int, flat_weights: np.ndarray,
+                 timesteps: int = 1000, device: int = 0, use_intrinsic_coords=True,
+                 use_distances=False, use_abs_coords=False, conservative=True):
+        self.lib = load_library()
+        self.cfg = DffConfig(n_beads, hidden, n_layers, timesteps, int(bool(use_intrinsic_coords)),
+                             int(bool(use_distances)), int(bool(use_abs_coords)), int(bool(conservative)))
+        w = np.ascontiguousarray(flat_weights, dtype=np.float32)
+        self.handle = C.c_void_p()
+        rc = self.lib.dff_model_create(C.byref(self.cfg), w.ctypes.data_as(C.c_void_p), w.size, device,
+                                       C.byref(self.handle))
+        _check(self.lib, rc, "dff_model_create")
+        self.device = device
+        self.n_beads, self.hidden, self.n_layers, self.timesteps = n_beads, hidden, n_layers, timesteps
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h is not None and h.value:
+            self.lib.dff_model_destroy(h)
+            self.handle = C.c_void_p()
+
+    # ---- helpers
+    def _stream(self):
+        import torch
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev_tensor(self, t, shape=None, name="tensor"):
+        import torch
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError(f"{name} must be a contiguous float32 CUDA tensor")
+        if t.device.index != self.device:
+            raise ValueError(f"{name} is on {t.device}, model is on cuda:{self.device}")
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
+        return t
+
+    def schedule(self, name: str) -> np.ndarray:
+        out = np.empty(self.timesteps, np.float32)
+        _check(self.lib, self.lib.dff_schedule(self.handle, SCHEDULE_NAMES.index(name), out.ctypes.data_as(C.c_void_p)),
+               "dff_schedule")
+        return out
+
+    def set_group(self, g: int):
+        _check(self.lib, self.lib.dff_set_group(self.handle, int(g)), "dff_set_group")
+
+    def last_launch(self):
+        name, grid, lds = C.c_char_p(), C.c_int(), C.c_int()
+        _check(self.lib, self.lib.dff_last_launch(self.handle, C.byref(name), C.byref(grid), C.byref(lds)), "dff_last_launch")
+        return (name.value or b"").decode(), grid.value, lds.value
+
+    # ---- the three entry points
+    def score(self, x, tnorm, return_energy=False):
+        import torch
+        B = x.shape[0]
+        self._dev_tensor(x, (B, self.n_beads, 3), "x")
+        self._dev_tensor(tnorm, (B,), "t")
+        force = torch.empty_like(x)
+        energy = torch.empty(B, self.n_beads, device=x.device, dtype=torch.float32) if return_energy else None
+        rc = self.lib.dff_score(self.handle, _ptr(x), _ptr(tnorm), B, _ptr(force), _ptr(energy), self._stream())
+        _check(self.lib, rc, "dff_score")
+        return (force, energy) if return_energy else force
+
+    def langevin_run(self, params: DffLangevinParams, x, v, n_steps: int, save_interval: int,
+                     noise=None, seed: int = 0, traj_offset: int = 0, step_offset: int = 0,
+                     frames=None, ke=None):
+        P = x.shape[0]
+        self._dev_tensor(x, (P, self.n_beads, 3), "x")
+        if v is not None:
+            self._dev_tensor(v, (P, self.n_beads, 3), "v")
+        if noise is not None:
+            self._dev_tensor(noise, (n_steps, P, self.n_beads, 3), "noise")
+        nf = n_steps // save_interval if save_interval > 0 else 0
+        if frames is not None:
+            self._dev_tensor(frames, (nf, P, self.n_beads, 3), "frames")
+        if ke is not None:
+            self._dev_tensor(ke, (nf, P), "ke")
+        rc = self.lib.dff_langevin_run(self.handle, C.byref(params), P, _ptr(x), _ptr(v), _ptr(noise),
+                                       seed & (2 ** 64 - 1), traj_offset, step_offset, n_steps, save_interval,
+                                       _ptr(frames), _ptr(ke), self._stream())
+        _check(self.lib, rc, "dff_langevin_run")
+
+    def ddpm_run(self, x, t_start: int, t_end: int = 0, noise=None, seed: int = 0, sample_offset: int = 0,
+                 init_prior: bool = False, clamp_flag=None):
+        B = x.shape[0]
+        self._dev_tensor(x, (B, self.n_beads, 3), "x")
+        if noise is not None:
+            self._dev_tensor(noise, (t_start - t_end + 1, B, self.n_beads, 3), "noise")
+        rc = self.lib.dff_ddpm_run(self.handle, B, _ptr(x), _ptr(noise), seed & (2 ** 64 - 1), sample_offset,
+                                   t_start, t_end, int(init_prior), _ptr(clamp_flag), self._stream())
+        _check(self.lib, rc, "dff_ddpm_run")
+
+    # ---- debugging
+    def debug_stash(self, b: int, layer: int, what: str) -> np.ndarray:
+        N, H = self.n_beads, self.hidden
+        items = dict(nodes_in=(0, (N, H)), attn_out=(1, (N, H)), ff=(2, (N, H)), h_pre=(3, (N, 4 * H)),
+                     q=(4, (N, 512)), k=(5, (N, 512)), v=(6, (N, 512)), P=(7, (8, N, N)), u=(8, (N, 32)))
+        code, shape = items[what]
+        out = np.empty(shape, np.float32)
+        rc = self.lib.dff_debug_stash(self.handle, b, layer, code, out.ctypes.data_as(C.c_void_p), out.size)
+        _check(self.lib, rc, "dff_debug_stash")
+        return out
+
+
+def debug_gemm(A: np.ndarray, W: np.ndarray, device: int = 0) -> np.ndarray:
+    lib = load_library()
+    A = np.ascontiguousarray(A, np.float32)
+    W = np.ascontiguousarray(W, np.float32)
+    M, K = A.shape
+    K2, Nout = W.shape
+    assert K == K2
+    out = np.empty((M, Nout), np.float32)
+    rc = lib.dff_debug_gemm(device, A.ctypes.data_as(C.c_void_p), W.ctypes.data_as(C.c_void_p), M, K, Nout,
+                            out.ctypes.data_as(C.c_void_p))
+    _check(lib, rc, "dff_debug_gemm")
+    return out

@@ -1,0 +1,461 @@
+// dff_host.hip -- host half of libdff_amd.so: weight folding + MFMA packing, schedule tables,
+// scratch management, kernel dispatch and the extern "C" ABI declared in include/dff.h.
+#include "../../include/dff.h"
+#include "dff_internal.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+// device code: one translation unit (kernel handles, layouts and templates are shared)
+#include "dff_kernels.hip"
+
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(x)                                                                              \
+    do {                                                                                       \
+        hipError_t e_ = (x);                                                                   \
+        if (e_ != hipSuccess) return fail(DFF_EHIP, "%s failed: %s", #x, hipGetErrorString(e_)); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// packing for the v_mfma_f32_16x16x4_f32 B operand (layout: dff_internal.h)
+// ------------------------------------------------------------------------------------------
+static std::vector<float> pack_b(int K, int Nout, const std::function<double(int, int)>& w) {
+    const int KB = (K + 15) / 16, NT = (Nout + 15) / 16;
+    std::vector<float> out((size_t)KB * NT * 256, 0.f);
+    for (int nt = 0; nt < NT; ++nt)
+        for (int kb = 0; kb < KB; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int s = 0; s < 4; ++s) {
+                    const int k = 16 * kb + 4 * (lane >> 4) + s, n = 16 * nt + (lane & 15);
+                    if (k < K && n < Nout) out[(((size_t)nt * KB + kb) * 64 + lane) * 4 + s] = (float)w(k, n);
+                }
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------
+// model handle
+// ------------------------------------------------------------------------------------------
+struct Variant {
+    int H, MT, HGS;
+    bool spill;
+    const void* fn;
+    unsigned (*lds_floats)(int N, int G);
+    const char* name;
+};
+template <int H, int MT, int HGS, bool SP>
+static unsigned lds_floats_of(int N, int G) { return LdsLayout<H, MT, HGS, SP>(N, G).total; }
+#define VAR(H, MT, HGS, SP)                                                                       \
+    { H, MT, HGS, SP, (const void*)&dff_fused_kernel<H, MT, HGS, SP>, &lds_floats_of<H, MT, HGS, SP>, \
+      "dff_fused_kernel<" #H "," #MT "," #HGS "," #SP ">" }
+static const Variant g_variants[] = {
+    VAR(64, 1, 4, false),  VAR(64, 2, 2, false),  VAR(96, 1, 4, false),  VAR(96, 2, 2, false),
+    VAR(128, 1, 4, false), VAR(128, 2, 2, false), VAR(128, 3, 1, false), VAR(128, 4, 1, true),
+};
+
+struct dff_model {
+    dff_config cfg;
+    int device;
+    DffModelDev dev;
+    std::vector<void*> allocs;
+    std::vector<std::vector<float>> sched;  // 12 tables, host fp32
+    float* stash = nullptr;
+    size_t stash_floats = 0;
+    int group_override = 0;
+    // last launch
+    const char* last_kernel = "";
+    int last_grid = 0, last_lds = 0, last_G = 0, last_B = 0;
+    unsigned long long last_stride = 0;
+};
+
+static int upload(dff_model* m, const std::vector<float>& h, const float** out) {
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, h.size() * sizeof(float)));
+    m->allocs.push_back(p);
+    HIPCHK(hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    *out = (const float*)p;
+    return DFF_OK;
+}
+#define UP(vec, dst)                                  \
+    do {                                              \
+        int rc_ = upload(m, vec, &(dst));             \
+        if (rc_) return rc_;                          \
+    } while (0)
+
+extern "C" size_t dff_weight_count(const dff_config* c) {
+    if (!c) return 0;
+    const size_t H = c->hidden, N = c->n_beads, I = DFF_INNER, F = 4 * H;
+    size_t n = H * (N + 1) + H + H * 3 + H + H + 1;
+    const size_t per_layer = I * H + I + 2 * I * H + 2 * I + I * H + I + H * I + H + H + H + 3 * H +
+                             F * H + F + H * F + H + H + H + 3 * H;
+    return n + per_layer * c->n_layers;
+}
+
+// cosine schedule + derived tables, float64 -> float32  (utils.py:52-62, models/ddpm.py:52-99)
+static void build_schedule(int T, std::vector<std::vector<float>>& out) {
+    const double s = 0.008, pi = 3.14159265358979323846;
+    std::vector<double> ac0(T + 1), betas(T), alphas(T), ac(T), acp(T);
+    for (int i = 0; i <= T; ++i) {
+        const double x = (double)i;  // torch.linspace(0, T, T+1) is exact for integer steps
+        const double cv = std::cos(((x / T) + s) / (1 + s) * pi * 0.5);
+        ac0[i] = cv * cv;
+    }
+    for (int i = T; i >= 0; --i) ac0[i] = ac0[i] / ac0[0];
+    for (int i = 0; i < T; ++i) {
+        double b = 1 - (ac0[i + 1] / ac0[i]);
+        betas[i] = b < 0 ? 0 : (b > 0.999 ? 0.999 : b);
+        alphas[i] = 1.0 - betas[i];
+    }
+    double cp = 1.0;
+    for (int i = 0; i < T; ++i) { cp *= alphas[i]; ac[i] = cp; }
+    for (int i = 0; i < T; ++i) acp[i] = i == 0 ? 1.0 : ac[i - 1];
+    out.assign(12, std::vector<float>(T));
+    for (int i = 0; i < T; ++i) {
+        const double pv = betas[i] * (1.0 - acp[i]) / (1.0 - ac[i]);
+        out[0][i] = (float)betas[i];
+        out[1][i] = (float)ac[i];
+        out[2][i] = (float)acp[i];
+        out[3][i] = (float)std::sqrt(ac[i]);
+        out[4][i] = (float)std::sqrt(1.0 - ac[i]);
+        out[5][i] = (float)std::log(1.0 - ac[i]);
+        out[6][i] = (float)std::sqrt(1.0 / ac[i]);
+        out[7][i] = (float)std::sqrt(1.0 / ac[i] - 1);
+        out[8][i] = (float)pv;
+        out[9][i] = (float)std::log(pv < 1e-20 ? 1e-20 : pv);
+        out[10][i] = (float)(betas[i] * std::sqrt(acp[i]) / (1.0 - ac[i]));
+        out[11][i] = (float)((1.0 - acp[i]) * std::sqrt(alphas[i]) / (1.0 - ac[i]));
+    }
+}
+
+extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_weights, int device,
+                                dff_model** out) {
+    if (!cfg || !w || !out) return fail(DFF_EINVAL, "null argument");
+    if (!(cfg->use_intrinsic_coords == 1 && cfg->use_distances == 0 && cfg->use_abs_coords == 0 &&
+          cfg->conservative == 1))
+        return fail(DFF_EINVAL, "only use_intrinsic_coords=1,use_distances=0,use_abs_coords=0,conservative=1 is implemented");
+    const int H = cfg->hidden, N = cfg->n_beads, L = cfg->n_layers, I = DFF_INNER, F = 4 * H;
+    if (!(H == 64 || H == 96 || H == 128)) return fail(DFF_EINVAL, "hidden must be 64, 96 or 128 (got %d)", H);
+    if (N < 2 || N > DFF_MAX_BEADS) return fail(DFF_EINVAL, "n_beads must be in [2,%d] (got %d)", DFF_MAX_BEADS, N);
+    if (H < 128 && N > 32) return fail(DFF_EINVAL, "n_beads > 32 needs hidden = 128 in this build");
+    if (L < 1 || L > DFF_MAX_LAYERS) return fail(DFF_EINVAL, "n_layers must be in [1,%d]", DFF_MAX_LAYERS);
+    if (cfg->timesteps < 1) return fail(DFF_EINVAL, "timesteps must be >= 1");
+    if (n_weights != dff_weight_count(cfg))
+        return fail(DFF_EINVAL, "expected %zu weights, got %zu", dff_weight_count(cfg), n_weights);
+    HIPCHK(hipSetDevice(device));
+    dff_model* m = new dff_model();
+    m->cfg = *cfg;
+    m->device = device;
+    memset(&m->dev, 0, sizeof m->dev);
+    m->dev.N = N; m->dev.H = H; m->dev.L = L; m->dev.T = cfg->timesteps;
+
+    const float* p = w;
+    auto take = [&](size_t n) { const float* r = p; p += n; return r; };
+    const float* Wn = take((size_t)H * (N + 1));
+    const float* bn = take(H);
+    const float* We = take((size_t)H * 3);
+    const float* be = take(H);
+    const float* wd = take(H);
+    const float* bd = take(1);
+    {
+        std::vector<float> WnT((size_t)(N + 1) * H);
+        for (int c = 0; c < H; ++c)
+            for (int i = 0; i <= N; ++i) WnT[(size_t)i * H + c] = Wn[(size_t)c * (N + 1) + i];
+        UP(WnT, m->dev.WnT);
+        UP(std::vector<float>(bn, bn + H), m->dev.bn);
+        UP(std::vector<float>(wd, wd + H), m->dev.wdec);
+        m->dev.bdec = bd[0];
+    }
+    for (int l = 0; l < L; ++l) {
+        const float* Wq = take((size_t)I * H);  const float* bq = take(I);
+        const float* Wkv = take((size_t)2 * I * H); const float* bkv = take(2 * I);
+        const float* Wek = take((size_t)I * H); const float* bek = take(I);
+        const float* Wo = take((size_t)H * I);  const float* bo = take(H);
+        const float* ln1g = take(H); const float* ln1b = take(H);
+        const float* g1 = take(3 * H);
+        const float* W1 = take((size_t)F * H);  const float* b1 = take(F);
+        const float* W2 = take((size_t)H * F);  const float* b2 = take(H);
+        const float* ln2g = take(H); const float* ln2b = take(H);
+        const float* g2 = take(3 * H);
+        DffLayerDev& d = m->dev.layer[l];
+        // ---- fold edge_embedding into edges_to_kv (float64): W_c (512x3), b_c (512) ----
+        std::vector<double> Wc((size_t)I * 3), bc(I);
+        for (int r = 0; r < I; ++r) {
+            double s0 = 0, s1 = 0, s2 = 0, sb = 0;
+            for (int c = 0; c < H; ++c) {
+                const double e = Wek[(size_t)r * H + c];
+                s0 += e * We[c * 3 + 0]; s1 += e * We[c * 3 + 1]; s2 += e * We[c * 3 + 2];
+                sb += e * be[c];
+            }
+            Wc[r * 3 + 0] = s0; Wc[r * 3 + 1] = s1; Wc[r * 3 + 2] = s2;
+            bc[r] = sb + bek[r];
+        }
+        // W_u (24xH), b_u (24): u_ih = W_c,h^T q_ih ; W_oc (Hx24) = W_o,h W_c,h ; b_o' = b_o + W_o b_c
+        std::vector<double> Wu((size_t)24 * H, 0.0), bu(24, 0.0), Woc((size_t)H * 24, 0.0), bof(H);
+        for (int h = 0; h < DFF_HEADS; ++h)
+            for (int cc = 0; cc < 3; ++cc) {
+                for (int c = 0; c < H; ++c) {
+                    double s = 0;
+                    for (int dd = 0; dd < DFF_DH; ++dd) s += Wc[(h * 64 + dd) * 3 + cc] * Wq[(size_t)(h * 64 + dd) * H + c];
+                    Wu[(size_t)(3 * h + cc) * H + c] = s;
+                }
+                double s = 0;
+                for (int dd = 0; dd < DFF_DH; ++dd) s += Wc[(h * 64 + dd) * 3 + cc] * bq[h * 64 + dd];
+                bu[3 * h + cc] = s;
+                for (int c = 0; c < H; ++c) {
+                    double t = 0;
+                    for (int dd = 0; dd < DFF_DH; ++dd) t += (double)Wo[(size_t)c * I + h * 64 + dd] * Wc[(h * 64 + dd) * 3 + cc];
+                    Woc[(size_t)c * 24 + 3 * h + cc] = t;
+                }
+            }
+        for (int c = 0; c < H; ++c) {
+            double s = bo[c];
+            for (int r = 0; r < I; ++r) s += (double)Wo[(size_t)c * I + r] * bc[r];
+            bof[c] = s;
+        }
+        // head-major q|k|v column order: col = h*192 + part*64 + d
+        auto wqkv = [&](int col, int c) -> double {
+            const int h = col / 192, part = (col % 192) / 64, dd = col % 64;
+            const int r = h * 64 + dd;
+            return part == 0 ? Wq[(size_t)r * H + c] : part == 1 ? Wkv[(size_t)r * H + c] : Wkv[(size_t)(I + r) * H + c];
+        };
+        std::vector<float> bqkv(3 * I), bu32(32, 0.f), bo32(H);
+        for (int col = 0; col < 3 * I; ++col) {
+            const int h = col / 192, part = (col % 192) / 64, dd = col % 64, r = h * 64 + dd;
+            bqkv[col] = part == 0 ? bq[r] : part == 1 ? bkv[r] : bkv[I + r];
+        }
+        for (int i = 0; i < 24; ++i) bu32[i] = (float)bu[i];
+        for (int c = 0; c < H; ++c) bo32[c] = (float)bof[c];
+
+        UP(std::vector<float>(ln1g, ln1g + H), d.ln1_g); UP(std::vector<float>(ln1b, ln1b + H), d.ln1_b);
+        UP(pack_b(H, 3 * I, [&](int k, int n) { return wqkv(n, k); }), d.Wqkv_p);
+        UP(bqkv, d.bqkv);
+        UP(pack_b(H, 32, [&](int k, int n) { return n < 24 ? Wu[(size_t)n * H + k] : 0.0; }), d.Wu_p);
+        UP(bu32, d.bu);
+        UP(pack_b(I, H, [&](int k, int n) { return (double)Wo[(size_t)n * I + k]; }), d.Wo_p);
+        UP(pack_b(32, H, [&](int k, int n) { return k < 24 ? Woc[(size_t)n * 24 + k] : 0.0; }), d.Woc_p);
+        UP(bo32, d.bo);
+        UP(std::vector<float>(g1, g1 + 3 * H), d.g1);
+        UP(std::vector<float>(ln2g, ln2g + H), d.ln2_g); UP(std::vector<float>(ln2b, ln2b + H), d.ln2_b);
+        UP(pack_b(H, F, [&](int k, int n) { return (double)W1[(size_t)n * H + k]; }), d.W1_p);
+        UP(std::vector<float>(b1, b1 + F), d.b1);
+        UP(pack_b(F, H, [&](int k, int n) { return (double)W2[(size_t)n * F + k]; }), d.W2_p);
+        UP(std::vector<float>(b2, b2 + H), d.b2);
+        UP(std::vector<float>(g2, g2 + 3 * H), d.g2);
+        // transposed orientation for the VJP
+        UP(pack_b(H, F, [&](int k, int n) { return (double)W2[(size_t)k * F + n]; }), d.W2T_p);
+        UP(pack_b(F, H, [&](int k, int n) { return (double)W1[(size_t)k * H + n]; }), d.W1T_p);
+        UP(pack_b(H, I, [&](int k, int n) { return (double)Wo[(size_t)k * I + n]; }), d.WoT_p);
+        UP(pack_b(H, 32, [&](int k, int n) { return n < 24 ? Woc[(size_t)k * 24 + n] : 0.0; }), d.WocT_p);
+        UP(pack_b(3 * I, H, [&](int k, int n) { return wqkv(k, n); }), d.WqkvT_p);
+        UP(pack_b(32, H, [&](int k, int n) { return k < 24 ? Wu[(size_t)k * H + n] : 0.0; }), d.WuT_p);
+    }
+    build_schedule(cfg->timesteps, m->sched);
+    UP(m->sched[6], m->dev.sqrt_recip_ac);
+    UP(m->sched[7], m->dev.sqrt_recipm1_ac);
+    UP(m->sched[10], m->dev.post_c1);
+    UP(m->sched[11], m->dev.post_c2);
+    UP(m->sched[9], m->dev.post_logvar);
+    *out = m;
+    return DFF_OK;
+}
+
+extern "C" void dff_model_destroy(dff_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    for (void* p : m->allocs) (void)hipFree(p);
+    if (m->stash) (void)hipFree(m->stash);
+    delete m;
+}
+
+extern "C" int dff_schedule(const dff_model* m, int which, float* out_host) {
+    if (!m || !out_host || which < 0 || which >= 12) return fail(DFF_EINVAL, "bad schedule request");
+    memcpy(out_host, m->sched[which].data(), m->sched[which].size() * sizeof(float));
+    return DFF_OK;
+}
+
+extern "C" int dff_set_group(dff_model* m, int g) {
+    if (!m || g < 0) return fail(DFF_EINVAL, "bad group");
+    m->group_override = g;
+    return DFF_OK;
+}
+
+extern "C" int dff_last_launch(const dff_model* m, const char** name, int* grid, int* lds) {
+    if (!m) return fail(DFF_EINVAL, "null model");
+    if (name) *name = m->last_kernel;
+    if (grid) *grid = m->last_grid;
+    if (lds) *lds = m->last_lds;
+    return DFF_OK;
+}
+
+// choose proteins-per-workgroup and the kernel variant, make sure scratch is large enough, launch
+static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
+    const int N = m->cfg.n_beads, H = m->cfg.hidden, L = m->cfg.n_layers;
+    HIPCHK(hipSetDevice(m->device));
+    const int mt_min = (N + 15) / 16;
+    // default: one protein per workgroup while that fills the 256 CUs at most ~2x; otherwise
+    // pack as many proteins as fit in the row tiles of the smallest variant that holds one.
+    int G = m->group_override;
+    if (G <= 0) {
+        G = 1;
+        const int cap = (16 * mt_min) / N;  // proteins that fit the padded rows anyway
+        if (a.B >= 512 * cap && cap > 1) G = cap;
+    }
+    if (G > 16) G = 16;
+    int mt = (G * N + 15) / 16;
+    if (mt > 4) { G = 64 / N; mt = (G * N + 15) / 16; }
+    const Variant* v = nullptr;
+    for (const Variant& c : g_variants)
+        if (c.H == H && c.MT == mt) { v = &c; break; }
+    if (!v) {  // fall back to one protein per workgroup
+        G = 1; mt = mt_min;
+        for (const Variant& c : g_variants)
+            if (c.H == H && c.MT == mt) { v = &c; break; }
+    }
+    if (!v) return fail(DFF_EINVAL, "no kernel variant for hidden=%d rows=%d", H, G * N);
+    const unsigned lds = v->lds_floats(N, G) * (unsigned)sizeof(float);
+    if (lds > 160 * 1024) return fail(DFF_EINVAL, "LDS budget exceeded (%u bytes) for N=%d G=%d H=%d", lds, N, G, H);
+    const int grid = (a.B + G - 1) / G;
+    const StashLayout sl = dff_stash_layout(N, G, H, L);
+    const size_t need = (size_t)grid * sl.total;
+    if (need > m->stash_floats) {
+        if (m->stash) HIPCHK(hipFree(m->stash));
+        m->stash = nullptr; m->stash_floats = 0;
+        HIPCHK(hipMalloc((void**)&m->stash, need * sizeof(float)));
+        m->stash_floats = need;
+    }
+    a.G = G;
+    a.stash = m->stash;
+    a.stash_stride = sl.total;
+    HIPCHK(hipFuncSetAttribute(v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    void* args[] = {(void*)&m->dev, (void*)&a};
+    HIPCHK(hipLaunchKernel(v->fn, dim3(grid), dim3(DFF_NTHREADS), args, lds, stream));
+    m->last_kernel = v->name; m->last_grid = grid; m->last_lds = (int)lds; m->last_G = G; m->last_B = a.B;
+    m->last_stride = sl.total;
+    return DFF_OK;
+}
+
+extern "C" int dff_score(dff_model* m, const float* x, const float* tnorm, int batch, float* force,
+                         float* energy, void* stream) {
+    if (!m || !x || !tnorm || !force) return fail(DFF_EINVAL, "null argument");
+    if (batch <= 0) return batch == 0 ? DFF_OK : fail(DFF_EINVAL, "negative batch");
+    DffRunArgs a;
+    memset(&a, 0, sizeof a);
+    a.mode = DFF_MODE_SCORE; a.B = batch; a.n_steps = 1;
+    a.x_in = x; a.tnorm = tnorm; a.force_out = force; a.energy_out = energy;
+    a.save_interval = 1;
+    return launch(m, a, (hipStream_t)stream);
+}
+
+extern "C" int dff_langevin_run(dff_model* m, const dff_langevin_params* p, int n_traj, float* x, float* v,
+                                const float* noise, uint64_t seed, uint64_t traj_offset, uint64_t step_offset,
+                                int n_steps, int save_interval, float* frames, float* ke, void* stream) {
+    if (!m || !p || !x) return fail(DFF_EINVAL, "null argument");
+    if (!p->overdamped && !v) return fail(DFF_EINVAL, "v_dev required unless overdamped");
+    if (n_traj <= 0 || n_steps < 0) return fail(DFF_EINVAL, "bad sizes");
+    if (n_steps == 0) return DFF_OK;
+    if (save_interval <= 0) save_interval = n_steps;
+    // "The save_interval must be a factor of the simulation length" (langevin_cgnet.py:305-309)
+    if (frames && n_steps % save_interval != 0)
+        return fail(DFF_EINVAL, "The save_interval must be a factor of the simulation length");
+    DffRunArgs a;
+    memset(&a, 0, sizeof a);
+    a.mode = DFF_MODE_LANGEVIN; a.B = n_traj; a.n_steps = n_steps;
+    a.x_io = x; a.v_io = v; a.noise = noise; a.seed = seed; a.item_offset = traj_offset; a.step_offset = step_offset;
+    a.t_norm = p->t_norm; a.force_scale = p->force_scale; a.dt = p->dt; a.vscale = p->vscale;
+    a.noisescale = p->noisescale; a.dtau = p->dtau; a.overdamped = p->overdamped;
+    a.save_interval = save_interval; a.frames = frames; a.ke = ke;
+    const float inv_beta = (float)(1.0 / (double)p->beta);
+    for (int i = 0; i < m->cfg.n_beads; ++i) {
+        const float mass = p->masses[i];
+        if (!(mass > 0.f) && !p->overdamped) return fail(DFF_EINVAL, "masses must be positive");
+        a.mass[i] = mass;
+        a.inv_mass[i] = 1.0f / mass;
+        a.noise_sigma[i] = sqrtf(inv_beta / mass);  // torch.sqrt(1.0 / beta / masses)  :465
+    }
+    a.brown_sigma = (float)std::sqrt(2.0 * (double)p->dtau / (double)p->beta);  // :497
+    return launch(m, a, (hipStream_t)stream);
+}
+
+extern "C" int dff_ddpm_run(dff_model* m, int batch, float* x, const float* noise, uint64_t seed,
+                            uint64_t sample_offset, int t_start, int t_end, int init_prior, int* clamp_flag,
+                            void* stream) {
+    if (!m || !x) return fail(DFF_EINVAL, "null argument");
+    if (batch <= 0) return batch == 0 ? DFF_OK : fail(DFF_EINVAL, "negative batch");
+    if (t_start >= m->cfg.timesteps || t_end < 0 || t_end > t_start) return fail(DFF_EINVAL, "bad timestep range");
+    DffRunArgs a;
+    memset(&a, 0, sizeof a);
+    a.mode = DFF_MODE_DDPM; a.B = batch; a.n_steps = t_start - t_end + 1;
+    a.x_io = x; a.noise = noise; a.seed = seed; a.item_offset = sample_offset;
+    a.t_start = t_start; a.init_prior = init_prior; a.clamp_flag = clamp_flag; a.save_interval = 1;
+    return launch(m, a, (hipStream_t)stream);
+}
+
+extern "C" int dff_debug_gemm(int device, const float* A, const float* W, int M, int K, int Nout, float* out) {
+    if (!A || !W || !out || M < 1 || M > 64 || Nout % 16 || !(K == 64 || K == 128))
+        return fail(DFF_EINVAL, "dff_debug_gemm: M<=64, K in {64,128}, Nout%%16==0");
+    HIPCHK(hipSetDevice(device));
+    std::vector<float> Wp = pack_b(K, Nout, [&](int k, int n) { return (double)W[(size_t)k * Nout + n]; });
+    float *dA, *dW, *dO;
+    HIPCHK(hipMalloc((void**)&dA, (size_t)M * K * 4));
+    HIPCHK(hipMalloc((void**)&dW, Wp.size() * 4));
+    HIPCHK(hipMalloc((void**)&dO, (size_t)M * Nout * 4));
+    HIPCHK(hipMemcpy(dA, A, (size_t)M * K * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dW, Wp.data(), Wp.size() * 4, hipMemcpyHostToDevice));
+    const size_t lds = (size_t)(64 * (K + 4) + 64) * 4;
+    if (K == 64) hipLaunchKernelGGL(dff_debug_gemm_kernel<4>, dim3(1), dim3(DFF_NTHREADS), lds, 0, dA, dW, M, Nout, dO);
+    else hipLaunchKernelGGL(dff_debug_gemm_kernel<8>, dim3(1), dim3(DFF_NTHREADS), lds, 0, dA, dW, M, Nout, dO);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, dO, (size_t)M * Nout * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(dA); (void)hipFree(dW); (void)hipFree(dO);
+    return DFF_OK;
+}
+
+extern "C" int dff_debug_stash(dff_model* m, int b, int layer, int what, float* out, size_t n) {
+    if (!m || !out || !m->stash || m->last_G <= 0) return fail(DFF_EINVAL, "no stash (run dff_score first)");
+    const int N = m->cfg.n_beads, H = m->cfg.hidden, L = m->cfg.n_layers, G = m->last_G;
+    if (b < 0 || b >= m->last_B || layer < 0 || layer >= L) return fail(DFF_EINVAL, "bad sample / layer");
+    const StashLayout sl = dff_stash_layout(N, G, H, L);
+    const int wg = b / G, g = b % G;
+    const float* base = m->stash + (size_t)wg * sl.total + (size_t)layer * sl.layer_stride;
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipDeviceSynchronize());
+    auto rows = [&](unsigned off, int width) -> int {
+        if (n != (size_t)N * width) return fail(DFF_EINVAL, "expected %d values", N * width);
+        HIPCHK(hipMemcpy(out, base + off + (size_t)g * N * width, (size_t)N * width * 4, hipMemcpyDeviceToHost));
+        return DFF_OK;
+    };
+    switch (what) {
+        case 0: return rows(sl.nodes_in, H);
+        case 1: return rows(sl.attn_out, H);
+        case 2: return rows(sl.ff, H);
+        case 3: return rows(sl.h_pre, 4 * H);
+        case 4: return rows(sl.q, DFF_INNER);
+        case 5: return rows(sl.k, DFF_INNER);
+        case 6: return rows(sl.v, DFF_INNER);
+        case 8: return rows(sl.u, 32);
+        case 7: {
+            if (n != (size_t)DFF_HEADS * N * N) return fail(DFF_EINVAL, "expected %d values", DFF_HEADS * N * N);
+            for (int h = 0; h < DFF_HEADS; ++h)
+                HIPCHK(hipMemcpy(out + (size_t)h * N * N, base + sl.P + ((size_t)h * G + g) * N * N,
+                                 (size_t)N * N * 4, hipMemcpyDeviceToHost));
+            return DFF_OK;
+        }
+    }
+    return fail(DFF_EINVAL, "unknown stash item %d", what);
+}
+
+extern "C" const char* dff_last_error(void) { return g_err.c_str(); }
+extern "C" const char* dff_version(void) { return "dff-amd 0.1 (gfx950, mfma_f32_16x16x4f32)"; }

@@ -1,0 +1,86 @@
+// dff_internal.h -- structures shared by the host API (dff_host.hip) and the device code
+// (dff_kernels.hip).  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DFF_MAX_LAYERS 8
+#define DFF_HEADS 8
+#define DFF_DH 64
+#define DFF_INNER 512
+#define DFF_NTHREADS 256
+#define DFF_NWAVES 4
+#define DFF_SMALL_LD 36   // leading dim of the 32-column u / xrel / r / du buffers
+
+// Packed B-operand layout for v_mfma_f32_16x16x4_f32 (see pack_b in dff_host.hip):
+//   block (nt, kb) = 256 floats holding W[16kb .. 16kb+15][16nt .. 16nt+15];
+//   inside a block lane l = (kk = l>>4, nn = l&15) owns 4 consecutive floats
+//   s = 0..3  <->  W[16kb + 4kk + s][16nt + nn];   blocks ordered [nt][kb].
+// MFMA step s of k-block kb therefore contracts k = 16kb + 4kk + s (a permutation of the
+// natural k order inside each 16-block; A fragments are read with the same permutation).
+
+struct DffLayerDev {
+    // forward
+    const float *ln1_g, *ln1_b;
+    const float *Wqkv_p, *bqkv;   // K=H, Nout=1536 head-major columns [h][q|k|v][d]
+    const float *Wu_p, *bu;       // K=H, Nout=32 (24 used: [h][c])
+    const float *Wo_p;            // K=512, Nout=H
+    const float *Woc_p;           // K=32 (24 used), Nout=H
+    const float *bo;              // folded: bo + Wo b_c
+    const float *g1;              // (3H) gate weights [x | res | x-res]
+    const float *ln2_g, *ln2_b;
+    const float *W1_p, *b1;       // K=H, Nout=4H
+    const float *W2_p, *b2;       // K=4H, Nout=H
+    const float *g2;
+    // backward (transposed orientation)
+    const float *W2T_p;           // K=H, Nout=4H   dh  = dff  W2
+    const float *W1T_p;           // K=4H, Nout=H   df  = dhp  W1
+    const float *WoT_p;           // K=H, Nout=512  G   = dattn Wo
+    const float *WocT_p;          // K=H, Nout=32   r   = dattn Woc
+    const float *WqkvT_p;         // K=1536 (head-major), Nout=H
+    const float *WuT_p;           // K=32, Nout=H
+};
+
+struct DffModelDev {
+    int N, H, L, T;
+    const float *WnT;   // (N+1, H): node_embedding.weight transposed (one-hot columns, then t)
+    const float *bn;    // (H)
+    const float *wdec;  // (H)
+    float bdec;
+    DffLayerDev layer[DFF_MAX_LAYERS];
+    // schedule tables, float32 (T each)
+    const float *sqrt_recip_ac, *sqrt_recipm1_ac, *post_c1, *post_c2, *post_logvar;
+};
+
+enum DffMode { DFF_MODE_SCORE = 0, DFF_MODE_LANGEVIN = 1, DFF_MODE_DDPM = 2 };
+
+struct DffRunArgs {
+    int mode;
+    int B;            // proteins (samples / trajectories) in this launch
+    int G;            // proteins per workgroup
+    int n_steps;
+    // state
+    const float* x_in;    // SCORE: (B,N,3) input
+    float* x_io;          // LANGEVIN/DDPM: (B,N,3) in/out
+    float* v_io;          // LANGEVIN: (B,N,3) in/out
+    const float* tnorm;   // SCORE: (B)
+    float* force_out;     // SCORE: (B,N,3)
+    float* energy_out;    // SCORE: (B,N) or null
+    // noise
+    const float* noise;   // (n_steps,B,N,3) or null -> philox
+    uint64_t seed, item_offset, step_offset;
+    // langevin
+    float t_norm, force_scale, dt, vscale, noisescale, dtau, brown_sigma;
+    int overdamped, save_interval;
+    float inv_mass[64];     // 1/m
+    float noise_sigma[64];  // sqrt(1/beta/m)
+    float mass[64];
+    float* frames;          // (n_steps/save, B, N, 3) or null
+    float* ke;              // (n_steps/save, B) or null
+    // ddpm
+    int t_start, init_prior;
+    int* clamp_flag;
+    // scratch
+    float* stash;               // per-workgroup stash slots
+    unsigned long long stash_stride; // floats per workgroup
+};

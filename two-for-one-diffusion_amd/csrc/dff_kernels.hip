@@ -1,0 +1,1189 @@
+// dff_kernels.hip -- the MI355X (gfx950 / CDNA4) device code of the denoising-force-field sampler.
+//
+// ONE persistent kernel runs the whole hot path for a group of proteins per workgroup:
+//
+//   for step in 0 .. n_steps-1:
+//       x <- center(x)                                      utils.py:65-70
+//       E  = energy(x, t)         forward, all layers        models/graph_transformer.py:90-108
+//       dx = d(sum E)/dx          hand-written VJP           models/graph_transformer.py:143-159
+//       x,v <- BAOAB / Brownian / DDPM p_sample update       dynamics/langevin_cgnet.py:447-500,
+//                                                            models/ddpm.py:195-232,248-251
+//
+// Trajectories / samples are independent, so there is no inter-workgroup communication at all:
+// a workgroup owns G proteins (rows = G*N <= 16*MT bead rows) for the entire launch, keeps x, v
+// and every activation of the current layer in LDS, streams the (pre-packed) weights from L2
+// straight into MFMA B-operand registers, and parks what the backward pass needs (q, k, v,
+// attention probabilities, gate inputs, FFN pre-activations) in a per-workgroup global "stash"
+// that never leaves L2 / Infinity Cache.
+//
+// Formulation: the reference materialises e_kv = edges_to_kv(edge_embedding(x_j - x_i)) as a
+// (B*8, N, N, 64) tensor (graph_transformer.py:96,235-245).  There is no nonlinearity between
+// the two Linear layers, so it is folded away exactly (see oracle/kernel_model.py and
+// SURVEY.md section 0.3): x enters only through  u_ih . x_j  in the logits and
+// xrel_ih = sum_j a_ihj x_j - x_i  in the values, with u = LN1(nodes) W_u^T + b_u and the xrel
+// term routed through W_oc = W_o W_c.  All dense projections (q|k|v, u, W_o, W_oc, FFN and
+// their transposes for the VJP) run on v_mfma_f32_16x16x4_f32 (exact fp32 == fmaf chain);
+// softmax / LayerNorm / GELU / gates / the N x N contractions run on the VALU out of LDS.
+#include "dff_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define DEVI __device__ __forceinline__
+
+// ------------------------------------------------------------------------------------------
+// Stash layout (floats, per workgroup).  R = G*N allocated rows, F = 4H.
+// ------------------------------------------------------------------------------------------
+struct StashLayout {
+    unsigned nodes_in, attn_out, ff, h_pre, q, k, v, u, P;  // offsets inside a layer slot
+    unsigned layer_stride;
+    unsigned dn_spill;   // offset of the (R,H) spill slot for nodes / dn (after all layers)
+    unsigned total;
+};
+
+__host__ __device__ inline StashLayout dff_stash_layout(int N, int G, int H, int L) {
+    StashLayout s;
+    const unsigned R = (unsigned)(G * N), F = 4u * H;
+    unsigned o = 0;
+    s.nodes_in = o; o += R * H;
+    s.attn_out = o; o += R * H;
+    s.ff = o;       o += R * H;
+    s.h_pre = o;    o += R * F;
+    s.q = o;        o += R * DFF_INNER;
+    s.k = o;        o += R * DFF_INNER;
+    s.v = o;        o += R * DFF_INNER;
+    s.u = o;        o += R * 32;
+    s.P = o;        o += ((unsigned)(DFF_HEADS * G * N * N) + 3u) & ~3u;
+    s.layer_stride = o;
+    s.dn_spill = o * (unsigned)L;
+    s.total = s.dn_spill + R * H;
+    s.total = (s.total + 63u) & ~63u;
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS layout (floats).  Computed identically on host (for the launch size) and device.
+// ------------------------------------------------------------------------------------------
+template <int H, int MT, int HGS, bool SPILL>
+struct LdsLayout {
+    static constexpr int LH = H + 4;
+    static constexpr int LQ = 64 * HGS + 4;
+    static constexpr int F = 4 * H;
+    static constexpr int FC = (F % 256 == 0) ? 256 : 128;
+    static constexpr int LF = FC + 4;
+    unsigned xst, xs, dxs, vst, cm, tn, ubuf, sbuf, dubuf, abuf, resbuf, Pbuf, dSbuf, Rg, total;
+    __host__ __device__ LdsLayout(int N, int G) {
+        const unsigned R = (unsigned)(G * N);
+        unsigned o = 0;
+        xst = o;   o += R * 4;
+        xs = o;    o += R * 4;
+        dxs = o;   o += R * 4;
+        vst = o;   o += R * 4;
+        cm = o;    o += 16 * 4 * 2;
+        tn = o;    o += 16;
+        ubuf = o;  o += R * DFF_SMALL_LD;
+        sbuf = o;  o += R * DFF_SMALL_LD;
+        dubuf = o; o += R * DFF_SMALL_LD;
+        abuf = o;  o += R * LH;
+        resbuf = o; if (!SPILL) o += R * LH;
+        const unsigned psz = ((unsigned)(HGS * G * N * N) + 3u) & ~3u;
+        Pbuf = o;  o += psz;
+        dSbuf = o; o += psz;
+        Rg = o;
+        unsigned rsz = 4u * R * LQ;
+        if (R * LF > rsz) rsz = R * LF;
+        if (R * LH > rsz) rsz = R * LH;
+        o += rsz + 64;  // slack: clamped A-fragment reads never leave the allocation
+        total = o;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+DEVI float grp16_sum(float v) {
+    v += __shfl_xor(v, 8, 16);
+    v += __shfl_xor(v, 4, 16);
+    v += __shfl_xor(v, 2, 16);
+    v += __shfl_xor(v, 1, 16);
+    return v;
+}
+DEVI float grp_sum(float v, int np) {
+    for (int o = np >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+DEVI float grp_max(float v, int np) {
+    for (int o = np >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+DEVI float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+DEVI float gelu_grad_f(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) +
+           x * expf(-0.5f * x * x) * 0.39894228040143267794f;
+}
+DEVI float sigmoid_f(float z) { return 1.0f / (1.0f + expf(-z)); }
+DEVI void st_nt(float* p, float v) { __builtin_nontemporal_store(v, p); }
+DEVI float ld_nt(const float* p) { return __builtin_nontemporal_load(p); }
+
+// Philox4x32-10 (Salmon et al. 2011), counter-based: the same (key, counter) always gives the
+// same 4 words, so a trajectory's noise does not depend on how the batch is sharded.
+DEVI void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2,
+                        uint32_t c3, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// standard normal number `c` (0..2) for (item, step, bead): Box-Muller on Philox words.
+DEVI float philox_normal(uint64_t seed, uint64_t item, uint64_t step, uint32_t bead, int c) {
+    uint32_t w[4];
+    philox4x32_10((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)item,
+                  (uint32_t)(item >> 32) ^ (bead << 8), (uint32_t)step, (uint32_t)(step >> 32), w);
+    const float inv = 2.3283064365386963e-10f;  // 2^-32
+    const float u0 = ((float)w[(c >> 1) * 2] + 0.5f) * inv;          // (0,1]
+    const float u1 = ((float)w[(c >> 1) * 2 + 1] + 0.5f) * inv;
+    const float r = sqrtf(-2.0f * logf(u0));
+    const float th = 6.28318530717958647692f * u1;
+    return (c & 1) ? r * sinf(th) : r * cosf(th);
+}
+
+// ------------------------------------------------------------------------------------------
+// MFMA GEMM stages.  A (rows x K) lives in LDS with leading dimension lda (multiple of 4);
+// B is the packed weight image in global memory (see dff_internal.h); C layout of
+// v_mfma_f32_16x16x4_f32: lane l holds column (l & 15), rows 4*(l >> 4) + r, r = 0..3.
+// ------------------------------------------------------------------------------------------
+DEVI void mfma4(f32x4& acc, const f32x4 a, const f32x4 b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc, 0, 0, 0);
+}
+
+// "wide" GEMM: K = 16*KB (small, compile time), many output tiles; the 4 waves take tiles
+// round-robin.  epi(nt_local, mt, acc) consumes one 16x16 output tile.
+template <int MT, int KB, class Epi>
+DEVI void gemm_wide(const float* A, int lda, int rowsA, const float* __restrict__ Wp, int KBtot,
+                    int kb0, int nt0, int ntn, Epi epi) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kk = lane >> 4, mm = lane & 15;
+    f32x4 a[MT][KB];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int row = mt * 16 + mm;
+        row = row < rowsA ? row : rowsA - 1;
+        const float* ap = A + row * lda + 4 * kk;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) a[mt][kb] = *(const f32x4*)(ap + 16 * kb);
+    }
+    const f32x4* wp = (const f32x4*)Wp + lane;
+    f32x4 bn[KB];
+    int nt = wave;
+    if (nt < ntn) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) bn[kb] = wp[((size_t)(nt0 + nt) * KBtot + kb0 + kb) * 64];
+    }
+    for (; nt < ntn; nt += DFF_NWAVES) {
+        f32x4 bc[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) bc[kb] = bn[kb];
+        if (nt + DFF_NWAVES < ntn) {
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+                bn[kb] = wp[((size_t)(nt0 + nt + DFF_NWAVES) * KBtot + kb0 + kb) * 64];
+        }
+        f32x4 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) mfma4(acc[mt], a[mt][kb], bc[kb]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) epi(nt, mt, acc[mt]);
+    }
+}
+
+// "tall" GEMM: few output tiles (Nout = H: wave w owns tiles w, w+4), long K given as `nseg`
+// segments of SKB k-blocks each; segf(s, A_ptr&, kb0&) names segment s.  Accumulates into acc,
+// which lives in registers across calls (head groups / FFN chunks).
+template <int MT, int NTW, int SKB, class SegF>
+DEVI void gemm_tall(f32x4 (&acc)[NTW][MT], int nseg, SegF segf, int lda, int rowsA,
+                    const float* __restrict__ Wp, int KBtot, int ntiles) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kk = lane >> 4, mm = lane & 15;
+    int rowoff[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int row = mt * 16 + mm;
+        row = row < rowsA ? row : rowsA - 1;
+        rowoff[mt] = row * lda + 4 * kk;
+    }
+    const f32x4* wp = (const f32x4*)Wp + lane;
+    size_t tbase[NTW];
+    bool tok[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int nt = wave + DFF_NWAVES * i;
+        tok[i] = nt < ntiles;
+        tbase[i] = (size_t)(tok[i] ? nt : 0) * KBtot;
+    }
+    if (!tok[0]) return;
+    f32x4 bn[NTW][SKB];
+    const float* An; int kbn;
+    if (nseg > 0) {
+        segf(0, An, kbn);
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int kb = 0; kb < SKB; ++kb) bn[i][kb] = wp[(tbase[i] + kbn + kb) * 64];
+    }
+    for (int s = 0; s < nseg; ++s) {
+        const float* Ac = An;
+        f32x4 bc[NTW][SKB];
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int kb = 0; kb < SKB; ++kb) bc[i][kb] = bn[i][kb];
+        if (s + 1 < nseg) {
+            segf(s + 1, An, kbn);
+#pragma unroll
+            for (int i = 0; i < NTW; ++i)
+#pragma unroll
+                for (int kb = 0; kb < SKB; ++kb) bn[i][kb] = wp[(tbase[i] + kbn + kb) * 64];
+        }
+#pragma unroll
+        for (int kb = 0; kb < SKB; ++kb) {
+            f32x4 a[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = *(const f32x4*)(Ac + rowoff[mt] + 16 * kb);
+#pragma unroll
+            for (int i = 0; i < NTW; ++i)
+                if (tok[i]) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) mfma4(acc[i][mt], a[mt], bc[i][kb]);
+                }
+        }
+    }
+}
+
+template <int MT, int NTW>
+DEVI void acc_zero(f32x4 (&acc)[NTW][MT]) {
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[i][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+
+// write the tall accumulators (+ optional bias) to an LDS row buffer
+template <int MT, int NTW>
+DEVI void store_tall(const f32x4 (&acc)[NTW][MT], float* out, int ld, int rows, int ntiles,
+                     const float* __restrict__ bias) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int quad = lane >> 4, col = lane & 15;
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int nt = wave + DFF_NWAVES * i;
+        if (nt >= ntiles) continue;
+        const float bv = bias ? bias[16 * nt + col] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = mt * 16 + quad * 4 + r;
+                if (row < rows) out[row * ld + 16 * nt + col] = acc[i][mt][r] + bv;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-workgroup context
+// ------------------------------------------------------------------------------------------
+struct Ctx {
+    int N, G, gcnt, rows, NP, L;
+    int b0;
+    float *xst, *xs, *dxs, *vst, *cm, *tn, *ubuf, *sbuf, *dubuf, *abuf, *resbuf, *Pbuf, *dSbuf, *Rg;
+    float* stash;  // this workgroup's slot
+    StashLayout sl;
+};
+
+// x-independent layer-0 node features: node_embedding([one_hot(i), t])  (graph_transformer.py:
+// 91-92,100-103) -> resbuf, stashed as nodes_in of layer 0.
+template <int H>
+DEVI void node_embed(const Ctx& c, const DffModelDev& m) {
+    for (int idx = threadIdx.x; idx < c.rows * H; idx += DFF_NTHREADS) {
+        const int row = idx / H, col = idx - row * H;
+        const int g = row / c.N, i = row - g * c.N;
+        const float v = m.WnT[i * H + col] + c.tn[g] * m.WnT[c.N * H + col] + m.bn[col];
+        c.resbuf[row * (H + 4) + col] = v;
+    }
+}
+
+// LayerNorm of one row held as HC values per lane of a 16-lane group
+template <int H>
+DEVI void ln_stats(const float (&x)[H / 16], float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < H / 16; ++i) s += x[i];
+    mean = grp16_sum(s) * (1.0f / H);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < H / 16; ++i) { const float d = x[i] - mean; q += d * d; }
+    const float var = grp16_sum(q) * (1.0f / H);
+    rstd = 1.0f / sqrtf(var + 1e-5f);
+}
+
+// gate = sigmoid(w . [x, res, x-res])   (graph_transformer.py:197-205)
+template <int H>
+DEVI float gate_value(const float (&x)[H / 16], const float (&res)[H / 16], const float* __restrict__ w, int sub) {
+    float z = 0.f;
+#pragma unroll
+    for (int i = 0; i < H / 16; ++i) {
+        const int col = sub + 16 * i;
+        z += x[i] * w[col] + res[i] * w[H + col] + (x[i] - res[i]) * w[2 * H + col];
+    }
+    return sigmoid_f(grp16_sum(z));
+}
+
+// R0: nodes (resbuf) -> stash nodes_in ; LN1 -> abuf
+template <int H>
+DEVI void row_ln1(const Ctx& c, const DffLayerDev& lw, int l) {
+    constexpr int HC = H / 16, LH = H + 4;
+    const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    float* s_nodes = c.stash + (size_t)l * c.sl.layer_stride + c.sl.nodes_in;
+    for (int row = grp; row < c.rows; row += 16) {
+        float x[HC];
+#pragma unroll
+        for (int i = 0; i < HC; ++i) {
+            x[i] = c.resbuf[row * LH + sub + 16 * i];
+            st_nt(s_nodes + row * H + sub + 16 * i, x[i]);
+        }
+        float mean, rstd;
+        ln_stats<H>(x, mean, rstd);
+#pragma unroll
+        for (int i = 0; i < HC; ++i) {
+            const int col = sub + 16 * i;
+            c.abuf[row * LH + col] = (x[i] - mean) * rstd * lw.ln1_g[col] + lw.ln1_b[col];
+        }
+    }
+}
+
+// R1: tbuf = attn_out, resbuf = nodes -> nodes1 (resbuf), stash attn_out, LN2 -> abuf
+template <int H>
+DEVI void row_gate1_ln2(const Ctx& c, const DffLayerDev& lw, int l, const float* tbuf) {
+    constexpr int HC = H / 16, LH = H + 4;
+    const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    float* s_att = c.stash + (size_t)l * c.sl.layer_stride + c.sl.attn_out;
+    for (int row = grp; row < c.rows; row += 16) {
+        float x[HC], res[HC], n1[HC];
+#pragma unroll
+        for (int i = 0; i < HC; ++i) {
+            x[i] = tbuf[row * LH + sub + 16 * i];
+            res[i] = c.resbuf[row * LH + sub + 16 * i];
+            st_nt(s_att + row * H + sub + 16 * i, x[i]);
+        }
+        const float g = gate_value<H>(x, res, lw.g1, sub);
+#pragma unroll
+        for (int i = 0; i < HC; ++i) {
+            n1[i] = x[i] * g + res[i] * (1.0f - g);
+            c.resbuf[row * LH + sub + 16 * i] = n1[i];
+        }
+        float mean, rstd;
+        ln_stats<H>(n1, mean, rstd);
+#pragma unroll
+        for (int i = 0; i < HC; ++i) {
+            const int col = sub + 16 * i;
+            c.abuf[row * LH + col] = (n1[i] - mean) * rstd * lw.ln2_g[col] + lw.ln2_b[col];
+        }
+    }
+}
+
+// R2: tbuf = ff, resbuf = nodes1 -> nodes2 (resbuf), stash ff.  Last layer: energy + dn = w_dec.
+template <int H>
+DEVI void row_gate2(const Ctx& c, const DffModelDev& m, const DffLayerDev& lw, int l, const float* tbuf,
+                    bool last, float* energy_out) {
+    constexpr int HC = H / 16, LH = H + 4;
+    const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    float* s_ff = c.stash + (size_t)l * c.sl.layer_stride + c.sl.ff;
+    for (int row = grp; row < c.rows; row += 16) {
+        float x[HC], res[HC];
+#pragma unroll
+        for (int i = 0; i < HC; ++i) {
+            x[i] = tbuf[row * LH + sub + 16 * i];
+            res[i] = c.resbuf[row * LH + sub + 16 * i];
+            st_nt(s_ff + row * H + sub + 16 * i, x[i]);
+        }
+        const float g = gate_value<H>(x, res, lw.g2, sub);
+        float e = 0.f;
+#pragma unroll
+        for (int i = 0; i < HC; ++i) {
+            const int col = sub + 16 * i;
+            const float n2 = x[i] * g + res[i] * (1.0f - g);
+            if (last) {
+                e += n2 * m.wdec[col];
+                c.resbuf[row * LH + col] = m.wdec[col];  // d(sum_i e_i)/d nodes_L
+            } else {
+                c.resbuf[row * LH + col] = n2;
+            }
+        }
+        if (last && energy_out) {
+            e = grp16_sum(e);
+            if (sub == 0) energy_out[(size_t)c.b0 * c.N + row] = e + m.bdec;
+        }
+    }
+}
+
+// RB1: dn (resbuf) through gate2 -> dff (abuf), dn1 partial (resbuf)
+template <int H>
+DEVI void rowb_gate2(const Ctx& c, const DffLayerDev& lw, int l) {
+    constexpr int HC = H / 16, LH = H + 4;
+    const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    const float* sb = c.stash + (size_t)l * c.sl.layer_stride;
+    for (int row = grp; row < c.rows; row += 16) {
+        float ao[HC], nin[HC], n1[HC], ff[HC], dn[HC];
+#pragma unroll
+        for (int i = 0; i < HC; ++i) {
+            const int col = sub + 16 * i;
+            ao[i] = ld_nt(sb + c.sl.attn_out + row * H + col);
+            nin[i] = ld_nt(sb + c.sl.nodes_in + row * H + col);
+            ff[i] = ld_nt(sb + c.sl.ff + row * H + col);
+            dn[i] = c.resbuf[row * LH + col];
+        }
+        const float g1 = gate_value<H>(ao, nin, lw.g1, sub);
+#pragma unroll
+        for (int i = 0; i < HC; ++i) n1[i] = ao[i] * g1 + nin[i] * (1.0f - g1);
+        const float g2 = gate_value<H>(ff, n1, lw.g2, sub);
+        float dg = 0.f;
+#pragma unroll
+        for (int i = 0; i < HC; ++i) dg += dn[i] * (ff[i] - n1[i]);
+        dg = grp16_sum(dg);
+        const float dz = dg * g2 * (1.0f - g2);
+#pragma unroll
+        for (int i = 0; i < HC; ++i) {
+            const int col = sub + 16 * i;
+            c.abuf[row * LH + col] = dn[i] * g2 + dz * (lw.g2[col] + lw.g2[2 * H + col]);
+            c.resbuf[row * LH + col] = dn[i] * (1.0f - g2) + dz * (lw.g2[H + col] - lw.g2[2 * H + col]);
+        }
+    }
+}
+
+// RB2: tbuf = df ; dn1 = resbuf + LN2bwd(df) ; gate1 bwd -> dattn (abuf), dn_in partial (resbuf)
+template <int H>
+DEVI void rowb_ln2_gate1(const Ctx& c, const DffLayerDev& lw, int l, const float* tbuf) {
+    constexpr int HC = H / 16, LH = H + 4;
+    const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    const float* sb = c.stash + (size_t)l * c.sl.layer_stride;
+    for (int row = grp; row < c.rows; row += 16) {
+        float ao[HC], nin[HC], n1[HC], d1[HC];
+#pragma unroll
+        for (int i = 0; i < HC; ++i) {
+            const int col = sub + 16 * i;
+            ao[i] = ld_nt(sb + c.sl.attn_out + row * H + col);
+            nin[i] = ld_nt(sb + c.sl.nodes_in + row * H + col);
+        }
+        const float g1 = gate_value<H>(ao, nin, lw.g1, sub);
+#pragma unroll
+        for (int i = 0; i < HC; ++i) n1[i] = ao[i] * g1 + nin[i] * (1.0f - g1);
+        float mean, rstd;
+        ln_stats<H>(n1, mean, rstd);
+        float s1 = 0.f, s2 = 0.f;
+        float dyg[HC], xh[HC];
+#pragma unroll
+        for (int i = 0; i < HC; ++i) {
+            const int col = sub + 16 * i;
+            xh[i] = (n1[i] - mean) * rstd;
+            dyg[i] = tbuf[row * LH + col] * lw.ln2_g[col];
+            s1 += dyg[i];
+            s2 += dyg[i] * xh[i];
+        }
+        s1 = grp16_sum(s1) * (1.0f / H);
+        s2 = grp16_sum(s2) * (1.0f / H);
+        float dg = 0.f;
+#pragma unroll
+        for (int i = 0; i < HC; ++i) {
+            const int col = sub + 16 * i;
+            d1[i] = c.resbuf[row * LH + col] + rstd * (dyg[i] - s1 - xh[i] * s2);
+            dg += d1[i] * (ao[i] - nin[i]);
+        }
+        dg = grp16_sum(dg);
+        const float dz = dg * g1 * (1.0f - g1);
+#pragma unroll
+        for (int i = 0; i < HC; ++i) {
+            const int col = sub + 16 * i;
+            c.abuf[row * LH + col] = d1[i] * g1 + dz * (lw.g1[col] + lw.g1[2 * H + col]);
+            c.resbuf[row * LH + col] = d1[i] * (1.0f - g1) + dz * (lw.g1[H + col] - lw.g1[2 * H + col]);
+        }
+    }
+}
+
+// RB3: tbuf = d(LN1 out) ; dn = resbuf + LN1bwd
+template <int H>
+DEVI void rowb_ln1(const Ctx& c, const DffLayerDev& lw, int l, const float* tbuf) {
+    constexpr int HC = H / 16, LH = H + 4;
+    const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    const float* sb = c.stash + (size_t)l * c.sl.layer_stride;
+    for (int row = grp; row < c.rows; row += 16) {
+        float nin[HC];
+#pragma unroll
+        for (int i = 0; i < HC; ++i) nin[i] = ld_nt(sb + c.sl.nodes_in + row * H + sub + 16 * i);
+        float mean, rstd;
+        ln_stats<H>(nin, mean, rstd);
+        float s1 = 0.f, s2 = 0.f, dyg[HC], xh[HC];
+#pragma unroll
+        for (int i = 0; i < HC; ++i) {
+            const int col = sub + 16 * i;
+            xh[i] = (nin[i] - mean) * rstd;
+            dyg[i] = tbuf[row * LH + col] * lw.ln1_g[col];
+            s1 += dyg[i];
+            s2 += dyg[i] * xh[i];
+        }
+        s1 = grp16_sum(s1) * (1.0f / H);
+        s2 = grp16_sum(s2) * (1.0f / H);
+#pragma unroll
+        for (int i = 0; i < HC; ++i) {
+            const int col = sub + 16 * i;
+            c.resbuf[row * LH + col] += rstd * (dyg[i] - s1 - xh[i] * s2);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// attention stages (VALU out of LDS).  Head-group buffers: R0 = q, R1 = k, R2 = v, R3 = o / G.
+// ------------------------------------------------------------------------------------------
+// logits + softmax:  a_ihj = softmax_j( scale (q_ih.k_jh + u_ih.x_j) )   (graph_transformer.py:
+// 247-255 with the j-constant terms dropped).  NP lanes (power of two >= N) share one (g,hh,i).
+template <int HGS>
+DEVI void attn_softmax(const Ctx& c, int hg, int l) {
+    constexpr int LQ = 64 * HGS + 4;
+    const int N = c.N, NP = c.NP;
+    const float* qs = c.Rg;
+    const float* ks = c.Rg + c.G * N * LQ;
+    const int nrow = c.gcnt * HGS * N;  // (hh, g, i) items
+    const int total = nrow * NP;
+    float* sP = c.stash + (size_t)l * c.sl.layer_stride + c.sl.P + (size_t)hg * HGS * c.G * N * N;
+    for (int base = 0; base < total; base += DFF_NTHREADS) {
+        const int it = base + threadIdx.x;
+        const bool act = it < total;
+        const int itc = act ? it : total - 1;
+        const int j = itc % NP, ri = itc / NP;     // ri = (hh*gcnt + g)*N + i
+        const int i = ri % N, hgi = ri / N;
+        const int g = hgi % c.gcnt, hh = hgi / c.gcnt;
+        const bool jok = j < N;
+        const int qrow = g * N + i, krow = g * N + (jok ? j : N - 1);
+        const f32x4* qp = (const f32x4*)(qs + qrow * LQ + hh * 64);
+        const f32x4* kp = (const f32x4*)(ks + krow * LQ + hh * 64);
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+            const f32x4 a = qp[d], b = kp[d];
+            s += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+        }
+        const int h = hg * HGS + hh;
+        const float* up = c.ubuf + qrow * DFF_SMALL_LD + 3 * h;
+        const float* xp = c.xs + krow * 4;
+        s += up[0] * xp[0] + up[1] * xp[1] + up[2] * xp[2];
+        s = jok ? s * 0.125f : -INFINITY;
+        const float mx = grp_max(s, NP);
+        const float e = jok ? expf(s - mx) : 0.f;
+        const float den = grp_sum(e, NP);
+        const float p = e / den;
+        if (act && jok) {
+            const int pidx = ((hh * c.G + g) * N + i) * N + j;
+            c.Pbuf[pidx] = p;
+            st_nt(sP + pidx, p);
+        }
+    }
+}
+
+// o_ih = sum_j a_ihj v_jh  -> R3 ;  xrel_ih = sum_j a_ihj x_j - x_i -> sbuf[:, 3h..3h+2]
+template <int HGS>
+DEVI void attn_pv(const Ctx& c, int hg) {
+    constexpr int LQ = 64 * HGS + 4;
+    const int N = c.N;
+    const float* vs = c.Rg + 2 * c.G * N * LQ;
+    float* os = c.Rg + 3 * c.G * N * LQ;
+    const int total = c.gcnt * HGS * N * 16;
+    for (int it = threadIdx.x; it < total; it += DFF_NTHREADS) {
+        const int d4 = it & 15, ri = it >> 4;
+        const int i = ri % N, hgi = ri / N;
+        const int g = hgi % c.gcnt, hh = hgi / c.gcnt;
+        const float* pp = c.Pbuf + ((hh * c.G + g) * N + i) * N;
+        const float* vp = vs + (g * N) * LQ + hh * 64 + d4 * 4;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < N; ++j) {
+            const float p = pp[j];
+            const f32x4 v = *(const f32x4*)(vp + j * LQ);
+            o[0] += p * v[0]; o[1] += p * v[1]; o[2] += p * v[2]; o[3] += p * v[3];
+        }
+        *(f32x4*)(os + (g * N + i) * LQ + hh * 64 + d4 * 4) = o;
+    }
+    const int t2 = c.gcnt * HGS * N * 4;
+    for (int it = threadIdx.x; it < t2; it += DFF_NTHREADS) {
+        const int cc = it & 3, ri = it >> 2;
+        if (cc == 3) continue;
+        const int i = ri % N, hgi = ri / N;
+        const int g = hgi % c.gcnt, hh = hgi / c.gcnt;
+        const float* pp = c.Pbuf + ((hh * c.G + g) * N + i) * N;
+        float a = 0.f;
+        for (int j = 0; j < N; ++j) a += pp[j] * c.xs[(g * N + j) * 4 + cc];
+        c.sbuf[(g * N + i) * DFF_SMALL_LD + 3 * (hg * HGS + hh) + cc] = a - c.xs[(g * N + i) * 4 + cc];
+    }
+}
+
+// backward, step 2: da_ij = G_i.v_j + r_i.x_j ; ds = a (da - sum_j a da) -> dSbuf ;
+// du_ih = scale sum_j ds_ij x_j -> dubuf
+template <int HGS>
+DEVI void attnb_ds(const Ctx& c, int hg) {
+    constexpr int LQ = 64 * HGS + 4;
+    const int N = c.N, NP = c.NP;
+    const float* vs = c.Rg + 2 * c.G * N * LQ;
+    const float* Gs = c.Rg + 3 * c.G * N * LQ;
+    const int nrow = c.gcnt * HGS * N;
+    const int total = nrow * NP;
+    for (int base = 0; base < total; base += DFF_NTHREADS) {
+        const int it = base + threadIdx.x;
+        const bool act = it < total;
+        const int itc = act ? it : total - 1;
+        const int j = itc % NP, ri = itc / NP;
+        const int i = ri % N, hgi = ri / N;
+        const int g = hgi % c.gcnt, hh = hgi / c.gcnt;
+        const bool jok = j < N;
+        const int irow = g * N + i, jrow = g * N + (jok ? j : N - 1);
+        const f32x4* gp = (const f32x4*)(Gs + irow * LQ + hh * 64);
+        const f32x4* vp = (const f32x4*)(vs + jrow * LQ + hh * 64);
+        float da = 0.f;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+            const f32x4 a = gp[d], b = vp[d];
+            da += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+        }
+        const int h = hg * HGS + hh;
+        const float* rp = c.sbuf + irow * DFF_SMALL_LD + 3 * h;
+        const float* xp = c.xs + jrow * 4;
+        da += rp[0] * xp[0] + rp[1] * xp[1] + rp[2] * xp[2];
+        const int pidx = ((hh * c.G + g) * N + i) * N + (jok ? j : 0);
+        const float p = jok ? c.Pbuf[pidx] : 0.f;
+        const float sm = grp_sum(p * da, NP);
+        const float ds = p * (da - sm);
+        const float dux = grp_sum(ds * xp[0], NP);
+        const float duy = grp_sum(ds * xp[1], NP);
+        const float duz = grp_sum(ds * xp[2], NP);
+        if (act && jok) c.dSbuf[pidx] = ds;
+        if (act && j == 0) {
+            float* dup = c.dubuf + irow * DFF_SMALL_LD + 3 * h;
+            dup[0] = 0.125f * dux; dup[1] = 0.125f * duy; dup[2] = 0.125f * duz;
+        }
+    }
+}
+
+// backward, step 3: dx_j += sum_{hh,i} (a_ij r_i + scale ds_ij u_i) ; dx_i -= sum_hh r_i
+template <int HGS>
+DEVI void attnb_dx(const Ctx& c, int hg) {
+    const int N = c.N;
+    const int total = c.gcnt * N * 4;
+    for (int it = threadIdx.x; it < total; it += DFF_NTHREADS) {
+        const int cc = it & 3, row = it >> 2;
+        if (cc == 3) continue;
+        const int g = row / N, j = row - g * N;
+        float acc = 0.f;
+        for (int hh = 0; hh < HGS; ++hh) {
+            const int h = hg * HGS + hh;
+            const float* pp = c.Pbuf + ((hh * c.G + g) * N) * N + j;
+            const float* dp = c.dSbuf + ((hh * c.G + g) * N) * N + j;
+            float a = 0.f;
+            for (int i = 0; i < N; ++i) {
+                const int irow = g * N + i;
+                a += pp[i * N] * c.sbuf[irow * DFF_SMALL_LD + 3 * h + cc] +
+                     0.125f * dp[i * N] * c.ubuf[irow * DFF_SMALL_LD + 3 * h + cc];
+            }
+            acc += a - c.sbuf[row * DFF_SMALL_LD + 3 * h + cc];
+        }
+        c.dxs[row * 4 + cc] += acc;
+    }
+}
+
+// backward, steps 4-6.  WHICH 0: dv_j = sum_i a_ij G_i      (reads P, R3)  -> R2
+//                       WHICH 1: dq_i = scale sum_j ds_ij k_j (reads dS, R1) -> R3
+//                       WHICH 2: dk_j = scale sum_i ds_ij q_i (reads dS, R0) -> R1
+template <int HGS, int WHICH>
+DEVI void attnb_dqkv(const Ctx& c) {
+    constexpr int LQ = 64 * HGS + 4;
+    const int N = c.N, RN = c.G * N;
+    const float* src = c.Rg + (WHICH == 0 ? 3 : WHICH == 1 ? 1 : 0) * RN * LQ;
+    float* dst = c.Rg + (WHICH == 0 ? 2 : WHICH == 1 ? 3 : 1) * RN * LQ;
+    const float* W = (WHICH == 0) ? c.Pbuf : c.dSbuf;
+    const float mul = (WHICH == 0) ? 1.0f : 0.125f;
+    const int total = c.gcnt * HGS * N * 16;
+    for (int it = threadIdx.x; it < total; it += DFF_NTHREADS) {
+        const int d4 = it & 15, ri = it >> 4;
+        const int o = ri % N, hgi = ri / N;     // o = output row index within the protein
+        const int g = hgi % c.gcnt, hh = hgi / c.gcnt;
+        const float* wp = W + ((hh * c.G + g) * N) * N;
+        const float* sp = src + (g * N) * LQ + hh * 64 + d4 * 4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < N; ++s) {
+            // dq: W[o][s] (row o, sum over j=s) ; dv/dk: W[s][o] (sum over i=s)
+            const float w = (WHICH == 1) ? wp[o * N + s] : wp[s * N + o];
+            const f32x4 v = *(const f32x4*)(sp + s * LQ);
+            acc[0] += w * v[0]; acc[1] += w * v[1]; acc[2] += w * v[2]; acc[3] += w * v[3];
+        }
+        acc[0] *= mul; acc[1] *= mul; acc[2] *= mul; acc[3] *= mul;
+        *(f32x4*)(dst + (g * N + o) * LQ + hh * 64 + d4 * 4) = acc;
+    }
+}
+
+// reload q (optional), k (optional), v, P, u of layer l / head group hg from the stash
+template <int HGS>
+DEVI void reload_heads(const Ctx& c, int l, int hg, bool need_qk) {
+    constexpr int LQ = 64 * HGS + 4;
+    const int N = c.N, RN = c.G * N;
+    const float* sb = c.stash + (size_t)l * c.sl.layer_stride;
+    const int per_row = 16 * HGS;  // float4 per row per tensor
+    const int total = c.rows * per_row;
+    for (int it = threadIdx.x; it < total; it += DFF_NTHREADS) {
+        const int row = it / per_row, c4 = it - row * per_row;
+        const size_t so = (size_t)row * DFF_INNER + hg * HGS * 64 + c4 * 4;
+        const int lo = row * LQ + c4 * 4;
+        *(f32x4*)(c.Rg + 2 * RN * LQ + lo) = __builtin_nontemporal_load((const f32x4*)(sb + c.sl.v + so));
+        if (need_qk) {
+            *(f32x4*)(c.Rg + lo) = __builtin_nontemporal_load((const f32x4*)(sb + c.sl.q + so));
+            *(f32x4*)(c.Rg + RN * LQ + lo) = __builtin_nontemporal_load((const f32x4*)(sb + c.sl.k + so));
+        }
+    }
+    const int pn = HGS * c.G * N * N;
+    const float* sP = sb + c.sl.P + (size_t)hg * pn;
+    for (int it = threadIdx.x; it < pn; it += DFF_NTHREADS) c.Pbuf[it] = ld_nt(sP + it);
+}
+
+// ------------------------------------------------------------------------------------------
+// centring helpers (utils.py:65-70): per-protein mean over beads
+// ------------------------------------------------------------------------------------------
+DEVI void bead_mean(const Ctx& c, const float* src, float* cm) {
+    if ((int)threadIdx.x < c.gcnt * 4) {
+        const int g = threadIdx.x >> 2, cc = threadIdx.x & 3;
+        float s = 0.f;
+        for (int i = 0; i < c.N; ++i) s += src[(g * c.N + i) * 4 + cc];
+        cm[threadIdx.x] = s / (float)c.N;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// the kernel
+// ------------------------------------------------------------------------------------------
+template <int H, int MT, int HGS, bool SPILL>
+__global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelDev m, const DffRunArgs a) {
+    using LL = LdsLayout<H, MT, HGS, SPILL>;
+    constexpr int LH = LL::LH, LQ = LL::LQ, F = LL::F, FC = LL::FC, LF = LL::LF;
+    constexpr int NT_H = H / 16;                       // output tiles of an H-wide GEMM
+    constexpr int NTW = (NT_H + DFF_NWAVES - 1) / DFF_NWAVES;
+    constexpr int NHG = DFF_HEADS / HGS;
+    constexpr int NCH = F / FC;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    Ctx c;
+    c.N = m.N; c.G = a.G; c.L = m.L;
+    c.b0 = blockIdx.x * a.G;
+    c.gcnt = min(a.G, a.B - c.b0);
+    if (c.gcnt <= 0) return;
+    c.rows = c.gcnt * c.N;
+    c.NP = c.N <= 8 ? 8 : c.N <= 16 ? 16 : c.N <= 32 ? 32 : 64;
+    const LL ll(c.N, c.G);
+    c.xst = smem + ll.xst; c.xs = smem + ll.xs; c.dxs = smem + ll.dxs; c.vst = smem + ll.vst;
+    c.cm = smem + ll.cm; c.tn = smem + ll.tn;
+    c.ubuf = smem + ll.ubuf; c.sbuf = smem + ll.sbuf; c.dubuf = smem + ll.dubuf;
+    c.abuf = smem + ll.abuf;
+    c.Pbuf = smem + ll.Pbuf; c.dSbuf = smem + ll.dSbuf; c.Rg = smem + ll.Rg;
+    c.sl = dff_stash_layout(c.N, c.G, H, m.L);
+    c.stash = a.stash + (size_t)blockIdx.x * a.stash_stride;
+    c.resbuf = SPILL ? (c.stash + c.sl.dn_spill) : (smem + ll.resbuf);
+    float* tbuf = c.Rg;  // GEMM outputs of width H alias the start of the head-group region
+    const int tid = threadIdx.x;
+    const int N = c.N, RN = c.G * N, rows = c.rows;
+
+    // zero LDS once (pad columns of the 32-wide buffers must be 0; pad rows must be finite)
+    for (int i = tid; i < (int)ll.total; i += DFF_NTHREADS) smem[i] = 0.f;
+    __syncthreads();
+
+    // ---- load state ----
+    {
+        const float* xin = (a.mode == DFF_MODE_SCORE) ? a.x_in : a.x_io;
+        if (tid < rows * 4) {
+            const int row = tid >> 2, cc = tid & 3;
+            float xv = 0.f, vv = 0.f;
+            if (cc < 3) {
+                const size_t gi = ((size_t)c.b0 * N + row) * 3 + cc;
+                if (a.mode == DFF_MODE_DDPM && a.init_prior) {
+                    xv = philox_normal(a.seed, a.item_offset + c.b0 + row / N, 0xFFFFFFFFull, row % N, cc);
+                } else {
+                    xv = xin[gi];
+                }
+                if (a.mode == DFF_MODE_LANGEVIN && !a.overdamped) vv = a.v_io[gi];
+            }
+            c.xst[tid] = xv;
+            c.vst[tid] = vv;
+        }
+        if (tid < c.gcnt) c.tn[tid] = (a.mode == DFF_MODE_SCORE) ? a.tnorm[c.b0 + tid] : a.t_norm;
+        __syncthreads();
+        if (a.mode == DFF_MODE_DDPM && a.init_prior) {  // x_T = center_zero(randn)  ddpm.py:242
+            bead_mean(c, c.xst, c.cm);
+            __syncthreads();
+            if (tid < rows * 4) c.xst[tid] -= c.cm[(tid >> 2) / N * 4 + (tid & 3)];
+            __syncthreads();
+        }
+    }
+
+    for (int step = 0; step < a.n_steps; ++step) {
+        int t_int = 0;
+        if (a.mode == DFF_MODE_DDPM) {
+            t_int = a.t_start - step;
+            if (tid < c.gcnt) c.tn[tid] = (1.0f * (float)t_int) / (float)m.T;  // ddpm.py:203
+        }
+        // ---- centring: Langevin re-centres the state itself (langevin_cgnet.py:739); the score
+        // op always centres its own input (graph_transformer.py:87) ----
+        bead_mean(c, c.xst, c.cm);
+        __syncthreads();
+        if (tid < rows * 4) {
+            const float xc = c.xst[tid] - c.cm[(tid >> 2) / N * 4 + (tid & 3)];
+            if (a.mode == DFF_MODE_LANGEVIN) c.xst[tid] = xc;
+            c.xs[tid] = xc;
+            c.dxs[tid] = 0.f;
+        }
+        __syncthreads();
+        if (a.mode == DFF_MODE_LANGEVIN) {  // second (no-op-sized) centring inside the score op
+            bead_mean(c, c.xs, c.cm);
+            __syncthreads();
+            if (tid < rows * 4) c.xs[tid] -= c.cm[(tid >> 2) / N * 4 + (tid & 3)];
+            __syncthreads();
+        }
+
+        // =============================== forward ===============================
+        node_embed<H>(c, m);
+        __syncthreads();
+        for (int l = 0; l < m.L; ++l) {
+            const DffLayerDev& lw = m.layer[l];
+            float* sb = c.stash + (size_t)l * c.sl.layer_stride;
+            row_ln1<H>(c, lw, l);
+            __syncthreads();
+            // u = LN1(nodes) W_u^T + b_u  (all 8 heads, 24 of 32 columns used)
+            gemm_wide<MT, NT_H>(c.abuf, LH, RN, lw.Wu_p, NT_H, 0, 0, 2,
+                [&](int nt, int mt, const f32x4& acc) {
+                    const int lane = tid & 63, quad = lane >> 4, col = 16 * nt + (lane & 15);
+                    const float bv = lw.bu[col];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = mt * 16 + quad * 4 + r;
+                        if (row < rows) {
+                            const float v = acc[r] + bv;
+                            c.ubuf[row * DFF_SMALL_LD + col] = v;
+                            st_nt(sb + c.sl.u + row * 32 + col, v);
+                        }
+                    }
+                });
+            f32x4 acc_o[NTW][MT];
+            acc_zero<MT, NTW>(acc_o);
+            for (int hg = 0; hg < NHG; ++hg) {
+                // q|k|v of HGS heads -> R0,R1,R2 (+ stash)
+                gemm_wide<MT, NT_H>(c.abuf, LH, RN, lw.Wqkv_p, NT_H, 0, hg * HGS * 12, HGS * 12,
+                    [&](int nt, int mt, const f32x4& acc) {
+                        const int lane = tid & 63, quad = lane >> 4, cl = lane & 15;
+                        const int cg = (hg * HGS * 12 + nt) * 16;         // global column (head-major)
+                        const int h = cg / 192, part = (cg % 192) / 64, d = (cg % 64) + cl;
+                        const float bv = lw.bqkv[cg + cl];
+                        float* dstl = c.Rg + part * RN * LQ + (h - hg * HGS) * 64 + d;
+                        float* dsts = sb + (part == 0 ? c.sl.q : part == 1 ? c.sl.k : c.sl.v) + h * 64 + d;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = mt * 16 + quad * 4 + r;
+                            if (row < rows) {
+                                const float v = acc[r] + bv;
+                                dstl[row * LQ] = v;
+                                st_nt(dsts + (size_t)row * DFF_INNER, v);
+                            }
+                        }
+                    });
+                __syncthreads();
+                attn_softmax<HGS>(c, hg, l);
+                __syncthreads();
+                attn_pv<HGS>(c, hg);
+                __syncthreads();
+                gemm_tall<MT, NTW, 4>(acc_o, HGS,
+                    [&](int s, const float*& Ap, int& kb0) { Ap = c.Rg + 3 * RN * LQ + s * 64; kb0 = (hg * HGS + s) * 4; },
+                    LQ, RN, lw.Wo_p, DFF_INNER / 16, NT_H);
+            }
+            // + W_oc xrel  (K = 32, columns 24..31 of sbuf are zero)
+            gemm_tall<MT, NTW, 2>(acc_o, 1,
+                [&](int, const float*& Ap, int& kb0) { Ap = c.sbuf; kb0 = 0; },
+                DFF_SMALL_LD, RN, lw.Woc_p, 2, NT_H);
+            __syncthreads();
+            store_tall<MT, NTW>(acc_o, tbuf, LH, rows, NT_H, lw.bo);
+            __syncthreads();
+            row_gate1_ln2<H>(c, lw, l, tbuf);
+            __syncthreads();
+            // FFN: Linear(H,4H) -> GELU(erf) -> Linear(4H,H)   (graph_transformer.py:264-267)
+            f32x4 acc_f[NTW][MT];
+            acc_zero<MT, NTW>(acc_f);
+            for (int ch = 0; ch < NCH; ++ch) {
+                gemm_wide<MT, NT_H>(c.abuf, LH, RN, lw.W1_p, NT_H, 0, ch * (FC / 16), FC / 16,
+                    [&](int nt, int mt, const f32x4& acc) {
+                        const int lane = tid & 63, quad = lane >> 4, cl = 16 * nt + (lane & 15);
+                        const int colg = ch * FC + cl;
+                        const float bv = lw.b1[colg];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = mt * 16 + quad * 4 + r;
+                            if (row < rows) {
+                                const float hp = acc[r] + bv;
+                                st_nt(sb + c.sl.h_pre + (size_t)row * F + colg, hp);
+                                c.Rg[row * LF + cl] = gelu_f(hp);
+                            }
+                        }
+                    });
+                __syncthreads();
+                gemm_tall<MT, NTW, 4>(acc_f, FC / 64,
+                    [&](int s, const float*& Ap, int& kb0) { Ap = c.Rg + s * 64; kb0 = ch * (FC / 16) + s * 4; },
+                    LF, RN, lw.W2_p, F / 16, NT_H);
+                __syncthreads();
+            }
+            store_tall<MT, NTW>(acc_f, tbuf, LH, rows, NT_H, lw.b2);
+            __syncthreads();
+            row_gate2<H>(c, m, lw, l, tbuf, l == m.L - 1, a.energy_out);
+            __syncthreads();
+        }
+
+        // =============================== backward ===============================
+        for (int l = m.L - 1; l >= 0; --l) {
+            const DffLayerDev& lw = m.layer[l];
+            const float* sb = c.stash + (size_t)l * c.sl.layer_stride;
+            rowb_gate2<H>(c, lw, l);
+            __syncthreads();
+            // dh = dff W2 ; dh_pre = dh * gelu'(h_pre) ; df = dh_pre W1
+            f32x4 acc_f[NTW][MT];
+            acc_zero<MT, NTW>(acc_f);
+            for (int ch = 0; ch < NCH; ++ch) {
+                gemm_wide<MT, NT_H>(c.abuf, LH, RN, lw.W2T_p, NT_H, 0, ch * (FC / 16), FC / 16,
+                    [&](int nt, int mt, const f32x4& acc) {
+                        const int lane = tid & 63, quad = lane >> 4, cl = 16 * nt + (lane & 15);
+                        const int colg = ch * FC + cl;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = mt * 16 + quad * 4 + r;
+                            if (row < rows) {
+                                const float hp = ld_nt(sb + c.sl.h_pre + (size_t)row * F + colg);
+                                c.Rg[row * LF + cl] = acc[r] * gelu_grad_f(hp);
+                            }
+                        }
+                    });
+                __syncthreads();
+                gemm_tall<MT, NTW, 4>(acc_f, FC / 64,
+                    [&](int s, const float*& Ap, int& kb0) { Ap = c.Rg + s * 64; kb0 = ch * (FC / 16) + s * 4; },
+                    LF, RN, lw.W1T_p, F / 16, NT_H);
+                __syncthreads();
+            }
+            store_tall<MT, NTW>(acc_f, tbuf, LH, rows, NT_H, nullptr);
+            __syncthreads();
+            rowb_ln2_gate1<H>(c, lw, l, tbuf);
+            __syncthreads();
+            // r = dattn W_oc (dE/dxrel) -> sbuf ; u of this layer -> ubuf
+            gemm_wide<MT, NT_H>(c.abuf, LH, RN, lw.WocT_p, NT_H, 0, 0, 2,
+                [&](int nt, int mt, const f32x4& acc) {
+                    const int lane = tid & 63, quad = lane >> 4, col = 16 * nt + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = mt * 16 + quad * 4 + r;
+                        if (row < rows) c.sbuf[row * DFF_SMALL_LD + col] = acc[r];
+                    }
+                });
+            for (int it = tid; it < rows * 32; it += DFF_NTHREADS)
+                c.ubuf[(it >> 5) * DFF_SMALL_LD + (it & 31)] = ld_nt(sb + c.sl.u + it);
+            f32x4 acc_a[NTW][MT];
+            acc_zero<MT, NTW>(acc_a);
+            for (int hg = 0; hg < NHG; ++hg) {
+                reload_heads<HGS>(c, l, hg, l > 0);
+                // G = dattn W_o (dE/do) for the heads of this group -> R3
+                gemm_wide<MT, NT_H>(c.abuf, LH, RN, lw.WoT_p, NT_H, 0, hg * HGS * 4, HGS * 4,
+                    [&](int nt, int mt, const f32x4& acc) {
+                        const int lane = tid & 63, quad = lane >> 4, cl = 16 * nt + (lane & 15);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = mt * 16 + quad * 4 + r;
+                            if (row < rows) c.Rg[3 * RN * LQ + row * LQ + cl] = acc[r];
+                        }
+                    });
+                __syncthreads();
+                attnb_ds<HGS>(c, hg);
+                __syncthreads();
+                attnb_dx<HGS>(c, hg);
+                if (l > 0) {
+                    attnb_dqkv<HGS, 0>(c);
+                    __syncthreads();
+                    attnb_dqkv<HGS, 1>(c);
+                    __syncthreads();
+                    attnb_dqkv<HGS, 2>(c);
+                    __syncthreads();
+                    // d(LN1 out) += dq Wq + dk Wk + dv Wv   (head-major K order [h][q|k|v][d])
+                    gemm_tall<MT, NTW, 4>(acc_a, 3 * HGS,
+                        [&](int s, const float*& Ap, int& kb0) {
+                            const int hh = s / 3, part = s - 3 * hh;
+                            const int reg = part == 0 ? 3 : part == 1 ? 1 : 2;  // dq in R3, dk in R1, dv in R2
+                            Ap = c.Rg + reg * RN * LQ + hh * 64;
+                            kb0 = ((hg * HGS + hh) * 3 + part) * 4;
+                        },
+                        LQ, RN, lw.WqkvT_p, 3 * DFF_INNER / 16, NT_H);
+                }
+                __syncthreads();
+            }
+            if (l > 0) {
+                // + du W_u   (K = 32)
+                gemm_tall<MT, NTW, 2>(acc_a, 1,
+                    [&](int, const float*& Ap, int& kb0) { Ap = c.dubuf; kb0 = 0; },
+                    DFF_SMALL_LD, RN, lw.WuT_p, 2, NT_H);
+                __syncthreads();
+                store_tall<MT, NTW>(acc_a, tbuf, LH, rows, NT_H, nullptr);
+                __syncthreads();
+                rowb_ln1<H>(c, lw, l, tbuf);
+                __syncthreads();
+            }
+        }
+
+        // =============================== update ===============================
+        // dxs = d(sum E)/dx ; the score op returns -dxs (graph_transformer.py:159)
+        if (a.mode == DFF_MODE_SCORE) {
+            if (tid < rows * 4 && (tid & 3) < 3)
+                a.force_out[((size_t)c.b0 * N + (tid >> 2)) * 3 + (tid & 3)] = -c.dxs[tid];
+        } else if (a.mode == DFF_MODE_LANGEVIN) {
+            const bool save = ((step + 1) % a.save_interval) == 0;
+            const int fi = (step + 1) / a.save_interval - 1;
+            if (tid < rows * 4 && (tid & 3) < 3) {
+                const int row = tid >> 2, cc = tid & 3;
+                const int g = row / N, i = row - g * N;
+                const size_t item = (size_t)c.b0 + g;
+                float xi;
+                if (a.noise) xi = a.noise[(((size_t)step * a.B + item) * N + i) * 3 + cc];
+                else xi = philox_normal(a.seed, a.item_offset + item, a.step_offset + step, i, cc);
+                // forces = -GNN(x) / kbt_inv / sigma_t = dxs * force_scale   (langevin.py:79-87)
+                const float f = c.dxs[tid] * a.force_scale;
+                const float x = c.xst[tid];
+                float xn, vn = 0.f;
+                if (a.overdamped) {  // langevin_cgnet.py:481-500
+                    xn = x + f * a.dtau + a.brown_sigma * xi;
+                } else {             // BAOA(F)B, langevin_cgnet.py:447-479
+                    vn = c.vst[tid] + (a.dt * f) / a.mass[i];
+                    xn = x + (vn * a.dt) / 2.0f;
+                    const float nz = a.noise_sigma[i] * xi;
+                    vn = vn * a.vscale;
+                    vn = vn + a.noisescale * nz;
+                    xn = xn + (vn * a.dt) / 2.0f;
+                }
+                c.xst[tid] = xn;
+                c.vst[tid] = vn;
+                if (save && a.frames) a.frames[(((size_t)fi * a.B + item) * N + i) * 3 + cc] = xn;
+            }
+            __syncthreads();
+            if (save && a.ke && !a.overdamped && tid < c.gcnt) {  // langevin_cgnet.py:538-542
+                float ke = 0.f;
+                for (int i = 0; i < N; ++i) {
+                    const float* vp = c.vst + (tid * N + i) * 4;
+                    ke += a.mass[i] * (vp[0] * vp[0] + vp[1] * vp[1] + vp[2] * vp[2]);
+                }
+                a.ke[(size_t)fi * a.B + c.b0 + tid] = 0.5f * ke;
+            }
+        } else {  // DDPM p_sample (ddpm.py:195-232) + clamp/centre of p_sample_loop (:248-251)
+            const bool act = tid < rows * 4 && (tid & 3) < 3;
+            const int row = tid >> 2, cc = tid & 3;
+            const int g = act ? row / N : 0, i = act ? row - g * N : 0;
+            const size_t item = (size_t)c.b0 + g;
+            float eps = act ? -c.dxs[tid] : 0.f;
+            float xi = 0.f;
+            if (act) {
+                if (a.noise) xi = a.noise[(((size_t)step * a.B + item) * N + i) * 3 + cc];
+                else xi = philox_normal(a.seed, a.item_offset + item, (uint64_t)t_int, i, cc);
+            }
+            // centre eps and noise (two bead-means)
+            if (tid < rows * 4) { c.dxs[tid] = eps; c.xs[tid] = xi; }
+            __syncthreads();
+            bead_mean(c, c.dxs, c.cm);
+            bead_mean(c, c.xs, c.cm + 64);
+            __syncthreads();
+            const float x = act ? c.xst[tid] : 0.f;
+            float x0 = 0.f;
+            if (act) {
+                eps -= c.cm[g * 4 + cc];
+                xi -= c.cm[64 + g * 4 + cc];
+                x0 = m.sqrt_recip_ac[t_int] * x - m.sqrt_recipm1_ac[t_int] * eps;  // ddpm.py:140-147
+            }
+            __syncthreads();
+            if (tid < rows * 4) c.dxs[tid] = x0;
+            __syncthreads();
+            bead_mean(c, c.dxs, c.cm);
+            __syncthreads();
+            float xn = 0.f;
+            if (act) {
+                x0 -= c.cm[g * 4 + cc];
+                const float mean = m.post_c1[t_int] * x0 + m.post_c2[t_int] * x;  // ddpm.py:149-161
+                const float nzm = (t_int == 0) ? 0.f : 1.f;
+                xn = mean + nzm * expf(0.5f * m.post_logvar[t_int]) * xi;
+                if (xn > 1000.f || xn < -1000.f) {
+                    if (a.clamp_flag) *a.clamp_flag = 1;
+                    xn = fminf(fmaxf(xn, -1000.f), 1000.f);
+                }
+            }
+            __syncthreads();
+            if (tid < rows * 4) c.dxs[tid] = xn;
+            __syncthreads();
+            bead_mean(c, c.dxs, c.cm);
+            __syncthreads();
+            if (act) c.xst[tid] = xn - c.cm[g * 4 + cc];
+        }
+        __syncthreads();
+    }
+
+    // ---- write back state ----
+    if (a.mode != DFF_MODE_SCORE && tid < rows * 4 && (tid & 3) < 3) {
+        const size_t gi = ((size_t)c.b0 * N + (tid >> 2)) * 3 + (tid & 3);
+        a.x_io[gi] = c.xst[tid];
+        if (a.mode == DFF_MODE_LANGEVIN && !a.overdamped) a.v_io[gi] = c.vst[tid];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// debug GEMM kernel: one wide GEMM stage through the same device routine and packing
+// ------------------------------------------------------------------------------------------
+template <int KB>
+__global__ __launch_bounds__(DFF_NTHREADS) void dff_debug_gemm_kernel(const float* A, const float* Wp, int M,
+                                                                     int Nout, float* out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int K = 16 * KB, LD = K + 4;
+    for (int i = threadIdx.x; i < 64 * LD + 64; i += DFF_NTHREADS) smem[i] = 0.f;
+    __syncthreads();
+    for (int i = threadIdx.x; i < M * K; i += DFF_NTHREADS) smem[(i / K) * LD + (i % K)] = A[i];
+    __syncthreads();
+    gemm_wide<4, KB>(smem, LD, M, Wp, KB, 0, 0, Nout / 16,
+        [&](int nt, int mt, const f32x4& acc) {
+            const int lane = threadIdx.x & 63, quad = lane >> 4, col = 16 * nt + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = mt * 16 + quad * 4 + r;
+                if (row < M) out[row * Nout + col] = acc[r];
+            }
+        });
+}
+
+// explicit instantiations used by the host dispatcher
+#define DFF_INST(H, MT, HGS, SPILL) \
+    template __global__ void dff_fused_kernel<H, MT, HGS, SPILL>(const DffModelDev, const DffRunArgs);
+DFF_INST(64, 1, 4, false)
+DFF_INST(64, 2, 2, false)
+DFF_INST(96, 1, 4, false)
+DFF_INST(96, 2, 2, false)
+DFF_INST(128, 1, 4, false)
+DFF_INST(128, 2, 2, false)
+DFF_INST(128, 3, 1, false)
+DFF_INST(128, 4, 1, true)
+template __global__ void dff_debug_gemm_kernel<4>(const float*, const float*, int, int, float*);
+template __global__ void dff_debug_gemm_kernel<8>(const float*, const float*, int, int, float*);

@@ -1,0 +1,133 @@
+"""Host mirror of ``GaussianDiffusion`` (models/ddpm.py:20-263), sampling half.
+
+The reverse loop itself -- 1000 score-network calls, each followed by the posterior update,
+the +-1000 clamp and the centring -- runs inside ONE persistent HIP kernel launch
+(``dff_ddpm_run``); nothing syncs with the host per step (the reference syncs three times per
+step: utils.py:79, ddpm.py:248).
+"""
+from __future__ import annotations
+
+import warnings
+from typing import Optional
+
+import torch
+
+from . import binding
+from .score import GraphTransformer
+
+
+def extract(a, t, x_shape):
+    """utils.py:33-39."""
+    b, *_ = t.shape
+    return a.gather(-1, t).reshape(b, *((1,) * (len(x_shape) - 1)))
+
+
+def center_zero(x):
+    """utils.py:65-70."""
+    assert len(x.shape) == 3 and x.shape[-1] == 3, "Dimensionality error"
+    return x - x.mean(dim=1, keepdim=True)
+
+
+def assert_center_zero(x, eps=1e-3):
+    """utils.py:73-86 (one host sync; used only at the very end of a chain)."""
+    assert len(x.shape) == 3 and x.shape[-1] == 3, "Dimensionality error"
+    center_max = x.mean(dim=1).abs().max().item()
+    if center_max >= eps:
+        raise AssertionError(f"Center not at zero: abs max at {center_max}")
+
+
+class GaussianDiffusion:
+    def __init__(self, model: GraphTransformer, features=None, num_atoms: Optional[int] = None,
+                 timesteps: int = 1000, loss_type="l2", objective="pred_noise", beta_schedule="cosine",
+                 norm_factor: float = 1, loss_weights="ones", seed: int = 0):
+        if objective != "pred_noise" or beta_schedule != "cosine":
+            raise ValueError("only objective='pred_noise', beta_schedule='cosine' (the shipped configs) are supported")
+        self.dims = 3
+        self.model = model
+        self.num_atoms = model.num_beads if num_atoms is None else num_atoms
+        self.device = model.device
+        self.h = torch.eye(self.num_atoms, device=self.device) if features is None else features.to(self.device)
+        self.objective = objective
+        self.num_timesteps = int(timesteps)
+        if model.native.timesteps != self.num_timesteps:
+            raise ValueError("model was built for a different number of diffusion steps")
+        self.norm_factor = norm_factor
+        self.loss_weights = loss_weights
+        for name in binding.SCHEDULE_NAMES:  # the 12 float32 buffers of ddpm.py:61-99
+            setattr(self, name, torch.from_numpy(model.native.schedule(name)).to(self.device))
+        self._seed = int(seed)
+        self._samples_drawn = 0
+        self.last_clamped = False
+
+    def eval(self):
+        return self
+
+    def to(self, *_a, **_k):
+        return self
+
+    def seed(self, seed: int):
+        self._seed, self._samples_drawn = int(seed), 0
+
+    @torch.no_grad()
+    def p_mean_variance(self, x, t):
+        """ddpm.py:195-219 with the score network on the HIP path (``dff_score``)."""
+        model_output = center_zero(self.model(x, self.h, 1.0 * t / self.num_timesteps))
+        x_start = (extract(self.sqrt_recip_alphas_cumprod, t, x.shape) * x
+                   - extract(self.sqrt_recipm1_alphas_cumprod, t, x.shape) * model_output)
+        x_start = center_zero(x_start)
+        mean = (extract(self.posterior_mean_coef1, t, x.shape) * x_start
+                + extract(self.posterior_mean_coef2, t, x.shape) * x)
+        return (mean, extract(self.posterior_variance, t, x.shape),
+                extract(self.posterior_log_variance_clipped, t, x.shape))
+
+    @torch.no_grad()
+    def p_sample(self, x, t, noise=None):
+        """One reverse step for arbitrary per-sample ``t`` (ddpm.py:221-232): score op on the
+        HIP kernel, the O(N) posterior arithmetic as device tensor ops.  The sampler proper does
+        not come through here -- ``p_sample_loop`` runs all steps fused in one launch."""
+        x = x.detach().to(self.device, torch.float32).contiguous()
+        t = t.to(self.device)
+        b = x.shape[0]
+        mean, _, logvar = self.p_mean_variance(x, t)
+        noise = torch.randn_like(x) if noise is None else noise.to(self.device, torch.float32)
+        noise = center_zero(noise)
+        nonzero_mask = (1 - (t == 0).float()).reshape(b, *((1,) * (len(x.shape) - 1)))
+        return mean + nonzero_mask * (0.5 * logvar).exp() * noise
+
+    @torch.no_grad()
+    def p_sample_loop_from(self, x, t_start: int, t_end: int = 0, noises=None):
+        """Reverse steps t_start..t_end from a given centred x, each followed by the clamp and
+        centring of p_sample_loop (ddpm.py:244-251); normalised units in and out."""
+        x = x.detach().to(self.device, torch.float32).contiguous().clone()
+        flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        if noises is not None:
+            noises = noises.detach().to(self.device, torch.float32).contiguous()
+        self.model.native.ddpm_run(x, t_start, t_end, noise=noises, seed=self._seed,
+                                   sample_offset=self._samples_drawn, clamp_flag=flag)
+        self._flag = flag
+        return x
+
+    @torch.no_grad()
+    def p_sample_loop(self, shape):
+        """ddpm.py:234-254: x_T = center_zero(randn) then T reverse steps, all on the device."""
+        b = shape[0]
+        x = torch.empty(shape, device=self.device, dtype=torch.float32)
+        flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.model.native.ddpm_run(x, self.num_timesteps - 1, 0, noise=None, seed=self._seed,
+                                   sample_offset=self._samples_drawn, init_prior=True, clamp_flag=flag)
+        self._samples_drawn += b
+        self._flag = flag
+        return x
+
+    def check_clamp(self) -> bool:
+        """Host-side read of the device clamp flag (the reference warns per step, ddpm.py:249)."""
+        f = getattr(self, "_flag", None)
+        self.last_clamped = bool(f.item()) if f is not None else False
+        if self.last_clamped:
+            warnings.warn("Large molecule encountered in sampling")
+        return self.last_clamped
+
+    @torch.no_grad()
+    def sample(self, batch_size):
+        """ddpm.py:256-263: (batch_size, N, 3) in Angstrom (x norm_factor), device tensor."""
+        return self.p_sample_loop((batch_size, self.num_atoms, self.dims)) * self.norm_factor

@@ -1,0 +1,84 @@
+"""Batch orchestration (evaluate/evaluators.py:874-901, utils.py:201-212) and the multi-GPU
+sharding that replaces the reference's ``nn.DataParallel`` (sample.py:180-190,204-214).
+
+Samples / trajectories are independent units: rank r of W takes a contiguous share, draws from
+its own Philox sub-stream (the global sample / trajectory index is the Philox counter, so results
+do not depend on W), and the only collective is one ``all_gather`` of the finished result.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Tuple
+
+import torch
+
+
+def num_to_groups(num: int, divisor: int) -> List[int]:
+    """evaluate/evaluators.py:891-901."""
+    groups, remainder = num // divisor, num % divisor
+    arr = [divisor] * groups
+    if remainder > 0:
+        arr.append(remainder)
+    return arr
+
+
+class SamplerWrapper:
+    """utils.py:201-212: ``sampler(batch_size=b) -> model.sample(batch_size=b)``."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def eval(self):
+        return self
+
+    def to(self, *_a, **_k):
+        return self
+
+    def __call__(self, **kwargs):
+        return self.model.sample(**kwargs)
+
+
+def sample_from_model(sampler, num_saved_samples: int, batch_size: int, verbose: bool = False):
+    """evaluate/evaluators.py:874-888: returns a CPU tensor (num_saved_samples, N, 3)."""
+    print(f"Generating {num_saved_samples} samples per GPU. This may take some time.")
+    batches = num_to_groups(num_saved_samples, batch_size)
+    all_mol_list = []
+    for i, bs in enumerate(batches):
+        all_mol_list.append(sampler(batch_size=bs))
+        if verbose:
+            print(f"Batch {i + 1} from {len(batches)} generated")
+    all_mol = torch.cat(all_mol_list, dim=0).cpu()
+    print(f"{len(all_mol)} samples generated")
+    return all_mol
+
+
+# ---------------------------------------------------------------------------- sharding
+def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [start, stop) share of ``total`` independent units for ``rank`` of ``world``;
+    the first ``total % world`` ranks take one extra unit."""
+    base, extra = divmod(total, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def dist_env() -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torchrun environment (1-process default)."""
+    return (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)),
+            int(os.environ.get("WORLD_SIZE", 1)))
+
+
+def gather_variable(local: torch.Tensor, total: int, world: int, group=None) -> torch.Tensor:
+    """all_gather of per-rank result blocks whose leading sizes follow ``shard_range``.
+
+    One collective (RCCL over xGMI on the GPU box, gloo in CPU tests): blocks are padded to the
+    largest share, gathered, and trimmed.  Returns the (total, ...) tensor on every rank."""
+    import torch.distributed as dist
+    if world == 1:
+        return local
+    sizes = [shard_range(total, r, world) for r in range(world)]
+    mx = max(b - a for a, b in sizes)
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad, group=group)
+    return torch.cat([o[: b - a] for o, (a, b) in zip(out, sizes)], dim=0)
