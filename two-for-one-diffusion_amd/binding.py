@@ -119,11 +119,17 @@ class Model:
         self.device = device
         self.n_beads, self.hidden, self.n_layers, self.timesteps = n_beads, hidden, n_layers, timesteps
 
-    def __del__(self):
+    def close(self):
         h = getattr(self, "handle", None)
         if h is not None and h.value:
             self.lib.dff_model_destroy(h)
-            self.handle = C.c_void_p()
+            h.value = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: ctypes may already be torn down
+            pass
 
     # ---- helpers
     def _stream(self):
