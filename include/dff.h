@@ -136,6 +136,12 @@ int dff_debug_gemm(int device, const float* A_host, const float* W_host, int M, 
  * 4 q (N,512), 5 k (N,512), 6 v (N,512), 7 P (8,N,N), 8 u (N,32). */
 int dff_debug_stash(dff_model* m, int b, int layer, int what, float* out_host, size_t n);
 
+/* Per-stage cycle accounting of workgroup 0 (s_memtime deltas accumulated at the stage
+ * boundaries of the fused kernel): enable != 0 makes subsequent launches record; _read copies
+ * the DFF_NPROF (=24) totals of the last launch (shader-clock cycles) to out_host. */
+int dff_debug_profile(dff_model* m, int enable);
+int dff_debug_profile_read(dff_model* m, unsigned long long* out_host);
+
 const char* dff_last_error(void);
 const char* dff_version(void);
 

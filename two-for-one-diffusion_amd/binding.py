@@ -57,6 +57,8 @@ SYMBOLS = {
     "dff_last_launch": (C.c_int, [_P, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dff_debug_gemm": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "dff_debug_stash": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_size_t]),
+    "dff_debug_profile": (C.c_int, [_P, C.c_int]),
+    "dff_debug_profile_read": (C.c_int, [_P, _P]),
     "dff_last_error": (C.c_char_p, []),
     "dff_version": (C.c_char_p, []),
 }
@@ -202,6 +204,19 @@ class Model:
         _check(self.lib, rc, "dff_ddpm_run")
 
     # ---- debugging
+    PROFILE_STAGES = ("centre", "embed+ln1", "gemm_u", "gemm_qkv", "softmax", "pv+xrel", "gemm_wo", "gate1+ln2",
+                      "gemm_w1+gelu", "gemm_w2", "gate2", "b_gate2", "b_gemm_w2T", "b_gemm_w1T", "b_ln2+gate1",
+                      "b_gemm_woc+u", "b_reload+gemm_woT", "b_ds", "b_dx+dqkv", "b_gemm_qkvT", "b_ln1", "update",
+                      "-", "-")
+
+    def profile(self, enable: bool = True):
+        _check(self.lib, self.lib.dff_debug_profile(self.handle, int(enable)), "dff_debug_profile")
+
+    def profile_read(self) -> dict:
+        out = np.zeros(24, np.uint64)
+        _check(self.lib, self.lib.dff_debug_profile_read(self.handle, out.ctypes.data_as(C.c_void_p)), "dff_debug_profile_read")
+        return {n: int(v) for n, v in zip(self.PROFILE_STAGES, out) if n != "-"}
+
     def debug_stash(self, b: int, layer: int, what: str) -> np.ndarray:
         N, H = self.n_beads, self.hidden
         items = dict(nodes_in=(0, (N, H)), attn_out=(1, (N, H)), ff=(2, (N, H)), h_pre=(3, (N, 4 * H)),

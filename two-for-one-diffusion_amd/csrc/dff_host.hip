@@ -75,6 +75,8 @@ struct dff_model {
     float* stash = nullptr;
     size_t stash_floats = 0;
     int group_override = 0;
+    unsigned long long* prof = nullptr;
+    bool prof_on = false;
     // last launch
     const char* last_kernel = "";
     int last_grid = 0, last_lds = 0, last_G = 0, last_B = 0;
@@ -277,6 +279,7 @@ extern "C" void dff_model_destroy(dff_model* m) {
     (void)hipSetDevice(m->device);
     for (void* p : m->allocs) (void)hipFree(p);
     if (m->stash) (void)hipFree(m->stash);
+    if (m->prof) (void)hipFree(m->prof);
     delete m;
 }
 
@@ -337,6 +340,7 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
         m->stash_floats = need;
     }
     a.G = G;
+    a.prof = m->prof_on ? m->prof : nullptr;
     a.stash = m->stash;
     a.stash_stride = sl.total;
     HIPCHK(hipFuncSetAttribute(v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -455,6 +459,25 @@ extern "C" int dff_debug_stash(dff_model* m, int b, int layer, int what, float* 
         }
     }
     return fail(DFF_EINVAL, "unknown stash item %d", what);
+}
+
+extern "C" int dff_debug_profile(dff_model* m, int enable) {
+    if (!m) return fail(DFF_EINVAL, "null model");
+    HIPCHK(hipSetDevice(m->device));
+    if (enable && !m->prof) {
+        HIPCHK(hipMalloc((void**)&m->prof, DFF_NPROF * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(m->prof, 0, DFF_NPROF * sizeof(unsigned long long)));
+    }
+    m->prof_on = enable != 0;
+    return DFF_OK;
+}
+
+extern "C" int dff_debug_profile_read(dff_model* m, unsigned long long* out) {
+    if (!m || !out || !m->prof) return fail(DFF_EINVAL, "profiling was never enabled");
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, m->prof, DFF_NPROF * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return DFF_OK;
 }
 
 extern "C" const char* dff_last_error(void) { return g_err.c_str(); }

@@ -10,6 +10,7 @@
 #define DFF_INNER 512
 #define DFF_NTHREADS 256
 #define DFF_NWAVES 4
+#define DFF_NPROF 24       // per-stage cycle counters (debug)
 #define DFF_SMALL_LD 36   // leading dim of the 32-column u / xrel / r / du buffers
 
 // Packed B-operand layout for v_mfma_f32_16x16x4_f32 (see pack_b in dff_host.hip):
@@ -81,6 +82,7 @@ struct DffRunArgs {
     int t_start, init_prior;
     int* clamp_flag;
     // scratch
+    unsigned long long* prof;   // optional: DFF_NPROF per-stage cycle totals of block 0
     float* stash;               // per-workgroup stash slots
     unsigned long long stash_stride; // floats per workgroup
 };

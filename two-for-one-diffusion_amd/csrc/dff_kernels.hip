@@ -70,7 +70,7 @@ struct LdsLayout {
     static constexpr int F = 4 * H;
     static constexpr int FC = (F % 256 == 0) ? 256 : 128;
     static constexpr int LF = FC + 4;
-    unsigned xst, xs, dxs, vst, cm, tn, ubuf, sbuf, dubuf, abuf, resbuf, Pbuf, dSbuf, Rg, total;
+    unsigned xst, xs, dxs, vst, cm, tn, prof, ubuf, sbuf, dubuf, abuf, resbuf, Pbuf, dSbuf, Rg, total;
     __host__ __device__ LdsLayout(int N, int G) {
         const unsigned R = (unsigned)(G * N);
         unsigned o = 0;
@@ -80,6 +80,7 @@ struct LdsLayout {
         vst = o;   o += R * 4;
         cm = o;    o += 16 * 4 * 2;
         tn = o;    o += 16;
+        prof = o;  o += 2 * DFF_NPROF;
         ubuf = o;  o += R * DFF_SMALL_LD;
         sbuf = o;  o += R * DFF_SMALL_LD;
         dubuf = o; o += R * DFF_SMALL_LD;
@@ -166,11 +167,23 @@ DEVI void mfma4(f32x4& acc, const f32x4 a, const f32x4 b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc, 0, 0, 0);
 }
 
+// Weight fetch latency out of L2 is ~1 us when all 256 CUs stream the same packed image, and a
+// workgroup has only 4 waves, so each wave keeps a ring of D tiles (wide) / segments (tall) of
+// B operands in flight in registers (Little: D * 4 KB * 4 waves per CU).
+#ifndef DFF_WIDE_DEPTH
+#define DFF_WIDE_DEPTH 4
+#endif
+#ifndef DFF_TALL_DEPTH
+#define DFF_TALL_DEPTH 3
+#endif
+
 // "wide" GEMM: K = 16*KB (small, compile time), many output tiles; the 4 waves take tiles
 // round-robin.  epi(nt_local, mt, acc) consumes one 16x16 output tile.
 template <int MT, int KB, class Epi>
 DEVI void gemm_wide(const float* A, int lda, int rowsA, const float* __restrict__ Wp, int KBtot,
                     int kb0, int nt0, int ntn, Epi epi) {
+    constexpr int D = DFF_WIDE_DEPTH;
+    static_assert(KB % 2 == 0, "KB must be even");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kk = lane >> 4, mm = lane & 15;
     f32x4 a[MT][KB];
@@ -182,31 +195,42 @@ DEVI void gemm_wide(const float* A, int lda, int rowsA, const float* __restrict_
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) a[mt][kb] = *(const f32x4*)(ap + 16 * kb);
     }
-    const f32x4* wp = (const f32x4*)Wp + lane;
-    f32x4 bn[KB];
-    int nt = wave;
-    if (nt < ntn) {
+    const f32x4* wp = (const f32x4*)Wp + lane + (size_t)kb0 * 64;
+    const int cnt = wave < ntn ? (ntn - wave + DFF_NWAVES - 1) / DFF_NWAVES : 0;
+    f32x4 b[D][KB];
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) bn[kb] = wp[((size_t)(nt0 + nt) * KBtot + kb0 + kb) * 64];
-    }
-    for (; nt < ntn; nt += DFF_NWAVES) {
-        f32x4 bc[KB];
+    for (int d = 0; d < D; ++d)
+        if (d < cnt) {
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) bc[kb] = bn[kb];
-        if (nt + DFF_NWAVES < ntn) {
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
-                bn[kb] = wp[((size_t)(nt0 + nt + DFF_NWAVES) * KBtot + kb0 + kb) * 64];
+            for (int kb = 0; kb < KB; ++kb) b[d][kb] = wp[((size_t)(nt0 + wave + DFF_NWAVES * d) * KBtot + kb) * 64];
         }
-        f32x4 acc[MT];
+    for (int i0 = 0; i0 < cnt; i0 += D) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int d = 0; d < D; ++d) {
+            const int i = i0 + d;
+            if (i < cnt) {
+                const int nt = wave + DFF_NWAVES * i;
+                f32x4 acc[MT], acc2[MT];
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
+                for (int mt = 0; mt < MT; ++mt) { acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) mfma4(acc[mt], a[mt][kb], bc[kb]);
+                for (int kb = 0; kb < KB; kb += 2)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) epi(nt, mt, acc[mt]);
+                    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][kb][s4], b[d][kb][s4], acc[mt], 0, 0, 0);
+                            acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][kb + 1][s4], b[d][kb + 1][s4], acc2[mt], 0, 0, 0);
+                        }
+                if (i + D < cnt) {
+#pragma unroll
+                    for (int kb = 0; kb < KB; ++kb)
+                        b[d][kb] = wp[((size_t)(nt0 + nt + DFF_NWAVES * D) * KBtot + kb) * 64];
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) epi(nt, mt, acc[mt] + acc2[mt]);
+            }
+        }
     }
 }
 
@@ -216,6 +240,7 @@ DEVI void gemm_wide(const float* A, int lda, int rowsA, const float* __restrict_
 template <int MT, int NTW, int SKB, class SegF>
 DEVI void gemm_tall(f32x4 (&acc)[NTW][MT], int nseg, SegF segf, int lda, int rowsA,
                     const float* __restrict__ Wp, int KBtot, int ntiles) {
+    constexpr int D = DFF_TALL_DEPTH;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kk = lane >> 4, mm = lane & 15;
     int rowoff[MT];
@@ -235,42 +260,62 @@ DEVI void gemm_tall(f32x4 (&acc)[NTW][MT], int nseg, SegF segf, int lda, int row
         tbase[i] = (size_t)(tok[i] ? nt : 0) * KBtot;
     }
     if (!tok[0]) return;
-    f32x4 bn[NTW][SKB];
-    const float* An; int kbn;
-    if (nseg > 0) {
-        segf(0, An, kbn);
+    f32x4 b[D][NTW][SKB];
+    const float* Ap[D];
 #pragma unroll
-        for (int i = 0; i < NTW; ++i)
-#pragma unroll
-            for (int kb = 0; kb < SKB; ++kb) bn[i][kb] = wp[(tbase[i] + kbn + kb) * 64];
-    }
-    for (int s = 0; s < nseg; ++s) {
-        const float* Ac = An;
-        f32x4 bc[NTW][SKB];
-#pragma unroll
-        for (int i = 0; i < NTW; ++i)
-#pragma unroll
-            for (int kb = 0; kb < SKB; ++kb) bc[i][kb] = bn[i][kb];
-        if (s + 1 < nseg) {
-            segf(s + 1, An, kbn);
+    for (int d = 0; d < D; ++d)
+        if (d < nseg) {
+            int kbn;
+            segf(d, Ap[d], kbn);
 #pragma unroll
             for (int i = 0; i < NTW; ++i)
 #pragma unroll
-                for (int kb = 0; kb < SKB; ++kb) bn[i][kb] = wp[(tbase[i] + kbn + kb) * 64];
+                for (int kb = 0; kb < SKB; ++kb) b[d][i][kb] = wp[(tbase[i] + kbn + kb) * 64];
         }
+    // second accumulator set breaks the dependent-MFMA chain when a wave owns one tile row
+    f32x4 acc2[NTW][MT];
 #pragma unroll
-        for (int kb = 0; kb < SKB; ++kb) {
-            f32x4 a[MT];
+    for (int i = 0; i < NTW; ++i)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[mt] = *(const f32x4*)(Ac + rowoff[mt] + 16 * kb);
+        for (int mt = 0; mt < MT; ++mt) acc2[i][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < nseg; s0 += D) {
 #pragma unroll
-            for (int i = 0; i < NTW; ++i)
-                if (tok[i]) {
+        for (int d = 0; d < D; ++d) {
+            const int s = s0 + d;
+            if (s < nseg) {
+                f32x4 a[MT][SKB];
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) mfma4(acc[i][mt], a[mt], bc[i][kb]);
+                for (int kb = 0; kb < SKB; ++kb)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) a[mt][kb] = *(const f32x4*)(Ap[d] + rowoff[mt] + 16 * kb);
+#pragma unroll
+                for (int kb = 0; kb < SKB; kb += 2)
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                        for (int i = 0; i < NTW; ++i)
+                            if (tok[i]) {
+#pragma unroll
+                                for (int mt = 0; mt < MT; ++mt) {
+                                    acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][kb][s4], b[d][i][kb][s4], acc[i][mt], 0, 0, 0);
+                                    acc2[i][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][kb + 1][s4], b[d][i][kb + 1][s4], acc2[i][mt], 0, 0, 0);
+                                }
+                            }
+                if (s + D < nseg) {
+                    int kbn;
+                    segf(s + D, Ap[d], kbn);
+#pragma unroll
+                    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+                        for (int kb = 0; kb < SKB; ++kb) b[d][i][kb] = wp[(tbase[i] + kbn + kb) * 64];
                 }
+            }
         }
     }
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[i][mt] += acc2[i][mt];
 }
 
 template <int MT, int NTW>
@@ -301,6 +346,24 @@ DEVI void store_tall(const f32x4 (&acc)[NTW][MT], float* out, int ld, int rows, 
             }
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// optional per-stage cycle accounting (a.prof != null): thread 0 of block 0 accumulates
+// s_memtime deltas per stage id at stage boundaries; written out at kernel end.
+// ------------------------------------------------------------------------------------------
+struct Prof {
+    unsigned long long* out;
+    unsigned long long last;
+    unsigned long long* acc;   // LDS
+    bool on;
+    DEVI void tick(int id) {
+        if (on) {
+            const unsigned long long t = __builtin_readcyclecounter();
+            acc[id] += t - last;
+            last = t;
+        }
+    }
+};
 
 // ------------------------------------------------------------------------------------------
 // per-workgroup context
@@ -740,7 +803,7 @@ DEVI void attnb_dqkv(const Ctx& c) {
 
 // reload q (optional), k (optional), v, P, u of layer l / head group hg from the stash
 template <int HGS>
-DEVI void reload_heads(const Ctx& c, int l, int hg, bool need_qk) {
+DEVI void reload_heads(const Ctx& c, int l, int hg, bool need_qk, bool need_p = true) {
     constexpr int LQ = 64 * HGS + 4;
     const int N = c.N, RN = c.G * N;
     const float* sb = c.stash + (size_t)l * c.sl.layer_stride;
@@ -756,9 +819,11 @@ DEVI void reload_heads(const Ctx& c, int l, int hg, bool need_qk) {
             *(f32x4*)(c.Rg + RN * LQ + lo) = __builtin_nontemporal_load((const f32x4*)(sb + c.sl.k + so));
         }
     }
-    const int pn = HGS * c.G * N * N;
-    const float* sP = sb + c.sl.P + (size_t)hg * pn;
-    for (int it = threadIdx.x; it < pn; it += DFF_NTHREADS) c.Pbuf[it] = ld_nt(sP + it);
+    if (need_p) {
+        const int pn = HGS * c.G * N * N;
+        const float* sP = sb + c.sl.P + (size_t)hg * pn;
+        for (int it = threadIdx.x; it < pn; it += DFF_NTHREADS) c.Pbuf[it] = ld_nt(sP + it);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -809,6 +874,11 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
     // zero LDS once (pad columns of the 32-wide buffers must be 0; pad rows must be finite)
     for (int i = tid; i < (int)ll.total; i += DFF_NTHREADS) smem[i] = 0.f;
     __syncthreads();
+
+    Prof pf;
+    pf.on = (a.prof != nullptr) && blockIdx.x == 0 && tid == 0;
+    pf.acc = (unsigned long long*)(smem + ll.prof);
+    pf.last = __builtin_readcyclecounter();
 
     // ---- load state ----
     {
@@ -862,14 +932,30 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             __syncthreads();
         }
 
+        pf.tick(0);
         // =============================== forward ===============================
-        node_embed<H>(c, m);
-        __syncthreads();
+        // Langevin: t is fixed, so the x-independent layer-0 inputs (node features, LN1, u, q, k, v)
+        // are the same every step: computed on step 0, re-read from the stash afterwards.
+        const bool cached0 = (a.mode == DFF_MODE_LANGEVIN) && step > 0;
+        if (!cached0) {
+            node_embed<H>(c, m);
+            __syncthreads();
+        }
         for (int l = 0; l < m.L; ++l) {
             const DffLayerDev& lw = m.layer[l];
             float* sb = c.stash + (size_t)l * c.sl.layer_stride;
+            const bool cached = cached0 && l == 0;
+            if (cached) {
+                for (int it = tid; it < rows * H; it += DFF_NTHREADS) {
+                    const int row = it / H, col = it - row * H;
+                    c.resbuf[row * LH + col] = ld_nt(sb + c.sl.nodes_in + it);
+                }
+                for (int it = tid; it < rows * 32; it += DFF_NTHREADS)
+                    c.ubuf[(it >> 5) * DFF_SMALL_LD + (it & 31)] = ld_nt(sb + c.sl.u + it);
+            } else {
             row_ln1<H>(c, lw, l);
             __syncthreads();
+            pf.tick(1);
             // u = LN1(nodes) W_u^T + b_u  (all 8 heads, 24 of 32 columns used)
             gemm_wide<MT, NT_H>(c.abuf, LH, RN, lw.Wu_p, NT_H, 0, 0, 2,
                 [&](int nt, int mt, const f32x4& acc) {
@@ -885,10 +971,14 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         }
                     }
                 });
+            }
             f32x4 acc_o[NTW][MT];
             acc_zero<MT, NTW>(acc_o);
+            pf.tick(2);
             for (int hg = 0; hg < NHG; ++hg) {
                 // q|k|v of HGS heads -> R0,R1,R2 (+ stash)
+                if (cached) reload_heads<HGS>(c, 0, hg, true, false);
+                else
                 gemm_wide<MT, NT_H>(c.abuf, LH, RN, lw.Wqkv_p, NT_H, 0, hg * HGS * 12, HGS * 12,
                     [&](int nt, int mt, const f32x4& acc) {
                         const int lane = tid & 63, quad = lane >> 4, cl = lane & 15;
@@ -908,10 +998,13 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         }
                     });
                 __syncthreads();
+                pf.tick(3);
                 attn_softmax<HGS>(c, hg, l);
                 __syncthreads();
+                pf.tick(4);
                 attn_pv<HGS>(c, hg);
                 __syncthreads();
+                pf.tick(5);
                 gemm_tall<MT, NTW, 4>(acc_o, HGS,
                     [&](int s, const float*& Ap, int& kb0) { Ap = c.Rg + 3 * RN * LQ + s * 64; kb0 = (hg * HGS + s) * 4; },
                     LQ, RN, lw.Wo_p, DFF_INNER / 16, NT_H);
@@ -921,10 +1014,12 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 [&](int, const float*& Ap, int& kb0) { Ap = c.sbuf; kb0 = 0; },
                 DFF_SMALL_LD, RN, lw.Woc_p, 2, NT_H);
             __syncthreads();
+            pf.tick(6);
             store_tall<MT, NTW>(acc_o, tbuf, LH, rows, NT_H, lw.bo);
             __syncthreads();
             row_gate1_ln2<H>(c, lw, l, tbuf);
             __syncthreads();
+            pf.tick(7);
             // FFN: Linear(H,4H) -> GELU(erf) -> Linear(4H,H)   (graph_transformer.py:264-267)
             f32x4 acc_f[NTW][MT];
             acc_zero<MT, NTW>(acc_f);
@@ -945,15 +1040,18 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         }
                     });
                 __syncthreads();
+                pf.tick(8);
                 gemm_tall<MT, NTW, 4>(acc_f, FC / 64,
                     [&](int s, const float*& Ap, int& kb0) { Ap = c.Rg + s * 64; kb0 = ch * (FC / 16) + s * 4; },
                     LF, RN, lw.W2_p, F / 16, NT_H);
                 __syncthreads();
+                pf.tick(9);
             }
             store_tall<MT, NTW>(acc_f, tbuf, LH, rows, NT_H, lw.b2);
             __syncthreads();
             row_gate2<H>(c, m, lw, l, tbuf, l == m.L - 1, a.energy_out);
             __syncthreads();
+            pf.tick(10);
         }
 
         // =============================== backward ===============================
@@ -962,6 +1060,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             const float* sb = c.stash + (size_t)l * c.sl.layer_stride;
             rowb_gate2<H>(c, lw, l);
             __syncthreads();
+            pf.tick(11);
             // dh = dff W2 ; dh_pre = dh * gelu'(h_pre) ; df = dh_pre W1
             f32x4 acc_f[NTW][MT];
             acc_zero<MT, NTW>(acc_f);
@@ -980,15 +1079,18 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         }
                     });
                 __syncthreads();
+                pf.tick(12);
                 gemm_tall<MT, NTW, 4>(acc_f, FC / 64,
                     [&](int s, const float*& Ap, int& kb0) { Ap = c.Rg + s * 64; kb0 = ch * (FC / 16) + s * 4; },
                     LF, RN, lw.W1T_p, F / 16, NT_H);
                 __syncthreads();
+                pf.tick(13);
             }
             store_tall<MT, NTW>(acc_f, tbuf, LH, rows, NT_H, nullptr);
             __syncthreads();
             rowb_ln2_gate1<H>(c, lw, l, tbuf);
             __syncthreads();
+            pf.tick(14);
             // r = dattn W_oc (dE/dxrel) -> sbuf ; u of this layer -> ubuf
             gemm_wide<MT, NT_H>(c.abuf, LH, RN, lw.WocT_p, NT_H, 0, 0, 2,
                 [&](int nt, int mt, const f32x4& acc) {
@@ -1003,6 +1105,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 c.ubuf[(it >> 5) * DFF_SMALL_LD + (it & 31)] = ld_nt(sb + c.sl.u + it);
             f32x4 acc_a[NTW][MT];
             acc_zero<MT, NTW>(acc_a);
+            pf.tick(15);
             for (int hg = 0; hg < NHG; ++hg) {
                 reload_heads<HGS>(c, l, hg, l > 0);
                 // G = dattn W_o (dE/do) for the heads of this group -> R3
@@ -1016,8 +1119,10 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         }
                     });
                 __syncthreads();
+                pf.tick(16);
                 attnb_ds<HGS>(c, hg);
                 __syncthreads();
+                pf.tick(17);
                 attnb_dx<HGS>(c, hg);
                 if (l > 0) {
                     attnb_dqkv<HGS, 0>(c);
@@ -1026,6 +1131,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     __syncthreads();
                     attnb_dqkv<HGS, 2>(c);
                     __syncthreads();
+                    pf.tick(18);
                     // d(LN1 out) += dq Wq + dk Wk + dv Wv   (head-major K order [h][q|k|v][d])
                     gemm_tall<MT, NTW, 4>(acc_a, 3 * HGS,
                         [&](int s, const float*& Ap, int& kb0) {
@@ -1037,6 +1143,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         LQ, RN, lw.WqkvT_p, 3 * DFF_INNER / 16, NT_H);
                 }
                 __syncthreads();
+                pf.tick(19);
             }
             if (l > 0) {
                 // + du W_u   (K = 32)
@@ -1048,6 +1155,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 __syncthreads();
                 rowb_ln1<H>(c, lw, l, tbuf);
                 __syncthreads();
+                pf.tick(20);
             }
         }
 
@@ -1141,7 +1249,10 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             if (act) c.xst[tid] = xn - c.cm[g * 4 + cc];
         }
         __syncthreads();
+        pf.tick(21);
     }
+    if (pf.on)
+        for (int i = 0; i < DFF_NPROF; ++i) a.prof[i] = pf.acc[i];
 
     // ---- write back state ----
     if (a.mode != DFF_MODE_SCORE && tid < rows * 4 && (tid & 3) < 3) {
