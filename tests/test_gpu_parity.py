@@ -133,6 +133,26 @@ def test_grouping_and_ragged_batches(dff, cfg, G):
     assert rel(f, ref) <= 1e-5
 
 
+@pytest.mark.parametrize("cfg", ["ala2", "chignolin"])
+def test_generic_kernel_on_small_configs(dff, cfg, golden):
+    """rows <= 16 normally take the one-head-per-wave kernel (dff_small.hip); the generic kernel
+    must give the same answer on the same inputs."""
+    g = golden(f"score_{cfg}.npz")
+    model, _ = get_model(dff, cfg)
+    x, t = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["t"]).cuda()
+    f_small = model.native.score(x, t).cpu().numpy()
+    k_small = model.native.last_launch()[0]
+    model.native.force_generic(True)
+    try:
+        f_gen = model.native.score(x, t).cpu().numpy()
+        k_gen = model.native.last_launch()[0]
+    finally:
+        model.native.force_generic(False)
+    assert "small" in k_small and "fused" in k_gen
+    assert rel(f_gen, g["forces64"]) <= 1e-5 and rel(f_small, g["forces64"]) <= 1e-5
+    assert rel(f_small, f_gen) <= 5e-6
+
+
 def test_score_invariances_full_batch(dff):
     """BASELINE config-2 size (chignolin, batch 256): size-independent properties."""
     model, params = get_model(dff, "chignolin")

@@ -54,6 +54,7 @@ SYMBOLS = {
     "dff_ddpm_run": (C.c_int, [_P, C.c_int, _P, _P, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int,
                                _P, _P]),
     "dff_set_group": (C.c_int, [_P, C.c_int]),
+    "dff_debug_force_generic": (C.c_int, [_P, C.c_int]),
     "dff_last_launch": (C.c_int, [_P, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dff_debug_gemm": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "dff_debug_stash": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_size_t]),
@@ -156,6 +157,9 @@ class Model:
 
     def set_group(self, g: int):
         _check(self.lib, self.lib.dff_set_group(self.handle, int(g)), "dff_set_group")
+
+    def force_generic(self, on: bool = True):
+        _check(self.lib, self.lib.dff_debug_force_generic(self.handle, int(on)), "dff_debug_force_generic")
 
     def last_launch(self):
         name, grid, lds = C.c_char_p(), C.c_int(), C.c_int()

@@ -13,6 +13,7 @@
 
 // device code: one translation unit (kernel handles, layouts and templates are shared)
 #include "dff_kernels.hip"
+#include "dff_small.hip"
 
 static thread_local std::string g_err;
 static int fail(int code, const char* fmt, ...) {
@@ -75,6 +76,8 @@ struct dff_model {
     float* stash = nullptr;
     size_t stash_floats = 0;
     int group_override = 0;
+    bool force_generic = false;   // debugging: never use the rows<=16 fast path
+    bool last_small = false;
     unsigned long long* prof = nullptr;
     bool prof_on = false;
     // last launch
@@ -263,6 +266,31 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
         UP(pack_b(H, 32, [&](int k, int n) { return n < 24 ? Woc[(size_t)k * 24 + n] : 0.0; }), d.WocT_p);
         UP(pack_b(3 * I, H, [&](int k, int n) { return wqkv(k, n); }), d.WqkvT_p);
         UP(pack_b(32, H, [&](int k, int n) { return k < 24 ? Wu[(size_t)k * H + n] : 0.0; }), d.WuT_p);
+        // extended-head images: column e of head h: [0,64) q, [64,67) u, [67,80) 0, [80,144) k, [144,208) v
+        auto wqkvx = [&](int col, int c) -> double {
+            const int h = col / 208, e = col % 208;
+            if (e < 64) return Wq[(size_t)(h * 64 + e) * H + c];
+            if (e < 80) return e < 67 ? Wu[(size_t)(3 * h + e - 64) * H + c] : 0.0;
+            if (e < 144) return Wkv[(size_t)(h * 64 + e - 80) * H + c];
+            return Wkv[(size_t)(I + h * 64 + e - 144) * H + c];
+        };
+        std::vector<float> bqkvx(8 * 208, 0.f);
+        for (int col = 0; col < 8 * 208; ++col) {
+            const int h = col / 208, e = col % 208;
+            bqkvx[col] = e < 64 ? bq[h * 64 + e] : e < 67 ? (float)bu[3 * h + e - 64] : e < 80 ? 0.f
+                         : e < 144 ? bkv[h * 64 + e - 80] : bkv[I + h * 64 + e - 144];
+        }
+        // output projection with the xrel rows: row e of head h: [0,64) W_o[:, h*64+e], [64,67) W_oc[:, 3h+e-64]
+        auto wox = [&](int krow, int c) -> double {
+            const int h = krow / 80, e = krow % 80;
+            if (e < 64) return Wo[(size_t)c * I + h * 64 + e];
+            return e < 67 ? Woc[(size_t)c * 24 + 3 * h + e - 64] : 0.0;
+        };
+        UP(pack_b(H, 8 * 208, [&](int k, int n) { return wqkvx(n, k); }), d.Wqkvx_p);
+        UP(bqkvx, d.bqkvx);
+        UP(pack_b(8 * 80, H, [&](int k, int n) { return wox(k, n); }), d.Wox_p);
+        UP(pack_b(H, 8 * 80, [&](int k, int n) { return wox(n, k); }), d.WoxT_p);
+        UP(pack_b(8 * 208, H, [&](int k, int n) { return wqkvx(k, n); }), d.WqkvxT_p);
     }
     build_schedule(cfg->timesteps, m->sched);
     UP(m->sched[6], m->dev.sqrt_recip_ac);
@@ -295,11 +323,52 @@ extern "C" int dff_set_group(dff_model* m, int g) {
     return DFF_OK;
 }
 
+extern "C" int dff_debug_force_generic(dff_model* m, int on) {
+    if (!m) return fail(DFF_EINVAL, "null model");
+    m->force_generic = on != 0;
+    return DFF_OK;
+}
+
 extern "C" int dff_last_launch(const dff_model* m, const char** name, int* grid, int* lds) {
     if (!m) return fail(DFF_EINVAL, "null model");
     if (name) *name = m->last_kernel;
     if (grid) *grid = m->last_grid;
     if (lds) *lds = m->last_lds;
+    return DFF_OK;
+}
+
+static int ensure_stash(dff_model* m, size_t need) {
+    if (need > m->stash_floats) {
+        if (m->stash) HIPCHK(hipFree(m->stash));
+        m->stash = nullptr; m->stash_floats = 0;
+        HIPCHK(hipMalloc((void**)&m->stash, need * sizeof(float)));
+        m->stash_floats = need;
+    }
+    return DFF_OK;
+}
+
+// rows <= 16: one-head-per-wave kernel (dff_small.hip)
+static int launch_small(dff_model* m, DffRunArgs& a, int G, hipStream_t stream) {
+    const int N = m->cfg.n_beads, H = m->cfg.hidden, L = m->cfg.n_layers;
+    const void* fn; unsigned lds; const char* name;
+    if (H == 64)      { fn = (const void*)&dff_small_kernel<64>;  lds = SmallLds<64>::total;  name = "dff_small_kernel<64>"; }
+    else if (H == 96) { fn = (const void*)&dff_small_kernel<96>;  lds = SmallLds<96>::total;  name = "dff_small_kernel<96>"; }
+    else              { fn = (const void*)&dff_small_kernel<128>; lds = SmallLds<128>::total; name = "dff_small_kernel<128>"; }
+    lds *= (unsigned)sizeof(float);
+    if (lds > 160 * 1024) return fail(DFF_EINVAL, "LDS budget exceeded (%u bytes)", lds);
+    const int grid = (a.B + G - 1) / G;
+    const SmallStash sl = dff_small_stash(N, G, H, L);
+    int rc = ensure_stash(m, (size_t)grid * sl.total);
+    if (rc) return rc;
+    a.G = G;
+    a.prof = m->prof_on ? m->prof : nullptr;
+    a.stash = m->stash;
+    a.stash_stride = sl.total;
+    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    void* args[] = {(void*)&m->dev, (void*)&a};
+    HIPCHK(hipLaunchKernel(fn, dim3(grid), dim3(DFF_NTHREADS), args, lds, stream));
+    m->last_kernel = name; m->last_grid = grid; m->last_lds = (int)lds; m->last_G = G; m->last_B = a.B;
+    m->last_stride = sl.total; m->last_small = true;
     return DFF_OK;
 }
 
@@ -319,6 +388,7 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
     if (G > 16) G = 16;
     int mt = (G * N + 15) / 16;
     if (mt > 4) { G = 64 / N; mt = (G * N + 15) / 16; }
+    if (G * N <= 16 && !m->force_generic) return launch_small(m, a, G, stream);
     const Variant* v = nullptr;
     for (const Variant& c : g_variants)
         if (c.H == H && c.MT == mt) { v = &c; break; }
@@ -332,13 +402,8 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
     if (lds > 160 * 1024) return fail(DFF_EINVAL, "LDS budget exceeded (%u bytes) for N=%d G=%d H=%d", lds, N, G, H);
     const int grid = (a.B + G - 1) / G;
     const StashLayout sl = dff_stash_layout(N, G, H, L);
-    const size_t need = (size_t)grid * sl.total;
-    if (need > m->stash_floats) {
-        if (m->stash) HIPCHK(hipFree(m->stash));
-        m->stash = nullptr; m->stash_floats = 0;
-        HIPCHK(hipMalloc((void**)&m->stash, need * sizeof(float)));
-        m->stash_floats = need;
-    }
+    { int rc = ensure_stash(m, (size_t)grid * sl.total); if (rc) return rc; }
+    m->last_small = false;
     a.G = G;
     a.prof = m->prof_on ? m->prof : nullptr;
     a.stash = m->stash;
@@ -431,11 +496,56 @@ extern "C" int dff_debug_stash(dff_model* m, int b, int layer, int what, float* 
     if (!m || !out || !m->stash || m->last_G <= 0) return fail(DFF_EINVAL, "no stash (run dff_score first)");
     const int N = m->cfg.n_beads, H = m->cfg.hidden, L = m->cfg.n_layers, G = m->last_G;
     if (b < 0 || b >= m->last_B || layer < 0 || layer >= L) return fail(DFF_EINVAL, "bad sample / layer");
-    const StashLayout sl = dff_stash_layout(N, G, H, L);
-    const int wg = b / G, g = b % G;
-    const float* base = m->stash + (size_t)wg * sl.total + (size_t)layer * sl.layer_stride;
     HIPCHK(hipSetDevice(m->device));
     HIPCHK(hipDeviceSynchronize());
+    const int wg = b / G, g = b % G;
+    if (m->last_small) {
+        const SmallStash ss = dff_small_stash(N, G, H, L);
+        const float* sb = m->stash + (size_t)wg * ss.total + (size_t)layer * ss.layer_stride;
+        const int R = G * N;
+        auto rowsS = [&](unsigned off, int width) -> int {
+            if (n != (size_t)N * width) return fail(DFF_EINVAL, "expected %d values", N * width);
+            HIPCHK(hipMemcpy(out, sb + off + (size_t)g * N * width, (size_t)N * width * 4, hipMemcpyDeviceToHost));
+            return DFF_OK;
+        };
+        auto heads = [&](unsigned off, int srcw, int c0, int w, int dstw, int dc0) -> int {
+            // per head h: rows (g*N .. g*N+N) x [c0, c0+w) of an (R x srcw) block -> out[row][dc0 + h*w ..]
+            std::vector<float> tmp((size_t)N * srcw);
+            for (int h = 0; h < DFF_HEADS; ++h) {
+                HIPCHK(hipMemcpy(tmp.data(), sb + off + ((size_t)h * R + (size_t)g * N) * srcw, tmp.size() * 4, hipMemcpyDeviceToHost));
+                for (int r = 0; r < N; ++r)
+                    for (int c2 = 0; c2 < w; ++c2) out[(size_t)r * dstw + dc0 + h * w + c2] = tmp[(size_t)r * srcw + c0 + c2];
+            }
+            return DFF_OK;
+        };
+        switch (what) {
+            case 0: return rowsS(ss.nodes_in, H);
+            case 1: return rowsS(ss.attn_out, H);
+            case 2: return rowsS(ss.ff, H);
+            case 3: return rowsS(ss.h_pre, 4 * H);
+            case 4: if (n != (size_t)N * 512) return fail(DFF_EINVAL, "size"); return heads(ss.qx, DFF_XH, 0, 64, 512, 0);
+            case 5: if (n != (size_t)N * 512) return fail(DFF_EINVAL, "size"); return heads(ss.k, 64, 0, 64, 512, 0);
+            case 6: if (n != (size_t)N * 512) return fail(DFF_EINVAL, "size"); return heads(ss.v, 64, 0, 64, 512, 0);
+            case 8: {
+                if (n != (size_t)N * 32) return fail(DFF_EINVAL, "size");
+                memset(out, 0, n * 4);
+                return heads(ss.qx, DFF_XH, 64, 3, 32, 0);
+            }
+            case 7: {
+                if (n != (size_t)DFF_HEADS * N * N) return fail(DFF_EINVAL, "size");
+                std::vector<float> tmp((size_t)N * 16);
+                for (int h = 0; h < DFF_HEADS; ++h) {
+                    HIPCHK(hipMemcpy(tmp.data(), sb + ss.P + ((size_t)h * R + (size_t)g * N) * 16, tmp.size() * 4, hipMemcpyDeviceToHost));
+                    for (int i = 0; i < N; ++i)
+                        for (int j = 0; j < N; ++j) out[((size_t)h * N + i) * N + j] = tmp[(size_t)i * 16 + g * N + j];
+                }
+                return DFF_OK;
+            }
+        }
+        return fail(DFF_EINVAL, "unknown stash item %d", what);
+    }
+    const StashLayout sl = dff_stash_layout(N, G, H, L);
+    const float* base = m->stash + (size_t)wg * sl.total + (size_t)layer * sl.layer_stride;
     auto rows = [&](unsigned off, int width) -> int {
         if (n != (size_t)N * width) return fail(DFF_EINVAL, "expected %d values", N * width);
         HIPCHK(hipMemcpy(out, base + off + (size_t)g * N * width, (size_t)N * width * 4, hipMemcpyDeviceToHost));

@@ -40,6 +40,11 @@ struct DffLayerDev {
     const float *WocT_p;          // K=H, Nout=32   r   = dattn Woc
     const float *WqkvT_p;         // K=1536 (head-major), Nout=H
     const float *WuT_p;           // K=32, Nout=H
+    // "extended head" images of the rows<=16 fast path (dff_small.hip): per head 80 = 64 + 16
+    const float *Wqkvx_p, *bqkvx; // K=H, Nout=8*208, per head [q 64 | u 16 | k 64 | v 64]
+    const float *Wox_p;           // K=8*80 per head [o 64 | xrel 16], Nout=H
+    const float *WoxT_p;          // K=H, Nout=8*80
+    const float *WqkvxT_p;        // K=8*208, Nout=H
 };
 
 struct DffModelDev {

@@ -179,9 +179,11 @@ DEVI void mfma4(f32x4& acc, const f32x4 a, const f32x4 b) {
 
 // "wide" GEMM: K = 16*KB (small, compile time), many output tiles; the 4 waves take tiles
 // round-robin.  epi(nt_local, mt, acc) consumes one 16x16 output tile.
-template <int MT, int KB, class Epi>
+// pre(nt_local, aux) issues the global loads the tile's epilogue needs (bias, stashed values)
+// together with the tile's weights, so their latency is hidden by the ring as well.
+template <int MT, int KB, int NAUX, class Pre, class Epi>
 DEVI void gemm_wide(const float* A, int lda, int rowsA, const float* __restrict__ Wp, int KBtot,
-                    int kb0, int nt0, int ntn, Epi epi) {
+                    int kb0, int nt0, int ntn, Pre pre, Epi epi) {
     constexpr int D = DFF_WIDE_DEPTH;
     static_assert(KB % 2 == 0, "KB must be even");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -198,11 +200,13 @@ DEVI void gemm_wide(const float* A, int lda, int rowsA, const float* __restrict_
     const f32x4* wp = (const f32x4*)Wp + lane + (size_t)kb0 * 64;
     const int cnt = wave < ntn ? (ntn - wave + DFF_NWAVES - 1) / DFF_NWAVES : 0;
     f32x4 b[D][KB];
+    float aux[D][NAUX];
 #pragma unroll
     for (int d = 0; d < D; ++d)
         if (d < cnt) {
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) b[d][kb] = wp[((size_t)(nt0 + wave + DFF_NWAVES * d) * KBtot + kb) * 64];
+            pre(wave + DFF_NWAVES * d, aux[d]);
         }
     for (int i0 = 0; i0 < cnt; i0 += D) {
 #pragma unroll
@@ -222,13 +226,17 @@ DEVI void gemm_wide(const float* A, int lda, int rowsA, const float* __restrict_
                             acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][kb][s4], b[d][kb][s4], acc[mt], 0, 0, 0);
                             acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][kb + 1][s4], b[d][kb + 1][s4], acc2[mt], 0, 0, 0);
                         }
+                float auxc[NAUX];
+#pragma unroll
+                for (int q = 0; q < NAUX; ++q) auxc[q] = aux[d][q];
                 if (i + D < cnt) {
 #pragma unroll
                     for (int kb = 0; kb < KB; ++kb)
                         b[d][kb] = wp[((size_t)(nt0 + nt + DFF_NWAVES * D) * KBtot + kb) * 64];
+                    pre(nt + DFF_NWAVES * D, aux[d]);
                 }
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) epi(nt, mt, acc[mt] + acc2[mt]);
+                for (int mt = 0; mt < MT; ++mt) epi(nt, mt, acc[mt] + acc2[mt], auxc);
             }
         }
     }
@@ -805,24 +813,56 @@ DEVI void attnb_dqkv(const Ctx& c) {
 template <int HGS>
 DEVI void reload_heads(const Ctx& c, int l, int hg, bool need_qk, bool need_p = true) {
     constexpr int LQ = 64 * HGS + 4;
+    constexpr int U = 4;  // loads in flight per thread per tensor before the LDS writes
     const int N = c.N, RN = c.G * N;
     const float* sb = c.stash + (size_t)l * c.sl.layer_stride;
     const int per_row = 16 * HGS;  // float4 per row per tensor
     const int total = c.rows * per_row;
-    for (int it = threadIdx.x; it < total; it += DFF_NTHREADS) {
-        const int row = it / per_row, c4 = it - row * per_row;
-        const size_t so = (size_t)row * DFF_INNER + hg * HGS * 64 + c4 * 4;
-        const int lo = row * LQ + c4 * 4;
-        *(f32x4*)(c.Rg + 2 * RN * LQ + lo) = __builtin_nontemporal_load((const f32x4*)(sb + c.sl.v + so));
-        if (need_qk) {
-            *(f32x4*)(c.Rg + lo) = __builtin_nontemporal_load((const f32x4*)(sb + c.sl.q + so));
-            *(f32x4*)(c.Rg + RN * LQ + lo) = __builtin_nontemporal_load((const f32x4*)(sb + c.sl.k + so));
+    for (int base = 0; base < total; base += DFF_NTHREADS * U) {
+        f32x4 tv[U], tq[U], tk[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int it = base + u * DFF_NTHREADS + threadIdx.x;
+            if (it < total) {
+                const int row = it / per_row, c4 = it - row * per_row;
+                const size_t so = (size_t)row * DFF_INNER + hg * HGS * 64 + c4 * 4;
+                tv[u] = __builtin_nontemporal_load((const f32x4*)(sb + c.sl.v + so));
+                if (need_qk) {
+                    tq[u] = __builtin_nontemporal_load((const f32x4*)(sb + c.sl.q + so));
+                    tk[u] = __builtin_nontemporal_load((const f32x4*)(sb + c.sl.k + so));
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int it = base + u * DFF_NTHREADS + threadIdx.x;
+            if (it < total) {
+                const int row = it / per_row, c4 = it - row * per_row;
+                const int lo = row * LQ + c4 * 4;
+                *(f32x4*)(c.Rg + 2 * RN * LQ + lo) = tv[u];
+                if (need_qk) {
+                    *(f32x4*)(c.Rg + lo) = tq[u];
+                    *(f32x4*)(c.Rg + RN * LQ + lo) = tk[u];
+                }
+            }
         }
     }
     if (need_p) {
         const int pn = HGS * c.G * N * N;
         const float* sP = sb + c.sl.P + (size_t)hg * pn;
-        for (int it = threadIdx.x; it < pn; it += DFF_NTHREADS) c.Pbuf[it] = ld_nt(sP + it);
+        for (int base = 0; base < pn; base += DFF_NTHREADS * U) {
+            float t[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int it = base + u * DFF_NTHREADS + threadIdx.x;
+                t[u] = it < pn ? ld_nt(sP + it) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int it = base + u * DFF_NTHREADS + threadIdx.x;
+                if (it < pn) c.Pbuf[it] = t[u];
+            }
+        }
     }
 }
 
@@ -957,10 +997,11 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             __syncthreads();
             pf.tick(1);
             // u = LN1(nodes) W_u^T + b_u  (all 8 heads, 24 of 32 columns used)
-            gemm_wide<MT, NT_H>(c.abuf, LH, RN, lw.Wu_p, NT_H, 0, 0, 2,
-                [&](int nt, int mt, const f32x4& acc) {
+            gemm_wide<MT, NT_H, 1>(c.abuf, LH, RN, lw.Wu_p, NT_H, 0, 0, 2,
+                [&](int nt, float (&aux)[1]) { aux[0] = lw.bu[16 * nt + (tid & 15)]; },
+                [&](int nt, int mt, const f32x4& acc, const float (&aux)[1]) {
                     const int lane = tid & 63, quad = lane >> 4, col = 16 * nt + (lane & 15);
-                    const float bv = lw.bu[col];
+                    const float bv = aux[0];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = mt * 16 + quad * 4 + r;
@@ -979,12 +1020,13 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 // q|k|v of HGS heads -> R0,R1,R2 (+ stash)
                 if (cached) reload_heads<HGS>(c, 0, hg, true, false);
                 else
-                gemm_wide<MT, NT_H>(c.abuf, LH, RN, lw.Wqkv_p, NT_H, 0, hg * HGS * 12, HGS * 12,
-                    [&](int nt, int mt, const f32x4& acc) {
+                gemm_wide<MT, NT_H, 1>(c.abuf, LH, RN, lw.Wqkv_p, NT_H, 0, hg * HGS * 12, HGS * 12,
+                    [&](int nt, float (&aux)[1]) { aux[0] = lw.bqkv[(hg * HGS * 12 + nt) * 16 + (tid & 15)]; },
+                    [&](int nt, int mt, const f32x4& acc, const float (&aux)[1]) {
                         const int lane = tid & 63, quad = lane >> 4, cl = lane & 15;
                         const int cg = (hg * HGS * 12 + nt) * 16;         // global column (head-major)
                         const int h = cg / 192, part = (cg % 192) / 64, d = (cg % 64) + cl;
-                        const float bv = lw.bqkv[cg + cl];
+                        const float bv = aux[0];
                         float* dstl = c.Rg + part * RN * LQ + (h - hg * HGS) * 64 + d;
                         float* dsts = sb + (part == 0 ? c.sl.q : part == 1 ? c.sl.k : c.sl.v) + h * 64 + d;
 #pragma unroll
@@ -1024,11 +1066,12 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             f32x4 acc_f[NTW][MT];
             acc_zero<MT, NTW>(acc_f);
             for (int ch = 0; ch < NCH; ++ch) {
-                gemm_wide<MT, NT_H>(c.abuf, LH, RN, lw.W1_p, NT_H, 0, ch * (FC / 16), FC / 16,
-                    [&](int nt, int mt, const f32x4& acc) {
+                gemm_wide<MT, NT_H, 1>(c.abuf, LH, RN, lw.W1_p, NT_H, 0, ch * (FC / 16), FC / 16,
+                    [&](int nt, float (&aux)[1]) { aux[0] = lw.b1[ch * FC + 16 * nt + (tid & 15)]; },
+                    [&](int nt, int mt, const f32x4& acc, const float (&aux)[1]) {
                         const int lane = tid & 63, quad = lane >> 4, cl = 16 * nt + (lane & 15);
                         const int colg = ch * FC + cl;
-                        const float bv = lw.b1[colg];
+                        const float bv = aux[0];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int row = mt * 16 + quad * 4 + r;
@@ -1065,17 +1108,24 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             f32x4 acc_f[NTW][MT];
             acc_zero<MT, NTW>(acc_f);
             for (int ch = 0; ch < NCH; ++ch) {
-                gemm_wide<MT, NT_H>(c.abuf, LH, RN, lw.W2T_p, NT_H, 0, ch * (FC / 16), FC / 16,
-                    [&](int nt, int mt, const f32x4& acc) {
+                gemm_wide<MT, NT_H, 4 * MT>(c.abuf, LH, RN, lw.W2T_p, NT_H, 0, ch * (FC / 16), FC / 16,
+                    [&](int nt, float (&aux)[4 * MT]) {
+                        const int lane = tid & 63, quad = lane >> 4, colg = ch * FC + 16 * nt + (lane & 15);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                int row = mt * 16 + quad * 4 + r;
+                                row = row < rows ? row : rows - 1;
+                                aux[mt * 4 + r] = ld_nt(sb + c.sl.h_pre + (size_t)row * F + colg);
+                            }
+                    },
+                    [&](int nt, int mt, const f32x4& acc, const float (&aux)[4 * MT]) {
                         const int lane = tid & 63, quad = lane >> 4, cl = 16 * nt + (lane & 15);
-                        const int colg = ch * FC + cl;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int row = mt * 16 + quad * 4 + r;
-                            if (row < rows) {
-                                const float hp = ld_nt(sb + c.sl.h_pre + (size_t)row * F + colg);
-                                c.Rg[row * LF + cl] = acc[r] * gelu_grad_f(hp);
-                            }
+                            if (row < rows) c.Rg[row * LF + cl] = acc[r] * gelu_grad_f(aux[mt * 4 + r]);
                         }
                     });
                 __syncthreads();
@@ -1092,8 +1142,9 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             __syncthreads();
             pf.tick(14);
             // r = dattn W_oc (dE/dxrel) -> sbuf ; u of this layer -> ubuf
-            gemm_wide<MT, NT_H>(c.abuf, LH, RN, lw.WocT_p, NT_H, 0, 0, 2,
-                [&](int nt, int mt, const f32x4& acc) {
+            gemm_wide<MT, NT_H, 1>(c.abuf, LH, RN, lw.WocT_p, NT_H, 0, 0, 2,
+                [&](int, float (&)[1]) {},
+                [&](int nt, int mt, const f32x4& acc, const float (&)[1]) {
                     const int lane = tid & 63, quad = lane >> 4, col = 16 * nt + (lane & 15);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -1109,8 +1160,9 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             for (int hg = 0; hg < NHG; ++hg) {
                 reload_heads<HGS>(c, l, hg, l > 0);
                 // G = dattn W_o (dE/do) for the heads of this group -> R3
-                gemm_wide<MT, NT_H>(c.abuf, LH, RN, lw.WoT_p, NT_H, 0, hg * HGS * 4, HGS * 4,
-                    [&](int nt, int mt, const f32x4& acc) {
+                gemm_wide<MT, NT_H, 1>(c.abuf, LH, RN, lw.WoT_p, NT_H, 0, hg * HGS * 4, HGS * 4,
+                    [&](int, float (&)[1]) {},
+                    [&](int nt, int mt, const f32x4& acc, const float (&)[1]) {
                         const int lane = tid & 63, quad = lane >> 4, cl = 16 * nt + (lane & 15);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -1274,8 +1326,9 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_debug_gemm_kernel(const floa
     __syncthreads();
     for (int i = threadIdx.x; i < M * K; i += DFF_NTHREADS) smem[(i / K) * LD + (i % K)] = A[i];
     __syncthreads();
-    gemm_wide<4, KB>(smem, LD, M, Wp, KB, 0, 0, Nout / 16,
-        [&](int nt, int mt, const f32x4& acc) {
+    gemm_wide<4, KB, 1>(smem, LD, M, Wp, KB, 0, 0, Nout / 16,
+        [&](int, float (&)[1]) {},
+        [&](int nt, int mt, const f32x4& acc, const float (&)[1]) {
             const int lane = threadIdx.x & 63, quad = lane >> 4, col = 16 * nt + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
