@@ -25,6 +25,12 @@ ld2 = LangevinDiffusion(diff, x0, a.steps, save_interval=a.steps, t=20, temp_dat
                         masses=[12.0] * N, friction=1.0, verbose=False)
 t0 = time.perf_counter(); ld2.simulate(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
 pr = model.native.profile_read()
+if "small" in model.native.last_launch()[0]:
+    names = ["centre", "rowA ln1(l0)", "attn fwd (wave-private)", "rowB gate1+ln2", "ffn fwd", "rowC gate2+ln1", "rowD b_gate2",
+             "ffn bwd", "rowE b_ln2+gate1", "attn bwd (wave-private)", "rowF b_ln1", "update",
+             "  f:qkv gemm", "  f:S+softmax+PV", "  f:wox gemm", "  b:gext gemm", "  b:dA+dS", "  b:dV,dQ,dK", "  b:qkvT gemm"]
+    vals = list(pr.values())
+    pr = {n: vals[i] for i, n in enumerate(names)}
 tot = sum(pr.values())
 print(f"{a.cfg} P={a.P} steps={a.steps} kernel={model.native.last_launch()} wall={1e6*dt/a.steps:.1f} us/step  cycles/step={tot/a.steps:.0f}")
 for k, v in pr.items():

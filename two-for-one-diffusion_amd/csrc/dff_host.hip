@@ -502,7 +502,7 @@ extern "C" int dff_debug_stash(dff_model* m, int b, int layer, int what, float* 
     if (m->last_small) {
         const SmallStash ss = dff_small_stash(N, G, H, L);
         const float* sb = m->stash + (size_t)wg * ss.total + (size_t)layer * ss.layer_stride;
-        const int R = G * N;
+        const int R = G * N + 1;   // arrays carry one dummy row
         auto rowsS = [&](unsigned off, int width) -> int {
             if (n != (size_t)N * width) return fail(DFF_EINVAL, "expected %d values", N * width);
             HIPCHK(hipMemcpy(out, sb + off + (size_t)g * N * width, (size_t)N * width * 4, hipMemcpyDeviceToHost));
@@ -523,19 +523,19 @@ extern "C" int dff_debug_stash(dff_model* m, int b, int layer, int what, float* 
             case 1: return rowsS(ss.attn_out, H);
             case 2: return rowsS(ss.ff, H);
             case 3: return rowsS(ss.h_pre, 4 * H);
-            case 4: if (n != (size_t)N * 512) return fail(DFF_EINVAL, "size"); return heads(ss.qx, DFF_XH, 0, 64, 512, 0);
-            case 5: if (n != (size_t)N * 512) return fail(DFF_EINVAL, "size"); return heads(ss.k, 64, 0, 64, 512, 0);
-            case 6: if (n != (size_t)N * 512) return fail(DFF_EINVAL, "size"); return heads(ss.v, 64, 0, 64, 512, 0);
+            case 4: if (n != (size_t)N * 512) return fail(DFF_EINVAL, "size"); return heads(ss.qkv, DFF_QKVW, 0, 64, 512, 0);
+            case 5: if (n != (size_t)N * 512) return fail(DFF_EINVAL, "size"); return heads(ss.qkv, DFF_QKVW, 80, 64, 512, 0);
+            case 6: if (n != (size_t)N * 512) return fail(DFF_EINVAL, "size"); return heads(ss.qkv, DFF_QKVW, 144, 64, 512, 0);
             case 8: {
                 if (n != (size_t)N * 32) return fail(DFF_EINVAL, "size");
                 memset(out, 0, n * 4);
-                return heads(ss.qx, DFF_XH, 64, 3, 32, 0);
+                return heads(ss.qkv, DFF_QKVW, 64, 3, 32, 0);
             }
             case 7: {
                 if (n != (size_t)DFF_HEADS * N * N) return fail(DFF_EINVAL, "size");
                 std::vector<float> tmp((size_t)N * 16);
                 for (int h = 0; h < DFF_HEADS; ++h) {
-                    HIPCHK(hipMemcpy(tmp.data(), sb + ss.P + ((size_t)h * R + (size_t)g * N) * 16, tmp.size() * 4, hipMemcpyDeviceToHost));
+                    HIPCHK(hipMemcpy(tmp.data(), sb + ss.P + ((size_t)h * 16 + (size_t)g * N) * 16, tmp.size() * 4, hipMemcpyDeviceToHost));
                     for (int i = 0; i < N; ++i)
                         for (int j = 0; j < N; ++j) out[((size_t)h * N + i) * N + j] = tmp[(size_t)i * 16 + g * N + j];
                 }

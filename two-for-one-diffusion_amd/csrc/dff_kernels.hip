@@ -25,6 +25,7 @@
 // their transposes for the VJP) run on v_mfma_f32_16x16x4_f32 (exact fp32 == fmaf chain);
 // softmax / LayerNorm / GELU / gates / the N x N contractions run on the VALU out of LDS.
 #include "dff_internal.h"
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -101,13 +102,27 @@ struct LdsLayout {
 // ------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------
-DEVI float grp16_sum(float v) {
-    v += __shfl_xor(v, 8, 16);
-    v += __shfl_xor(v, 4, 16);
-    v += __shfl_xor(v, 2, 16);
-    v += __shfl_xor(v, 1, 16);
+// all-reduce over an aligned group of 16 lanes (one DPP "row") without touching LDS:
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
+template <int CTRL>
+DEVI float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+DEVI float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
     return v;
 }
+DEVI float row16_max(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    return v;
+}
+DEVI float grp16_sum(float v) { return row16_sum(v); }
 DEVI float grp_sum(float v, int np) {
     for (int o = np >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;

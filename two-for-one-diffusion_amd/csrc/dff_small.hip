@@ -24,27 +24,41 @@
 #pragma once
 #include "dff_internal.h"
 
+// Explicitly address-space-typed pointers: the hot lambdas capture pointers by reference and some
+// closures end up in memory, where a plain `float*` loses its provenance and every access turns
+// into a FLAT op (which waits on BOTH counters and drains the weight ring).  Typed pointers keep
+// ds_* / global_* no matter how they travel.
+typedef __attribute__((address_space(3))) float lfloat;
+typedef __attribute__((address_space(1))) float gfloat;
+typedef f32x4 __attribute__((address_space(3))) lf32x4;
+typedef f32x4 __attribute__((address_space(1))) gf32x4;
+DEVI void st_ntg(gfloat* p, float v) { __builtin_nontemporal_store(v, p); }
+DEVI float ld_ntg(const gfloat* p) { return __builtin_nontemporal_load(p); }
+DEVI f32x4 ld_ntg4(const gfloat* p) { return __builtin_nontemporal_load((const gf32x4*)p); }
+
 #define DFF_XH 80       // extended head width
 #define DFF_XLD 84      // leading dim of the per-wave head buffers
 #define DFF_PLD 20      // leading dim of the per-wave P / dS tiles
 #define DFF_WREG (4 * 16 * DFF_XLD + 2 * 16 * DFF_PLD)   // floats per wave region
 
+#define DFF_QKVW 208    // stash row of one head: [q_ext 80 | k 64 | v 64]
 struct SmallStash {
-    unsigned nodes_in, attn_out, ff, h_pre, qx, k, v, P;
+    unsigned nodes_in, attn_out, ff, h_pre, qkv, P;
     unsigned layer_stride, total;
 };
 __host__ __device__ inline SmallStash dff_small_stash(int N, int G, int H, int L) {
     SmallStash s;
-    const unsigned R = (unsigned)(G * N), F = 4u * H;
+    // every array has one extra "dummy" row (index G*N) that absorbs the stores of pad lanes
+    // (rows >= real rows of the 16-row MFMA tile), so epilogues need no exec-masked branches;
+    // P keeps all 16 rows (its pad rows must read back as exact zeros).
+    const unsigned R = (unsigned)(G * N) + 1u, F = 4u * H;
     unsigned o = 0;
     s.nodes_in = o; o += R * H;
     s.attn_out = o; o += R * H;
     s.ff = o;       o += R * H;
     s.h_pre = o;    o += R * F;
-    s.qx = o;       o += DFF_HEADS * R * DFF_XH;
-    s.k = o;        o += DFF_HEADS * R * 64;
-    s.v = o;        o += DFF_HEADS * R * 64;
-    s.P = o;        o += DFF_HEADS * R * 16;
+    s.qkv = o;      o += DFF_HEADS * R * DFF_QKVW;
+    s.P = o;        o += DFF_HEADS * 16 * 16;
     s.layer_stride = o;
     s.total = (o * (unsigned)L + 63u) & ~63u;
     return s;
@@ -54,118 +68,160 @@ template <int H>
 struct SmallLds {
     static constexpr int LH = H + 4;
     static constexpr unsigned xst = 0, xs = 64, dxs = 128, vst = 192, cm = 256, tn = 384, prof = 400,
-                              dxw = 448,                      // [4][64] per-wave dx partials
-                              abuf = 704, resbuf = abuf + 16 * LH, part = resbuf + 16 * LH,
+                              dxw = 448,                      // [4][128] per-wave dx partials (+ dummies)
+                              abuf = 960, resbuf = abuf + 16 * LH, part = resbuf + 16 * LH,
                               wreg = part + 4 * 16 * LH, total = wreg + 4 * DFF_WREG + 64;
 };
 
-// ---------------------------------------------------------------- wave-private MFMA pieces
-// C layout: acc[r] <-> (row 4*(lane>>4)+r, col lane&15)
-DEVI void c_store(float* dst, int ld, int col0, const f32x4& acc, int rows) {
-    const int lane = threadIdx.x & 63, quad = lane >> 4, col = lane & 15;
+// ---------------------------------------------------------------- wave-private MFMA engine
+// One wave per SIMD means nothing hides a stall except the wave's own instruction stream, so the
+// per-wave GEMM streams are written to be straight-line: tile loops fully unrolled, epilogues
+// branch-free (pad lanes store to a dummy stash row / harmless LDS pad rows), and the weight
+// operands come out of a register ring of DFF_DR entries that is kept full ACROSS GEMMs: the tail
+// of one GEMM refills the ring with the head of the next, and every block ends by prefetching the
+// first entries of the block that follows the barrier.  Every GEMM of this kernel has either
+// K = H (wide: one entry = one 16-column output tile = H/16 k-blocks) or Nout = H (tall: one
+// entry = one k-block for all H/16 output tiles), so all ring entries are E = H/16 float4.
+// Lane-derived address offsets are loop-invariant, so LICM hoists every one of them out of the
+// step loop and keeps hundreds of VGPRs live for the whole kernel (-> scratch spills).  Reading
+// the lane id through an opaque asm makes each block re-derive its offsets locally (a few VALU
+// ops) instead.
+DEVI int lane_id() {
+    int x = threadIdx.x & 63;
+    asm volatile("" : "+v"(x));
+    return x;
+}
+DEVI int tid_id() {
+    int x = threadIdx.x;
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+#define DFF_DR 4
+template <int E>
+struct Ring {
+    f32x4 b[DFF_DR][E];
+};
+struct WStream {
+    const gf32x4* base; // wave-uniform
+    int estep;          // f32x4 stride between consecutive entries
+    int pstride;        // f32x4 stride between the E parts of one entry
+};
+// base stays wave-uniform (SGPR); the lane offset is added at the load
+DEVI WStream wide_stream(const float* Wp, int KBtot, int nt0) {
+    return WStream{(const gf32x4*)Wp + (size_t)nt0 * KBtot * 64, KBtot * 64, 64};
+}
+DEVI WStream tall_stream(const float* Wp, int KBtot, int kw0) {
+    return WStream{(const gf32x4*)Wp + (size_t)kw0 * 64, 64, KBtot * 64};
+}
+template <int E>
+DEVI void ring_fill(f32x4 (&slot)[E], const WStream& w, int j, int lane) {
+    const gf32x4* p = w.base + (size_t)j * w.estep;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = quad * 4 + r;
-        if (row < rows) dst[row * ld + col0 + col] = acc[r];
+    for (int e = 0; e < E; ++e) slot[e] = p[(size_t)e * w.pstride + lane];
+}
+template <int E>
+DEVI void ring_prefetch(Ring<E>& r, const WStream& w, int lane) {
+#pragma unroll
+    for (int j = 0; j < DFF_DR; ++j) ring_fill<E>(r.b[j], w, j, lane);
+}
+
+// wide GEMM of one wave: N output tiles (entries), A fragments `a` (K = 16 E) preloaded.
+// Ring phase PH = slot of entry 0.  Tail refills come from `wn`, the next GEMM's stream.
+// aux[slot][..]: per-tile epilogue operands (bias / stashed values); the caller preloads the first
+// DFF_DR tiles' worth, pre(t, aux_slot) refills.  The tile loop is ONE ring revolution unrolled
+// (static slots) inside a rolled loop, which keeps the live register set small.  Pre / Epi are
+// by-value functors (capture with [=]): a closure that ends up in memory costs a scratch reload
+// per tile, and a scratch reload is a VMEM op -- the compiler then waits vmcnt(0) and drains the
+// whole ring every tile.
+template <int SLOT, int N, int E, int NAUX, class Pre, class Epi>
+DEVI void wide_tile(Ring<E>& ring, float (&aux)[DFF_DR][NAUX], const f32x4 (&a)[E], const WStream& w,
+                    const WStream& wn, int lane, int t, const Pre& pre, const Epi& epi) {
+    f32x4 (&b)[E] = ring.b[SLOT];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < E; kb += 2)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb][s], b[kb][s], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb + 1][s], b[kb + 1][s], acc2, 0, 0, 0);
+        }
+    float auxc[NAUX];
+#pragma unroll
+    for (int q = 0; q < NAUX; ++q) auxc[q] = aux[SLOT][q];
+    if (t + DFF_DR < N) { ring_fill<E>(b, w, t + DFF_DR, lane); pre(t + DFF_DR, aux[SLOT]); }
+    else ring_fill<E>(b, wn, t + DFF_DR - N, lane);
+    epi(t, acc + acc2, auxc);
+}
+// NOTE: aux is indexed by ring SLOT (callers preload aux[(PH + d) % DFF_DR] for tile d).
+template <int PH, int N, int E, int NAUX, class Pre, class Epi>
+DEVI void wide_run(Ring<E>& ring, float (&aux)[DFF_DR][NAUX], const f32x4 (&a)[E], const WStream& w,
+                   const WStream& wn, int lane, const Pre pre, const Epi epi) {
+    static_assert(E % 2 == 0, "E even");
+    constexpr int NREV = N / DFF_DR, REM = N % DFF_DR;
+#pragma unroll 1
+    for (int rev = 0; rev < NREV; ++rev) {
+        const int t0 = rev * DFF_DR;
+        wide_tile<(PH + 0) % DFF_DR, N, E, NAUX>(ring, aux, a, w, wn, lane, t0, pre, epi);
+        wide_tile<(PH + 1) % DFF_DR, N, E, NAUX>(ring, aux, a, w, wn, lane, t0 + 1, pre, epi);
+        wide_tile<(PH + 2) % DFF_DR, N, E, NAUX>(ring, aux, a, w, wn, lane, t0 + 2, pre, epi);
+        wide_tile<(PH + 3) % DFF_DR, N, E, NAUX>(ring, aux, a, w, wn, lane, t0 + 3, pre, epi);
     }
+    if (REM > 0) wide_tile<(PH + 0) % DFF_DR, N, E, NAUX>(ring, aux, a, w, wn, lane, NREV * DFF_DR, pre, epi);
+    if (REM > 1) wide_tile<(PH + 1) % DFF_DR, N, E, NAUX>(ring, aux, a, w, wn, lane, NREV * DFF_DR + 1, pre, epi);
+    if (REM > 2) wide_tile<(PH + 2) % DFF_DR, N, E, NAUX>(ring, aux, a, w, wn, lane, NREV * DFF_DR + 2, pre, epi);
+}
+
+// tall GEMM of one wave: acc[nt] += A(:, k-block kb) . W(entry kb, tile nt), kb = 0..N-1
+template <int SLOT, int N, int E, class FA>
+DEVI void tall_step(Ring<E>& ring, f32x4 (&acc)[E], const FA& fa, const WStream& w, const WStream& wn, int lane, int kb) {
+    f32x4 (&b)[E] = ring.b[SLOT];
+    const f32x4 a = *(const lf32x4*)fa(kb);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int nt = 0; nt < E; ++nt)
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[nt][s], acc[nt], 0, 0, 0);
+    if (kb + DFF_DR < N) ring_fill<E>(b, w, kb + DFF_DR, lane);
+    else ring_fill<E>(b, wn, kb + DFF_DR - N, lane);
+}
+template <int PH, int N, int E, class FA>
+DEVI void tall_run(Ring<E>& ring, f32x4 (&acc)[E], const FA fa, const WStream& w, const WStream& wn, int lane) {
+    constexpr int NREV = N / DFF_DR, REM = N % DFF_DR;
+#pragma unroll 1
+    for (int rev = 0; rev < NREV; ++rev) {
+        const int k0 = rev * DFF_DR;
+        tall_step<(PH + 0) % DFF_DR, N, E>(ring, acc, fa, w, wn, lane, k0);
+        tall_step<(PH + 1) % DFF_DR, N, E>(ring, acc, fa, w, wn, lane, k0 + 1);
+        tall_step<(PH + 2) % DFF_DR, N, E>(ring, acc, fa, w, wn, lane, k0 + 2);
+        tall_step<(PH + 3) % DFF_DR, N, E>(ring, acc, fa, w, wn, lane, k0 + 3);
+    }
+    if (REM > 0) tall_step<(PH + 0) % DFF_DR, N, E>(ring, acc, fa, w, wn, lane, NREV * DFF_DR);
+    if (REM > 1) tall_step<(PH + 1) % DFF_DR, N, E>(ring, acc, fa, w, wn, lane, NREV * DFF_DR + 1);
+    if (REM > 2) tall_step<(PH + 2) % DFF_DR, N, E>(ring, acc, fa, w, wn, lane, NREV * DFF_DR + 2);
+}
+
+// C layout: acc[r] <-> (row 4*(lane>>4)+r, col lane&15); unconditional (pad rows hold finite junk)
+DEVI void c_store_all(lfloat* dst, int ld, int col0, const f32x4& acc, int lane) {
+    const int quad = lane >> 4, col = lane & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[(quad * 4 + r) * ld + col0 + col] = acc[r];
 }
 
 template <int KB>
-DEVI void load_afrag(f32x4 (&a)[KB], const float* A, int lda) {
-    const int lane = threadIdx.x & 63;
-    const float* ap = A + (lane & 15) * lda + 4 * (lane >> 4);
+DEVI void load_afrag(f32x4 (&a)[KB], const lfloat* A, int lda, int lane) {
+    const lfloat* ap = A + (lane & 15) * lda + 4 * (lane >> 4);
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) a[kb] = *(const f32x4*)(ap + 16 * kb);
-}
-
-// sequential tiles nt0 .. nt0+ntn-1 of ONE wave, K = 16*KB, ring of D tiles of B in flight
-template <int KB, int NAUX, class Pre, class Epi>
-DEVI void wv_wide(const f32x4 (&a)[KB], const float* __restrict__ Wp, int KBtot, int nt0, int ntn,
-                  Pre pre, Epi epi) {
-    constexpr int D = 4;
-    static_assert(KB % 2 == 0, "KB even");
-    const int lane = threadIdx.x & 63;
-    const f32x4* wp = (const f32x4*)Wp + lane;
-    f32x4 b[D][KB];
-    float aux[D][NAUX];
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-        if (d < ntn) {
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) b[d][kb] = wp[((size_t)(nt0 + d) * KBtot + kb) * 64];
-            pre(d, aux[d]);
-        }
-    for (int i0 = 0; i0 < ntn; i0 += D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int i = i0 + d;
-            if (i < ntn) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kb = 0; kb < KB; kb += 2)
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb][s], b[d][kb][s], acc, 0, 0, 0);
-                        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb + 1][s], b[d][kb + 1][s], acc2, 0, 0, 0);
-                    }
-                float auxc[NAUX];
-#pragma unroll
-                for (int q = 0; q < NAUX; ++q) auxc[q] = aux[d][q];
-                if (i + D < ntn) {
-#pragma unroll
-                    for (int kb = 0; kb < KB; ++kb) b[d][kb] = wp[((size_t)(nt0 + i + D) * KBtot + kb) * 64];
-                    pre(i + D, aux[d]);
-                }
-                epi(i, acc + acc2, auxc);
-            }
-        }
-    }
-}
-
-// acc[nt] += A(:, k-block kb) . W(k-block fw(kb), tile nt), kb = 0..nkb-1, for all NT tiles of an
-// H-wide output; fa(kb) = this lane's A fragment address; ring of D k-blocks of B in flight.
-template <int NT, class FA, class FW>
-DEVI void wv_tall(f32x4 (&acc)[NT], int nkb, FA fa, FW fw, const float* __restrict__ Wp, int KBtot) {
-    constexpr int D = NT <= 4 ? 4 : 2;
-    const int lane = threadIdx.x & 63;
-    const f32x4* wp = (const f32x4*)Wp + lane;
-    f32x4 b[D][NT];
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-        if (d < nkb) {
-            const int kw = fw(d);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b[d][nt] = wp[((size_t)nt * KBtot + kw) * 64];
-        }
-    for (int k0 = 0; k0 < nkb; k0 += D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int kb = k0 + d;
-            if (kb < nkb) {
-                const f32x4 a = *(const f32x4*)fa(kb);
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[d][nt][s], acc[nt], 0, 0, 0);
-                if (kb + D < nkb) {
-                    const int kw = fw(kb + D);
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) b[d][nt] = wp[((size_t)nt * KBtot + kw) * 64];
-                }
-            }
-        }
-    }
+    for (int kb = 0; kb < KB; ++kb) a[kb] = *(const lf32x4*)(ap + 16 * kb);
 }
 
 // C[i][j] = sum_k A[i][k] B[j][k], K = 80 (5 k-blocks), both operands rows of a head buffer
-DEVI f32x4 wv_dot_rows(const float* A, const float* B) {
-    const int lane = threadIdx.x & 63;
-    const float* ap = A + (lane & 15) * DFF_XLD + 4 * (lane >> 4);
-    const float* bp = B + (lane & 15) * DFF_XLD + 4 * (lane >> 4);
+DEVI f32x4 wv_dot_rows(const lfloat* A, const lfloat* B, int lane) {
+    const lfloat* ap = A + (lane & 15) * DFF_XLD + 4 * (lane >> 4);
+    const lfloat* bp = B + (lane & 15) * DFF_XLD + 4 * (lane >> 4);
     f32x4 av[5], bv[5];
 #pragma unroll
-    for (int kb = 0; kb < 5; ++kb) { av[kb] = *(const f32x4*)(ap + 16 * kb); bv[kb] = *(const f32x4*)(bp + 16 * kb); }
+    for (int kb = 0; kb < 5; ++kb) { av[kb] = *(const lf32x4*)(ap + 16 * kb); bv[kb] = *(const lf32x4*)(bp + 16 * kb); }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -185,14 +241,14 @@ DEVI f32x4 wv_dot_rows(const float* A, const float* B) {
 // C[m][16nt+n] = sum_{k<16} Aop[m][k] B[k][16nt+n] for tiles nt in [NT0, NT1).
 // TRANS = false: Aop[m][k] = T[m][k] (T = 16x16 tile, ld DFF_PLD);  true: Aop[m][k] = T[k][m].
 template <int NT0, int NT1, bool TRANS, class Epi>
-DEVI void wv_mm(const float* T, const float* B, Epi epi) {
-    const int lane = threadIdx.x & 63, kk = lane >> 4, mm = lane & 15;
+DEVI void wv_mm(const lfloat* T, const lfloat* B, int lane, Epi epi) {
+    const int kk = lane >> 4, mm = lane & 15;
     float as[4];
     if (TRANS) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) as[s] = T[(4 * kk + s) * DFF_PLD + mm];
     } else {
-        const f32x4 t = *(const f32x4*)(T + mm * DFF_PLD + 4 * kk);
+        const f32x4 t = *(const lf32x4*)(T + mm * DFF_PLD + 4 * kk);
 #pragma unroll
         for (int s = 0; s < 4; ++s) as[s] = t[s];
     }
@@ -213,32 +269,73 @@ DEVI void wv_mm(const float* T, const float* B, Epi epi) {
     for (int nt = NT0; nt < NT1; ++nt) epi(nt, acc[nt - NT0]);
 }
 
+// q_ext / k / v / P of one (layer, head) travelling stash -> registers -> LDS (16 rows each;
+// rows beyond the real ones come from the dummy stash row: finite, and P's are exact zeros)
+struct HeadRegs {
+    f32x4 q[5], k[4], v[4], p;
+};
+DEVI void head_fetch(HeadRegs& r, const gfloat* sqkv, const gfloat* sp, int RA, bool need_qk, int lane) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int it = lane + 64 * u, row = min(it >> 4, RA), c4 = it & 15;
+        r.v[u] = ld_ntg4(sqkv + row * DFF_QKVW + 144 + 4 * c4);
+        if (need_qk) r.k[u] = ld_ntg4(sqkv + row * DFF_QKVW + 80 + 4 * c4);
+    }
+    if (need_qk) {
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int it = lane + 64 * u, row = min(it / 20, RA), c4 = it % 20;
+            r.q[u] = ld_ntg4(sqkv + row * DFF_QKVW + 4 * c4);
+        }
+    }
+    if (sp) r.p = ld_ntg4(sp + 4 * lane);
+}
+DEVI void head_commit(const HeadRegs& r, lfloat* Qx, lfloat* Kx, lfloat* Vx, lfloat* pb, bool need_qk, bool need_p, int lane) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int it = lane + 64 * u, row = it >> 4, c4 = it & 15;
+        *(lf32x4*)(Vx + row * DFF_XLD + 4 * c4) = r.v[u];
+        if (need_qk) *(lf32x4*)(Kx + row * DFF_XLD + 4 * c4) = r.k[u];
+    }
+    if (need_qk) {
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int it = lane + 64 * u, row = it / 20, c4 = it % 20;
+            *(lf32x4*)(Qx + row * DFF_XLD + 4 * c4) = r.q[u];
+        }
+    }
+    if (need_p) *(lf32x4*)(pb + (lane >> 2) * DFF_PLD + 4 * (lane & 3)) = r.p;
+}
+
 // ---------------------------------------------------------------- the kernel
 template <int H>
 __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelDev m, const DffRunArgs a) {
     using LL = SmallLds<H>;
-    constexpr int LH = LL::LH, F = 4 * H, NT_H = H / 16, KB_H = H / 16;
+    constexpr int LH = LL::LH, F = 4 * H, E = H / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int quad = lane >> 4, col = lane & 15;
+    const int tid = threadIdx.x;
+    // the wave index is wave-uniform: say so (readfirstlane), so that every per-wave pointer and
+    // weight-stream base lives in SGPRs and its arithmetic runs on the scalar unit
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = m.N, G = a.G;
     const int b0 = blockIdx.x * G;
     const int gcnt = min(G, a.B - b0);
     if (gcnt <= 0) return;
-    const int rows = gcnt * N, RA = G * N;   // real rows of this workgroup / rows per stash slot
-    float* const xst = smem + LL::xst; float* const xs = smem + LL::xs; float* const dxs = smem + LL::dxs;
-    float* const vst = smem + LL::vst; float* const cm = smem + LL::cm; float* const tn = smem + LL::tn;
-    float* const abuf = smem + LL::abuf; float* const resbuf = smem + LL::resbuf;
-    float* const part = smem + LL::part;
-    float* const dxw = smem + LL::dxw + wave * 64;
-    float* const wr = smem + LL::wreg + wave * DFF_WREG;
-    float* const Qx = wr; float* const Kx = wr + 16 * DFF_XLD; float* const Vx = wr + 2 * 16 * DFF_XLD;
-    float* const Gx = wr + 3 * 16 * DFF_XLD;
-    float* const pb = wr + 4 * 16 * DFF_XLD; float* const dsb = pb + 16 * DFF_PLD;
-    float* const hbuf = wr;          // FFN hidden slice of this wave (aliases the head buffers)
-    float* const mypart = part + wave * 16 * LH;
+    const int rows = gcnt * N, RA = G * N;   // real rows of this workgroup / dummy stash row index
+    lfloat* const sm = (lfloat*)smem;
+    lfloat* const xst = sm + LL::xst; lfloat* const xs = sm + LL::xs; lfloat* const dxs = sm + LL::dxs;
+    lfloat* const vst = sm + LL::vst; lfloat* const cm = sm + LL::cm; lfloat* const tn = sm + LL::tn;
+    lfloat* const abuf = sm + LL::abuf; lfloat* const resbuf = sm + LL::resbuf;
+    lfloat* const part = sm + LL::part;
+    lfloat* const dxw = sm + LL::dxw + wave * 128;
+    lfloat* const wr = sm + LL::wreg + wave * DFF_WREG;
+    lfloat* const Qx = wr; lfloat* const Kx = wr + 16 * DFF_XLD; lfloat* const Vx = wr + 2 * 16 * DFF_XLD;
+    lfloat* const Gx = wr + 3 * 16 * DFF_XLD;
+    lfloat* const pb = wr + 4 * 16 * DFF_XLD; lfloat* const dsb = pb + 16 * DFF_PLD;
+    lfloat* const hbuf = wr;          // FFN hidden slice of this wave (aliases the head buffers)
+    lfloat* const mypart = part + wave * 16 * LH;
     const SmallStash sl = dff_small_stash(N, G, H, m.L);
-    float* const stash = a.stash + (size_t)blockIdx.x * a.stash_stride;
+    gfloat* const stash = (gfloat*)a.stash + (size_t)blockIdx.x * a.stash_stride;
     Ctx c;  // only what bead_mean() needs
     c.N = N; c.G = G; c.gcnt = gcnt; c.rows = rows;
 
@@ -248,6 +345,23 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
     pf.on = (a.prof != nullptr) && blockIdx.x == 0 && tid == 0;
     pf.acc = (unsigned long long*)(smem + LL::prof);
     pf.last = __builtin_readcyclecounter();
+
+    // per-lane constants of the MFMA C layout, re-derived inside each block (see lane_id()):
+    // stash row (pad rows -> dummy row RA), dx slot, protein of column j (block-diagonal attention)
+#define DFF_LANE_CONSTS                                                      \
+    const int lane = lane_id(), quad = lane >> 4, col = lane & 15;           \
+    int srow[4], dxi[4];                                                     \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                          \
+        const int row_ = quad * 4 + r;                                       \
+        srow[r] = row_ < rows ? row_ : RA;                                   \
+        dxi[r] = (row_ < rows && col < 3) ? row_ * 4 + col : 64 + lane;      \
+    }                                                                        \
+    const int pj = col / N;                                                  \
+    (void)srow; (void)dxi; (void)pj;
+#define DFF_ROW_CONSTS                                  \
+    const int tq_ = tid_id();                           \
+    const int rrow = tq_ >> 4, sub = tq_ & 15;          \
+    const bool ract = rrow < rows;
 
     // ---- load state (as dff_fused_kernel) ----
     {
@@ -269,16 +383,35 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
         if (tid < gcnt) tn[tid] = (a.mode == DFF_MODE_SCORE) ? a.tnorm[b0 + tid] : a.t_norm;
         __syncthreads();
         if (a.mode == DFF_MODE_DDPM && a.init_prior) {
-            bead_mean(c, xst, cm);
+            bead_mean(c, (float*)xst, (float*)cm);
             __syncthreads();
             if (tid < rows * 4) xst[tid] -= cm[(tid >> 2) / N * 4 + (tid & 3)];
             __syncthreads();
         }
     }
-    // row-stage thread mapping: 16 lanes per row
-    const int rrow = tid >> 4, sub = tid & 15;
-    const bool ract = rrow < rows;
-    constexpr int HC = H / 16;
+    constexpr int HC = H / 16;   // row stages: 16 lanes per row, HC columns per lane
+
+    Ring<E> ring;
+    HeadRegs hr;
+    // weight streams of this wave (per layer lw): helpers
+    auto s_qkv = [&](const DffLayerDev& lw, int h) { return wide_stream(lw.Wqkvx_p, E, h * 13); };
+    auto s_wox = [&](const DffLayerDev& lw, int h) { return tall_stream(lw.Wox_p, DFF_HEADS * 5, h * 5); };
+    auto s_w1 = [&](const DffLayerDev& lw) { return wide_stream(lw.W1_p, E, wave * E); };
+    auto s_w2 = [&](const DffLayerDev& lw) { return tall_stream(lw.W2_p, F / 16, wave * E); };
+    auto s_w2t = [&](const DffLayerDev& lw) { return wide_stream(lw.W2T_p, E, wave * E); };
+    auto s_w1t = [&](const DffLayerDev& lw) { return tall_stream(lw.W1T_p, F / 16, wave * E); };
+    auto s_woxt = [&](const DffLayerDev& lw, int h) { return wide_stream(lw.WoxT_p, E, h * 5); };
+    auto s_qkvt = [&](const DffLayerDev& lw, int h) { return tall_stream(lw.WqkvxT_p, DFF_HEADS * 13, h * 13); };
+    // x extension of K_ext / V_ext: columns 64..79 = [x_j, 0 ...]
+    auto write_xext = [&](int lane) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = lane + 64 * e, row = idx >> 4, cc = idx & 15;
+            const float xv = (cc < 3 && row < rows) ? xs[row * 4 + cc] : 0.f;
+            Kx[row * DFF_XLD + 64 + cc] = xv;
+            Vx[row * DFF_XLD + 64 + cc] = xv;
+        }
+    };
 
     for (int step = 0; step < a.n_steps; ++step) {
         int t_int = 0;
@@ -286,30 +419,35 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
             t_int = a.t_start - step;
             if (tid < gcnt) tn[tid] = (1.0f * (float)t_int) / (float)m.T;
         }
-        bead_mean(c, xst, cm);
+        const bool cached0 = (a.mode == DFF_MODE_LANGEVIN) && step > 0;
+        // first weights of the first block (hidden behind the centring below)
+        { const int lane = lane_id();
+        if (cached0) {
+            const gfloat* sb0 = stash;
+            head_fetch(hr, sb0 + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
+            ring_prefetch<E>(ring, s_wox(m.layer[0], wave), lane);
+        } else {
+            ring_prefetch<E>(ring, s_qkv(m.layer[0], wave), lane);
+        } }
+        bead_mean(c, (float*)xst, (float*)cm);
         __syncthreads();
         if (tid < rows * 4) {
             const float xc = xst[tid] - cm[(tid >> 2) / N * 4 + (tid & 3)];
             if (a.mode == DFF_MODE_LANGEVIN) xst[tid] = xc;
             xs[tid] = xc;
         }
-        dxw[lane] = 0.f;                              // every wave clears its own partial
+        { const int ln = lane_id(); dxw[ln] = 0.f; dxw[64 + ln] = 0.f; }
         __syncthreads();
         if (a.mode == DFF_MODE_LANGEVIN) {
-            bead_mean(c, xs, cm);
+            bead_mean(c, (float*)xs, (float*)cm);
             __syncthreads();
             if (tid < rows * 4) xs[tid] -= cm[(tid >> 2) / N * 4 + (tid & 3)];
             __syncthreads();
         }
         pf.tick(0);
 
-        // x extension values this lane writes into K_ext / V_ext: entries (row, 64+cc), 4 per lane
-        // idx = lane + 64 e -> row = idx >> 4, cc = idx & 15
-        const bool cached0 = (a.mode == DFF_MODE_LANGEVIN) && step > 0;
-
         // =============================== forward ===============================
         if (!cached0) {
-            // node features of layer 0 -> resbuf, LN1 -> abuf
             for (int idx = tid; idx < rows * H; idx += DFF_NTHREADS) {
                 const int row = idx / H, cl = idx - row * H;
                 const int g = row / N, i = row - g * N;
@@ -319,21 +457,22 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
         }
         for (int l = 0; l < m.L; ++l) {
             const DffLayerDev& lw = m.layer[l];
-            float* const sb = stash + (size_t)l * sl.layer_stride;
+            gfloat* const sb = stash + (size_t)l * sl.layer_stride;
             const bool cached = cached0 && l == 0;
-            // ---- row stage A: (l == 0 only; later layers get LN1 fused into stage C) nodes -> stash, LN1 -> abuf
+            // ---- row stage A (layer 0 only; later layers get LN1 fused into stage C) ----
             if (l == 0) {
+                DFF_ROW_CONSTS
                 if (cached) {
                     if (ract) {
 #pragma unroll
-                        for (int i = 0; i < HC; ++i) resbuf[rrow * LH + sub + 16 * i] = ld_nt(sb + sl.nodes_in + rrow * H + sub + 16 * i);
+                        for (int i = 0; i < HC; ++i) resbuf[rrow * LH + sub + 16 * i] = ld_ntg(sb + sl.nodes_in + rrow * H + sub + 16 * i);
                     }
                 } else if (ract) {
                     float x[HC];
 #pragma unroll
                     for (int i = 0; i < HC; ++i) {
                         x[i] = resbuf[rrow * LH + sub + 16 * i];
-                        st_nt(sb + sl.nodes_in + rrow * H + sub + 16 * i, x[i]);
+                        st_ntg(sb + sl.nodes_in + rrow * H + sub + 16 * i, x[i]);
                     }
                     float mean, rstd;
                     ln_stats<H>(x, mean, rstd);
@@ -346,99 +485,104 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
                 __syncthreads();
             }
             pf.tick(1);
-            // ---- attention block: wave w owns heads w and w+4 ----
+            // ---- attention block: wave w owns heads w and w+4 (ring holds the first entries) ----
             {
-                f32x4 afr[KB_H];
-                if (!cached) load_afrag<KB_H>(afr, abuf, LH);
-                f32x4 acc_o[NT_H];
+                DFF_LANE_CONSTS
+                f32x4 acc_o[E];
 #pragma unroll
-                for (int nt = 0; nt < NT_H; ++nt) acc_o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                for (int hp = 0; hp < 2; ++hp) {
-                    const int h = wave + 4 * hp;
-                    float* const sq = sb + sl.qx + (size_t)h * RA * DFF_XH;
-                    float* const sk = sb + sl.k + (size_t)h * RA * 64;
-                    float* const sv = sb + sl.v + (size_t)h * RA * 64;
-                    if (cached) {
-                        // q_ext, k, v of layer 0 from the stash (rows x 80 / 64 / 64 floats)
-                        for (int it = lane; it < rows * 20; it += 64) {
-                            const int row = it / 20, c4 = it - row * 20;
-                            *(f32x4*)(Qx + row * DFF_XLD + 4 * c4) = __builtin_nontemporal_load((const f32x4*)(sq + row * DFF_XH + 4 * c4));
-                        }
-                        for (int it = lane; it < rows * 16; it += 64) {
-                            const int row = it >> 4, c4 = it & 15;
-                            *(f32x4*)(Kx + row * DFF_XLD + 4 * c4) = __builtin_nontemporal_load((const f32x4*)(sk + row * 64 + 4 * c4));
-                            *(f32x4*)(Vx + row * DFF_XLD + 4 * c4) = __builtin_nontemporal_load((const f32x4*)(sv + row * 64 + 4 * c4));
-                        }
-                    } else {
-                        // 13 tiles: [q 4 | u 1 | k 4 | v 4] of head h
-                        wv_wide<KB_H, 1>(afr, lw.Wqkvx_p, KB_H, h * 13, 13,
-                            [&](int t, float (&aux)[1]) { aux[0] = lw.bqkvx[(h * 13 + t) * 16 + col]; },
-                            [&](int t, const f32x4& acc, const float (&aux)[1]) {
-                                float* dl; float* ds; int ldS, c0;
-                                if (t < 5)      { dl = Qx; ds = sq; ldS = DFF_XH; c0 = 16 * t; }
-                                else if (t < 9) { dl = Kx; ds = sk; ldS = 64; c0 = 16 * (t - 5); }
-                                else            { dl = Vx; ds = sv; ldS = 64; c0 = 16 * (t - 9); }
+                for (int nt = 0; nt < E; ++nt) acc_o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const WStream after = s_w1(lw);   // the FFN block follows
+                auto head_math = [&](int h) {
+                    write_xext(lane);
+                    const f32x4 S = wv_dot_rows(Qx, Kx, lane);
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    const int row = quad * 4 + r;
-                                    if (row < rows) {
-                                        const float v = acc[r] + aux[0];
-                                        dl[row * DFF_XLD + c0 + col] = v;
-                                        st_nt(ds + row * ldS + c0 + col, v);
-                                    }
-                                }
-                            });
-                    }
-                    // x extension of K and V: columns 64..79 = [x_j, 0...]
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int idx = lane + 64 * e, row = idx >> 4, cc = idx & 15;
-                        const float xv = (cc < 3 && row < rows) ? xs[row * 4 + cc] : 0.f;
-                        Kx[row * DFF_XLD + 64 + cc] = xv;
-                        Vx[row * DFF_XLD + 64 + cc] = xv;
-                    }
-                    // logits (C layout: rows i = 4 quad + r, col j) + softmax over j
-                    const f32x4 S = wv_dot_rows(Qx, Kx);
-                    {
-                        const int pj = col / N;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int i = quad * 4 + r;
-                            const bool ok = (col < rows) && (i < rows) && (i / N == pj);
-                            const float s = ok ? S[r] * 0.125f : -INFINITY;
-                            float mx = s;
-                            mx = fmaxf(mx, __shfl_xor(mx, 8, 16)); mx = fmaxf(mx, __shfl_xor(mx, 4, 16));
-                            mx = fmaxf(mx, __shfl_xor(mx, 2, 16)); mx = fmaxf(mx, __shfl_xor(mx, 1, 16));
-                            const float e = ok ? expf(s - mx) : 0.f;
-                            const float den = grp16_sum(e);
-                            const float p = den > 0.f ? e / den : 0.f;
-                            pb[i * DFF_PLD + col] = p;
-                            if (i < rows) st_nt(sb + sl.P + ((size_t)h * RA + i) * 16 + col, p);
-                        }
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = quad * 4 + r;
+                        const bool ok = (col < rows) && (i < rows) && (i / N == pj);
+                        const float s = ok ? S[r] * 0.125f : -INFINITY;
+                        const float mx = row16_max(s);
+                        const float e = ok ? expf(s - mx) : 0.f;
+                        const float den = row16_sum(e);
+                        const float p = den > 0.f ? e / den : 0.f;
+                        pb[i * DFF_PLD + col] = p;
+                        st_ntg(sb + sl.P + ((size_t)h * 16 + i) * 16 + col, p);
                     }
                     // O_ext = P V_ext (5 tiles) -> Q region; extension columns become xrel = xbar - x_i
-                    wv_mm<0, 5, false>(pb, Vx, [&](int nt, const f32x4& acc) {
+                    wv_mm<0, 5, false>(pb, Vx, lane, [&](int nt, const f32x4& acc) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int row = quad * 4 + r;
-                            if (row < rows) {
-                                float v = acc[r];
-                                if (nt == 4 && col < 3) v -= xs[row * 4 + col];
-                                Qx[row * DFF_XLD + 16 * nt + col] = v;
-                            }
+                            float v = acc[r];
+                            if (nt == 4) v -= (col < 3) ? xs[(quad * 4 + r) * 4 + col] : 0.f;
+                            Qx[(quad * 4 + r) * DFF_XLD + 16 * nt + col] = v;
                         }
                     });
-                    // partial output projection: acc_o += O_ext(16x80) W_o_ext[h]  (K = 80)
-                    wv_tall<NT_H>(acc_o, 5,
-                        [&](int kb) { return Qx + col * DFF_XLD + 4 * quad + 16 * kb; },
-                        [&](int kb) { return h * 5 + kb; }, lw.Wox_p, DFF_HEADS * 5);
+                };
+                const lfloat* const wox_a = Qx + col * DFF_XLD + 4 * quad;
+                auto wox_fa = [=](int kb) { return wox_a + 16 * kb; };
+                if (cached) {
+                    // layer-0 q_ext / k / v are x-independent and t is fixed: re-read, no GEMM
+                    head_commit(hr, Qx, Kx, Vx, pb, true, false, lane);
+                    head_fetch(hr, sb + sl.qkv + (size_t)(wave + 4) * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
+                    head_math(wave);
+                    tall_run<0, 5, E>(ring, acc_o, wox_fa, s_wox(lw, wave), s_wox(lw, wave + 4), lane);
+                    head_commit(hr, Qx, Kx, Vx, pb, true, false, lane);
+                    head_math(wave + 4);
+                    tall_run<1, 5, E>(ring, acc_o, wox_fa, s_wox(lw, wave + 4), after, lane);
+                    // 10 entries consumed: entries 0,1 of `after` sit in slots 2,3 -- re-stage at phase 0
+                    ring_prefetch<E>(ring, after, lane);
+                } else {
+                    f32x4 afr[E];
+                    load_afrag<E>(afr, abuf, LH, lane);
+                    const gfloat* const bqkvx = (const gfloat*)lw.bqkvx;
+                    const int s0 = srow[0], s1 = srow[1], s2 = srow[2], s3 = srow[3];
+                    // bias of tile d goes to the aux slot of ring phase ph
+                    auto qkv_bias = [&](auto ph, int h, float (&bq)[DFF_DR][1]) {
+#pragma unroll
+                        for (int d = 0; d < DFF_DR; ++d) bq[(decltype(ph)::value + d) % DFF_DR][0] = bqkvx[(h * 13 + d) * 16 + col];
+                    };
+                    auto qkv = [&](auto ph, int h, float (&bq)[DFF_DR][1], const WStream& wnext) {
+                        gfloat* const sqkv = sb + sl.qkv + (size_t)h * (RA + 1) * DFF_QKVW + col;
+                        const gfloat* const bh = bqkvx + h * 13 * 16 + col;
+                        lfloat* const wq = wr + quad * 4 * DFF_XLD + col;
+                        wide_run<decltype(ph)::value, 13, E, 1>(ring, bq, afr, s_qkv(lw, h), wnext, lane,
+                            [=](int t, float (&ax)[1]) { ax[0] = bh[t * 16]; },
+                            [=](int t, const f32x4& acc, const float (&ax)[1]) {
+                                // tiles 0-4 -> Q_ext, 5-8 -> K, 9-12 -> V (t is wave-uniform); pure
+                                // arithmetic, no pointer select (a 3-way select becomes a stack table)
+                                const int reg = (t >= 5) + (t >= 9);
+                                const int cl = 16 * (t - 5 * reg + (reg >> 1));
+                                lfloat* const dl = wq + reg * (16 * DFF_XLD) + cl;
+                                gfloat* const ds = sqkv + 16 * t;
+                                const float v0 = acc[0] + ax[0], v1 = acc[1] + ax[0], v2 = acc[2] + ax[0], v3 = acc[3] + ax[0];
+                                dl[0] = v0; dl[DFF_XLD] = v1; dl[2 * DFF_XLD] = v2; dl[3 * DFF_XLD] = v3;
+                                st_ntg(ds + s0 * DFF_QKVW, v0); st_ntg(ds + s1 * DFF_QKVW, v1);
+                                st_ntg(ds + s2 * DFF_QKVW, v2); st_ntg(ds + s3 * DFF_QKVW, v3);
+                            });
+                    };
+                    float bq[DFF_DR][1];
+                    qkv_bias(std::integral_constant<int, 0>{}, wave, bq);
+                    pf.tick(1);
+                    qkv(std::integral_constant<int, 0>{}, wave, bq, s_wox(lw, wave));
+                    pf.tick(12);
+                    qkv_bias(std::integral_constant<int, 2>{}, wave + 4, bq);
+                    head_math(wave);
+                    pf.tick(13);
+                    tall_run<1, 5, E>(ring, acc_o, wox_fa, s_wox(lw, wave), s_qkv(lw, wave + 4), lane);
+                    pf.tick(14);
+                    qkv(std::integral_constant<int, 2>{}, wave + 4, bq, s_wox(lw, wave + 4));
+                    pf.tick(12);
+                    head_math(wave + 4);
+                    pf.tick(13);
+                    tall_run<3, 5, E>(ring, acc_o, wox_fa, s_wox(lw, wave + 4), after, lane);   // ends at phase 0
+                    pf.tick(14);
                 }
 #pragma unroll
-                for (int nt = 0; nt < NT_H; ++nt) c_store(mypart, LH, 16 * nt, acc_o[nt], rows);
+                for (int nt = 0; nt < E; ++nt) c_store_all(mypart, LH, 16 * nt, acc_o[nt], lane);
             }
             __syncthreads();
             pf.tick(2);
             // ---- row stage B: attn_out = sum_w part + bo ; gate1 ; LN2 -> abuf ----
+            { DFF_ROW_CONSTS
             if (ract) {
                 float x[HC], res[HC], n1[HC];
 #pragma unroll
@@ -446,7 +590,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
                     const int cl = sub + 16 * i, o = rrow * LH + cl;
                     x[i] = part[o] + part[16 * LH + o] + part[32 * LH + o] + part[48 * LH + o] + lw.bo[cl];
                     res[i] = resbuf[o];
-                    st_nt(sb + sl.attn_out + rrow * H + cl, x[i]);
+                    st_ntg(sb + sl.attn_out + rrow * H + cl, x[i]);
                 }
                 const float g = gate_value<H>(x, res, lw.g1, sub);
 #pragma unroll
@@ -461,38 +605,49 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
                     const int cl = sub + 16 * i;
                     abuf[rrow * LH + cl] = (n1[i] - mean) * rstd * lw.ln2_g[cl] + lw.ln2_b[cl];
                 }
-            }
+            } }
             __syncthreads();
             pf.tick(3);
             // ---- FFN: wave w owns hidden columns [w H, (w+1) H) ----
             {
-                f32x4 afr[KB_H];
-                load_afrag<KB_H>(afr, abuf, LH);
-                wv_wide<KB_H, 1>(afr, lw.W1_p, KB_H, wave * NT_H, NT_H,
-                    [&](int t, float (&aux)[1]) { aux[0] = lw.b1[wave * H + 16 * t + col]; },
-                    [&](int t, const f32x4& acc, const float (&aux)[1]) {
+                DFF_LANE_CONSTS
+                const bool lastl = l == m.L - 1;
+                const WStream after = lastl ? s_w2t(lw) : s_qkv(m.layer[lastl ? l : l + 1], wave);
+                f32x4 afr[E];
+                load_afrag<E>(afr, abuf, LH, lane);
+                float b1r[DFF_DR][1];
+                const gfloat* const b1p = (const gfloat*)lw.b1 + wave * H + col;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = quad * 4 + r;
-                            if (row < rows) {
-                                const float hp = acc[r] + aux[0];
-                                st_nt(sb + sl.h_pre + (size_t)row * F + wave * H + 16 * t + col, hp);
-                                hbuf[row * LH + 16 * t + col] = gelu_f(hp);
-                            }
-                        }
-                    });
-                f32x4 acc_f[NT_H];
+                for (int d = 0; d < DFF_DR; ++d) b1r[d][0] = b1p[16 * d];
+                {
+                    gfloat* const shp = sb + sl.h_pre + wave * H + col;
+                    lfloat* const hb = hbuf + quad * 4 * LH + col;
+                    const int s0 = srow[0] * F, s1 = srow[1] * F, s2 = srow[2] * F, s3 = srow[3] * F;
+                    wide_run<0, E, E, 1>(ring, b1r, afr, s_w1(lw), s_w2(lw), lane,
+                        [=](int t, float (&ax)[1]) { ax[0] = b1p[16 * t]; },
+                        [=](int t, const f32x4& acc, const float (&ax)[1]) {
+                            const float h0 = acc[0] + ax[0], h1 = acc[1] + ax[0], h2 = acc[2] + ax[0], h3 = acc[3] + ax[0];
+                            st_ntg(shp + s0 + 16 * t, h0); st_ntg(shp + s1 + 16 * t, h1);
+                            st_ntg(shp + s2 + 16 * t, h2); st_ntg(shp + s3 + 16 * t, h3);
+                            hb[16 * t] = gelu_f(h0); hb[LH + 16 * t] = gelu_f(h1);
+                            hb[2 * LH + 16 * t] = gelu_f(h2); hb[3 * LH + 16 * t] = gelu_f(h3);
+                        });
+                }
+                f32x4 acc_f[E];
 #pragma unroll
-                for (int nt = 0; nt < NT_H; ++nt) acc_f[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                wv_tall<NT_H>(acc_f, KB_H,
-                    [&](int kb) { return hbuf + col * LH + 4 * quad + 16 * kb; },
-                    [&](int kb) { return wave * KB_H + kb; }, lw.W2_p, F / 16);
+                for (int nt = 0; nt < E; ++nt) acc_f[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                {
+                    const lfloat* const ha = hbuf + col * LH + 4 * quad;
+                    tall_run<E % DFF_DR, E, E>(ring, acc_f, [=](int kb) { return ha + 16 * kb; }, s_w2(lw), after, lane);
+                }
+                if ((2 * E) % DFF_DR != 0) ring_prefetch<E>(ring, after, lane);
 #pragma unroll
-                for (int nt = 0; nt < NT_H; ++nt) c_store(mypart, LH, 16 * nt, acc_f[nt], rows);
+                for (int nt = 0; nt < E; ++nt) c_store_all(mypart, LH, 16 * nt, acc_f[nt], lane);
             }
             __syncthreads();
             pf.tick(4);
-            // ---- row stage C: ff = sum_w part + b2 ; gate2 ; then next layer's LN1 or the energy head ----
+            // ---- row stage C: ff = sum_w part + b2 ; gate2 ; next layer's LN1 or the energy head ----
+            { DFF_ROW_CONSTS
             if (ract) {
                 const bool last = l == m.L - 1;
                 float x[HC], res[HC], n2[HC];
@@ -501,7 +656,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
                     const int cl = sub + 16 * i, o = rrow * LH + cl;
                     x[i] = part[o] + part[16 * LH + o] + part[32 * LH + o] + part[48 * LH + o] + lw.b2[cl];
                     res[i] = resbuf[o];
-                    st_nt(sb + sl.ff + rrow * H + cl, x[i]);
+                    st_ntg(sb + sl.ff + rrow * H + cl, x[i]);
                 }
                 const float g = gate_value<H>(x, res, lw.g2, sub);
 #pragma unroll
@@ -515,43 +670,43 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
                         resbuf[rrow * LH + cl] = m.wdec[cl];   // dn = d(sum e)/d nodes_L
                     }
                     if (a.energy_out) {
-                        e = grp16_sum(e);
+                        e = row16_sum(e);
                         if (sub == 0) a.energy_out[(size_t)b0 * N + rrow] = e + m.bdec;
                     }
                 } else {
                     const DffLayerDev& ln = m.layer[l + 1];
-                    float* const sbn = stash + (size_t)(l + 1) * sl.layer_stride;
+                    gfloat* const sbn = stash + (size_t)(l + 1) * sl.layer_stride;
                     float mean, rstd;
                     ln_stats<H>(n2, mean, rstd);
 #pragma unroll
                     for (int i = 0; i < HC; ++i) {
                         const int cl = sub + 16 * i;
                         resbuf[rrow * LH + cl] = n2[i];
-                        st_nt(sbn + sl.nodes_in + rrow * H + cl, n2[i]);
+                        st_ntg(sbn + sl.nodes_in + rrow * H + cl, n2[i]);
                         abuf[rrow * LH + cl] = (n2[i] - mean) * rstd * ln.ln1_g[cl] + ln.ln1_b[cl];
                     }
                 }
-            }
+            } }
+            // the stash written in the forward pass is re-read below by other lanes / waves
+            if (l == m.L - 1) __threadfence_block();
             __syncthreads();
             pf.tick(5);
         }
 
-        // the stash written above is re-read below by other lanes / waves of this workgroup
-        __threadfence_block();
-        __syncthreads();
         // =============================== backward ===============================
         for (int l = m.L - 1; l >= 0; --l) {
             const DffLayerDev& lw = m.layer[l];
-            const float* const sb = stash + (size_t)l * sl.layer_stride;
+            const gfloat* const sb = stash + (size_t)l * sl.layer_stride;
             // ---- row stage D: gate2 backward: dn (resbuf) -> dff (abuf), dn1 partial (resbuf) ----
+            { DFF_ROW_CONSTS
             if (ract) {
                 float ao[HC], nin[HC], n1[HC], ff[HC], dn[HC];
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
                     const int cl = sub + 16 * i;
-                    ao[i] = ld_nt(sb + sl.attn_out + rrow * H + cl);
-                    nin[i] = ld_nt(sb + sl.nodes_in + rrow * H + cl);
-                    ff[i] = ld_nt(sb + sl.ff + rrow * H + cl);
+                    ao[i] = ld_ntg(sb + sl.attn_out + rrow * H + cl);
+                    nin[i] = ld_ntg(sb + sl.nodes_in + rrow * H + cl);
+                    ff[i] = ld_ntg(sb + sl.ff + rrow * H + cl);
                     dn[i] = resbuf[rrow * LH + cl];
                 }
                 const float g1 = gate_value<H>(ao, nin, lw.g1, sub);
@@ -561,7 +716,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
                 float dg = 0.f;
 #pragma unroll
                 for (int i = 0; i < HC; ++i) dg += dn[i] * (ff[i] - n1[i]);
-                dg = grp16_sum(dg);
+                dg = row16_sum(dg);
                 const float dz = dg * g2 * (1.0f - g2);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
@@ -569,48 +724,57 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
                     abuf[rrow * LH + cl] = dn[i] * g2 + dz * (lw.g2[cl] + lw.g2[2 * H + cl]);
                     resbuf[rrow * LH + cl] = dn[i] * (1.0f - g2) + dz * (lw.g2[H + cl] - lw.g2[2 * H + cl]);
                 }
-            }
+            } }
             __syncthreads();
             pf.tick(6);
             // ---- FFN backward slice: dh = dff W2[:, slice] ; * gelu'(h_pre) ; partial df = dh_pre W1[slice, :] ----
             {
-                f32x4 afr[KB_H];
-                load_afrag<KB_H>(afr, abuf, LH);
-                wv_wide<KB_H, 4>(afr, lw.W2T_p, KB_H, wave * NT_H, NT_H,
-                    [&](int t, float (&aux)[4]) {
+                DFF_LANE_CONSTS
+                const WStream after = s_woxt(lw, wave);
+                f32x4 afr[E];
+                load_afrag<E>(afr, abuf, LH, lane);
+                float hp[DFF_DR][4];
+                const gfloat* const shp = sb + sl.h_pre + wave * H + col;
+                const int s0 = srow[0] * F, s1 = srow[1] * F, s2 = srow[2] * F, s3 = srow[3] * F;
+                auto hp_load = [=](int t, float (&ax)[4]) {
+                    ax[0] = ld_ntg(shp + s0 + 16 * t); ax[1] = ld_ntg(shp + s1 + 16 * t);
+                    ax[2] = ld_ntg(shp + s2 + 16 * t); ax[3] = ld_ntg(shp + s3 + 16 * t);
+                };
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            int row = quad * 4 + r;
-                            row = row < rows ? row : rows - 1;
-                            aux[r] = ld_nt(sb + sl.h_pre + (size_t)row * F + wave * H + 16 * t + col);
-                        }
-                    },
-                    [&](int t, const f32x4& acc, const float (&aux)[4]) {
+                for (int d = 0; d < DFF_DR; ++d) hp_load(d, hp[d]);
+                {
+                    lfloat* const hb = hbuf + quad * 4 * LH + col;
+                    wide_run<0, E, E, 4>(ring, hp, afr, s_w2t(lw), s_w1t(lw), lane, hp_load,
+                        [=](int t, const f32x4& acc, const float (&ax)[4]) {
+                            hb[16 * t] = acc[0] * gelu_grad_f(ax[0]); hb[LH + 16 * t] = acc[1] * gelu_grad_f(ax[1]);
+                            hb[2 * LH + 16 * t] = acc[2] * gelu_grad_f(ax[2]); hb[3 * LH + 16 * t] = acc[3] * gelu_grad_f(ax[3]);
+                        });
+                }
+                f32x4 acc_f[E];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = quad * 4 + r;
-                            if (row < rows) hbuf[row * LH + 16 * t + col] = acc[r] * gelu_grad_f(aux[r]);
-                        }
-                    });
-                f32x4 acc_f[NT_H];
+                for (int nt = 0; nt < E; ++nt) acc_f[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                {
+                    const lfloat* const ha = hbuf + col * LH + 4 * quad;
+                    tall_run<E % DFF_DR, E, E>(ring, acc_f, [=](int kb) { return ha + 16 * kb; }, s_w1t(lw), after, lane);
+                }
+                if ((2 * E) % DFF_DR != 0) ring_prefetch<E>(ring, after, lane);
 #pragma unroll
-                for (int nt = 0; nt < NT_H; ++nt) acc_f[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                wv_tall<NT_H>(acc_f, KB_H,
-                    [&](int kb) { return hbuf + col * LH + 4 * quad + 16 * kb; },
-                    [&](int kb) { return wave * KB_H + kb; }, lw.W1T_p, F / 16);
-#pragma unroll
-                for (int nt = 0; nt < NT_H; ++nt) c_store(mypart, LH, 16 * nt, acc_f[nt], rows);
+                for (int nt = 0; nt < E; ++nt) c_store_all(mypart, LH, 16 * nt, acc_f[nt], lane);
             }
             __syncthreads();
             pf.tick(7);
+            // first head of this layer's attention backward: start the stash read (hidden by row stage E)
+            { const int lane = lane_id();
+            head_fetch(hr, sb + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, l > 0, lane); }
             // ---- row stage E: df = sum_w part ; LN2 backward ; gate1 backward -> dattn (abuf), dn_in partial (resbuf) ----
+            { DFF_ROW_CONSTS
             if (ract) {
                 float ao[HC], nin[HC], n1[HC], d1[HC], dyg[HC], xh[HC];
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
                     const int cl = sub + 16 * i;
-                    ao[i] = ld_nt(sb + sl.attn_out + rrow * H + cl);
-                    nin[i] = ld_nt(sb + sl.nodes_in + rrow * H + cl);
+                    ao[i] = ld_ntg(sb + sl.attn_out + rrow * H + cl);
+                    nin[i] = ld_ntg(sb + sl.nodes_in + rrow * H + cl);
                 }
                 const float g1 = gate_value<H>(ao, nin, lw.g1, sub);
 #pragma unroll
@@ -626,15 +790,15 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
                     s1 += dyg[i];
                     s2 += dyg[i] * xh[i];
                 }
-                s1 = grp16_sum(s1) * (1.0f / H);
-                s2 = grp16_sum(s2) * (1.0f / H);
+                s1 = row16_sum(s1) * (1.0f / H);
+                s2 = row16_sum(s2) * (1.0f / H);
                 float dg = 0.f;
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
                     d1[i] = resbuf[rrow * LH + sub + 16 * i] + rstd * (dyg[i] - s1 - xh[i] * s2);
                     dg += d1[i] * (ao[i] - nin[i]);
                 }
-                dg = grp16_sum(dg);
+                dg = row16_sum(dg);
                 const float dz = dg * g1 * (1.0f - g1);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
@@ -642,127 +806,144 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
                     abuf[rrow * LH + cl] = d1[i] * g1 + dz * (lw.g1[cl] + lw.g1[2 * H + cl]);
                     resbuf[rrow * LH + cl] = d1[i] * (1.0f - g1) + dz * (lw.g1[H + cl] - lw.g1[2 * H + cl]);
                 }
-            }
+            } }
             __syncthreads();
             pf.tick(8);
             // ---- attention backward: wave w owns heads w and w+4 ----
             {
-                f32x4 afr[KB_H];
-                load_afrag<KB_H>(afr, abuf, LH);   // dattn
-                f32x4 acc_a[NT_H];
+                DFF_LANE_CONSTS
+                f32x4 afr[E];
+                load_afrag<E>(afr, abuf, LH, lane);   // dattn
+                f32x4 acc_a[E];
 #pragma unroll
-                for (int nt = 0; nt < NT_H; ++nt) acc_a[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                for (int hp = 0; hp < 2; ++hp) {
-                    const int h = wave + 4 * hp;
-                    const float* const sq = sb + sl.qx + (size_t)h * RA * DFF_XH;
-                    const float* const sk = sb + sl.k + (size_t)h * RA * 64;
-                    const float* const sv = sb + sl.v + (size_t)h * RA * 64;
-                    // reload Q_ext, K, V, P of (l, h)
-                    for (int it = lane; it < rows * 20; it += 64) {
-                        const int row = it / 20, c4 = it - row * 20;
-                        *(f32x4*)(Qx + row * DFF_XLD + 4 * c4) = __builtin_nontemporal_load((const f32x4*)(sq + row * DFF_XH + 4 * c4));
-                    }
-                    for (int it = lane; it < rows * 16; it += 64) {
-                        const int row = it >> 4, c4 = it & 15;
-                        *(f32x4*)(Kx + row * DFF_XLD + 4 * c4) = __builtin_nontemporal_load((const f32x4*)(sk + row * 64 + 4 * c4));
-                        *(f32x4*)(Vx + row * DFF_XLD + 4 * c4) = __builtin_nontemporal_load((const f32x4*)(sv + row * 64 + 4 * c4));
-                    }
-                    for (int it = lane; it < rows * 4; it += 64) {
-                        const int row = it >> 2, c4 = it & 3;
-                        *(f32x4*)(pb + row * DFF_PLD + 4 * c4) = __builtin_nontemporal_load((const f32x4*)(sb + sl.P + ((size_t)h * RA + row) * 16 + 4 * c4));
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int idx = lane + 64 * e, row = idx >> 4, cc = idx & 15;
-                        const float xv = (cc < 3 && row < rows) ? xs[row * 4 + cc] : 0.f;
-                        Kx[row * DFF_XLD + 64 + cc] = xv;
-                        Vx[row * DFF_XLD + 64 + cc] = xv;
-                    }
-                    // G_ext = dattn W_o_ext[h]^T  (5 tiles: [G 64 | r 3 | 0]) -> G region ; dx_i -= r_i
-                    wv_wide<KB_H, 1>(afr, lw.WoxT_p, KB_H, h * 5, 5,
-                        [&](int, float (&)[1]) {},
-                        [&](int t, const f32x4& acc, const float (&)[1]) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int row = quad * 4 + r;
-                                if (row < rows) {
-                                    Gx[row * DFF_XLD + 16 * t + col] = acc[r];
-                                    if (t == 4 && col < 3) dxw[row * 4 + col] -= acc[r];
-                                }
-                            }
+                for (int nt = 0; nt < E; ++nt) acc_a[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                // what follows this block: FFN backward of layer l-1, or (after layer 0) next step's first GEMM
+                const bool more = (step + 1 < a.n_steps);
+                const WStream after = l > 0 ? s_w2t(m.layer[l - 1])
+                                            : (a.mode == DFF_MODE_LANGEVIN ? s_wox(m.layer[0], wave) : s_qkv(m.layer[0], wave));
+                (void)more;
+                // G_ext = dattn W_o_ext[h]^T  (5 tiles: [G 64 | r 3 | 0]) -> G region ; dx_i -= r_i
+                auto gext = [&](auto ph, int h, const WStream& wnext) {
+                    float none[DFF_DR][1] = {{0.f}, {0.f}, {0.f}, {0.f}};
+                    lfloat* const gb = Gx + quad * 4 * DFF_XLD + col;
+                    lfloat* const dxp = dxw;
+                    const int d0 = dxi[0], d1 = dxi[1], d2 = dxi[2], d3 = dxi[3];
+                    wide_run<decltype(ph)::value, 5, E, 1>(ring, none, afr, s_woxt(lw, h), wnext, lane,
+                        [=](int, float (&)[1]) {},
+                        [=](int t, const f32x4& acc, const float (&)[1]) {
+                            gb[16 * t] = acc[0]; gb[DFF_XLD + 16 * t] = acc[1];
+                            gb[2 * DFF_XLD + 16 * t] = acc[2]; gb[3 * DFF_XLD + 16 * t] = acc[3];
+                            if (t == 4) { dxp[d0] -= acc[0]; dxp[d1] -= acc[1]; dxp[d2] -= acc[2]; dxp[d3] -= acc[3]; }
                         });
-                    // dA = G_ext V_ext^T ; dS = scale * P (dA - sum_j P dA)
-                    const f32x4 dA = wv_dot_rows(Gx, Vx);
+                };
+                // dA = G_ext V_ext^T ; dS = scale * P (dA - sum_j P dA) -> dsb
+                auto ds_math = [&]() {
+                    write_xext(lane);
+                    const f32x4 dA = wv_dot_rows(Gx, Vx, lane);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int i = quad * 4 + r;
                         const float p = pb[i * DFF_PLD + col];
-                        const float sm = grp16_sum(p * dA[r]);
+                        const float sm = row16_sum(p * dA[r]);
                         dsb[i * DFF_PLD + col] = 0.125f * p * (dA[r] - sm);
                     }
-                    if (l > 0) {
-                        // dV_ext = P^T G_ext -> V region (ext columns: dx term sum_i a_ij r_i)
-                        wv_mm<0, 5, true>(pb, Gx, [&](int nt, const f32x4& acc) {
+                };
+                const int fa_off = col * DFF_XLD + 4 * quad;
+                lfloat* const gx_ = Gx; lfloat* const kx_ = Kx; lfloat* const vx_ = Vx;
+                auto qkvt_fa = [=](int kb) {
+                    const lfloat* base = kb < 5 ? gx_ + 16 * kb : kb < 9 ? kx_ + 16 * (kb - 5) : vx_ + 16 * (kb - 9);
+                    return base + fa_off;
+                };
+                auto dqkv = [&]() {
+                    // dV_ext = P^T G_ext -> V region (ext columns: dx term sum_i a_ij r_i)
+                    wv_mm<0, 5, true>(pb, Gx, lane, [&](int nt, const f32x4& acc) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int row = quad * 4 + r;
-                                if (row < rows) {
-                                    Vx[row * DFF_XLD + 16 * nt + col] = acc[r];
-                                    if (nt == 4 && col < 3) dxw[row * 4 + col] += acc[r];
-                                }
-                            }
-                        });
-                        // dQ_ext = dS K_ext -> G region (ext columns: du)
-                        wv_mm<0, 5, false>(dsb, Kx, [&](int nt, const f32x4& acc) { c_store(Gx, DFF_XLD, 16 * nt, acc, rows); });
-                        // dK_ext = dS^T Q_ext -> K region (ext columns: dx term sum_i dS_ij u_i)
-                        wv_mm<0, 5, true>(dsb, Qx, [&](int nt, const f32x4& acc) {
+                        for (int r = 0; r < 4; ++r) {
+                            Vx[(quad * 4 + r) * DFF_XLD + 16 * nt + col] = acc[r];
+                            if (nt == 4) dxw[dxi[r]] += acc[r];
+                        }
+                    });
+                    // dQ_ext = dS K_ext -> G region (ext columns: du)
+                    wv_mm<0, 5, false>(dsb, Kx, lane, [&](int nt, const f32x4& acc) { c_store_all(Gx, DFF_XLD, 16 * nt, acc, lane); });
+                    // dK_ext = dS^T Q_ext -> K region (ext columns: dx term sum_i dS_ij u_i)
+                    wv_mm<0, 5, true>(dsb, Qx, lane, [&](int nt, const f32x4& acc) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int row = quad * 4 + r;
-                                if (row < rows) {
-                                    Kx[row * DFF_XLD + 16 * nt + col] = acc[r];
-                                    if (nt == 4 && col < 3) dxw[row * 4 + col] += acc[r];
-                                }
-                            }
-                        });
-                        // d(LN1 out) partial += [dQ_ext | dK | dV] W_qkv_ext[h]   (K = 80 + 64 + 64)
-                        wv_tall<NT_H>(acc_a, 13,
-                            [&](int kb) {
-                                const float* base = kb < 5 ? Gx + 16 * kb : kb < 9 ? Kx + 16 * (kb - 5) : Vx + 16 * (kb - 9);
-                                return base + col * DFF_XLD + 4 * quad;
-                            },
-                            [&](int kb) { return h * 13 + kb; }, lw.WqkvxT_p, DFF_HEADS * 13);
-                    } else {
-                        // layer 0: node inputs do not depend on x -> only the x-gradient tiles
-                        wv_mm<4, 5, true>(pb, Gx, [&](int, const f32x4& acc) {
+                        for (int r = 0; r < 4; ++r) {
+                            Kx[(quad * 4 + r) * DFF_XLD + 16 * nt + col] = acc[r];
+                            if (nt == 4) dxw[dxi[r]] += acc[r];
+                        }
+                    });
+                };
+                auto dx_only = [&]() {   // layer 0: node inputs do not depend on x
+                    wv_mm<4, 5, true>(pb, Gx, lane, [&](int, const f32x4& acc) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int row = quad * 4 + r;
-                                if (row < rows && col < 3) dxw[row * 4 + col] += acc[r];
-                            }
-                        });
-                        wv_mm<4, 5, true>(dsb, Qx, [&](int, const f32x4& acc) {
+                        for (int r = 0; r < 4; ++r) dxw[dxi[r]] += acc[r];
+                    });
+                    wv_mm<4, 5, true>(dsb, Qx, lane, [&](int, const f32x4& acc) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int row = quad * 4 + r;
-                                if (row < rows && col < 3) dxw[row * 4 + col] += acc[r];
-                            }
-                        });
-                    }
-                }
+                        for (int r = 0; r < 4; ++r) dxw[dxi[r]] += acc[r];
+                    });
+                };
+                const int h1 = wave + 4;
                 if (l > 0) {
+                    head_commit(hr, Qx, Kx, Vx, pb, true, true, lane);
+                    head_fetch(hr, sb + sl.qkv + (size_t)h1 * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)h1 * 256, RA, true, lane);
+                    pf.tick(8);
+                    gext(std::integral_constant<int, 0>{}, wave, s_qkvt(lw, wave));
+                    pf.tick(15);
+                    ds_math();
+                    pf.tick(16);
+                    dqkv();
+                    pf.tick(17);
+                    tall_run<1, 13, E>(ring, acc_a, qkvt_fa, s_qkvt(lw, wave), s_woxt(lw, h1), lane);
+                    pf.tick(18);
+                    head_commit(hr, Qx, Kx, Vx, pb, true, true, lane);
+                    gext(std::integral_constant<int, 2>{}, h1, s_qkvt(lw, h1));
+                    pf.tick(15);
+                    ds_math();
+                    pf.tick(16);
+                    dqkv();
+                    pf.tick(17);
+                    tall_run<3, 13, E>(ring, acc_a, qkvt_fa, s_qkvt(lw, h1), after, lane);   // ends at phase 0
+                    pf.tick(18);
 #pragma unroll
-                    for (int nt = 0; nt < NT_H; ++nt) c_store(mypart, LH, 16 * nt, acc_a[nt], rows);
+                    for (int nt = 0; nt < E; ++nt) c_store_all(mypart, LH, 16 * nt, acc_a[nt], lane);
+                } else {
+                    // layer 0 needs q_ext (for the dS^T u term) but not k
+                    head_commit(hr, Qx, Kx, Vx, pb, false, true, lane);
+                    {   // q_ext of head `wave`
+                        const gfloat* sq = sb + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW;
+#pragma unroll
+                        for (int u = 0; u < 5; ++u) {
+                            const int it = lane + 64 * u, row = it / 20, c4 = it % 20;
+                            hr.q[u] = ld_ntg4(sq + min(row, RA) * DFF_QKVW + 4 * c4);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 5; ++u) {
+                            const int it = lane + 64 * u, row = it / 20, c4 = it % 20;
+                            *(lf32x4*)(Qx + row * DFF_XLD + 4 * c4) = hr.q[u];
+                        }
+                    }
+                    head_fetch(hr, sb + sl.qkv + (size_t)h1 * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)h1 * 256, RA, true, lane);
+                    gext(std::integral_constant<int, 0>{}, wave, s_woxt(lw, h1));
+                    ds_math();
+                    dx_only();
+                    head_commit(hr, Qx, Kx, Vx, pb, true, true, lane);
+                    gext(std::integral_constant<int, 1>{}, h1, after);
+                    ds_math();
+                    dx_only();
+                    // the next step (if any) re-stages its own first entries at phase 0
                 }
             }
             __syncthreads();
             pf.tick(9);
             // ---- row stage F: dn = dn_in partial + LN1 backward(sum_w part)  (l > 0) ----
             if (l > 0) {
+                DFF_ROW_CONSTS
                 if (ract) {
                     float nin[HC], dyg[HC], xh[HC];
 #pragma unroll
-                    for (int i = 0; i < HC; ++i) nin[i] = ld_nt(sb + sl.nodes_in + rrow * H + sub + 16 * i);
+                    for (int i = 0; i < HC; ++i) nin[i] = ld_ntg(sb + sl.nodes_in + rrow * H + sub + 16 * i);
                     float mean, rstd;
                     ln_stats<H>(nin, mean, rstd);
                     float s1 = 0.f, s2 = 0.f;
@@ -774,8 +955,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
                         s1 += dyg[i];
                         s2 += dyg[i] * xh[i];
                     }
-                    s1 = grp16_sum(s1) * (1.0f / H);
-                    s2 = grp16_sum(s2) * (1.0f / H);
+                    s1 = row16_sum(s1) * (1.0f / H);
+                    s2 = row16_sum(s2) * (1.0f / H);
 #pragma unroll
                     for (int i = 0; i < HC; ++i) resbuf[rrow * LH + sub + 16 * i] += rstd * (dyg[i] - s1 - xh[i] * s2);
                 }
@@ -785,8 +966,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
         }
         // dxs = sum of the 4 waves' partial x-gradients
         if (tid < 64) {
-            const float* d0 = smem + LL::dxw;
-            dxs[tid] = d0[tid] + d0[64 + tid] + d0[128 + tid] + d0[192 + tid];
+            const lfloat* d0 = sm + LL::dxw;
+            dxs[tid] = d0[tid] + d0[128 + tid] + d0[256 + tid] + d0[384 + tid];
         }
         __syncthreads();
 
@@ -825,7 +1006,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
             if (save && a.ke && !a.overdamped && tid < gcnt) {
                 float ke = 0.f;
                 for (int i = 0; i < N; ++i) {
-                    const float* vp = vst + (tid * N + i) * 4;
+                    const lfloat* vp = vst + (tid * N + i) * 4;
                     ke += a.mass[i] * (vp[0] * vp[0] + vp[1] * vp[1] + vp[2] * vp[2]);
                 }
                 a.ke[(size_t)fi * a.B + b0 + tid] = 0.5f * ke;
@@ -843,8 +1024,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
             }
             if (tid < rows * 4) { dxs[tid] = eps; xs[tid] = xi; }
             __syncthreads();
-            bead_mean(c, dxs, cm);
-            bead_mean(c, xs, cm + 64);
+            bead_mean(c, (float*)dxs, (float*)cm);
+            bead_mean(c, (float*)xs, (float*)(cm + 64));
             __syncthreads();
             const float x = act ? xst[tid] : 0.f;
             float x0 = 0.f;
@@ -856,7 +1037,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
             __syncthreads();
             if (tid < rows * 4) dxs[tid] = x0;
             __syncthreads();
-            bead_mean(c, dxs, cm);
+            bead_mean(c, (float*)dxs, (float*)cm);
             __syncthreads();
             float xn = 0.f;
             if (act) {
@@ -872,7 +1053,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
             __syncthreads();
             if (tid < rows * 4) dxs[tid] = xn;
             __syncthreads();
-            bead_mean(c, dxs, cm);
+            bead_mean(c, (float*)dxs, (float*)cm);
             __syncthreads();
             if (act) xst[tid] = xn - cm[g * 4 + cc];
         }
