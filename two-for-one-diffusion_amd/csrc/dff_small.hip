@@ -393,6 +393,29 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
 
     Ring<E> ring;
     HeadRegs hr;
+    // Row-stage operand registers: every row stage ends by issuing the (global) loads of the NEXT
+    // row stage's per-column parameters and stashed activations -- the thread<->(row, column)
+    // mapping is the same in all row stages -- so they are in flight during the wave-private block
+    // in between and the row stages themselves never wait on global memory.
+    float ro[9][HC];
+    auto ro_load = [&](int k, const float* src, int sub) {
+        const gfloat* g = (const gfloat*)src;
+#pragma unroll
+        for (int i = 0; i < HC; ++i) ro[k][i] = g[sub + 16 * i];
+    };
+    auto ro_load3 = [&](int k, const float* w, int sub) {   // gate weights [x | res | x-res]
+        ro_load(k, w, sub); ro_load(k + 1, w + H, sub); ro_load(k + 2, w + 2 * H, sub);
+    };
+    auto ro_gate = [&](const float (&x)[HC], const float (&res)[HC], int k) {
+        float z = 0.f;
+#pragma unroll
+        for (int i = 0; i < HC; ++i) z += x[i] * ro[k][i] + res[i] * ro[k + 1][i] + (x[i] - res[i]) * ro[k + 2][i];
+        return sigmoid_f(row16_sum(z));
+    };
+    // stage B operands: bo, g1 (3), ln2 gamma, ln2 beta
+    auto pre_B = [&](const DffLayerDev& w, int sub) {
+        ro_load(0, w.bo, sub); ro_load3(1, w.g1, sub); ro_load(4, w.ln2_g, sub); ro_load(5, w.ln2_b, sub);
+    };
     // weight streams of this wave (per layer lw): helpers
     auto s_qkv = [&](const DffLayerDev& lw, int h) { return wide_stream(lw.Wqkvx_p, E, h * 13); };
     auto s_wox = [&](const DffLayerDev& lw, int h) { return tall_stream(lw.Wox_p, DFF_HEADS * 5, h * 5); };
@@ -482,6 +505,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
                         abuf[rrow * LH + cl] = (x[i] - mean) * rstd * lw.ln1_g[cl] + lw.ln1_b[cl];
                     }
                 }
+                if (ract) pre_B(lw, sub);
                 __syncthreads();
             }
             pf.tick(1);
@@ -588,11 +612,11 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
                     const int cl = sub + 16 * i, o = rrow * LH + cl;
-                    x[i] = part[o] + part[16 * LH + o] + part[32 * LH + o] + part[48 * LH + o] + lw.bo[cl];
+                    x[i] = part[o] + part[16 * LH + o] + part[32 * LH + o] + part[48 * LH + o] + ro[0][i];
                     res[i] = resbuf[o];
                     st_ntg(sb + sl.attn_out + rrow * H + cl, x[i]);
                 }
-                const float g = gate_value<H>(x, res, lw.g1, sub);
+                const float g = ro_gate(x, res, 1);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
                     n1[i] = x[i] * g + res[i] * (1.0f - g);
@@ -601,10 +625,10 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
                 float mean, rstd;
                 ln_stats<H>(n1, mean, rstd);
 #pragma unroll
-                for (int i = 0; i < HC; ++i) {
-                    const int cl = sub + 16 * i;
-                    abuf[rrow * LH + cl] = (n1[i] - mean) * rstd * lw.ln2_g[cl] + lw.ln2_b[cl];
-                }
+                for (int i = 0; i < HC; ++i) abuf[rrow * LH + sub + 16 * i] = (n1[i] - mean) * rstd * ro[4][i] + ro[5][i];
+                // stage C operands: b2, g2 (3), and the next layer's LN1 gamma / beta
+                ro_load(0, lw.b2, sub); ro_load3(1, lw.g2, sub);
+                if (l + 1 < m.L) { ro_load(4, m.layer[l + 1].ln1_g, sub); ro_load(5, m.layer[l + 1].ln1_b, sub); }
             } }
             __syncthreads();
             pf.tick(3);
@@ -654,11 +678,11 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
                     const int cl = sub + 16 * i, o = rrow * LH + cl;
-                    x[i] = part[o] + part[16 * LH + o] + part[32 * LH + o] + part[48 * LH + o] + lw.b2[cl];
+                    x[i] = part[o] + part[16 * LH + o] + part[32 * LH + o] + part[48 * LH + o] + ro[0][i];
                     res[i] = resbuf[o];
                     st_ntg(sb + sl.ff + rrow * H + cl, x[i]);
                 }
-                const float g = gate_value<H>(x, res, lw.g2, sub);
+                const float g = ro_gate(x, res, 1);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) n2[i] = x[i] * g + res[i] * (1.0f - g);
                 if (last) {
@@ -666,15 +690,22 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
 #pragma unroll
                     for (int i = 0; i < HC; ++i) {
                         const int cl = sub + 16 * i;
-                        e += n2[i] * m.wdec[cl];
-                        resbuf[rrow * LH + cl] = m.wdec[cl];   // dn = d(sum e)/d nodes_L
+                        const float wd = m.wdec[cl];
+                        e += n2[i] * wd;
+                        resbuf[rrow * LH + cl] = wd;   // dn = d(sum e)/d nodes_L
                     }
                     if (a.energy_out) {
                         e = row16_sum(e);
                         if (sub == 0) a.energy_out[(size_t)b0 * N + rrow] = e + m.bdec;
                     }
+                    // stage D operands of this (last) layer: attn_out, nodes_in from the stash, ff (kept),
+                    // g1 (3), g2 (3 -- already in ro[1..3], move up)
+#pragma unroll
+                    for (int i = 0; i < HC; ++i) { ro[6][i] = ro[1][i]; ro[7][i] = ro[2][i]; ro[8][i] = ro[3][i]; ro[2][i] = x[i]; }
+                    ro_load(0, (const float*)(sb + sl.attn_out + rrow * H), sub);
+                    ro_load(1, (const float*)(sb + sl.nodes_in + rrow * H), sub);
+                    ro_load3(3, lw.g1, sub);
                 } else {
-                    const DffLayerDev& ln = m.layer[l + 1];
                     gfloat* const sbn = stash + (size_t)(l + 1) * sl.layer_stride;
                     float mean, rstd;
                     ln_stats<H>(n2, mean, rstd);
@@ -683,8 +714,9 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
                         const int cl = sub + 16 * i;
                         resbuf[rrow * LH + cl] = n2[i];
                         st_ntg(sbn + sl.nodes_in + rrow * H + cl, n2[i]);
-                        abuf[rrow * LH + cl] = (n2[i] - mean) * rstd * ln.ln1_g[cl] + ln.ln1_b[cl];
+                        abuf[rrow * LH + cl] = (n2[i] - mean) * rstd * ro[4][i] + ro[5][i];
                     }
+                    pre_B(m.layer[l + 1], sub);
                 }
             } }
             // the stash written in the forward pass is re-read below by other lanes / waves
@@ -698,32 +730,29 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
             const DffLayerDev& lw = m.layer[l];
             const gfloat* const sb = stash + (size_t)l * sl.layer_stride;
             // ---- row stage D: gate2 backward: dn (resbuf) -> dff (abuf), dn1 partial (resbuf) ----
+            // operands (prefetched): ro[0] attn_out, ro[1] nodes_in, ro[2] ff, ro[3..5] g1, ro[6..8] g2
             { DFF_ROW_CONSTS
             if (ract) {
-                float ao[HC], nin[HC], n1[HC], ff[HC], dn[HC];
+                float n1[HC], dn[HC];
 #pragma unroll
-                for (int i = 0; i < HC; ++i) {
-                    const int cl = sub + 16 * i;
-                    ao[i] = ld_ntg(sb + sl.attn_out + rrow * H + cl);
-                    nin[i] = ld_ntg(sb + sl.nodes_in + rrow * H + cl);
-                    ff[i] = ld_ntg(sb + sl.ff + rrow * H + cl);
-                    dn[i] = resbuf[rrow * LH + cl];
-                }
-                const float g1 = gate_value<H>(ao, nin, lw.g1, sub);
+                for (int i = 0; i < HC; ++i) dn[i] = resbuf[rrow * LH + sub + 16 * i];
+                const float g1 = ro_gate(ro[0], ro[1], 3);
 #pragma unroll
-                for (int i = 0; i < HC; ++i) n1[i] = ao[i] * g1 + nin[i] * (1.0f - g1);
-                const float g2 = gate_value<H>(ff, n1, lw.g2, sub);
+                for (int i = 0; i < HC; ++i) n1[i] = ro[0][i] * g1 + ro[1][i] * (1.0f - g1);
+                const float g2 = ro_gate(ro[2], n1, 6);
                 float dg = 0.f;
 #pragma unroll
-                for (int i = 0; i < HC; ++i) dg += dn[i] * (ff[i] - n1[i]);
+                for (int i = 0; i < HC; ++i) dg += dn[i] * (ro[2][i] - n1[i]);
                 dg = row16_sum(dg);
                 const float dz = dg * g2 * (1.0f - g2);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
                     const int cl = sub + 16 * i;
-                    abuf[rrow * LH + cl] = dn[i] * g2 + dz * (lw.g2[cl] + lw.g2[2 * H + cl]);
-                    resbuf[rrow * LH + cl] = dn[i] * (1.0f - g2) + dz * (lw.g2[H + cl] - lw.g2[2 * H + cl]);
+                    abuf[rrow * LH + cl] = dn[i] * g2 + dz * (ro[6][i] + ro[8][i]);
+                    resbuf[rrow * LH + cl] = dn[i] * (1.0f - g2) + dz * (ro[7][i] - ro[8][i]);
                 }
+                // stage E operands: attn_out, nodes_in, g1 stay; LN2 gamma -> ro[2]
+                ro_load(2, lw.ln2_g, sub);
             } }
             __syncthreads();
             pf.tick(6);
@@ -767,26 +796,21 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
             { const int lane = lane_id();
             head_fetch(hr, sb + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, l > 0, lane); }
             // ---- row stage E: df = sum_w part ; LN2 backward ; gate1 backward -> dattn (abuf), dn_in partial (resbuf) ----
+            // operands: ro[0] attn_out, ro[1] nodes_in, ro[2] ln2 gamma, ro[3..5] g1
             { DFF_ROW_CONSTS
             if (ract) {
-                float ao[HC], nin[HC], n1[HC], d1[HC], dyg[HC], xh[HC];
+                float n1[HC], d1[HC], dyg[HC], xh[HC];
+                const float g1 = ro_gate(ro[0], ro[1], 3);
 #pragma unroll
-                for (int i = 0; i < HC; ++i) {
-                    const int cl = sub + 16 * i;
-                    ao[i] = ld_ntg(sb + sl.attn_out + rrow * H + cl);
-                    nin[i] = ld_ntg(sb + sl.nodes_in + rrow * H + cl);
-                }
-                const float g1 = gate_value<H>(ao, nin, lw.g1, sub);
-#pragma unroll
-                for (int i = 0; i < HC; ++i) n1[i] = ao[i] * g1 + nin[i] * (1.0f - g1);
+                for (int i = 0; i < HC; ++i) n1[i] = ro[0][i] * g1 + ro[1][i] * (1.0f - g1);
                 float mean, rstd;
                 ln_stats<H>(n1, mean, rstd);
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
-                    const int cl = sub + 16 * i, o = rrow * LH + cl;
+                    const int o = rrow * LH + sub + 16 * i;
                     xh[i] = (n1[i] - mean) * rstd;
-                    dyg[i] = (part[o] + part[16 * LH + o] + part[32 * LH + o] + part[48 * LH + o]) * lw.ln2_g[cl];
+                    dyg[i] = (part[o] + part[16 * LH + o] + part[32 * LH + o] + part[48 * LH + o]) * ro[2][i];
                     s1 += dyg[i];
                     s2 += dyg[i] * xh[i];
                 }
@@ -796,16 +820,18 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
                     d1[i] = resbuf[rrow * LH + sub + 16 * i] + rstd * (dyg[i] - s1 - xh[i] * s2);
-                    dg += d1[i] * (ao[i] - nin[i]);
+                    dg += d1[i] * (ro[0][i] - ro[1][i]);
                 }
                 dg = row16_sum(dg);
                 const float dz = dg * g1 * (1.0f - g1);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
                     const int cl = sub + 16 * i;
-                    abuf[rrow * LH + cl] = d1[i] * g1 + dz * (lw.g1[cl] + lw.g1[2 * H + cl]);
-                    resbuf[rrow * LH + cl] = d1[i] * (1.0f - g1) + dz * (lw.g1[H + cl] - lw.g1[2 * H + cl]);
+                    abuf[rrow * LH + cl] = d1[i] * g1 + dz * (ro[3][i] + ro[5][i]);
+                    resbuf[rrow * LH + cl] = d1[i] * (1.0f - g1) + dz * (ro[4][i] - ro[5][i]);
                 }
+                // stage F operands: nodes_in stays in ro[1]; LN1 gamma -> ro[2]
+                if (l > 0) ro_load(2, lw.ln1_g, sub);
             } }
             __syncthreads();
             pf.tick(8);
@@ -938,20 +964,19 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
             __syncthreads();
             pf.tick(9);
             // ---- row stage F: dn = dn_in partial + LN1 backward(sum_w part)  (l > 0) ----
+            // operands: ro[1] nodes_in, ro[2] ln1 gamma
             if (l > 0) {
                 DFF_ROW_CONSTS
                 if (ract) {
-                    float nin[HC], dyg[HC], xh[HC];
-#pragma unroll
-                    for (int i = 0; i < HC; ++i) nin[i] = ld_ntg(sb + sl.nodes_in + rrow * H + sub + 16 * i);
+                    float dyg[HC], xh[HC];
                     float mean, rstd;
-                    ln_stats<H>(nin, mean, rstd);
+                    ln_stats<H>(ro[1], mean, rstd);
                     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                     for (int i = 0; i < HC; ++i) {
-                        const int cl = sub + 16 * i, o = rrow * LH + cl;
-                        xh[i] = (nin[i] - mean) * rstd;
-                        dyg[i] = (part[o] + part[16 * LH + o] + part[32 * LH + o] + part[48 * LH + o]) * lw.ln1_g[cl];
+                        const int o = rrow * LH + sub + 16 * i;
+                        xh[i] = (ro[1][i] - mean) * rstd;
+                        dyg[i] = (part[o] + part[16 * LH + o] + part[32 * LH + o] + part[48 * LH + o]) * ro[2][i];
                         s1 += dyg[i];
                         s2 += dyg[i] * xh[i];
                     }
@@ -959,6 +984,13 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
                     s2 = row16_sum(s2) * (1.0f / H);
 #pragma unroll
                     for (int i = 0; i < HC; ++i) resbuf[rrow * LH + sub + 16 * i] += rstd * (dyg[i] - s1 - xh[i] * s2);
+                    // stage D operands of layer l-1
+                    const DffLayerDev& lp = m.layer[l - 1];
+                    const gfloat* const sp = stash + (size_t)(l - 1) * sl.layer_stride;
+                    ro_load(0, (const float*)(sp + sl.attn_out + rrow * H), sub);
+                    ro_load(1, (const float*)(sp + sl.nodes_in + rrow * H), sub);
+                    ro_load(2, (const float*)(sp + sl.ff + rrow * H), sub);
+                    ro_load3(3, lp.g1, sub); ro_load3(6, lp.g2, sub);
                 }
                 __syncthreads();
             }
