@@ -1,0 +1,170 @@
+"""Host-side logic that needs no GPU: C-ABI export check, weight flattening / checkpoint key
+handling, CLI parsing, PDB writer, batch grouping and the multi-rank sharding (gloo, world 2)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+import torch
+
+import dff_amd
+from dff_amd import binding, cli, pdbio, sampling, specs, weights
+from oracle import synth
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def test_library_exports_every_declared_symbol():
+    """Every function include/dff.h declares is exported by libdff_amd.so (no compute calls)."""
+    header = open(os.path.join(ROOT, "include", "dff.h")).read()
+    declared = set(re.findall(r"\b(dff_[a-z_0-9]+)\s*\(", header))
+    declared -= {"dff_model", "dff_config", "dff_langevin_params"}
+    assert declared == set(binding.SYMBOLS), (declared ^ set(binding.SYMBOLS))
+    lib = binding.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.dff_version()
+
+
+def test_weight_count_and_bad_configs_without_gpu():
+    lib = binding.load_library()
+    for cfg, (_, N, H, L) in synth.SHIPPED_CONFIGS.items():
+        c = binding.DffConfig(N, H, L, 1000, 1, 0, 0, 1)
+        assert lib.dff_weight_count(ctypes.byref(c)) == synth.count_params(N, H, L)
+    # unsupported branch (use_distances) is rejected before any device work
+    c = binding.DffConfig(10, 64, 3, 1000, 1, 1, 0, 1)
+    w = np.zeros(synth.count_params(10, 64, 3), np.float32)
+    h = ctypes.c_void_p()
+    rc = lib.dff_model_create(ctypes.byref(c), w.ctypes.data_as(ctypes.c_void_p), w.size, 0, ctypes.byref(h))
+    assert rc == 1 and b"use_intrinsic_coords" in lib.dff_last_error()
+    c = binding.DffConfig(10, 80, 3, 1000, 1, 0, 0, 1)
+    rc = lib.dff_model_create(ctypes.byref(c), w.ctypes.data_as(ctypes.c_void_p), w.size, 0, ctypes.byref(h))
+    assert rc == 1 and b"hidden" in lib.dff_last_error()
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(binding.DffLibraryError):
+        binding.load_library(str(tmp_path / "nope.so"))
+
+
+def test_flatten_order_and_shape_checks():
+    _, N, H, L = synth.SHIPPED_CONFIGS["chignolin"]
+    params = synth.synth_gnn_params(N, H, L)
+    flat = weights.flatten_gnn_params(params, N, H, L)
+    assert flat.dtype == np.float32 and flat.size == synth.count_params(N, H, L)
+    # the ABI order is the reference's registration order == synth.param_specs order
+    assert [k for k, _, _, _ in synth.param_specs(N, H, L)] == weights.abi_key_order(L)
+    off = 0
+    for k in weights.abi_key_order(L):
+        n = params[k].size
+        np.testing.assert_array_equal(flat[off:off + n], params[k].reshape(-1))
+        off += n
+    bad = dict(params)
+    bad["node_decoder.weight"] = np.zeros((2, H), np.float32)
+    with pytest.raises(ValueError):
+        weights.flatten_gnn_params(bad, N, H, L)
+    del bad["node_decoder.weight"]
+    with pytest.raises(KeyError):
+        weights.flatten_gnn_params(bad, N, H, L)
+
+
+def test_checkpoint_layouts():
+    _, N, H, L = synth.SHIPPED_CONFIGS["ala2"]
+    params = {k: torch.from_numpy(v) for k, v in synth.synth_gnn_params(N, H, L).items()}
+    gd = {"betas": torch.zeros(1000)}
+    gd.update({"model." + k: v for k, v in params.items()})
+    ema = {"initted": torch.tensor(True), "step": torch.tensor(5)}
+    ema.update({"ema_model." + k: v for k, v in gd.items()})
+    ema.update({"online_model." + k: v * 0 for k, v in gd.items()})  # must NOT be picked
+    for data in ({"ema": ema, "model": gd, "step": 3}, {"model": gd}, gd, params):
+        got = weights.gnn_params_from_checkpoint(data)
+        assert set(got) == set(params)
+        assert torch.equal(got["node_decoder.weight"], params["node_decoder.weight"])
+    with pytest.raises(KeyError):
+        weights.gnn_params_from_checkpoint({"ema": {"foo": 1}})
+
+
+def test_cli_flags_match_reference():
+    p = cli.build_parser()
+    a = p.parse_args(["--model_path", "m"])
+    assert (a.model_checkpoint, a.gen_mode, a.num_samples_eval, a.batch_size_gen) == ("best", "iid", 1000, 256)
+    assert (a.friction, a.parallel_sim, a.n_timesteps, a.save_interval, a.noise_level) == (1, 100, 10000, 250, 20)
+    assert a.dt is None and a.temp_data is None and a.temp_sim is None and a.kb == "consistent" and a.masses is None
+    a = p.parse_args(["--model_path", "m", "--masses", "[12.0]*10", "--gen_mode", "langevin"])
+    assert a.masses == [12.0] * 10
+    assert p.parse_args(["--model_path", "m", "--masses", "[1, 2.5] + [3]*2"]).masses == [1.0, 2.5, 3.0, 3.0]
+    with pytest.raises(SystemExit):
+        p.parse_args(["--model_path", "m", "--masses", "__import__('os').system('true')"])
+    with pytest.raises(SystemExit):
+        p.parse_args([])  # --model_path required
+
+
+def test_specs_tables():
+    # bead counts: datasets/folded_pdbs CA records; std: dataset_utils_empty.py:38-48
+    assert [specs.lookup(m).n_beads for m in ("CHIGNOLIN", "TRP_CAGE", "BBA", "VILLIN", "PROTEIN_G")] == [10, 20, 28, 35, 56]
+    assert specs.lookup("alanine_dipeptide_fuberlin").n_beads == 5
+    assert specs.norm_std("CHIGNOLIN") == 3.113133430480957
+    assert specs.norm_std("alanine_dipeptide_fuberlin", fold=3) == 0.9452606439590454
+    assert specs.default_masses("alanine_dipeptide_fuberlin") == [12.8] * 5
+    assert specs.default_masses("VILLIN") == [12.0] * 35
+    with pytest.raises(NotImplementedError):
+        specs.lookup("unknown")
+
+
+def test_pdb_writer(tmp_path):
+    xyz = np.arange(2 * 10 * 3, dtype=np.float32).reshape(2, 10, 3) / 7.0
+    out = tmp_path / "s.pdb"
+    pdbio.save_pdb(str(out), xyz, "CHIGNOLIN")
+    txt = out.read_text().splitlines()
+    atoms = [l for l in txt if l.startswith("ATOM")]
+    assert len(atoms) == 20 and sum(l.startswith("MODEL") for l in txt) == 2 and txt[-1] == "END"
+    first = atoms[0]
+    assert first[12:16].strip() == "CA" and first[17:20] == "TYR"
+    assert float(first[30:38]) == pytest.approx(0.0) and float(atoms[1][30:38]) == pytest.approx(3 / 7, abs=1e-3)
+    with pytest.raises(ValueError):
+        pdbio.save_pdb(str(out), xyz[:, :5], "CHIGNOLIN")
+
+
+def test_grouping_and_sharding():
+    assert sampling.num_to_groups(1000, 256) == [256, 256, 256, 232]
+    for total, world in [(256, 8), (100000, 8), (7, 3), (3, 8)]:
+        spans = [sampling.shard_range(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+_GLOO_WORKER = textwrap.dedent("""
+    import os, sys, torch, torch.distributed as dist
+    sys.path.insert(0, {root!r})
+    import dff_amd
+    from dff_amd import sampling
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    total = 7
+    lo, hi = sampling.shard_range(total, rank, world)
+    local = torch.arange(lo, hi, dtype=torch.float32).reshape(-1, 1, 1).repeat(1, 2, 3)  # unit i holds value i
+    full = sampling.gather_variable(local, total, world)
+    assert full.shape == (total, 2, 3), full.shape
+    assert torch.equal(full[:, 0, 0], torch.arange(total, dtype=torch.float32)), full[:, 0, 0]
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.stdout.write("rank%d-ok;" % rank); sys.stdout.flush()
+""")
+
+
+def test_two_rank_gather_gloo(tmp_path):
+    """The N>1 path on CPU: shard_range + the single all_gather, world_size 2, gloo backend."""
+    script = tmp_path / "w.py"
+    script.write_text(_GLOO_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29731", str(script)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("-ok") == 2 and "rank0" in r.stdout and "rank1" in r.stdout, r.stdout
