@@ -270,3 +270,88 @@ def test_iid_sample_properties(dff):
     assert a.shape == (6, 5, 3) and torch.isfinite(a).all() and torch.equal(a, b)
     assert (a / NORM_STD["ala2"]).mean(1).abs().max().item() < 1e-3
     assert a.std().item() > 1e-3
+
+
+def _write_model_dir(path, cfg, decoder_scale=1e-2):
+    """A saved_models/<mol>-style directory in the reference's format: args.pickle (argparse
+    Namespace that also pickles an nn.Module, as the shipped ones do) + model-best.pt whose
+    ["ema"] entry is an EMA(GaussianDiffusion) state-dict (trainer.py:181-206, sample.py:154-167)."""
+    import argparse
+    import pickle
+    mol, N, H, L = synth.SHIPPED_CONFIGS[cfg]
+    ns = argparse.Namespace(mol=mol, mean0=True, fold=1, shuffle_data_before_splitting=True, scale_data=True,
+                            backbone_network="graph-transformer", hidden_features_gnn=H, num_layers_gnn=L,
+                            use_intrinsic_coords=True, use_abs_coords=False, use_distances=False, conservative=True,
+                            diffusion_steps=1000, loss_weights="higheruntil_100", activation=torch.nn.Tanh())
+    with open(path / "args.pickle", "wb") as f:
+        pickle.dump(ns, f)
+    params = synth.synth_gnn_params(N, H, L, decoder_scale=decoder_scale)
+    gd = {k: v.clone() for k, v in twin.make_schedule().items()}
+    gd["p2_loss_weight"] = torch.ones(1000)
+    gd.update({"model." + k: torch.from_numpy(v) for k, v in params.items()})
+    ema = {"initted": torch.tensor([True]), "step": torch.tensor([123])}
+    ema.update({"ema_model." + k: v for k, v in gd.items()})
+    ema.update({"online_model." + k: torch.zeros_like(v) for k, v in gd.items()})
+    torch.save({"step": 123, "model": {k: torch.zeros_like(v) for k, v in gd.items()}, "ema": ema}, path / "model-best.pt")
+    return params, (N, H, L)
+
+
+def test_cli_end_to_end(dff, tmp_path):
+    """sample.py flags, input files and output files of the reference (sample.py:101-249)."""
+    from dff_amd import cli
+    params, (N, H, L) = _write_model_dir(tmp_path, "chignolin")
+    out = cli.main(["--model_path", str(tmp_path), "--gen_mode", "iid", "--num_samples_eval", "10",
+                    "--batch_size_gen", "4", "--seed", "3"])
+    f = tmp_path / "main_eval_output_iid" / "sample-iid.pt"
+    saved = torch.load(f)
+    assert saved.shape == (10, N, 3) and saved.dtype == torch.float32 and torch.equal(saved, out)
+    assert torch.isfinite(saved).all() and (saved / 3.113133430480957).mean(1).abs().max() < 1e-3
+    pdb = (tmp_path / "main_eval_output_iid" / "sample-iid.pdb").read_text()
+    assert pdb.count("MODEL") == 10 and pdb.count("ATOM") == 10 * N
+    # batches of 4,4,2 draw from one global Philox stream: same seed, other batching, same samples
+    out2 = cli.main(["--model_path", str(tmp_path), "--gen_mode", "iid", "--num_samples_eval", "10",
+                     "--batch_size_gen", "10", "--seed", "3", "--append_exp_name", "b10"])
+    assert (tmp_path / "main_eval_output_iid_b10" / "sample-iid.pt").exists()
+    assert torch.equal(out, out2)
+    # langevin: P * n_timesteps / save_interval frames, simulation-major
+    out3 = cli.main(["--model_path", str(tmp_path), "--gen_mode", "langevin", "--parallel_sim", "3",
+                     "--n_timesteps", "20", "--save_interval", "10", "--batch_size_gen", "3", "--masses", "[12.0]*10"])
+    assert out3.shape == (3 * 2, N, 3) and torch.isfinite(out3).all()
+    assert (tmp_path / "main_eval_output_langevin" / "sample-langevin.pt").exists()
+    with pytest.raises(Exception):
+        cli.main(["--model_path", str(tmp_path), "--gen_mode", "bogus"])
+    with pytest.raises(ValueError):  # save_interval must divide n_timesteps (langevin_cgnet.py:305-309)
+        cli.main(["--model_path", str(tmp_path), "--gen_mode", "langevin", "--parallel_sim", "2", "--n_timesteps", "25",
+                  "--save_interval", "10", "--batch_size_gen", "2"])
+
+
+def test_checkpoint_loading_matches_direct_params(dff, tmp_path):
+    from dff_amd import cli
+    params, (N, H, L) = _write_model_dir(tmp_path, "ala2", decoder_scale=1.0)
+    args = cli.load_training_args(str(tmp_path))
+    ddpm, mol = cli.build_diffusion(args, str(tmp_path), "best", torch.device("cuda", 0))
+    assert ddpm.norm_factor == 0.9449278712272644 and mol.n_beads == 5
+    x = torch.from_numpy(synth.normal((4, N, 3), 8, 8).astype(np.float32))
+    t = torch.tensor([0.1, 0.2, 0.3, 0.4])
+    f = ddpm.model(x.cuda(), torch.eye(N), t.cuda()).cpu().numpy()
+    ref = twin.score(twin.to_torch(params), x, t, L).numpy()
+    assert rel(f, ref) <= 1e-5
+    e = ddpm.model(x.cuda(), torch.eye(N), t.cuda(), return_energy=True)
+    assert e.shape == (4, N, 1)
+
+
+@pytest.mark.parametrize("cfg", CFGS)
+def test_many_workgroups_identical_copies(dff, cfg, golden):
+    """The golden inputs replicated over many workgroups, repeatedly: every copy must reproduce the
+    same (correct) forces bit for bit -- catches cross-workgroup scratch overlap and races, which
+    a 3-sample launch cannot see (the per-workgroup stash slots are adjacent in memory)."""
+    g = golden(f"score_{cfg}.npz")
+    model, _ = get_model(dff, cfg)
+    N = model.num_beads
+    copies = 48
+    x = torch.from_numpy(np.tile(g["x"], (copies, 1, 1))).cuda()
+    t = torch.from_numpy(np.tile(g["t"], copies)).cuda()
+    for rep in range(4):
+        f = model.native.score(x, t).reshape(copies, 3, N, 3)
+        assert torch.equal(f, f[:1].expand_as(f)), f"copies differ (rep {rep})"
+        assert rel(f[0].cpu().numpy(), g["forces64"]) <= 1e-5

@@ -56,7 +56,7 @@ __host__ __device__ inline StashLayout dff_stash_layout(int N, int G, int H, int
     s.P = o;        o += ((unsigned)(DFF_HEADS * G * N * N) + 3u) & ~3u;
     s.layer_stride = o;
     s.dn_spill = o * (unsigned)L;
-    s.total = s.dn_spill + R * H;
+    s.total = s.dn_spill + R * (H + 4);   // indexed with the LDS leading dimension H + 4
     s.total = (s.total + 63u) & ~63u;
     return s;
 }
@@ -896,6 +896,15 @@ DEVI void bead_mean(const Ctx& c, const float* src, float* cm) {
 // ------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------
+// Workgroup barrier.  With SPILL the residual stream lives in global memory (the stash) and is
+// handed between different threads of the workgroup, so the barrier must also wait for this
+// wave's outstanding global stores (hipcc's plain __syncthreads() does not emit that wait).
+template <bool SPILL>
+DEVI void wg_sync() {
+    if (SPILL) __threadfence_block();
+    __syncthreads();
+}
+
 template <int H, int MT, int HGS, bool SPILL>
 __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelDev m, const DffRunArgs a) {
     using LL = LdsLayout<H, MT, HGS, SPILL>;
@@ -928,7 +937,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
 
     // zero LDS once (pad columns of the 32-wide buffers must be 0; pad rows must be finite)
     for (int i = tid; i < (int)ll.total; i += DFF_NTHREADS) smem[i] = 0.f;
-    __syncthreads();
+    wg_sync<SPILL>();
 
     Prof pf;
     pf.on = (a.prof != nullptr) && blockIdx.x == 0 && tid == 0;
@@ -954,12 +963,12 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             c.vst[tid] = vv;
         }
         if (tid < c.gcnt) c.tn[tid] = (a.mode == DFF_MODE_SCORE) ? a.tnorm[c.b0 + tid] : a.t_norm;
-        __syncthreads();
+        wg_sync<SPILL>();
         if (a.mode == DFF_MODE_DDPM && a.init_prior) {  // x_T = center_zero(randn)  ddpm.py:242
             bead_mean(c, c.xst, c.cm);
-            __syncthreads();
+            wg_sync<SPILL>();
             if (tid < rows * 4) c.xst[tid] -= c.cm[(tid >> 2) / N * 4 + (tid & 3)];
-            __syncthreads();
+            wg_sync<SPILL>();
         }
     }
 
@@ -972,19 +981,19 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
         // ---- centring: Langevin re-centres the state itself (langevin_cgnet.py:739); the score
         // op always centres its own input (graph_transformer.py:87) ----
         bead_mean(c, c.xst, c.cm);
-        __syncthreads();
+        wg_sync<SPILL>();
         if (tid < rows * 4) {
             const float xc = c.xst[tid] - c.cm[(tid >> 2) / N * 4 + (tid & 3)];
             if (a.mode == DFF_MODE_LANGEVIN) c.xst[tid] = xc;
             c.xs[tid] = xc;
             c.dxs[tid] = 0.f;
         }
-        __syncthreads();
+        wg_sync<SPILL>();
         if (a.mode == DFF_MODE_LANGEVIN) {  // second (no-op-sized) centring inside the score op
             bead_mean(c, c.xs, c.cm);
-            __syncthreads();
+            wg_sync<SPILL>();
             if (tid < rows * 4) c.xs[tid] -= c.cm[(tid >> 2) / N * 4 + (tid & 3)];
-            __syncthreads();
+            wg_sync<SPILL>();
         }
 
         pf.tick(0);
@@ -994,7 +1003,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
         const bool cached0 = (a.mode == DFF_MODE_LANGEVIN) && step > 0;
         if (!cached0) {
             node_embed<H>(c, m);
-            __syncthreads();
+            wg_sync<SPILL>();
         }
         for (int l = 0; l < m.L; ++l) {
             const DffLayerDev& lw = m.layer[l];
@@ -1009,7 +1018,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     c.ubuf[(it >> 5) * DFF_SMALL_LD + (it & 31)] = ld_nt(sb + c.sl.u + it);
             } else {
             row_ln1<H>(c, lw, l);
-            __syncthreads();
+            wg_sync<SPILL>();
             pf.tick(1);
             // u = LN1(nodes) W_u^T + b_u  (all 8 heads, 24 of 32 columns used)
             gemm_wide<MT, NT_H, 1>(c.abuf, LH, RN, lw.Wu_p, NT_H, 0, 0, 2,
@@ -1054,13 +1063,13 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                             }
                         }
                     });
-                __syncthreads();
+                wg_sync<SPILL>();
                 pf.tick(3);
                 attn_softmax<HGS>(c, hg, l);
-                __syncthreads();
+                wg_sync<SPILL>();
                 pf.tick(4);
                 attn_pv<HGS>(c, hg);
-                __syncthreads();
+                wg_sync<SPILL>();
                 pf.tick(5);
                 gemm_tall<MT, NTW, 4>(acc_o, HGS,
                     [&](int s, const float*& Ap, int& kb0) { Ap = c.Rg + 3 * RN * LQ + s * 64; kb0 = (hg * HGS + s) * 4; },
@@ -1070,12 +1079,12 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             gemm_tall<MT, NTW, 2>(acc_o, 1,
                 [&](int, const float*& Ap, int& kb0) { Ap = c.sbuf; kb0 = 0; },
                 DFF_SMALL_LD, RN, lw.Woc_p, 2, NT_H);
-            __syncthreads();
+            wg_sync<SPILL>();
             pf.tick(6);
             store_tall<MT, NTW>(acc_o, tbuf, LH, rows, NT_H, lw.bo);
-            __syncthreads();
+            wg_sync<SPILL>();
             row_gate1_ln2<H>(c, lw, l, tbuf);
-            __syncthreads();
+            wg_sync<SPILL>();
             pf.tick(7);
             // FFN: Linear(H,4H) -> GELU(erf) -> Linear(4H,H)   (graph_transformer.py:264-267)
             f32x4 acc_f[NTW][MT];
@@ -1097,18 +1106,18 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                             }
                         }
                     });
-                __syncthreads();
+                wg_sync<SPILL>();
                 pf.tick(8);
                 gemm_tall<MT, NTW, 4>(acc_f, FC / 64,
                     [&](int s, const float*& Ap, int& kb0) { Ap = c.Rg + s * 64; kb0 = ch * (FC / 16) + s * 4; },
                     LF, RN, lw.W2_p, F / 16, NT_H);
-                __syncthreads();
+                wg_sync<SPILL>();
                 pf.tick(9);
             }
             store_tall<MT, NTW>(acc_f, tbuf, LH, rows, NT_H, lw.b2);
-            __syncthreads();
+            wg_sync<SPILL>();
             row_gate2<H>(c, m, lw, l, tbuf, l == m.L - 1, a.energy_out);
-            __syncthreads();
+            wg_sync<SPILL>();
             pf.tick(10);
         }
 
@@ -1117,7 +1126,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             const DffLayerDev& lw = m.layer[l];
             const float* sb = c.stash + (size_t)l * c.sl.layer_stride;
             rowb_gate2<H>(c, lw, l);
-            __syncthreads();
+            wg_sync<SPILL>();
             pf.tick(11);
             // dh = dff W2 ; dh_pre = dh * gelu'(h_pre) ; df = dh_pre W1
             f32x4 acc_f[NTW][MT];
@@ -1143,18 +1152,18 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                             if (row < rows) c.Rg[row * LF + cl] = acc[r] * gelu_grad_f(aux[mt * 4 + r]);
                         }
                     });
-                __syncthreads();
+                wg_sync<SPILL>();
                 pf.tick(12);
                 gemm_tall<MT, NTW, 4>(acc_f, FC / 64,
                     [&](int s, const float*& Ap, int& kb0) { Ap = c.Rg + s * 64; kb0 = ch * (FC / 16) + s * 4; },
                     LF, RN, lw.W1T_p, F / 16, NT_H);
-                __syncthreads();
+                wg_sync<SPILL>();
                 pf.tick(13);
             }
             store_tall<MT, NTW>(acc_f, tbuf, LH, rows, NT_H, nullptr);
-            __syncthreads();
+            wg_sync<SPILL>();
             rowb_ln2_gate1<H>(c, lw, l, tbuf);
-            __syncthreads();
+            wg_sync<SPILL>();
             pf.tick(14);
             // r = dattn W_oc (dE/dxrel) -> sbuf ; u of this layer -> ubuf
             gemm_wide<MT, NT_H, 1>(c.abuf, LH, RN, lw.WocT_p, NT_H, 0, 0, 2,
@@ -1185,19 +1194,19 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                             if (row < rows) c.Rg[3 * RN * LQ + row * LQ + cl] = acc[r];
                         }
                     });
-                __syncthreads();
+                wg_sync<SPILL>();
                 pf.tick(16);
                 attnb_ds<HGS>(c, hg);
-                __syncthreads();
+                wg_sync<SPILL>();
                 pf.tick(17);
                 attnb_dx<HGS>(c, hg);
                 if (l > 0) {
                     attnb_dqkv<HGS, 0>(c);
-                    __syncthreads();
+                    wg_sync<SPILL>();
                     attnb_dqkv<HGS, 1>(c);
-                    __syncthreads();
+                    wg_sync<SPILL>();
                     attnb_dqkv<HGS, 2>(c);
-                    __syncthreads();
+                    wg_sync<SPILL>();
                     pf.tick(18);
                     // d(LN1 out) += dq Wq + dk Wk + dv Wv   (head-major K order [h][q|k|v][d])
                     gemm_tall<MT, NTW, 4>(acc_a, 3 * HGS,
@@ -1209,7 +1218,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         },
                         LQ, RN, lw.WqkvT_p, 3 * DFF_INNER / 16, NT_H);
                 }
-                __syncthreads();
+                wg_sync<SPILL>();
                 pf.tick(19);
             }
             if (l > 0) {
@@ -1217,11 +1226,11 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 gemm_tall<MT, NTW, 2>(acc_a, 1,
                     [&](int, const float*& Ap, int& kb0) { Ap = c.dubuf; kb0 = 0; },
                     DFF_SMALL_LD, RN, lw.WuT_p, 2, NT_H);
-                __syncthreads();
+                wg_sync<SPILL>();
                 store_tall<MT, NTW>(acc_a, tbuf, LH, rows, NT_H, nullptr);
-                __syncthreads();
+                wg_sync<SPILL>();
                 rowb_ln1<H>(c, lw, l, tbuf);
-                __syncthreads();
+                wg_sync<SPILL>();
                 pf.tick(20);
             }
         }
@@ -1259,7 +1268,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 c.vst[tid] = vn;
                 if (save && a.frames) a.frames[(((size_t)fi * a.B + item) * N + i) * 3 + cc] = xn;
             }
-            __syncthreads();
+            wg_sync<SPILL>();
             if (save && a.ke && !a.overdamped && tid < c.gcnt) {  // langevin_cgnet.py:538-542
                 float ke = 0.f;
                 for (int i = 0; i < N; ++i) {
@@ -1281,10 +1290,10 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             }
             // centre eps and noise (two bead-means)
             if (tid < rows * 4) { c.dxs[tid] = eps; c.xs[tid] = xi; }
-            __syncthreads();
+            wg_sync<SPILL>();
             bead_mean(c, c.dxs, c.cm);
             bead_mean(c, c.xs, c.cm + 64);
-            __syncthreads();
+            wg_sync<SPILL>();
             const float x = act ? c.xst[tid] : 0.f;
             float x0 = 0.f;
             if (act) {
@@ -1292,11 +1301,11 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 xi -= c.cm[64 + g * 4 + cc];
                 x0 = m.sqrt_recip_ac[t_int] * x - m.sqrt_recipm1_ac[t_int] * eps;  // ddpm.py:140-147
             }
-            __syncthreads();
+            wg_sync<SPILL>();
             if (tid < rows * 4) c.dxs[tid] = x0;
-            __syncthreads();
+            wg_sync<SPILL>();
             bead_mean(c, c.dxs, c.cm);
-            __syncthreads();
+            wg_sync<SPILL>();
             float xn = 0.f;
             if (act) {
                 x0 -= c.cm[g * 4 + cc];
@@ -1308,14 +1317,14 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     xn = fminf(fmaxf(xn, -1000.f), 1000.f);
                 }
             }
-            __syncthreads();
+            wg_sync<SPILL>();
             if (tid < rows * 4) c.dxs[tid] = xn;
-            __syncthreads();
+            wg_sync<SPILL>();
             bead_mean(c, c.dxs, c.cm);
-            __syncthreads();
+            wg_sync<SPILL>();
             if (act) c.xst[tid] = xn - c.cm[g * 4 + cc];
         }
-        __syncthreads();
+        wg_sync<SPILL>();
         pf.tick(21);
     }
     if (pf.on)
