@@ -1,33 +1,37 @@
 #!/bin/bash
 # rocprofv3 passes for bench.py (run on the GPU box; outputs under gpurun_out/prof_<tag>/).
 # usage: tools_rocprof.sh <tag> [bench args...]
+# Counters are collected in their own runs (no trace domains together with --pmc).
 set -u
 TAG=${1:-r01}; shift || true
 cd /tmp && export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
-mkdir -p $OUT
-BENCH="python $ROOT/bench.py --steps 500 --warmup 250 --no-cpu $*"
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
+rm -rf $OUT; mkdir -p $OUT
+BENCH="python $ROOT/bench.py --steps 1000 --warmup 250 --no-cpu $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
+i=0
 for set in "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA" \
-           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU" \
            "GRBM_GUI_ACTIVE"; do
-  name=$(echo $set | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $set -d $OUT/pmc_$name -o pmc -- $BENCH > $OUT/pmc_$name.log 2>&1
+  i=$((i+1))
+  rocprofv3 --pmc $set --output-format csv -d $OUT/pmc$i -o pmc -- $BENCH > $OUT/pmc$i.log 2>&1
 done
-cd $OUT && find . -name "*.csv" | head -50
 python - <<PY
-import csv, glob, os, collections
+import csv, glob, os, collections, json
 out = "$OUT"
-for f in sorted(glob.glob(out + "/**/*kernel_stats.csv", recursive=True)):
-    print("==", os.path.relpath(f, out)); print(open(f).read()[:1500])
-for f in sorted(glob.glob(out + "/**/*counter_collection.csv", recursive=True)):
+summ = {"kernels": [], "counters": {}}
+for f in sorted(glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True)):
+    for r in csv.DictReader(open(f)):
+        summ["kernels"].append({k: r[k] for k in r})
+for f in sorted(glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True)):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "dff_fused" in r.get("Kernel_Name", ""):
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    print("==", os.path.relpath(f, out))
-    for k, v in agg.items():
-        print(f"   {k:32s} n={len(v):3d} mean={sum(v)/len(v):.4g}")
+        if "dff_" in r.get("Kernel_Name", ""):
+            agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for (k, c), v in agg.items():
+        summ["counters"][c] = {"kernel": k, "launches": len(v), "mean_per_launch": sum(v) / len(v)}
+json.dump(summ, open(out + "/summary.json", "w"), indent=1)
+print(json.dumps(summ, indent=1)[:6000])
 PY

@@ -32,9 +32,18 @@ typedef __attribute__((address_space(3))) float lfloat;
 typedef __attribute__((address_space(1))) float gfloat;
 typedef f32x4 __attribute__((address_space(3))) lf32x4;
 typedef f32x4 __attribute__((address_space(1))) gf32x4;
+#ifndef DFF_STASH_NT
+#define DFF_STASH_NT 0   // 1: non-temporal stash traffic. Measured: default policy is 3% faster (stash stays in L2/MALL)
+#endif
+#if DFF_STASH_NT
 DEVI void st_ntg(gfloat* p, float v) { __builtin_nontemporal_store(v, p); }
 DEVI float ld_ntg(const gfloat* p) { return __builtin_nontemporal_load(p); }
 DEVI f32x4 ld_ntg4(const gfloat* p) { return __builtin_nontemporal_load((const gf32x4*)p); }
+#else
+DEVI void st_ntg(gfloat* p, float v) { *p = v; }
+DEVI float ld_ntg(const gfloat* p) { return *p; }
+DEVI f32x4 ld_ntg4(const gfloat* p) { return *(const gf32x4*)p; }
+#endif
 
 #define DFF_XH 80       // extended head width
 #define DFF_XLD 84      // leading dim of the per-wave head buffers
