@@ -45,6 +45,37 @@ DEVI float ld_ntg(const gfloat* p) { return *p; }
 DEVI f32x4 ld_ntg4(const gfloat* p) { return *(const gf32x4*)p; }
 #endif
 
+// GELU(erf) value and derivative in one go: the forward FFN epilogue stashes gelu'(h_pre) so that the
+// backward epilogue is a single multiply (one erf + one exp per element per step instead of two + one)
+// Branch-free erf: |x| <= 0.8: x * P5(x^2);  else 1 - exp(P8(|x|)) with P8 ~ log erfc on [0.8, 4.2]
+// (least-squares fits on Chebyshev nodes; max abs error 1.2e-7 against scipy.special.erf over
+// [-6, 6] in float32 -- the same 1-2 ulp class as the library erff, at about half its instructions).
+#ifndef DFF_FAST_ERF
+#define DFF_FAST_ERF 0   // measured: no faster than the library erff here (the FFN epilogue is not erf-bound)
+#endif
+DEVI float erf_fast(float x) {
+#if DFF_FAST_ERF
+    const float t = fminf(fabsf(x), 4.2f), s = x * x;
+    float a = -6.546706740e-04f;
+    a = fmaf(a, s, 5.086977565e-03f); a = fmaf(a, s, -2.682184972e-02f); a = fmaf(a, s, 1.128313692e-01f);
+    a = fmaf(a, s, -3.761260335e-01f); a = fmaf(a, s, 1.128379164e+00f);
+    a *= x;
+    float b = 1.534366307e-06f;
+    b = fmaf(b, t, -4.404490910e-05f); b = fmaf(b, t, 5.800263089e-04f); b = fmaf(b, t, -4.682034248e-03f);
+    b = fmaf(b, t, 2.620414818e-02f); b = fmaf(b, t, -1.097046865e-01f); b = fmaf(b, t, -6.322175036e-01f);
+    b = fmaf(b, t, -1.130008818e+00f); b = fmaf(b, t, 2.658824129e-04f);
+    b = copysignf(1.0f - __expf(b), x);
+    return t <= 0.8f ? a : b;
+#else
+    return erff(x);
+#endif
+}
+DEVI void gelu_both(float x, float& g, float& gp) {
+    const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
+    g = x * cdf;
+    gp = cdf + x * expf(-0.5f * x * x) * 0.39894228040143267794f;
+}
+
 #define DFF_XH 80       // extended head width
 #define DFF_XLD 84      // leading dim of the per-wave head buffers
 #define DFF_PLD 20      // leading dim of the per-wave P / dS tiles
@@ -659,11 +690,13 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
                     wide_run<0, E, E, 1>(ring, b1r, afr, s_w1(lw), s_w2(lw), lane,
                         [=](int t, float (&ax)[1]) { ax[0] = b1p[16 * t]; },
                         [=](int t, const f32x4& acc, const float (&ax)[1]) {
-                            const float h0 = acc[0] + ax[0], h1 = acc[1] + ax[0], h2 = acc[2] + ax[0], h3 = acc[3] + ax[0];
-                            st_ntg(shp + s0 + 16 * t, h0); st_ntg(shp + s1 + 16 * t, h1);
-                            st_ntg(shp + s2 + 16 * t, h2); st_ntg(shp + s3 + 16 * t, h3);
-                            hb[16 * t] = gelu_f(h0); hb[LH + 16 * t] = gelu_f(h1);
-                            hb[2 * LH + 16 * t] = gelu_f(h2); hb[3 * LH + 16 * t] = gelu_f(h3);
+                            float g0, g1, g2, g3, p0, p1, p2, p3;
+                            gelu_both(acc[0] + ax[0], g0, p0); gelu_both(acc[1] + ax[0], g1, p1);
+                            gelu_both(acc[2] + ax[0], g2, p2); gelu_both(acc[3] + ax[0], g3, p3);
+                            // the stash slot "h_pre" holds gelu'(h_pre) in this kernel
+                            st_ntg(shp + s0 + 16 * t, p0); st_ntg(shp + s1 + 16 * t, p1);
+                            st_ntg(shp + s2 + 16 * t, p2); st_ntg(shp + s3 + 16 * t, p3);
+                            hb[16 * t] = g0; hb[LH + 16 * t] = g1; hb[2 * LH + 16 * t] = g2; hb[3 * LH + 16 * t] = g3;
                         });
                 }
                 f32x4 acc_f[E];
@@ -784,8 +817,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
                     lfloat* const hb = hbuf + quad * 4 * LH + col;
                     wide_run<0, E, E, 4>(ring, hp, afr, s_w2t(lw), s_w1t(lw), lane, hp_load,
                         [=](int t, const f32x4& acc, const float (&ax)[4]) {
-                            hb[16 * t] = acc[0] * gelu_grad_f(ax[0]); hb[LH + 16 * t] = acc[1] * gelu_grad_f(ax[1]);
-                            hb[2 * LH + 16 * t] = acc[2] * gelu_grad_f(ax[2]); hb[3 * LH + 16 * t] = acc[3] * gelu_grad_f(ax[3]);
+                            hb[16 * t] = acc[0] * ax[0]; hb[LH + 16 * t] = acc[1] * ax[1];
+                            hb[2 * LH + 16 * t] = acc[2] * ax[2]; hb[3 * LH + 16 * t] = acc[3] * ax[3];
                         });
                 }
                 f32x4 acc_f[E];
