@@ -127,6 +127,8 @@ int dff_ddpm_run(dff_model* m, int batch, float* x_dev, const float* noise_dev, 
 int dff_set_group(dff_model* m, int proteins_per_workgroup);
 /* Debugging: on != 0 disables the rows<=16 fast-path kernel so the generic kernel runs. */
 int dff_debug_force_generic(dff_model* m, int on);
+/* Debugging: waves per workgroup of the rows<=16 kernel: 0 auto (8 where it applies), 4 or 8. */
+int dff_debug_small_waves(dff_model* m, int waves);
 /* Name of the kernel the last call launched, grid size and dynamic LDS bytes. */
 int dff_last_launch(const dff_model* m, const char** kernel_name, int* grid, int* lds_bytes);
 /* Run one MFMA GEMM stage out(M,Nout) = A(M,K) W(K,Nout) through the same device routine and

@@ -356,3 +356,31 @@ def test_many_workgroups_identical_copies(dff, cfg, golden):
         f = model.native.score(x, t).reshape(copies, 3, N, 3)
         assert torch.equal(f, f[:1].expand_as(f)), f"copies differ (rep {rep})"
         assert rel(f[0].cpu().numpy(), g["forces64"]) <= 1e-5
+
+
+def test_small_kernel_wave_variants(dff, golden):
+    """chignolin runs the 8-wave (two waves per SIMD, one head per wave) variant by default; the
+    4-wave variant must agree, in score mode and over a fused multi-step Langevin launch."""
+    from dff_amd.langevin import LangevinDiffusion
+    g = golden("score_chignolin.npz")
+    model, _ = get_model(dff, "chignolin")
+    x, t = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["t"]).cuda()
+    out = {}
+    for w in (8, 4):
+        model.native.small_waves(w)
+        out[w] = (model.native.score(x, t).cpu().numpy(), model.native.last_launch()[0])
+    model.native.small_waves(0)
+    assert "64,8" in out[8][1] and "64,4" in out[4][1], (out[8][1], out[4][1])
+    for w in (8, 4):
+        assert rel(out[w][0], g["forces64"]) <= 1e-5
+    assert rel(out[8][0], out[4][0]) <= 5e-6
+    diff, _ = _diffusion(dff, "chignolin", decoder_scale=1e-2, norm=NORM_STD["chignolin"])
+    init = torch.from_numpy(synth.normal((6, 10, 3), 3, 9).astype(np.float32)) * 3.0
+    kw = dict(n_timesteps=30, save_interval=10, t=20, temp_data=340, temp_sim=340, dt=None, masses=[12.0] * 10,
+              friction=1.0, verbose=False, seed=11)
+    tr = {}
+    for w in (8, 4):
+        diff.model.native.small_waves(w)
+        tr[w] = LangevinDiffusion(diff, init, **kw).sample().numpy()
+    diff.model.native.small_waves(0)
+    np.testing.assert_allclose(tr[8], tr[4], rtol=2e-4, atol=2e-4 * np.abs(tr[4]).max())

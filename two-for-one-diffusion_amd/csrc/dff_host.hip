@@ -77,6 +77,7 @@ struct dff_model {
     size_t stash_floats = 0;
     int group_override = 0;
     bool force_generic = false;   // debugging: never use the rows<=16 fast path
+    int small_waves = 0;          // 0 auto, 4: never use the 8-wave variant
     bool last_small = false;
     unsigned long long* prof = nullptr;
     bool prof_on = false;
@@ -329,6 +330,12 @@ extern "C" int dff_debug_force_generic(dff_model* m, int on) {
     return DFF_OK;
 }
 
+extern "C" int dff_debug_small_waves(dff_model* m, int waves) {
+    if (!m || !(waves == 0 || waves == 4 || waves == 8)) return fail(DFF_EINVAL, "waves must be 0 (auto), 4 or 8");
+    m->small_waves = waves;
+    return DFF_OK;
+}
+
 extern "C" int dff_last_launch(const dff_model* m, const char** name, int* grid, int* lds) {
     if (!m) return fail(DFF_EINVAL, "null model");
     if (name) *name = m->last_kernel;
@@ -350,10 +357,13 @@ static int ensure_stash(dff_model* m, size_t need) {
 // rows <= 16: one-head-per-wave kernel (dff_small.hip)
 static int launch_small(dff_model* m, DffRunArgs& a, int G, hipStream_t stream) {
     const int N = m->cfg.n_beads, H = m->cfg.hidden, L = m->cfg.n_layers;
-    const void* fn; unsigned lds; const char* name;
-    if (H == 64)      { fn = (const void*)&dff_small_kernel<64>;  lds = SmallLds<64>::total;  name = "dff_small_kernel<64>"; }
-    else if (H == 96) { fn = (const void*)&dff_small_kernel<96>;  lds = SmallLds<96>::total;  name = "dff_small_kernel<96>"; }
-    else              { fn = (const void*)&dff_small_kernel<128>; lds = SmallLds<128>::total; name = "dff_small_kernel<128>"; }
+    const void* fn; unsigned lds; const char* name; int nthreads = 256;
+    // 8 waves (two per SIMD, one head per wave) when the rows fit its 11-row head buffers
+    const bool eight = H == 64 && G * N <= 10 && m->small_waves != 4;
+    if (eight)        { fn = (const void*)&dff_small_kernel<64, 8>; lds = SmallLds<64, 8>::total; name = "dff_small_kernel<64,8>"; nthreads = 512; }
+    else if (H == 64) { fn = (const void*)&dff_small_kernel<64, 4>;  lds = SmallLds<64, 4>::total;  name = "dff_small_kernel<64,4>"; }
+    else if (H == 96) { fn = (const void*)&dff_small_kernel<96, 4>;  lds = SmallLds<96, 4>::total;  name = "dff_small_kernel<96,4>"; }
+    else              { fn = (const void*)&dff_small_kernel<128, 4>; lds = SmallLds<128, 4>::total; name = "dff_small_kernel<128,4>"; }
     lds *= (unsigned)sizeof(float);
     if (lds > 160 * 1024) return fail(DFF_EINVAL, "LDS budget exceeded (%u bytes)", lds);
     const int grid = (a.B + G - 1) / G;
@@ -366,7 +376,7 @@ static int launch_small(dff_model* m, DffRunArgs& a, int G, hipStream_t stream) 
     a.stash_stride = sl.total;
     HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void* args[] = {(void*)&m->dev, (void*)&a};
-    HIPCHK(hipLaunchKernel(fn, dim3(grid), dim3(DFF_NTHREADS), args, lds, stream));
+    HIPCHK(hipLaunchKernel(fn, dim3(grid), dim3(nthreads), args, lds, stream));
     m->last_kernel = name; m->last_grid = grid; m->last_lds = (int)lds; m->last_G = G; m->last_B = a.B;
     m->last_stride = sl.total; m->last_small = true;
     return DFF_OK;

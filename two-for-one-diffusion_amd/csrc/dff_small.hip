@@ -79,7 +79,6 @@ DEVI void gelu_both(float x, float& g, float& gp) {
 #define DFF_XH 80       // extended head width
 #define DFF_XLD 84      // leading dim of the per-wave head buffers
 #define DFF_PLD 20      // leading dim of the per-wave P / dS tiles
-#define DFF_WREG (4 * 16 * DFF_XLD + 2 * 16 * DFF_PLD)   // floats per wave region
 
 #define DFF_QKVW 208    // stash row of one head: [q_ext 80 | k 64 | v 64]
 struct SmallStash {
@@ -104,13 +103,21 @@ __host__ __device__ inline SmallStash dff_small_stash(int N, int G, int H, int L
     return s;
 }
 
-template <int H>
+// NW = waves per workgroup.  NW = 4: one wave per SIMD, two heads per wave, 16-row head buffers.
+// NW = 8: two waves per SIMD (each hides the other's stalls), one head per wave; to fit 8 wave
+// regions in 160 KB the head buffers hold RLA = 11 rows (10 real + 1 dummy row that absorbs the
+// pad lanes' stores; MFMA operand reads of rows 11..15 run into the next buffer, which is finite
+// data multiplied by exact zeros of P / dS or landing in discarded output rows).
+template <int H, int NW>
 struct SmallLds {
     static constexpr int LH = H + 4;
+    static constexpr int RLA = NW == 4 ? 16 : 11;
+    static constexpr unsigned WREG = 4 * RLA * DFF_XLD + 2 * 16 * DFF_PLD;   // floats per wave region
+    static_assert(WREG >= 16 * (H + 4), "wave region must hold a 16 x (H+4) partial-sum tile");
     static constexpr unsigned xst = 0, xs = 64, dxs = 128, vst = 192, cm = 256, tn = 384, prof = 400,
-                              dxw = 448,                      // [4][128] per-wave dx partials (+ dummies)
-                              abuf = 960, resbuf = abuf + 16 * LH, part = resbuf + 16 * LH,
-                              wreg = part + 4 * 16 * LH, total = wreg + 4 * DFF_WREG + 64;
+                              dxw = 448,                      // [NW][128] per-wave dx partials (+ dummies)
+                              abuf = 448 + NW * 128, resbuf = abuf + 16 * LH,
+                              wreg = resbuf + 16 * LH, total = wreg + NW * WREG + 64;
 };
 
 // ---------------------------------------------------------------- wave-private MFMA engine
@@ -137,10 +144,9 @@ DEVI int tid_id() {
     return x;
 }
 
-#define DFF_DR 4
-template <int E>
+template <int E, int DR>
 struct Ring {
-    f32x4 b[DFF_DR][E];
+    f32x4 b[DR][E];
 };
 struct WStream {
     const gf32x4* base; // wave-uniform
@@ -160,10 +166,10 @@ DEVI void ring_fill(f32x4 (&slot)[E], const WStream& w, int j, int lane) {
 #pragma unroll
     for (int e = 0; e < E; ++e) slot[e] = p[(size_t)e * w.pstride + lane];
 }
-template <int E>
-DEVI void ring_prefetch(Ring<E>& r, const WStream& w, int lane) {
+template <int E, int DR>
+DEVI void ring_prefetch(Ring<E, DR>& r, const WStream& w, int lane) {
 #pragma unroll
-    for (int j = 0; j < DFF_DR; ++j) ring_fill<E>(r.b[j], w, j, lane);
+    for (int j = 0; j < DR; ++j) ring_fill<E>(r.b[j], w, j, lane);
 }
 
 // wide GEMM of one wave: N output tiles (entries), A fragments `a` (K = 16 E) preloaded.
@@ -174,8 +180,8 @@ DEVI void ring_prefetch(Ring<E>& r, const WStream& w, int lane) {
 // by-value functors (capture with [=]): a closure that ends up in memory costs a scratch reload
 // per tile, and a scratch reload is a VMEM op -- the compiler then waits vmcnt(0) and drains the
 // whole ring every tile.
-template <int SLOT, int N, int E, int NAUX, class Pre, class Epi>
-DEVI void wide_tile(Ring<E>& ring, float (&aux)[DFF_DR][NAUX], const f32x4 (&a)[E], const WStream& w,
+template <int SLOT, int N, int E, int NAUX, int DR, class Pre, class Epi>
+DEVI void wide_tile(Ring<E, DR>& ring, float (&aux)[DR][NAUX], const f32x4 (&a)[E], const WStream& w,
                     const WStream& wn, int lane, int t, const Pre& pre, const Epi& epi) {
     f32x4 (&b)[E] = ring.b[SLOT];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
@@ -189,32 +195,36 @@ DEVI void wide_tile(Ring<E>& ring, float (&aux)[DFF_DR][NAUX], const f32x4 (&a)[
     float auxc[NAUX];
 #pragma unroll
     for (int q = 0; q < NAUX; ++q) auxc[q] = aux[SLOT][q];
-    if (t + DFF_DR < N) { ring_fill<E>(b, w, t + DFF_DR, lane); pre(t + DFF_DR, aux[SLOT]); }
-    else ring_fill<E>(b, wn, t + DFF_DR - N, lane);
+    if (t + DR < N) { ring_fill<E>(b, w, t + DR, lane); pre(t + DR, aux[SLOT]); }
+    else ring_fill<E>(b, wn, t + DR - N, lane);
     epi(t, acc + acc2, auxc);
 }
-// NOTE: aux is indexed by ring SLOT (callers preload aux[(PH + d) % DFF_DR] for tile d).
-template <int PH, int N, int E, int NAUX, class Pre, class Epi>
-DEVI void wide_run(Ring<E>& ring, float (&aux)[DFF_DR][NAUX], const f32x4 (&a)[E], const WStream& w,
+// NOTE: aux is indexed by ring SLOT (callers preload aux[(PH + d) % DR] for tile d).  DR (ring depth,
+// 2 or 4) is deduced from the ring argument.
+template <int PH, int N, int E, int NAUX, int DR, class Pre, class Epi>
+DEVI void wide_run(Ring<E, DR>& ring, float (&aux)[DR][NAUX], const f32x4 (&a)[E], const WStream& w,
                    const WStream& wn, int lane, const Pre pre, const Epi epi) {
     static_assert(E % 2 == 0, "E even");
-    constexpr int NREV = N / DFF_DR, REM = N % DFF_DR;
+    static_assert(DR == 2 || DR == 4, "ring depth");
+    constexpr int NREV = N / DR, REM = N % DR;
 #pragma unroll 1
     for (int rev = 0; rev < NREV; ++rev) {
-        const int t0 = rev * DFF_DR;
-        wide_tile<(PH + 0) % DFF_DR, N, E, NAUX>(ring, aux, a, w, wn, lane, t0, pre, epi);
-        wide_tile<(PH + 1) % DFF_DR, N, E, NAUX>(ring, aux, a, w, wn, lane, t0 + 1, pre, epi);
-        wide_tile<(PH + 2) % DFF_DR, N, E, NAUX>(ring, aux, a, w, wn, lane, t0 + 2, pre, epi);
-        wide_tile<(PH + 3) % DFF_DR, N, E, NAUX>(ring, aux, a, w, wn, lane, t0 + 3, pre, epi);
+        const int t0 = rev * DR;
+        wide_tile<(PH + 0) % DR, N, E, NAUX>(ring, aux, a, w, wn, lane, t0, pre, epi);
+        wide_tile<(PH + 1) % DR, N, E, NAUX>(ring, aux, a, w, wn, lane, t0 + 1, pre, epi);
+        if constexpr (DR == 4) {
+            wide_tile<(PH + 2) % DR, N, E, NAUX>(ring, aux, a, w, wn, lane, t0 + 2, pre, epi);
+            wide_tile<(PH + 3) % DR, N, E, NAUX>(ring, aux, a, w, wn, lane, t0 + 3, pre, epi);
+        }
     }
-    if (REM > 0) wide_tile<(PH + 0) % DFF_DR, N, E, NAUX>(ring, aux, a, w, wn, lane, NREV * DFF_DR, pre, epi);
-    if (REM > 1) wide_tile<(PH + 1) % DFF_DR, N, E, NAUX>(ring, aux, a, w, wn, lane, NREV * DFF_DR + 1, pre, epi);
-    if (REM > 2) wide_tile<(PH + 2) % DFF_DR, N, E, NAUX>(ring, aux, a, w, wn, lane, NREV * DFF_DR + 2, pre, epi);
+    if constexpr (REM > 0) wide_tile<(PH + 0) % DR, N, E, NAUX>(ring, aux, a, w, wn, lane, NREV * DR, pre, epi);
+    if constexpr (REM > 1) wide_tile<(PH + 1) % DR, N, E, NAUX>(ring, aux, a, w, wn, lane, NREV * DR + 1, pre, epi);
+    if constexpr (REM > 2) wide_tile<(PH + 2) % DR, N, E, NAUX>(ring, aux, a, w, wn, lane, NREV * DR + 2, pre, epi);
 }
 
 // tall GEMM of one wave: acc[nt] += A(:, k-block kb) . W(entry kb, tile nt), kb = 0..N-1
-template <int SLOT, int N, int E, class FA>
-DEVI void tall_step(Ring<E>& ring, f32x4 (&acc)[E], const FA& fa, const WStream& w, const WStream& wn, int lane, int kb) {
+template <int SLOT, int N, int E, int DR, class FA>
+DEVI void tall_step(Ring<E, DR>& ring, f32x4 (&acc)[E], const FA& fa, const WStream& w, const WStream& wn, int lane, int kb) {
     f32x4 (&b)[E] = ring.b[SLOT];
     const f32x4 a = *(const lf32x4*)fa(kb);
 #pragma unroll
@@ -222,30 +232,33 @@ DEVI void tall_step(Ring<E>& ring, f32x4 (&acc)[E], const FA& fa, const WStream&
 #pragma unroll
         for (int nt = 0; nt < E; ++nt)
             acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[nt][s], acc[nt], 0, 0, 0);
-    if (kb + DFF_DR < N) ring_fill<E>(b, w, kb + DFF_DR, lane);
-    else ring_fill<E>(b, wn, kb + DFF_DR - N, lane);
+    if (kb + DR < N) ring_fill<E>(b, w, kb + DR, lane);
+    else ring_fill<E>(b, wn, kb + DR - N, lane);
 }
-template <int PH, int N, int E, class FA>
-DEVI void tall_run(Ring<E>& ring, f32x4 (&acc)[E], const FA fa, const WStream& w, const WStream& wn, int lane) {
-    constexpr int NREV = N / DFF_DR, REM = N % DFF_DR;
+template <int PH, int N, int E, int DR, class FA>
+DEVI void tall_run(Ring<E, DR>& ring, f32x4 (&acc)[E], const FA fa, const WStream& w, const WStream& wn, int lane) {
+    constexpr int NREV = N / DR, REM = N % DR;
 #pragma unroll 1
     for (int rev = 0; rev < NREV; ++rev) {
-        const int k0 = rev * DFF_DR;
-        tall_step<(PH + 0) % DFF_DR, N, E>(ring, acc, fa, w, wn, lane, k0);
-        tall_step<(PH + 1) % DFF_DR, N, E>(ring, acc, fa, w, wn, lane, k0 + 1);
-        tall_step<(PH + 2) % DFF_DR, N, E>(ring, acc, fa, w, wn, lane, k0 + 2);
-        tall_step<(PH + 3) % DFF_DR, N, E>(ring, acc, fa, w, wn, lane, k0 + 3);
+        const int k0 = rev * DR;
+        tall_step<(PH + 0) % DR, N, E>(ring, acc, fa, w, wn, lane, k0);
+        tall_step<(PH + 1) % DR, N, E>(ring, acc, fa, w, wn, lane, k0 + 1);
+        if constexpr (DR == 4) {
+            tall_step<(PH + 2) % DR, N, E>(ring, acc, fa, w, wn, lane, k0 + 2);
+            tall_step<(PH + 3) % DR, N, E>(ring, acc, fa, w, wn, lane, k0 + 3);
+        }
     }
-    if (REM > 0) tall_step<(PH + 0) % DFF_DR, N, E>(ring, acc, fa, w, wn, lane, NREV * DFF_DR);
-    if (REM > 1) tall_step<(PH + 1) % DFF_DR, N, E>(ring, acc, fa, w, wn, lane, NREV * DFF_DR + 1);
-    if (REM > 2) tall_step<(PH + 2) % DFF_DR, N, E>(ring, acc, fa, w, wn, lane, NREV * DFF_DR + 2);
+    if constexpr (REM > 0) tall_step<(PH + 0) % DR, N, E>(ring, acc, fa, w, wn, lane, NREV * DR);
+    if constexpr (REM > 1) tall_step<(PH + 1) % DR, N, E>(ring, acc, fa, w, wn, lane, NREV * DR + 1);
+    if constexpr (REM > 2) tall_step<(PH + 2) % DR, N, E>(ring, acc, fa, w, wn, lane, NREV * DR + 2);
 }
 
 // C layout: acc[r] <-> (row 4*(lane>>4)+r, col lane&15); unconditional (pad rows hold finite junk)
-DEVI void c_store_all(lfloat* dst, int ld, int col0, const f32x4& acc, int lane) {
+// rmax: last row of dst (pad lanes beyond it store to that dummy row)
+DEVI void c_store_all(lfloat* dst, int ld, int col0, const f32x4& acc, int lane, int rmax = 15) {
     const int quad = lane >> 4, col = lane & 15;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dst[(quad * 4 + r) * ld + col0 + col] = acc[r];
+    for (int r = 0; r < 4; ++r) dst[min(quad * 4 + r, rmax) * ld + col0 + col] = acc[r];
 }
 
 template <int KB>
@@ -330,28 +343,38 @@ DEVI void head_fetch(HeadRegs& r, const gfloat* sqkv, const gfloat* sp, int RA, 
     }
     if (sp) r.p = ld_ntg4(sp + 4 * lane);
 }
-DEVI void head_commit(const HeadRegs& r, lfloat* Qx, lfloat* Kx, lfloat* Vx, lfloat* pb, bool need_qk, bool need_p, int lane) {
+DEVI void head_commit(const HeadRegs& r, lfloat* Qx, lfloat* Kx, lfloat* Vx, lfloat* pb, bool need_qk, bool need_p, int lane,
+                      int rla = 16) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int it = lane + 64 * u, row = it >> 4, c4 = it & 15;
-        *(lf32x4*)(Vx + row * DFF_XLD + 4 * c4) = r.v[u];
-        if (need_qk) *(lf32x4*)(Kx + row * DFF_XLD + 4 * c4) = r.k[u];
+        if (row < rla) {
+            *(lf32x4*)(Vx + row * DFF_XLD + 4 * c4) = r.v[u];
+            if (need_qk) *(lf32x4*)(Kx + row * DFF_XLD + 4 * c4) = r.k[u];
+        }
     }
     if (need_qk) {
 #pragma unroll
         for (int u = 0; u < 5; ++u) {
             const int it = lane + 64 * u, row = it / 20, c4 = it % 20;
-            *(lf32x4*)(Qx + row * DFF_XLD + 4 * c4) = r.q[u];
+            if (row < rla) *(lf32x4*)(Qx + row * DFF_XLD + 4 * c4) = r.q[u];
         }
     }
     if (need_p) *(lf32x4*)(pb + (lane >> 2) * DFF_PLD + 4 * (lane & 3)) = r.p;
 }
 
 // ---------------------------------------------------------------- the kernel
-template <int H>
-__global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelDev m, const DffRunArgs a) {
-    using LL = SmallLds<H>;
+template <int H, int NW>
+__global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m, const DffRunArgs a) {
+    using LL = SmallLds<H, NW>;
     constexpr int LH = LL::LH, F = 4 * H, E = H / 16;
+    constexpr int NTHR = NW * 64;            // threads
+    constexpr int HPW = DFF_HEADS / NW;      // heads per wave (2 or 1)
+    constexpr int DR = NW == 4 ? 4 : 2;      // weight-ring depth (2 waves/SIMD need less run-ahead)
+    constexpr int RLA = LL::RLA;             // rows allocated per head buffer
+    constexpr int RS = RLA * DFF_XLD;        // floats between the Q / K / V / G buffers of a wave
+    constexpr int FS = F / NW, NTS = FS / 16, LF = FS + 4;   // FFN hidden slice of a wave
+    static_assert(HPW == 1 || HPW == 2, "4 or 8 waves");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     // the wave index is wave-uniform: say so (readfirstlane), so that every per-wave pointer and
@@ -366,20 +389,25 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
     lfloat* const xst = sm + LL::xst; lfloat* const xs = sm + LL::xs; lfloat* const dxs = sm + LL::dxs;
     lfloat* const vst = sm + LL::vst; lfloat* const cm = sm + LL::cm; lfloat* const tn = sm + LL::tn;
     lfloat* const abuf = sm + LL::abuf; lfloat* const resbuf = sm + LL::resbuf;
-    lfloat* const part = sm + LL::part;
     lfloat* const dxw = sm + LL::dxw + wave * 128;
-    lfloat* const wr = sm + LL::wreg + wave * DFF_WREG;
-    lfloat* const Qx = wr; lfloat* const Kx = wr + 16 * DFF_XLD; lfloat* const Vx = wr + 2 * 16 * DFF_XLD;
-    lfloat* const Gx = wr + 3 * 16 * DFF_XLD;
-    lfloat* const pb = wr + 4 * 16 * DFF_XLD; lfloat* const dsb = pb + 16 * DFF_PLD;
+    lfloat* const wr = sm + LL::wreg + wave * LL::WREG;
+    lfloat* const Qx = wr; lfloat* const Kx = wr + RS; lfloat* const Vx = wr + 2 * RS;
+    lfloat* const Gx = wr + 3 * RS;
+    lfloat* const pb = wr + 4 * RS; lfloat* const dsb = pb + 16 * DFF_PLD;
     lfloat* const hbuf = wr;          // FFN hidden slice of this wave (aliases the head buffers)
-    lfloat* const mypart = part + wave * 16 * LH;
+    lfloat* const mypart = wr;        // this wave's partial H-wide output (ditto; summed by the row stages)
+    auto psum = [=](int o) {          // sum of the NW waves' partial outputs at offset o
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += sm[LL::wreg + w * LL::WREG + o];
+        return t;
+    };
     const SmallStash sl = dff_small_stash(N, G, H, m.L);
     gfloat* const stash = (gfloat*)a.stash + (size_t)blockIdx.x * a.stash_stride;
     Ctx c;  // only what bead_mean() needs
     c.N = N; c.G = G; c.gcnt = gcnt; c.rows = rows;
 
-    for (int i = tid; i < (int)LL::total; i += DFF_NTHREADS) smem[i] = 0.f;
+    for (int i = tid; i < (int)LL::total; i += NTHR) smem[i] = 0.f;
     __syncthreads();
     Prof pf;
     pf.on = (a.prof != nullptr) && blockIdx.x == 0 && tid == 0;
@@ -390,14 +418,15 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
     // stash row (pad rows -> dummy row RA), dx slot, protein of column j (block-diagonal attention)
 #define DFF_LANE_CONSTS                                                      \
     const int lane = lane_id(), quad = lane >> 4, col = lane & 15;           \
-    int srow[4], dxi[4];                                                     \
+    int srow[4], dxi[4], lro[4];                                             \
     _Pragma("unroll") for (int r = 0; r < 4; ++r) {                          \
         const int row_ = quad * 4 + r;                                       \
         srow[r] = row_ < rows ? row_ : RA;                                   \
+        lro[r] = min(row_, RLA - 1) * DFF_XLD;                               \
         dxi[r] = (row_ < rows && col < 3) ? row_ * 4 + col : 64 + lane;      \
     }                                                                        \
     const int pj = col / N;                                                  \
-    (void)srow; (void)dxi; (void)pj;
+    (void)srow; (void)dxi; (void)pj; (void)lro;
 #define DFF_ROW_CONSTS                                  \
     const int tq_ = tid_id();                           \
     const int rrow = tq_ >> 4, sub = tq_ & 15;          \
@@ -431,7 +460,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
     }
     constexpr int HC = H / 16;   // row stages: 16 lanes per row, HC columns per lane
 
-    Ring<E> ring;
+    Ring<E, DR> ring;
     HeadRegs hr;
     // Row-stage operand registers: every row stage ends by issuing the (global) loads of the NEXT
     // row stage's per-column parameters and stashed activations -- the thread<->(row, column)
@@ -459,10 +488,10 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
     // weight streams of this wave (per layer lw): helpers
     auto s_qkv = [&](const DffLayerDev& lw, int h) { return wide_stream(lw.Wqkvx_p, E, h * 13); };
     auto s_wox = [&](const DffLayerDev& lw, int h) { return tall_stream(lw.Wox_p, DFF_HEADS * 5, h * 5); };
-    auto s_w1 = [&](const DffLayerDev& lw) { return wide_stream(lw.W1_p, E, wave * E); };
-    auto s_w2 = [&](const DffLayerDev& lw) { return tall_stream(lw.W2_p, F / 16, wave * E); };
-    auto s_w2t = [&](const DffLayerDev& lw) { return wide_stream(lw.W2T_p, E, wave * E); };
-    auto s_w1t = [&](const DffLayerDev& lw) { return tall_stream(lw.W1T_p, F / 16, wave * E); };
+    auto s_w1 = [&](const DffLayerDev& lw) { return wide_stream(lw.W1_p, E, wave * NTS); };
+    auto s_w2 = [&](const DffLayerDev& lw) { return tall_stream(lw.W2_p, F / 16, wave * NTS); };
+    auto s_w2t = [&](const DffLayerDev& lw) { return wide_stream(lw.W2T_p, E, wave * NTS); };
+    auto s_w1t = [&](const DffLayerDev& lw) { return tall_stream(lw.W1T_p, F / 16, wave * NTS); };
     auto s_woxt = [&](const DffLayerDev& lw, int h) { return wide_stream(lw.WoxT_p, E, h * 5); };
     auto s_qkvt = [&](const DffLayerDev& lw, int h) { return tall_stream(lw.WqkvxT_p, DFF_HEADS * 13, h * 13); };
     // x extension of K_ext / V_ext: columns 64..79 = [x_j, 0 ...]
@@ -471,8 +500,10 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
         for (int e = 0; e < 4; ++e) {
             const int idx = lane + 64 * e, row = idx >> 4, cc = idx & 15;
             const float xv = (cc < 3 && row < rows) ? xs[row * 4 + cc] : 0.f;
-            Kx[row * DFF_XLD + 64 + cc] = xv;
-            Vx[row * DFF_XLD + 64 + cc] = xv;
+            if (row < RLA) {
+                Kx[row * DFF_XLD + 64 + cc] = xv;
+                Vx[row * DFF_XLD + 64 + cc] = xv;
+            }
         }
     };
 
@@ -487,7 +518,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
         { const int lane = lane_id();
         if (cached0) {
             const gfloat* sb0 = stash;
-            head_fetch(hr, sb0 + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
+            if constexpr (HPW == 2) head_fetch(hr, sb0 + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
             ring_prefetch<E>(ring, s_wox(m.layer[0], wave), lane);
         } else {
             ring_prefetch<E>(ring, s_qkv(m.layer[0], wave), lane);
@@ -511,7 +542,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
 
         // =============================== forward ===============================
         if (!cached0) {
-            for (int idx = tid; idx < rows * H; idx += DFF_NTHREADS) {
+            for (int idx = tid; idx < rows * H; idx += NTHR) {
                 const int row = idx / H, cl = idx - row * H;
                 const int g = row / N, i = row - g * N;
                 resbuf[row * LH + cl] = m.WnT[i * H + cl] + tn[g] * m.WnT[N * H + cl] + m.bn[cl];
@@ -577,7 +608,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
                         for (int r = 0; r < 4; ++r) {
                             float v = acc[r];
                             if (nt == 4) v -= (col < 3) ? xs[(quad * 4 + r) * 4 + col] : 0.f;
-                            Qx[(quad * 4 + r) * DFF_XLD + 16 * nt + col] = v;
+                            Qx[lro[r] + 16 * nt + col] = v;
                         }
                     });
                 };
@@ -585,29 +616,37 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
                 auto wox_fa = [=](int kb) { return wox_a + 16 * kb; };
                 if (cached) {
                     // layer-0 q_ext / k / v are x-independent and t is fixed: re-read, no GEMM
-                    head_commit(hr, Qx, Kx, Vx, pb, true, false, lane);
-                    head_fetch(hr, sb + sl.qkv + (size_t)(wave + 4) * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
-                    head_math(wave);
-                    tall_run<0, 5, E>(ring, acc_o, wox_fa, s_wox(lw, wave), s_wox(lw, wave + 4), lane);
-                    head_commit(hr, Qx, Kx, Vx, pb, true, false, lane);
-                    head_math(wave + 4);
-                    tall_run<1, 5, E>(ring, acc_o, wox_fa, s_wox(lw, wave + 4), after, lane);
-                    // 10 entries consumed: entries 0,1 of `after` sit in slots 2,3 -- re-stage at phase 0
+                    if constexpr (HPW == 2) {
+                        head_commit(hr, Qx, Kx, Vx, pb, true, false, lane, RLA);
+                        head_fetch(hr, sb + sl.qkv + (size_t)(wave + 4) * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
+                        head_math(wave);
+                        tall_run<0, 5, E>(ring, acc_o, wox_fa, s_wox(lw, wave), s_wox(lw, wave + 4), lane);
+                        head_commit(hr, Qx, Kx, Vx, pb, true, false, lane, RLA);
+                        head_math(wave + 4);
+                        tall_run<1, 5, E>(ring, acc_o, wox_fa, s_wox(lw, wave + 4), after, lane);
+                    } else {
+                        head_fetch(hr, sb + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
+                        head_commit(hr, Qx, Kx, Vx, pb, true, false, lane, RLA);
+                        head_math(wave);
+                        tall_run<0, 5, E>(ring, acc_o, wox_fa, s_wox(lw, wave), after, lane);
+                    }
+                    // the ring did not end on phase 0: re-stage the next block's first entries
                     ring_prefetch<E>(ring, after, lane);
                 } else {
                     f32x4 afr[E];
                     load_afrag<E>(afr, abuf, LH, lane);
                     const gfloat* const bqkvx = (const gfloat*)lw.bqkvx;
                     const int s0 = srow[0], s1 = srow[1], s2 = srow[2], s3 = srow[3];
+                    const int l0 = lro[0], l1 = lro[1], l2 = lro[2], l3 = lro[3];
                     // bias of tile d goes to the aux slot of ring phase ph
-                    auto qkv_bias = [&](auto ph, int h, float (&bq)[DFF_DR][1]) {
+                    auto qkv_bias = [&](auto ph, int h, float (&bq)[DR][1]) {
 #pragma unroll
-                        for (int d = 0; d < DFF_DR; ++d) bq[(decltype(ph)::value + d) % DFF_DR][0] = bqkvx[(h * 13 + d) * 16 + col];
+                        for (int d = 0; d < DR; ++d) bq[(decltype(ph)::value + d) % DR][0] = bqkvx[(h * 13 + d) * 16 + col];
                     };
-                    auto qkv = [&](auto ph, int h, float (&bq)[DFF_DR][1], const WStream& wnext) {
+                    auto qkv = [&](auto ph, int h, float (&bq)[DR][1], const WStream& wnext) {
                         gfloat* const sqkv = sb + sl.qkv + (size_t)h * (RA + 1) * DFF_QKVW + col;
                         const gfloat* const bh = bqkvx + h * 13 * 16 + col;
-                        lfloat* const wq = wr + quad * 4 * DFF_XLD + col;
+                        lfloat* const wq = wr + col;
                         wide_run<decltype(ph)::value, 13, E, 1>(ring, bq, afr, s_qkv(lw, h), wnext, lane,
                             [=](int t, float (&ax)[1]) { ax[0] = bh[t * 16]; },
                             [=](int t, const f32x4& acc, const float (&ax)[1]) {
@@ -615,30 +654,40 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
                                 // arithmetic, no pointer select (a 3-way select becomes a stack table)
                                 const int reg = (t >= 5) + (t >= 9);
                                 const int cl = 16 * (t - 5 * reg + (reg >> 1));
-                                lfloat* const dl = wq + reg * (16 * DFF_XLD) + cl;
+                                lfloat* const dl = wq + reg * RS + cl;
                                 gfloat* const ds = sqkv + 16 * t;
                                 const float v0 = acc[0] + ax[0], v1 = acc[1] + ax[0], v2 = acc[2] + ax[0], v3 = acc[3] + ax[0];
-                                dl[0] = v0; dl[DFF_XLD] = v1; dl[2 * DFF_XLD] = v2; dl[3 * DFF_XLD] = v3;
+                                dl[l0] = v0; dl[l1] = v1; dl[l2] = v2; dl[l3] = v3;
                                 st_ntg(ds + s0 * DFF_QKVW, v0); st_ntg(ds + s1 * DFF_QKVW, v1);
                                 st_ntg(ds + s2 * DFF_QKVW, v2); st_ntg(ds + s3 * DFF_QKVW, v3);
                             });
                     };
-                    float bq[DFF_DR][1];
+                    float bq[DR][1];
                     qkv_bias(std::integral_constant<int, 0>{}, wave, bq);
                     pf.tick(1);
-                    qkv(std::integral_constant<int, 0>{}, wave, bq, s_wox(lw, wave));
-                    pf.tick(12);
-                    qkv_bias(std::integral_constant<int, 2>{}, wave + 4, bq);
-                    head_math(wave);
-                    pf.tick(13);
-                    tall_run<1, 5, E>(ring, acc_o, wox_fa, s_wox(lw, wave), s_qkv(lw, wave + 4), lane);
-                    pf.tick(14);
-                    qkv(std::integral_constant<int, 2>{}, wave + 4, bq, s_wox(lw, wave + 4));
-                    pf.tick(12);
-                    head_math(wave + 4);
-                    pf.tick(13);
-                    tall_run<3, 5, E>(ring, acc_o, wox_fa, s_wox(lw, wave + 4), after, lane);   // ends at phase 0
-                    pf.tick(14);
+                    if constexpr (HPW == 2) {
+                        qkv(std::integral_constant<int, 0>{}, wave, bq, s_wox(lw, wave));
+                        pf.tick(12);
+                        qkv_bias(std::integral_constant<int, 2>{}, wave + 4, bq);
+                        head_math(wave);
+                        pf.tick(13);
+                        tall_run<1, 5, E>(ring, acc_o, wox_fa, s_wox(lw, wave), s_qkv(lw, wave + 4), lane);
+                        pf.tick(14);
+                        qkv(std::integral_constant<int, 2>{}, wave + 4, bq, s_wox(lw, wave + 4));
+                        pf.tick(12);
+                        head_math(wave + 4);
+                        pf.tick(13);
+                        tall_run<3, 5, E>(ring, acc_o, wox_fa, s_wox(lw, wave + 4), after, lane);   // ends at phase 0
+                        pf.tick(14);
+                    } else {
+                        qkv(std::integral_constant<int, 0>{}, wave, bq, s_wox(lw, wave));
+                        pf.tick(12);
+                        head_math(wave);
+                        pf.tick(13);
+                        tall_run<13 % DR, 5, E>(ring, acc_o, wox_fa, s_wox(lw, wave), after, lane);       // 18 entries: phase 0
+                        pf.tick(14);
+                        static_assert(18 % DR == 0, "ring phase");
+                    }
                 }
 #pragma unroll
                 for (int nt = 0; nt < E; ++nt) c_store_all(mypart, LH, 16 * nt, acc_o[nt], lane);
@@ -652,7 +701,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
                     const int cl = sub + 16 * i, o = rrow * LH + cl;
-                    x[i] = part[o] + part[16 * LH + o] + part[32 * LH + o] + part[48 * LH + o] + ro[0][i];
+                    x[i] = psum(o) + ro[0][i];
                     res[i] = resbuf[o];
                     st_ntg(sb + sl.attn_out + rrow * H + cl, x[i]);
                 }
@@ -679,15 +728,15 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
                 const WStream after = lastl ? s_w2t(lw) : s_qkv(m.layer[lastl ? l : l + 1], wave);
                 f32x4 afr[E];
                 load_afrag<E>(afr, abuf, LH, lane);
-                float b1r[DFF_DR][1];
-                const gfloat* const b1p = (const gfloat*)lw.b1 + wave * H + col;
+                float b1r[DR][1];
+                const gfloat* const b1p = (const gfloat*)lw.b1 + wave * FS + col;
 #pragma unroll
-                for (int d = 0; d < DFF_DR; ++d) b1r[d][0] = b1p[16 * d];
+                for (int d = 0; d < DR; ++d) b1r[d][0] = b1p[16 * d];
                 {
-                    gfloat* const shp = sb + sl.h_pre + wave * H + col;
-                    lfloat* const hb = hbuf + quad * 4 * LH + col;
+                    gfloat* const shp = sb + sl.h_pre + wave * FS + col;
+                    lfloat* const hb = hbuf + quad * 4 * LF + col;
                     const int s0 = srow[0] * F, s1 = srow[1] * F, s2 = srow[2] * F, s3 = srow[3] * F;
-                    wide_run<0, E, E, 1>(ring, b1r, afr, s_w1(lw), s_w2(lw), lane,
+                    wide_run<0, NTS, E, 1>(ring, b1r, afr, s_w1(lw), s_w2(lw), lane,
                         [=](int t, float (&ax)[1]) { ax[0] = b1p[16 * t]; },
                         [=](int t, const f32x4& acc, const float (&ax)[1]) {
                             float g0, g1, g2, g3, p0, p1, p2, p3;
@@ -696,17 +745,17 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
                             // the stash slot "h_pre" holds gelu'(h_pre) in this kernel
                             st_ntg(shp + s0 + 16 * t, p0); st_ntg(shp + s1 + 16 * t, p1);
                             st_ntg(shp + s2 + 16 * t, p2); st_ntg(shp + s3 + 16 * t, p3);
-                            hb[16 * t] = g0; hb[LH + 16 * t] = g1; hb[2 * LH + 16 * t] = g2; hb[3 * LH + 16 * t] = g3;
+                            hb[16 * t] = g0; hb[LF + 16 * t] = g1; hb[2 * LF + 16 * t] = g2; hb[3 * LF + 16 * t] = g3;
                         });
                 }
                 f32x4 acc_f[E];
 #pragma unroll
                 for (int nt = 0; nt < E; ++nt) acc_f[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 {
-                    const lfloat* const ha = hbuf + col * LH + 4 * quad;
-                    tall_run<E % DFF_DR, E, E>(ring, acc_f, [=](int kb) { return ha + 16 * kb; }, s_w2(lw), after, lane);
+                    const lfloat* const ha = hbuf + col * LF + 4 * quad;
+                    tall_run<NTS % DR, NTS, E>(ring, acc_f, [=](int kb) { return ha + 16 * kb; }, s_w2(lw), after, lane);
                 }
-                if ((2 * E) % DFF_DR != 0) ring_prefetch<E>(ring, after, lane);
+                static_assert((2 * NTS) % DR == 0, "ring phase");
 #pragma unroll
                 for (int nt = 0; nt < E; ++nt) c_store_all(mypart, LH, 16 * nt, acc_f[nt], lane);
             }
@@ -720,7 +769,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
                     const int cl = sub + 16 * i, o = rrow * LH + cl;
-                    x[i] = part[o] + part[16 * LH + o] + part[32 * LH + o] + part[48 * LH + o] + ro[0][i];
+                    x[i] = psum(o) + ro[0][i];
                     res[i] = resbuf[o];
                     st_ntg(sb + sl.ff + rrow * H + cl, x[i]);
                 }
@@ -804,39 +853,40 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
                 const WStream after = s_woxt(lw, wave);
                 f32x4 afr[E];
                 load_afrag<E>(afr, abuf, LH, lane);
-                float hp[DFF_DR][4];
-                const gfloat* const shp = sb + sl.h_pre + wave * H + col;
+                float hp[DR][4];
+                const gfloat* const shp = sb + sl.h_pre + wave * FS + col;
                 const int s0 = srow[0] * F, s1 = srow[1] * F, s2 = srow[2] * F, s3 = srow[3] * F;
                 auto hp_load = [=](int t, float (&ax)[4]) {
                     ax[0] = ld_ntg(shp + s0 + 16 * t); ax[1] = ld_ntg(shp + s1 + 16 * t);
                     ax[2] = ld_ntg(shp + s2 + 16 * t); ax[3] = ld_ntg(shp + s3 + 16 * t);
                 };
 #pragma unroll
-                for (int d = 0; d < DFF_DR; ++d) hp_load(d, hp[d]);
+                for (int d = 0; d < DR; ++d) hp_load(d, hp[d]);
                 {
-                    lfloat* const hb = hbuf + quad * 4 * LH + col;
-                    wide_run<0, E, E, 4>(ring, hp, afr, s_w2t(lw), s_w1t(lw), lane, hp_load,
+                    lfloat* const hb = hbuf + quad * 4 * LF + col;
+                    wide_run<0, NTS, E, 4>(ring, hp, afr, s_w2t(lw), s_w1t(lw), lane, hp_load,
                         [=](int t, const f32x4& acc, const float (&ax)[4]) {
-                            hb[16 * t] = acc[0] * ax[0]; hb[LH + 16 * t] = acc[1] * ax[1];
-                            hb[2 * LH + 16 * t] = acc[2] * ax[2]; hb[3 * LH + 16 * t] = acc[3] * ax[3];
+                            hb[16 * t] = acc[0] * ax[0]; hb[LF + 16 * t] = acc[1] * ax[1];
+                            hb[2 * LF + 16 * t] = acc[2] * ax[2]; hb[3 * LF + 16 * t] = acc[3] * ax[3];
                         });
                 }
                 f32x4 acc_f[E];
 #pragma unroll
                 for (int nt = 0; nt < E; ++nt) acc_f[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 {
-                    const lfloat* const ha = hbuf + col * LH + 4 * quad;
-                    tall_run<E % DFF_DR, E, E>(ring, acc_f, [=](int kb) { return ha + 16 * kb; }, s_w1t(lw), after, lane);
+                    const lfloat* const ha = hbuf + col * LF + 4 * quad;
+                    tall_run<NTS % DR, NTS, E>(ring, acc_f, [=](int kb) { return ha + 16 * kb; }, s_w1t(lw), after, lane);
                 }
-                if ((2 * E) % DFF_DR != 0) ring_prefetch<E>(ring, after, lane);
 #pragma unroll
                 for (int nt = 0; nt < E; ++nt) c_store_all(mypart, LH, 16 * nt, acc_f[nt], lane);
             }
             __syncthreads();
             pf.tick(7);
             // first head of this layer's attention backward: start the stash read (hidden by row stage E)
-            { const int lane = lane_id();
-            head_fetch(hr, sb + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, l > 0, lane); }
+            if constexpr (HPW == 2) {
+                const int lane = lane_id();
+                head_fetch(hr, sb + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, l > 0, lane);
+            }
             // ---- row stage E: df = sum_w part ; LN2 backward ; gate1 backward -> dattn (abuf), dn_in partial (resbuf) ----
             // operands: ro[0] attn_out, ro[1] nodes_in, ro[2] ln2 gamma, ro[3..5] g1
             { DFF_ROW_CONSTS
@@ -852,7 +902,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
                 for (int i = 0; i < HC; ++i) {
                     const int o = rrow * LH + sub + 16 * i;
                     xh[i] = (n1[i] - mean) * rstd;
-                    dyg[i] = (part[o] + part[16 * LH + o] + part[32 * LH + o] + part[48 * LH + o]) * ro[2][i];
+                    dyg[i] = (psum(o)) * ro[2][i];
                     s1 += dyg[i];
                     s2 += dyg[i] * xh[i];
                 }
@@ -892,15 +942,16 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
                 (void)more;
                 // G_ext = dattn W_o_ext[h]^T  (5 tiles: [G 64 | r 3 | 0]) -> G region ; dx_i -= r_i
                 auto gext = [&](auto ph, int h, const WStream& wnext) {
-                    float none[DFF_DR][1] = {{0.f}, {0.f}, {0.f}, {0.f}};
-                    lfloat* const gb = Gx + quad * 4 * DFF_XLD + col;
+                    float none[DR][1] = {};
+                    lfloat* const gb = Gx + col;
+                    const int l0 = lro[0], l1 = lro[1], l2 = lro[2], l3 = lro[3];
                     lfloat* const dxp = dxw;
                     const int d0 = dxi[0], d1 = dxi[1], d2 = dxi[2], d3 = dxi[3];
                     wide_run<decltype(ph)::value, 5, E, 1>(ring, none, afr, s_woxt(lw, h), wnext, lane,
                         [=](int, float (&)[1]) {},
                         [=](int t, const f32x4& acc, const float (&)[1]) {
-                            gb[16 * t] = acc[0]; gb[DFF_XLD + 16 * t] = acc[1];
-                            gb[2 * DFF_XLD + 16 * t] = acc[2]; gb[3 * DFF_XLD + 16 * t] = acc[3];
+                            gb[l0 + 16 * t] = acc[0]; gb[l1 + 16 * t] = acc[1];
+                            gb[l2 + 16 * t] = acc[2]; gb[l3 + 16 * t] = acc[3];
                             if (t == 4) { dxp[d0] -= acc[0]; dxp[d1] -= acc[1]; dxp[d2] -= acc[2]; dxp[d3] -= acc[3]; }
                         });
                 };
@@ -927,17 +978,17 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
                     wv_mm<0, 5, true>(pb, Gx, lane, [&](int nt, const f32x4& acc) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            Vx[(quad * 4 + r) * DFF_XLD + 16 * nt + col] = acc[r];
+                            Vx[lro[r] + 16 * nt + col] = acc[r];
                             if (nt == 4) dxw[dxi[r]] += acc[r];
                         }
                     });
                     // dQ_ext = dS K_ext -> G region (ext columns: du)
-                    wv_mm<0, 5, false>(dsb, Kx, lane, [&](int nt, const f32x4& acc) { c_store_all(Gx, DFF_XLD, 16 * nt, acc, lane); });
+                    wv_mm<0, 5, false>(dsb, Kx, lane, [&](int nt, const f32x4& acc) { c_store_all(Gx, DFF_XLD, 16 * nt, acc, lane, RLA - 1); });
                     // dK_ext = dS^T Q_ext -> K region (ext columns: dx term sum_i dS_ij u_i)
                     wv_mm<0, 5, true>(dsb, Qx, lane, [&](int nt, const f32x4& acc) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            Kx[(quad * 4 + r) * DFF_XLD + 16 * nt + col] = acc[r];
+                            Kx[lro[r] + 16 * nt + col] = acc[r];
                             if (nt == 4) dxw[dxi[r]] += acc[r];
                         }
                     });
@@ -953,32 +1004,47 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
                     });
                 };
                 const int h1 = wave + 4;
+                (void)h1;
                 if (l > 0) {
-                    head_commit(hr, Qx, Kx, Vx, pb, true, true, lane);
-                    head_fetch(hr, sb + sl.qkv + (size_t)h1 * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)h1 * 256, RA, true, lane);
-                    pf.tick(8);
-                    gext(std::integral_constant<int, 0>{}, wave, s_qkvt(lw, wave));
-                    pf.tick(15);
-                    ds_math();
-                    pf.tick(16);
-                    dqkv();
-                    pf.tick(17);
-                    tall_run<1, 13, E>(ring, acc_a, qkvt_fa, s_qkvt(lw, wave), s_woxt(lw, h1), lane);
-                    pf.tick(18);
-                    head_commit(hr, Qx, Kx, Vx, pb, true, true, lane);
-                    gext(std::integral_constant<int, 2>{}, h1, s_qkvt(lw, h1));
-                    pf.tick(15);
-                    ds_math();
-                    pf.tick(16);
-                    dqkv();
-                    pf.tick(17);
-                    tall_run<3, 13, E>(ring, acc_a, qkvt_fa, s_qkvt(lw, h1), after, lane);   // ends at phase 0
-                    pf.tick(18);
+                    if constexpr (HPW == 2) {
+                        head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
+                        head_fetch(hr, sb + sl.qkv + (size_t)h1 * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)h1 * 256, RA, true, lane);
+                        pf.tick(8);
+                        gext(std::integral_constant<int, 0>{}, wave, s_qkvt(lw, wave));
+                        pf.tick(15);
+                        ds_math();
+                        pf.tick(16);
+                        dqkv();
+                        pf.tick(17);
+                        tall_run<1, 13, E>(ring, acc_a, qkvt_fa, s_qkvt(lw, wave), s_woxt(lw, h1), lane);
+                        pf.tick(18);
+                        head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
+                        gext(std::integral_constant<int, 2>{}, h1, s_qkvt(lw, h1));
+                        pf.tick(15);
+                        ds_math();
+                        pf.tick(16);
+                        dqkv();
+                        pf.tick(17);
+                        tall_run<3, 13, E>(ring, acc_a, qkvt_fa, s_qkvt(lw, h1), after, lane);   // ends at phase 0
+                        pf.tick(18);
+                    } else {
+                        head_fetch(hr, sb + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, true, lane);
+                        head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
+                        pf.tick(8);
+                        gext(std::integral_constant<int, 0>{}, wave, s_qkvt(lw, wave));
+                        pf.tick(15);
+                        ds_math();
+                        pf.tick(16);
+                        dqkv();
+                        pf.tick(17);
+                        tall_run<5 % DR, 13, E>(ring, acc_a, qkvt_fa, s_qkvt(lw, wave), after, lane);   // 18 entries: phase 0
+                        pf.tick(18);
+                    }
 #pragma unroll
                     for (int nt = 0; nt < E; ++nt) c_store_all(mypart, LH, 16 * nt, acc_a[nt], lane);
-                } else {
+                } else if constexpr (HPW == 2) {
                     // layer 0 needs q_ext (for the dS^T u term) but not k
-                    head_commit(hr, Qx, Kx, Vx, pb, false, true, lane);
+                    head_commit(hr, Qx, Kx, Vx, pb, false, true, lane, RLA);
                     {   // q_ext of head `wave`
                         const gfloat* sq = sb + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW;
 #pragma unroll
@@ -989,18 +1055,24 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
 #pragma unroll
                         for (int u = 0; u < 5; ++u) {
                             const int it = lane + 64 * u, row = it / 20, c4 = it % 20;
-                            *(lf32x4*)(Qx + row * DFF_XLD + 4 * c4) = hr.q[u];
+                            if (row < RLA) *(lf32x4*)(Qx + row * DFF_XLD + 4 * c4) = hr.q[u];
                         }
                     }
                     head_fetch(hr, sb + sl.qkv + (size_t)h1 * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)h1 * 256, RA, true, lane);
                     gext(std::integral_constant<int, 0>{}, wave, s_woxt(lw, h1));
                     ds_math();
                     dx_only();
-                    head_commit(hr, Qx, Kx, Vx, pb, true, true, lane);
+                    head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
                     gext(std::integral_constant<int, 1>{}, h1, after);
                     ds_math();
                     dx_only();
                     // the next step (if any) re-stages its own first entries at phase 0
+                } else {
+                    head_fetch(hr, sb + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, true, lane);
+                    head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
+                    gext(std::integral_constant<int, 0>{}, wave, after);
+                    ds_math();
+                    dx_only();
                 }
             }
             __syncthreads();
@@ -1018,7 +1090,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
                     for (int i = 0; i < HC; ++i) {
                         const int o = rrow * LH + sub + 16 * i;
                         xh[i] = (ro[1][i] - mean) * rstd;
-                        dyg[i] = (part[o] + part[16 * LH + o] + part[32 * LH + o] + part[48 * LH + o]) * ro[2][i];
+                        dyg[i] = (psum(o)) * ro[2][i];
                         s1 += dyg[i];
                         s2 += dyg[i] * xh[i];
                     }
@@ -1041,7 +1113,10 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
         // dxs = sum of the 4 waves' partial x-gradients
         if (tid < 64) {
             const lfloat* d0 = sm + LL::dxw;
-            dxs[tid] = d0[tid] + d0[128 + tid] + d0[256 + tid] + d0[384 + tid];
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += d0[w * 128 + tid];
+            dxs[tid] = t;
         }
         __syncthreads();
 
@@ -1143,6 +1218,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_small_kernel(const DffModelD
     }
 }
 
-template __global__ void dff_small_kernel<64>(const DffModelDev, const DffRunArgs);
-template __global__ void dff_small_kernel<96>(const DffModelDev, const DffRunArgs);
-template __global__ void dff_small_kernel<128>(const DffModelDev, const DffRunArgs);
+template __global__ void dff_small_kernel<64, 4>(const DffModelDev, const DffRunArgs);
+template __global__ void dff_small_kernel<96, 4>(const DffModelDev, const DffRunArgs);
+template __global__ void dff_small_kernel<128, 4>(const DffModelDev, const DffRunArgs);
+template __global__ void dff_small_kernel<64, 8>(const DffModelDev, const DffRunArgs);
