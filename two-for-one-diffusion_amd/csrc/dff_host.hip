@@ -359,8 +359,9 @@ static int launch_small(dff_model* m, DffRunArgs& a, int G, hipStream_t stream) 
     const int N = m->cfg.n_beads, H = m->cfg.hidden, L = m->cfg.n_layers;
     const void* fn; unsigned lds; const char* name; int nthreads = 256;
     // 8 waves (two per SIMD, one head per wave) when the rows fit its 11-row head buffers
-    const bool eight = H == 64 && G * N <= 10 && m->small_waves != 4;
-    if (eight)        { fn = (const void*)&dff_small_kernel<64, 8>; lds = SmallLds<64, 8>::total; name = "dff_small_kernel<64,8>"; nthreads = 512; }
+    const bool eight = (H == 64 || H == 96) && G * N <= 10 && m->small_waves != 4;
+    if (eight && H == 64) { fn = (const void*)&dff_small_kernel<64, 8>; lds = SmallLds<64, 8>::total; name = "dff_small_kernel<64,8>"; nthreads = 512; }
+    else if (eight)       { fn = (const void*)&dff_small_kernel<96, 8>; lds = SmallLds<96, 8>::total; name = "dff_small_kernel<96,8>"; nthreads = 512; }
     else if (H == 64) { fn = (const void*)&dff_small_kernel<64, 4>;  lds = SmallLds<64, 4>::total;  name = "dff_small_kernel<64,4>"; }
     else if (H == 96) { fn = (const void*)&dff_small_kernel<96, 4>;  lds = SmallLds<96, 4>::total;  name = "dff_small_kernel<96,4>"; }
     else              { fn = (const void*)&dff_small_kernel<128, 4>; lds = SmallLds<128, 4>::total; name = "dff_small_kernel<128,4>"; }

@@ -1222,3 +1222,4 @@ template __global__ void dff_small_kernel<64, 4>(const DffModelDev, const DffRun
 template __global__ void dff_small_kernel<96, 4>(const DffModelDev, const DffRunArgs);
 template __global__ void dff_small_kernel<128, 4>(const DffModelDev, const DffRunArgs);
 template __global__ void dff_small_kernel<64, 8>(const DffModelDev, const DffRunArgs);
+template __global__ void dff_small_kernel<96, 8>(const DffModelDev, const DffRunArgs);
