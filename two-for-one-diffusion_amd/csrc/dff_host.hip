@@ -510,72 +510,60 @@ extern "C" int dff_debug_stash(dff_model* m, int b, int layer, int what, float* 
     HIPCHK(hipSetDevice(m->device));
     HIPCHK(hipDeviceSynchronize());
     const int wg = b / G, g = b % G;
+    // both kernels stash the same per-head blocks; they differ in offsets, allocated rows and P stride
+    unsigned o_nodes, o_attn, o_ff, o_hpre, o_qkv, o_P, lstride, total;
+    int R, PS;
     if (m->last_small) {
         const SmallStash ss = dff_small_stash(N, G, H, L);
-        const float* sb = m->stash + (size_t)wg * ss.total + (size_t)layer * ss.layer_stride;
-        const int R = G * N + 1;   // arrays carry one dummy row
-        auto rowsS = [&](unsigned off, int width) -> int {
-            if (n != (size_t)N * width) return fail(DFF_EINVAL, "expected %d values", N * width);
-            HIPCHK(hipMemcpy(out, sb + off + (size_t)g * N * width, (size_t)N * width * 4, hipMemcpyDeviceToHost));
-            return DFF_OK;
-        };
-        auto heads = [&](unsigned off, int srcw, int c0, int w, int dstw, int dc0) -> int {
-            // per head h: rows (g*N .. g*N+N) x [c0, c0+w) of an (R x srcw) block -> out[row][dc0 + h*w ..]
-            std::vector<float> tmp((size_t)N * srcw);
-            for (int h = 0; h < DFF_HEADS; ++h) {
-                HIPCHK(hipMemcpy(tmp.data(), sb + off + ((size_t)h * R + (size_t)g * N) * srcw, tmp.size() * 4, hipMemcpyDeviceToHost));
-                for (int r = 0; r < N; ++r)
-                    for (int c2 = 0; c2 < w; ++c2) out[(size_t)r * dstw + dc0 + h * w + c2] = tmp[(size_t)r * srcw + c0 + c2];
-            }
-            return DFF_OK;
-        };
-        switch (what) {
-            case 0: return rowsS(ss.nodes_in, H);
-            case 1: return rowsS(ss.attn_out, H);
-            case 2: return rowsS(ss.ff, H);
-            case 3: return rowsS(ss.h_pre, 4 * H);
-            case 4: if (n != (size_t)N * 512) return fail(DFF_EINVAL, "size"); return heads(ss.qkv, DFF_QKVW, 0, 64, 512, 0);
-            case 5: if (n != (size_t)N * 512) return fail(DFF_EINVAL, "size"); return heads(ss.qkv, DFF_QKVW, 80, 64, 512, 0);
-            case 6: if (n != (size_t)N * 512) return fail(DFF_EINVAL, "size"); return heads(ss.qkv, DFF_QKVW, 144, 64, 512, 0);
-            case 8: {
-                if (n != (size_t)N * 32) return fail(DFF_EINVAL, "size");
-                memset(out, 0, n * 4);
-                return heads(ss.qkv, DFF_QKVW, 64, 3, 32, 0);
-            }
-            case 7: {
-                if (n != (size_t)DFF_HEADS * N * N) return fail(DFF_EINVAL, "size");
-                std::vector<float> tmp((size_t)N * 16);
-                for (int h = 0; h < DFF_HEADS; ++h) {
-                    HIPCHK(hipMemcpy(tmp.data(), sb + ss.P + ((size_t)h * 16 + (size_t)g * N) * 16, tmp.size() * 4, hipMemcpyDeviceToHost));
-                    for (int i = 0; i < N; ++i)
-                        for (int j = 0; j < N; ++j) out[((size_t)h * N + i) * N + j] = tmp[(size_t)i * 16 + g * N + j];
-                }
-                return DFF_OK;
-            }
-        }
-        return fail(DFF_EINVAL, "unknown stash item %d", what);
+        o_nodes = ss.nodes_in; o_attn = ss.attn_out; o_ff = ss.ff; o_hpre = ss.h_pre; o_qkv = ss.qkv; o_P = ss.P;
+        lstride = ss.layer_stride; total = ss.total;
+        R = G * N + 1;   // arrays carry one dummy row
+        PS = 16;
+    } else {
+        const StashLayout sl = dff_stash_layout(N, G, H, L);
+        o_nodes = sl.nodes_in; o_attn = sl.attn_out; o_ff = sl.ff; o_hpre = sl.h_pre; o_qkv = sl.qkvx; o_P = sl.P;
+        lstride = sl.layer_stride; total = sl.total;
+        R = G * N;
+        PS = (int)sl.PS;
     }
-    const StashLayout sl = dff_stash_layout(N, G, H, L);
-    const float* base = m->stash + (size_t)wg * sl.total + (size_t)layer * sl.layer_stride;
-    auto rows = [&](unsigned off, int width) -> int {
+    const int Prows = m->last_small ? 16 : R;   // rows of one head's P block
+    const float* sb = m->stash + (size_t)wg * total + (size_t)layer * lstride;
+    auto rowsS = [&](unsigned off, int width) -> int {
         if (n != (size_t)N * width) return fail(DFF_EINVAL, "expected %d values", N * width);
-        HIPCHK(hipMemcpy(out, base + off + (size_t)g * N * width, (size_t)N * width * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(out, sb + off + (size_t)g * N * width, (size_t)N * width * 4, hipMemcpyDeviceToHost));
+        return DFF_OK;
+    };
+    auto heads = [&](int c0, int w, int dstw) -> int {
+        // per head h: rows (g*N .. g*N+N) x [c0, c0+w) of its (R x 208) block -> out[row][h*w ..]
+        std::vector<float> tmp((size_t)N * DFF_QKVW);
+        for (int h = 0; h < DFF_HEADS; ++h) {
+            HIPCHK(hipMemcpy(tmp.data(), sb + o_qkv + ((size_t)h * R + (size_t)g * N) * DFF_QKVW, tmp.size() * 4, hipMemcpyDeviceToHost));
+            for (int r = 0; r < N; ++r)
+                for (int c2 = 0; c2 < w; ++c2) out[(size_t)r * dstw + h * w + c2] = tmp[(size_t)r * DFF_QKVW + c0 + c2];
+        }
         return DFF_OK;
     };
     switch (what) {
-        case 0: return rows(sl.nodes_in, H);
-        case 1: return rows(sl.attn_out, H);
-        case 2: return rows(sl.ff, H);
-        case 3: return rows(sl.h_pre, 4 * H);
-        case 4: return rows(sl.q, DFF_INNER);
-        case 5: return rows(sl.k, DFF_INNER);
-        case 6: return rows(sl.v, DFF_INNER);
-        case 8: return rows(sl.u, 32);
+        case 0: return rowsS(o_nodes, H);
+        case 1: return rowsS(o_attn, H);
+        case 2: return rowsS(o_ff, H);
+        case 3: return rowsS(o_hpre, 4 * H);
+        case 4: if (n != (size_t)N * 512) return fail(DFF_EINVAL, "size"); return heads(0, 64, 512);
+        case 5: if (n != (size_t)N * 512) return fail(DFF_EINVAL, "size"); return heads(80, 64, 512);
+        case 6: if (n != (size_t)N * 512) return fail(DFF_EINVAL, "size"); return heads(144, 64, 512);
+        case 8: {
+            if (n != (size_t)N * 32) return fail(DFF_EINVAL, "size");
+            memset(out, 0, n * 4);
+            return heads(64, 3, 32);
+        }
         case 7: {
-            if (n != (size_t)DFF_HEADS * N * N) return fail(DFF_EINVAL, "expected %d values", DFF_HEADS * N * N);
-            for (int h = 0; h < DFF_HEADS; ++h)
-                HIPCHK(hipMemcpy(out + (size_t)h * N * N, base + sl.P + ((size_t)h * G + g) * N * N,
-                                 (size_t)N * N * 4, hipMemcpyDeviceToHost));
+            if (n != (size_t)DFF_HEADS * N * N) return fail(DFF_EINVAL, "size");
+            std::vector<float> tmp((size_t)N * PS);
+            for (int h = 0; h < DFF_HEADS; ++h) {
+                HIPCHK(hipMemcpy(tmp.data(), sb + o_P + ((size_t)h * Prows + (size_t)g * N) * PS, tmp.size() * 4, hipMemcpyDeviceToHost));
+                for (int i = 0; i < N; ++i)
+                    for (int j = 0; j < N; ++j) out[((size_t)h * N + i) * N + j] = tmp[(size_t)i * PS + g * N + j];
+            }
             return DFF_OK;
         }
     }

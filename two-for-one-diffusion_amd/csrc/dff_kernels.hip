@@ -31,29 +31,54 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define DEVI __device__ __forceinline__
 
+#define DFF_QKVW 208    // stash row of one head: [q_ext 80 | k 64 | v 64]
+
+// Explicitly address-space-typed pointers: the hot lambdas capture pointers by reference and some
+// closures end up in memory, where a plain `float*` loses its provenance and every access turns
+// into a FLAT op (which waits on BOTH counters and drains the weight ring).  Typed pointers keep
+// ds_* / global_* no matter how they travel.
+typedef __attribute__((address_space(3))) float lfloat;
+typedef __attribute__((address_space(1))) float gfloat;
+typedef f32x4 __attribute__((address_space(3))) lf32x4;
+typedef f32x4 __attribute__((address_space(1))) gf32x4;
+#ifndef DFF_STASH_NT
+#define DFF_STASH_NT 0   // 1: non-temporal stash traffic. Measured: default policy is 3% faster (stash stays in L2/MALL)
+#endif
+#if DFF_STASH_NT
+DEVI void st_ntg(gfloat* p, float v) { __builtin_nontemporal_store(v, p); }
+DEVI float ld_ntg(const gfloat* p) { return __builtin_nontemporal_load(p); }
+DEVI f32x4 ld_ntg4(const gfloat* p) { return __builtin_nontemporal_load((const gf32x4*)p); }
+#else
+DEVI void st_ntg(gfloat* p, float v) { *p = v; }
+DEVI float ld_ntg(const gfloat* p) { return *p; }
+DEVI f32x4 ld_ntg4(const gfloat* p) { return *(const gf32x4*)p; }
+#endif
+
 // ------------------------------------------------------------------------------------------
 // Stash layout (floats, per workgroup).  R = G*N allocated rows, F = 4H.
 // ------------------------------------------------------------------------------------------
 struct StashLayout {
-    unsigned nodes_in, attn_out, ff, h_pre, q, k, v, u, P;  // offsets inside a layer slot
+    unsigned nodes_in, attn_out, ff, h_pre, qkvx, P;  // offsets inside a layer slot
+    unsigned PS;          // leading dimension of a stashed probability row (16 * row tiles)
     unsigned layer_stride;
     unsigned dn_spill;   // offset of the (R,H) spill slot for nodes / dn (after all layers)
     unsigned total;
 };
 
+// qkvx: per head an (R x 208) block, row = [q(64) | u(16) | k(64) | v(64)] (the "extended head" of
+// dff_internal.h); P: per head an (R x PS) block of softmax rows over ALL rows of the workgroup
+// (zeros outside the row's own protein).
 __host__ __device__ inline StashLayout dff_stash_layout(int N, int G, int H, int L) {
     StashLayout s;
     const unsigned R = (unsigned)(G * N), F = 4u * H;
     unsigned o = 0;
+    s.PS = 16u * ((R + 15u) / 16u);
     s.nodes_in = o; o += R * H;
     s.attn_out = o; o += R * H;
     s.ff = o;       o += R * H;
     s.h_pre = o;    o += R * F;
-    s.q = o;        o += R * DFF_INNER;
-    s.k = o;        o += R * DFF_INNER;
-    s.v = o;        o += R * DFF_INNER;
-    s.u = o;        o += R * 32;
-    s.P = o;        o += ((unsigned)(DFF_HEADS * G * N * N) + 3u) & ~3u;
+    s.qkvx = o;     o += (unsigned)DFF_HEADS * R * DFF_QKVW;
+    s.P = o;        o += (unsigned)DFF_HEADS * R * s.PS;
     s.layer_stride = o;
     s.dn_spill = o * (unsigned)L;
     s.total = s.dn_spill + R * (H + 4);   // indexed with the LDS leading dimension H + 4
@@ -63,15 +88,19 @@ __host__ __device__ inline StashLayout dff_stash_layout(int N, int G, int H, int
 
 // ------------------------------------------------------------------------------------------
 // LDS layout (floats).  Computed identically on host (for the launch size) and device.
+// Head-group region Rg: four (R x LQ) buffers Q_ext | K_ext | V_ext | G_ext, a head being 80
+// columns [64 | 16 extension]; Pbuf / dSbuf: per head of the group a (16MT x PL) tile array.
 // ------------------------------------------------------------------------------------------
 template <int H, int MT, int HGS, bool SPILL>
 struct LdsLayout {
     static constexpr int LH = H + 4;
-    static constexpr int LQ = 64 * HGS + 4;
+    static constexpr int LQ = 80 * HGS + 4;
+    static constexpr int PL = 16 * MT + 4;
+    static constexpr int PT = 16 * MT * PL;   // one head's tile array
     static constexpr int F = 4 * H;
     static constexpr int FC = (F % 256 == 0) ? 256 : 128;
     static constexpr int LF = FC + 4;
-    unsigned xst, xs, dxs, vst, cm, tn, prof, ubuf, sbuf, dubuf, abuf, resbuf, Pbuf, dSbuf, Rg, total;
+    unsigned xst, xs, dxs, vst, cm, tn, prof, dxw, abuf, resbuf, Pbuf, dSbuf, Rg, total;
     __host__ __device__ LdsLayout(int N, int G) {
         const unsigned R = (unsigned)(G * N);
         unsigned o = 0;
@@ -82,14 +111,11 @@ struct LdsLayout {
         cm = o;    o += 16 * 4 * 2;
         tn = o;    o += 16;
         prof = o;  o += 2 * DFF_NPROF;
-        ubuf = o;  o += R * DFF_SMALL_LD;
-        sbuf = o;  o += R * DFF_SMALL_LD;
-        dubuf = o; o += R * DFF_SMALL_LD;
+        dxw = o;   o += DFF_NWAVES * R * 4;   // per-wave partial dE/dx (summed once per step)
         abuf = o;  o += R * LH;
         resbuf = o; if (!SPILL) o += R * LH;
-        const unsigned psz = ((unsigned)(HGS * G * N * N) + 3u) & ~3u;
-        Pbuf = o;  o += psz;
-        dSbuf = o; o += psz;
+        Pbuf = o;  o += HGS * PT;
+        dSbuf = o; o += HGS * PT;
         Rg = o;
         unsigned rsz = 4u * R * LQ;
         if (R * LF > rsz) rsz = R * LF;
@@ -341,6 +367,65 @@ DEVI void gemm_tall(f32x4 (&acc)[NTW][MT], int nseg, SegF segf, int lda, int row
         for (int mt = 0; mt < MT; ++mt) acc[i][mt] += acc2[i][mt];
 }
 
+// "tall" GEMM over an explicit list of 16-wide k-blocks: kf(i, aoff, wkb) names the i-th block (its A
+// columns start at A + aoff, its weights are k-block wkb of the packed image).  Ring of D k-blocks.
+template <int MT, int NTW, class KF>
+DEVI void gemm_tall_kb(f32x4 (&acc)[NTW][MT], int nkb, KF kf, const lfloat* A, int lda, int rowsA,
+                       const float* __restrict__ Wp, int KBtot, int ntiles) {
+    constexpr int D = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kk = lane >> 4, mm = lane & 15;
+    int rowoff[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) rowoff[mt] = min(mt * 16 + mm, rowsA - 1) * lda + 4 * kk;
+    const gf32x4* wp = (const gf32x4*)Wp + lane;
+    size_t tbase[NTW];
+    bool tok[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int nt = wave + DFF_NWAVES * i;
+        tok[i] = nt < ntiles;
+        tbase[i] = (size_t)(tok[i] ? nt : 0) * KBtot;
+    }
+    if (!tok[0]) return;
+    f32x4 b[D][NTW];
+    int aoff[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < nkb) {
+            int wkb;
+            kf(d, aoff[d], wkb);
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) b[d][i] = wp[(tbase[i] + wkb) * 64];
+        }
+    for (int i0 = 0; i0 < nkb; i0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int ib = i0 + d;
+            if (ib < nkb) {
+                f32x4 a[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a[mt] = *(const lf32x4*)(A + aoff[d] + rowoff[mt]);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int i = 0; i < NTW; ++i)
+                        if (tok[i]) {
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt)
+                                acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s4], b[d][i][s4], acc[i][mt], 0, 0, 0);
+                        }
+                if (ib + D < nkb) {
+                    int wkb;
+                    kf(ib + D, aoff[d], wkb);
+#pragma unroll
+                    for (int i = 0; i < NTW; ++i) b[d][i] = wp[(tbase[i] + wkb) * 64];
+                }
+            }
+        }
+    }
+}
+
 template <int MT, int NTW>
 DEVI void acc_zero(f32x4 (&acc)[NTW][MT]) {
 #pragma unroll
@@ -394,7 +479,7 @@ struct Prof {
 struct Ctx {
     int N, G, gcnt, rows, NP, L;
     int b0;
-    float *xst, *xs, *dxs, *vst, *cm, *tn, *ubuf, *sbuf, *dubuf, *abuf, *resbuf, *Pbuf, *dSbuf, *Rg;
+    float *xst, *xs, *dxs, *vst, *cm, *tn, *abuf, *resbuf, *Pbuf, *dSbuf, *Rg;
     float* stash;  // this workgroup's slot
     StashLayout sl;
 };
@@ -640,242 +725,272 @@ DEVI void rowb_ln1(const Ctx& c, const DffLayerDev& lw, int l, const float* tbuf
 }
 
 // ------------------------------------------------------------------------------------------
-// attention stages (VALU out of LDS).  Head-group buffers: R0 = q, R1 = k, R2 = v, R3 = o / G.
+// attention stages on MFMA.  Head-group buffers (R x LQ each, a head = 80 columns [64 | 16 ext]):
+//   R0 = Q_ext = [q | u]   (u = W_c,h^T q: the edge term of the logits, 3 of 16 columns used)
+//   R1 = K_ext = [k | x]   R2 = V_ext = [v | x]   R3 = o_ext (forward) / G_ext = [dE/do | r] (backward)
+// so that logits = Q_ext K_ext^T, o_ext = P V_ext = [o | sum_j a_ij x_j], da = G_ext V_ext^T, and the
+// extension columns of dQ_ext / dK_ext / dV_ext are du / dE/dx_j / dE/dx_j: every N x N contraction is
+// a 16x16x4 tile product.  A workgroup's G proteins share the tiles; pairs from different proteins are
+// masked in the softmax (exact zeros in P, hence in dS).
+// The phases are cooperative: tiles go round-robin over the 4 waves, barriers between phases.
 // ------------------------------------------------------------------------------------------
-// logits + softmax:  a_ihj = softmax_j( scale (q_ih.k_jh + u_ih.x_j) )   (graph_transformer.py:
-// 247-255 with the j-constant terms dropped).  NP lanes (power of two >= N) share one (g,hh,i).
-template <int HGS>
-DEVI void attn_softmax(const Ctx& c, int hg, int l) {
-    constexpr int LQ = 64 * HGS + 4;
-    const int N = c.N, NP = c.NP;
-    const float* qs = c.Rg;
-    const float* ks = c.Rg + c.G * N * LQ;
-    const int nrow = c.gcnt * HGS * N;  // (hh, g, i) items
-    const int total = nrow * NP;
-    float* sP = c.stash + (size_t)l * c.sl.layer_stride + c.sl.P + (size_t)hg * HGS * c.G * N * N;
-    for (int base = 0; base < total; base += DFF_NTHREADS) {
-        const int it = base + threadIdx.x;
-        const bool act = it < total;
-        const int itc = act ? it : total - 1;
-        const int j = itc % NP, ri = itc / NP;     // ri = (hh*gcnt + g)*N + i
-        const int i = ri % N, hgi = ri / N;
-        const int g = hgi % c.gcnt, hh = hgi / c.gcnt;
-        const bool jok = j < N;
-        const int qrow = g * N + i, krow = g * N + (jok ? j : N - 1);
-        const f32x4* qp = (const f32x4*)(qs + qrow * LQ + hh * 64);
-        const f32x4* kp = (const f32x4*)(ks + krow * LQ + hh * 64);
-        float s = 0.f;
+// acc[jt] = A[rows of tile it] . B[rows of tile jt]^T over K = 80
+template <int MT>
+DEVI void co_dot_rows(f32x4 (&acc)[MT], const lfloat* A, const lfloat* B, int ld, int RN, int it, int lane) {
+    const int kk = lane >> 4, mm = lane & 15;
+    const lfloat* ap = A + min(16 * it + mm, RN - 1) * ld + 4 * kk;
+    f32x4 av[5];
 #pragma unroll
-        for (int d = 0; d < 16; ++d) {
-            const f32x4 a = qp[d], b = kp[d];
-            s += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
-        }
-        const int h = hg * HGS + hh;
-        const float* up = c.ubuf + qrow * DFF_SMALL_LD + 3 * h;
-        const float* xp = c.xs + krow * 4;
-        s += up[0] * xp[0] + up[1] * xp[1] + up[2] * xp[2];
-        s = jok ? s * 0.125f : -INFINITY;
-        const float mx = grp_max(s, NP);
-        const float e = jok ? expf(s - mx) : 0.f;
-        const float den = grp_sum(e, NP);
-        const float p = e / den;
-        if (act && jok) {
-            const int pidx = ((hh * c.G + g) * N + i) * N + j;
-            c.Pbuf[pidx] = p;
-            st_nt(sP + pidx, p);
-        }
-    }
-}
-
-// o_ih = sum_j a_ihj v_jh  -> R3 ;  xrel_ih = sum_j a_ihj x_j - x_i -> sbuf[:, 3h..3h+2]
-template <int HGS>
-DEVI void attn_pv(const Ctx& c, int hg) {
-    constexpr int LQ = 64 * HGS + 4;
-    const int N = c.N;
-    const float* vs = c.Rg + 2 * c.G * N * LQ;
-    float* os = c.Rg + 3 * c.G * N * LQ;
-    const int total = c.gcnt * HGS * N * 16;
-    for (int it = threadIdx.x; it < total; it += DFF_NTHREADS) {
-        const int d4 = it & 15, ri = it >> 4;
-        const int i = ri % N, hgi = ri / N;
-        const int g = hgi % c.gcnt, hh = hgi / c.gcnt;
-        const float* pp = c.Pbuf + ((hh * c.G + g) * N + i) * N;
-        const float* vp = vs + (g * N) * LQ + hh * 64 + d4 * 4;
-        f32x4 o = {0.f, 0.f, 0.f, 0.f};
-        for (int j = 0; j < N; ++j) {
-            const float p = pp[j];
-            const f32x4 v = *(const f32x4*)(vp + j * LQ);
-            o[0] += p * v[0]; o[1] += p * v[1]; o[2] += p * v[2]; o[3] += p * v[3];
-        }
-        *(f32x4*)(os + (g * N + i) * LQ + hh * 64 + d4 * 4) = o;
-    }
-    const int t2 = c.gcnt * HGS * N * 4;
-    for (int it = threadIdx.x; it < t2; it += DFF_NTHREADS) {
-        const int cc = it & 3, ri = it >> 2;
-        if (cc == 3) continue;
-        const int i = ri % N, hgi = ri / N;
-        const int g = hgi % c.gcnt, hh = hgi / c.gcnt;
-        const float* pp = c.Pbuf + ((hh * c.G + g) * N + i) * N;
-        float a = 0.f;
-        for (int j = 0; j < N; ++j) a += pp[j] * c.xs[(g * N + j) * 4 + cc];
-        c.sbuf[(g * N + i) * DFF_SMALL_LD + 3 * (hg * HGS + hh) + cc] = a - c.xs[(g * N + i) * 4 + cc];
-    }
-}
-
-// backward, step 2: da_ij = G_i.v_j + r_i.x_j ; ds = a (da - sum_j a da) -> dSbuf ;
-// du_ih = scale sum_j ds_ij x_j -> dubuf
-template <int HGS>
-DEVI void attnb_ds(const Ctx& c, int hg) {
-    constexpr int LQ = 64 * HGS + 4;
-    const int N = c.N, NP = c.NP;
-    const float* vs = c.Rg + 2 * c.G * N * LQ;
-    const float* Gs = c.Rg + 3 * c.G * N * LQ;
-    const int nrow = c.gcnt * HGS * N;
-    const int total = nrow * NP;
-    for (int base = 0; base < total; base += DFF_NTHREADS) {
-        const int it = base + threadIdx.x;
-        const bool act = it < total;
-        const int itc = act ? it : total - 1;
-        const int j = itc % NP, ri = itc / NP;
-        const int i = ri % N, hgi = ri / N;
-        const int g = hgi % c.gcnt, hh = hgi / c.gcnt;
-        const bool jok = j < N;
-        const int irow = g * N + i, jrow = g * N + (jok ? j : N - 1);
-        const f32x4* gp = (const f32x4*)(Gs + irow * LQ + hh * 64);
-        const f32x4* vp = (const f32x4*)(vs + jrow * LQ + hh * 64);
-        float da = 0.f;
+    for (int kb = 0; kb < 5; ++kb) av[kb] = *(const lf32x4*)(ap + 16 * kb);
 #pragma unroll
-        for (int d = 0; d < 16; ++d) {
-            const f32x4 a = gp[d], b = vp[d];
-            da += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
-        }
-        const int h = hg * HGS + hh;
-        const float* rp = c.sbuf + irow * DFF_SMALL_LD + 3 * h;
-        const float* xp = c.xs + jrow * 4;
-        da += rp[0] * xp[0] + rp[1] * xp[1] + rp[2] * xp[2];
-        const int pidx = ((hh * c.G + g) * N + i) * N + (jok ? j : 0);
-        const float p = jok ? c.Pbuf[pidx] : 0.f;
-        const float sm = grp_sum(p * da, NP);
-        const float ds = p * (da - sm);
-        const float dux = grp_sum(ds * xp[0], NP);
-        const float duy = grp_sum(ds * xp[1], NP);
-        const float duz = grp_sum(ds * xp[2], NP);
-        if (act && jok) c.dSbuf[pidx] = ds;
-        if (act && j == 0) {
-            float* dup = c.dubuf + irow * DFF_SMALL_LD + 3 * h;
-            dup[0] = 0.125f * dux; dup[1] = 0.125f * duy; dup[2] = 0.125f * duz;
-        }
-    }
-}
-
-// backward, step 3: dx_j += sum_{hh,i} (a_ij r_i + scale ds_ij u_i) ; dx_i -= sum_hh r_i
-template <int HGS>
-DEVI void attnb_dx(const Ctx& c, int hg) {
-    const int N = c.N;
-    const int total = c.gcnt * N * 4;
-    for (int it = threadIdx.x; it < total; it += DFF_NTHREADS) {
-        const int cc = it & 3, row = it >> 2;
-        if (cc == 3) continue;
-        const int g = row / N, j = row - g * N;
-        float acc = 0.f;
-        for (int hh = 0; hh < HGS; ++hh) {
-            const int h = hg * HGS + hh;
-            const float* pp = c.Pbuf + ((hh * c.G + g) * N) * N + j;
-            const float* dp = c.dSbuf + ((hh * c.G + g) * N) * N + j;
-            float a = 0.f;
-            for (int i = 0; i < N; ++i) {
-                const int irow = g * N + i;
-                a += pp[i * N] * c.sbuf[irow * DFF_SMALL_LD + 3 * h + cc] +
-                     0.125f * dp[i * N] * c.ubuf[irow * DFF_SMALL_LD + 3 * h + cc];
+    for (int jt = 0; jt < MT; ++jt) {
+        const lfloat* bp = B + min(16 * jt + mm, RN - 1) * ld + 4 * kk;
+        f32x4 bv[5];
+#pragma unroll
+        for (int kb = 0; kb < 5; ++kb) bv[kb] = *(const lf32x4*)(bp + 16 * kb);
+        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 4; kb += 2)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb][s], bv[kb][s], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb + 1][s], bv[kb + 1][s], c1, 0, 0, 0);
             }
-            acc += a - c.sbuf[row * DFF_SMALL_LD + 3 * h + cc];
-        }
-        c.dxs[row * 4 + cc] += acc;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4][s], bv[4][s], c0, 0, 0, 0);
+        acc[jt] = c0 + c1;
     }
 }
 
-// backward, steps 4-6.  WHICH 0: dv_j = sum_i a_ij G_i      (reads P, R3)  -> R2
-//                       WHICH 1: dq_i = scale sum_j ds_ij k_j (reads dS, R1) -> R3
-//                       WHICH 2: dk_j = scale sum_i ds_ij q_i (reads dS, R0) -> R1
-template <int HGS, int WHICH>
-DEVI void attnb_dqkv(const Ctx& c) {
-    constexpr int LQ = 64 * HGS + 4;
-    const int N = c.N, RN = c.G * N;
-    const float* src = c.Rg + (WHICH == 0 ? 3 : WHICH == 1 ? 1 : 0) * RN * LQ;
-    float* dst = c.Rg + (WHICH == 0 ? 2 : WHICH == 1 ? 3 : 1) * RN * LQ;
-    const float* W = (WHICH == 0) ? c.Pbuf : c.dSbuf;
-    const float mul = (WHICH == 0) ? 1.0f : 0.125f;
-    const int total = c.gcnt * HGS * N * 16;
-    for (int it = threadIdx.x; it < total; it += DFF_NTHREADS) {
-        const int d4 = it & 15, ri = it >> 4;
-        const int o = ri % N, hgi = ri / N;     // o = output row index within the protein
-        const int g = hgi % c.gcnt, hh = hgi / c.gcnt;
-        const float* wp = W + ((hh * c.G + g) * N) * N;
-        const float* sp = src + (g * N) * LQ + hh * 64 + d4 * 4;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < N; ++s) {
-            // dq: W[o][s] (row o, sum over j=s) ; dv/dk: W[s][o] (sum over i=s)
-            const float w = (WHICH == 1) ? wp[o * N + s] : wp[s * N + o];
-            const f32x4 v = *(const f32x4*)(sp + s * LQ);
-            acc[0] += w * v[0]; acc[1] += w * v[1]; acc[2] += w * v[2]; acc[3] += w * v[3];
+// one 16x16 output tile  C[m][n] = sum_k Aop[16 mo + m][k] B[k][n],  k over all 16 MT rows:
+// TRANS = false: Aop[i][k] = T[i][k] ; true: Aop[i][k] = T[k][i]   (T = a head's (16MT x PL) tile array)
+// B points at column 0 of the wanted 16-column slice of a head-group buffer (rows clamped to RN-1:
+// the matching T entries are exact zeros).
+template <int MT, bool TRANS>
+DEVI f32x4 co_mm(const lfloat* T, int mo, const lfloat* B, int ldb, int RN, int lane) {
+    constexpr int PL = 16 * MT + 4;
+    const int kk = lane >> 4, mm = lane & 15;
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < MT; ++kt) {
+        float as[4], bs[4];
+        if (TRANS) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) as[s] = T[(16 * kt + 4 * kk + s) * PL + 16 * mo + mm];
+        } else {
+            const f32x4 t = *(const lf32x4*)(T + (16 * mo + mm) * PL + 16 * kt + 4 * kk);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) as[s] = t[s];
         }
-        acc[0] *= mul; acc[1] *= mul; acc[2] *= mul; acc[3] *= mul;
-        *(f32x4*)(dst + (g * N + o) * LQ + hh * 64 + d4 * 4) = acc;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bs[s] = B[min(16 * kt + 4 * kk + s, RN - 1) * ldb + mm];
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(as[0], bs[0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(as[1], bs[1], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(as[2], bs[2], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(as[3], bs[3], c1, 0, 0, 0);
     }
+    return c0 + c1;
 }
 
-// reload q (optional), k (optional), v, P, u of layer l / head group hg from the stash
+// geometry every attention phase needs
+struct CoGeo {
+    lfloat *Rg, *Pbuf, *dSbuf, *xs, *dxw;   // dxw: this wave's partial dE/dx
+    int N, RN, rows;
+};
+
+// K_ext / V_ext extension columns <- x (columns 3..15 zero)
 template <int HGS>
-DEVI void reload_heads(const Ctx& c, int l, int hg, bool need_qk, bool need_p = true) {
-    constexpr int LQ = 64 * HGS + 4;
-    constexpr int U = 4;  // loads in flight per thread per tensor before the LDS writes
-    const int N = c.N, RN = c.G * N;
-    const float* sb = c.stash + (size_t)l * c.sl.layer_stride;
-    const int per_row = 16 * HGS;  // float4 per row per tensor
-    const int total = c.rows * per_row;
+DEVI void co_fill_x(const CoGeo& g) {
+    constexpr int LQ = 80 * HGS + 4;
+    const int total = g.rows * HGS * 16;
+    for (int it = threadIdx.x; it < total; it += DFF_NTHREADS) {
+        const int cc = it & 15, r2 = it >> 4;
+        const int hh = r2 % HGS, row = r2 / HGS;
+        const float v = cc < 3 ? g.xs[row * 4 + cc] : 0.f;
+        lfloat* d = g.Rg + g.RN * LQ + row * LQ + hh * 80 + 64 + cc;
+        d[0] = v;
+        d[g.RN * LQ] = v;
+    }
+}
+
+// logits + softmax:  a_ihj = softmax_j( scale (q_ih.k_jh + u_ih.x_j) ) over the beads j of i's own
+// protein (graph_transformer.py:247-255 with the j-constant terms dropped) -> Pbuf (+ stash)
+template <int MT, int HGS>
+DEVI void co_softmax(const CoGeo& g, gfloat* sP /* P block of head hg*HGS */, int lane, int wave) {
+    constexpr int LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL, PS = 16 * MT;
+    const int quad = lane >> 4, col = lane & 15;
+    int gj[MT];
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt) {
+        const int j = 16 * jt + col;
+        gj[jt] = j < g.rows ? j / g.N : -1;
+    }
+    for (int item = wave; item < HGS * MT; item += DFF_NWAVES) {
+        const int hh = item / MT, it = item - hh * MT;
+        f32x4 acc[MT];
+        co_dot_rows<MT>(acc, g.Rg + hh * 80, g.Rg + g.RN * LQ + hh * 80, LQ, g.RN, it, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * it + 4 * quad + r;
+            const int gi = i < g.rows ? i / g.N : -2;
+            float s[MT], mx = -INFINITY;
+#pragma unroll
+            for (int jt = 0; jt < MT; ++jt) {
+                s[jt] = gj[jt] == gi ? acc[jt][r] * 0.125f : -INFINITY;
+                mx = fmaxf(mx, s[jt]);
+            }
+            mx = row16_max(mx);
+            float e[MT], den = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < MT; ++jt) {
+                e[jt] = gj[jt] == gi ? expf(s[jt] - mx) : 0.f;
+                den += e[jt];
+            }
+            den = row16_sum(den);
+            lfloat* pl = g.Pbuf + hh * PT + i * PL + col;
+            gfloat* ps = sP + ((size_t)hh * g.RN + min(i, g.RN - 1)) * PS + col;
+#pragma unroll
+            for (int jt = 0; jt < MT; ++jt) {
+                const float p = gi >= 0 ? e[jt] / den : 0.f;
+                pl[16 * jt] = p;
+                if (gi >= 0) st_ntg(ps + 16 * jt, p);
+            }
+        }
+    }
+}
+
+// o_ext = P V_ext -> R0 (Q_ext is dead after the logits); extension tile: xrel_i = sum_j a_ij x_j - x_i
+template <int MT, int HGS>
+DEVI void co_pv(const CoGeo& g, int lane, int wave) {
+    constexpr int LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL;
+    const int quad = lane >> 4, col = lane & 15;
+    for (int item = wave; item < HGS * MT * 5; item += DFF_NWAVES) {
+        const int hh = item / (MT * 5), rem = item - hh * (MT * 5);
+        const int it = rem / 5, nt = rem - it * 5;
+        const f32x4 acc = co_mm<MT, false>(g.Pbuf + hh * PT, it, g.Rg + 2 * g.RN * LQ + hh * 80 + 16 * nt, LQ, g.RN, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * it + 4 * quad + r;
+            if (row < g.rows) {
+                float v = acc[r];
+                if (nt == 4) v -= g.xs[row * 4 + min(col, 3)];
+                g.Rg[row * LQ + hh * 80 + 16 * nt + col] = v;
+            }
+        }
+    }
+}
+
+// backward: da = G_ext V_ext^T ; ds = scale a (da - sum_j a da) -> dSbuf
+template <int MT, int HGS>
+DEVI void co_ds(const CoGeo& g, int lane, int wave) {
+    constexpr int LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL;
+    const int quad = lane >> 4, col = lane & 15;
+    for (int item = wave; item < HGS * MT; item += DFF_NWAVES) {
+        const int hh = item / MT, it = item - hh * MT;
+        f32x4 acc[MT];
+        co_dot_rows<MT>(acc, g.Rg + 3 * g.RN * LQ + hh * 80, g.Rg + 2 * g.RN * LQ + hh * 80, LQ, g.RN, it, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * it + 4 * quad + r;
+            const lfloat* pl = g.Pbuf + hh * PT + i * PL + col;
+            float p[MT], sm = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < MT; ++jt) {
+                p[jt] = pl[16 * jt];
+                sm += p[jt] * acc[jt][r];
+            }
+            sm = row16_sum(sm);
+            lfloat* dl = g.dSbuf + hh * PT + i * PL + col;
+#pragma unroll
+            for (int jt = 0; jt < MT; ++jt) dl[16 * jt] = 0.125f * (p[jt] * (acc[jt][r] - sm));
+        }
+    }
+}
+
+// backward tile products.  WHICH 0: dV_ext = P^T G_ext      (reads Pbuf, R3)  -> R2
+//                          WHICH 1: dQ_ext = dS K_ext       (reads dSbuf, R1) -> R3
+//                          WHICH 2: dK_ext = dS^T Q_ext     (reads dSbuf, R0) -> R1
+// the extension tiles of dV_ext / dK_ext are dE/dx_j and go to this wave's dxw instead.
+// EXT_ONLY (layer 0: nothing upstream of q, k, v depends on x): only those two extension tiles.
+template <int MT, int HGS, int WHICH, bool EXT_ONLY>
+DEVI void co_dqkv(const CoGeo& g, int lane, int wave) {
+    constexpr int LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL;
+    constexpr int SRC = WHICH == 0 ? 3 : WHICH == 1 ? 1 : 0;
+    constexpr int DST = WHICH == 0 ? 2 : WHICH == 1 ? 3 : 1;
+    constexpr int NTI = EXT_ONLY ? 1 : 5;
+    const int quad = lane >> 4, col = lane & 15;
+    const lfloat* T = WHICH == 0 ? g.Pbuf : g.dSbuf;
+    for (int item = wave; item < HGS * MT * NTI; item += DFF_NWAVES) {
+        const int hh = item / (MT * NTI), rem = item - hh * (MT * NTI);
+        const int mo = rem / NTI, nt = EXT_ONLY ? 4 : rem - mo * NTI;
+        const f32x4 acc = co_mm<MT, WHICH != 1>(T + hh * PT, mo, g.Rg + SRC * g.RN * LQ + hh * 80 + 16 * nt, LQ, g.RN, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * mo + 4 * quad + r;
+            if (row < g.rows) {
+                if (WHICH != 1 && nt == 4) {
+                    if (col < 3) g.dxw[row * 4 + col] += acc[r];
+                } else {
+                    g.Rg[DST * g.RN * LQ + row * LQ + hh * 80 + 16 * nt + col] = acc[r];
+                }
+            }
+        }
+    }
+}
+
+// reload Q_ext, K, V (-> R0, R1, R2) and optionally P (-> Pbuf) of layer l / head group hg from the stash
+template <int MT, int HGS>
+DEVI void co_reload(const CoGeo& g, const gfloat* sqkv /* head hg*HGS */, const gfloat* sP, bool need_p) {
+    constexpr int LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL, PS = 16 * MT;
+    constexpr int U = 4;  // loads in flight per thread before the LDS writes
+    constexpr int per_row = (DFF_QKVW / 4) * HGS;
+    const int total = g.rows * per_row;
     for (int base = 0; base < total; base += DFF_NTHREADS * U) {
-        f32x4 tv[U], tq[U], tk[U];
+        f32x4 t[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int it = base + u * DFF_NTHREADS + threadIdx.x;
             if (it < total) {
-                const int row = it / per_row, c4 = it - row * per_row;
-                const size_t so = (size_t)row * DFF_INNER + hg * HGS * 64 + c4 * 4;
-                tv[u] = __builtin_nontemporal_load((const f32x4*)(sb + c.sl.v + so));
-                if (need_qk) {
-                    tq[u] = __builtin_nontemporal_load((const f32x4*)(sb + c.sl.q + so));
-                    tk[u] = __builtin_nontemporal_load((const f32x4*)(sb + c.sl.k + so));
-                }
+                const int row = it / per_row, r2 = it - row * per_row;
+                const int hh = r2 / (DFF_QKVW / 4), c4 = r2 - hh * (DFF_QKVW / 4);
+                t[u] = ld_ntg4(sqkv + ((size_t)hh * g.RN + row) * DFF_QKVW + 4 * c4);
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int it = base + u * DFF_NTHREADS + threadIdx.x;
             if (it < total) {
-                const int row = it / per_row, c4 = it - row * per_row;
-                const int lo = row * LQ + c4 * 4;
-                *(f32x4*)(c.Rg + 2 * RN * LQ + lo) = tv[u];
-                if (need_qk) {
-                    *(f32x4*)(c.Rg + lo) = tq[u];
-                    *(f32x4*)(c.Rg + RN * LQ + lo) = tk[u];
-                }
+                const int row = it / per_row, r2 = it - row * per_row;
+                const int hh = r2 / (DFF_QKVW / 4), c4 = r2 - hh * (DFF_QKVW / 4);
+                const int colq = 4 * c4;
+                const int reg = (colq >= 80) + (colq >= 144);
+                const int cl = colq - (reg == 0 ? 0 : reg == 1 ? 80 : 144);
+                *(lf32x4*)(g.Rg + reg * g.RN * LQ + row * LQ + hh * 80 + cl) = t[u];
             }
         }
     }
     if (need_p) {
-        const int pn = HGS * c.G * N * N;
-        const float* sP = sb + c.sl.P + (size_t)hg * pn;
+        constexpr int ppr = PS / 4;
+        const int pn = HGS * g.rows * ppr;
         for (int base = 0; base < pn; base += DFF_NTHREADS * U) {
-            float t[U];
+            f32x4 t[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int it = base + u * DFF_NTHREADS + threadIdx.x;
-                t[u] = it < pn ? ld_nt(sP + it) : 0.f;
+                if (it < pn) {
+                    const int hh = it / (g.rows * ppr), r2 = it - hh * (g.rows * ppr);
+                    const int row = r2 / ppr, c4 = r2 - row * ppr;
+                    t[u] = ld_ntg4(sP + ((size_t)hh * g.RN + row) * PS + 4 * c4);
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int it = base + u * DFF_NTHREADS + threadIdx.x;
-                if (it < pn) c.Pbuf[it] = t[u];
+                if (it < pn) {
+                    const int hh = it / (g.rows * ppr), r2 = it - hh * (g.rows * ppr);
+                    const int row = r2 / ppr, c4 = r2 - row * ppr;
+                    *(lf32x4*)(g.Pbuf + hh * PT + row * PL + 4 * c4) = t[u];
+                }
             }
         }
     }
@@ -925,7 +1040,6 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
     const LL ll(c.N, c.G);
     c.xst = smem + ll.xst; c.xs = smem + ll.xs; c.dxs = smem + ll.dxs; c.vst = smem + ll.vst;
     c.cm = smem + ll.cm; c.tn = smem + ll.tn;
-    c.ubuf = smem + ll.ubuf; c.sbuf = smem + ll.sbuf; c.dubuf = smem + ll.dubuf;
     c.abuf = smem + ll.abuf;
     c.Pbuf = smem + ll.Pbuf; c.dSbuf = smem + ll.dSbuf; c.Rg = smem + ll.Rg;
     c.sl = dff_stash_layout(c.N, c.G, H, m.L);
@@ -933,7 +1047,15 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
     c.resbuf = SPILL ? (c.stash + c.sl.dn_spill) : (smem + ll.resbuf);
     float* tbuf = c.Rg;  // GEMM outputs of width H alias the start of the head-group region
     const int tid = threadIdx.x;
+    const int lane_ = tid & 63, wave_ = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = c.N, RN = c.G * N, rows = c.rows;
+    CoGeo geo;
+    {
+        lfloat* const sm = (lfloat*)smem;
+        geo.Rg = sm + ll.Rg; geo.Pbuf = sm + ll.Pbuf; geo.dSbuf = sm + ll.dSbuf; geo.xs = sm + ll.xs;
+        geo.dxw = sm + ll.dxw + wave_ * RN * 4;
+        geo.N = N; geo.RN = RN; geo.rows = rows;
+    }
 
     // zero LDS once (pad columns of the 32-wide buffers must be 0; pad rows must be finite)
     for (int i = tid; i < (int)ll.total; i += DFF_NTHREADS) smem[i] = 0.f;
@@ -987,6 +1109,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             if (a.mode == DFF_MODE_LANGEVIN) c.xst[tid] = xc;
             c.xs[tid] = xc;
             c.dxs[tid] = 0.f;
+#pragma unroll
+            for (int w = 0; w < DFF_NWAVES; ++w) (smem + ll.dxw)[w * RN * 4 + tid] = 0.f;
         }
         wg_sync<SPILL>();
         if (a.mode == DFF_MODE_LANGEVIN) {  // second (no-op-sized) centring inside the score op
@@ -1009,78 +1133,67 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             const DffLayerDev& lw = m.layer[l];
             float* sb = c.stash + (size_t)l * c.sl.layer_stride;
             const bool cached = cached0 && l == 0;
+            gfloat* const sqkv = (gfloat*)sb + c.sl.qkvx;
+            gfloat* const sPl = (gfloat*)sb + c.sl.P;
             if (cached) {
                 for (int it = tid; it < rows * H; it += DFF_NTHREADS) {
                     const int row = it / H, col = it - row * H;
                     c.resbuf[row * LH + col] = ld_nt(sb + c.sl.nodes_in + it);
                 }
-                for (int it = tid; it < rows * 32; it += DFF_NTHREADS)
-                    c.ubuf[(it >> 5) * DFF_SMALL_LD + (it & 31)] = ld_nt(sb + c.sl.u + it);
             } else {
-            row_ln1<H>(c, lw, l);
-            wg_sync<SPILL>();
-            pf.tick(1);
-            // u = LN1(nodes) W_u^T + b_u  (all 8 heads, 24 of 32 columns used)
-            gemm_wide<MT, NT_H, 1>(c.abuf, LH, RN, lw.Wu_p, NT_H, 0, 0, 2,
-                [&](int nt, float (&aux)[1]) { aux[0] = lw.bu[16 * nt + (tid & 15)]; },
-                [&](int nt, int mt, const f32x4& acc, const float (&aux)[1]) {
-                    const int lane = tid & 63, quad = lane >> 4, col = 16 * nt + (lane & 15);
-                    const float bv = aux[0];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = mt * 16 + quad * 4 + r;
-                        if (row < rows) {
-                            const float v = acc[r] + bv;
-                            c.ubuf[row * DFF_SMALL_LD + col] = v;
-                            st_nt(sb + c.sl.u + row * 32 + col, v);
-                        }
-                    }
-                });
+                row_ln1<H>(c, lw, l);
+                wg_sync<SPILL>();
             }
+            pf.tick(1);
             f32x4 acc_o[NTW][MT];
             acc_zero<MT, NTW>(acc_o);
-            pf.tick(2);
             for (int hg = 0; hg < NHG; ++hg) {
-                // q|k|v of HGS heads -> R0,R1,R2 (+ stash)
-                if (cached) reload_heads<HGS>(c, 0, hg, true, false);
-                else
-                gemm_wide<MT, NT_H, 1>(c.abuf, LH, RN, lw.Wqkv_p, NT_H, 0, hg * HGS * 12, HGS * 12,
-                    [&](int nt, float (&aux)[1]) { aux[0] = lw.bqkv[(hg * HGS * 12 + nt) * 16 + (tid & 15)]; },
-                    [&](int nt, int mt, const f32x4& acc, const float (&aux)[1]) {
-                        const int lane = tid & 63, quad = lane >> 4, cl = lane & 15;
-                        const int cg = (hg * HGS * 12 + nt) * 16;         // global column (head-major)
-                        const int h = cg / 192, part = (cg % 192) / 64, d = (cg % 64) + cl;
-                        const float bv = aux[0];
-                        float* dstl = c.Rg + part * RN * LQ + (h - hg * HGS) * 64 + d;
-                        float* dsts = sb + (part == 0 ? c.sl.q : part == 1 ? c.sl.k : c.sl.v) + h * 64 + d;
+                // [q|u|k|v] of HGS heads -> R0,R1,R2 (+ stash)
+                if (cached) co_reload<MT, HGS>(geo, sqkv + (size_t)hg * HGS * RN * DFF_QKVW, sPl, false);
+                else {
+                    const gfloat* bq = (const gfloat*)lw.bqkvx + hg * HGS * DFF_QKVW;
+                    gfloat* const sq = sqkv + (size_t)hg * HGS * RN * DFF_QKVW;
+                    lfloat* const Rl = geo.Rg;
+                    gemm_wide<MT, NT_H, 1>(c.abuf, LH, RN, lw.Wqkvx_p, NT_H, 0, hg * HGS * 13, HGS * 13,
+                        [=](int nt, float (&aux)[1]) { aux[0] = bq[nt * 16 + (tid & 15)]; },
+                        [=](int nt, int mt, const f32x4& acc, const float (&aux)[1]) {
+                            const int lane = tid & 63, quad = lane >> 4, cl = lane & 15;
+                            const int hh = nt / 13, tt = nt - 13 * hh;
+                            const int reg = (tt >= 5) + (tt >= 9);
+                            const float bv = aux[0];
+                            lfloat* dstl = Rl + reg * RN * LQ + hh * 80 + 16 * (tt - 5 * reg + (reg >> 1)) + cl;
+                            gfloat* dsts = sq + (size_t)hh * RN * DFF_QKVW + 16 * tt + cl;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = mt * 16 + quad * 4 + r;
-                            if (row < rows) {
-                                const float v = acc[r] + bv;
-                                dstl[row * LQ] = v;
-                                st_nt(dsts + (size_t)row * DFF_INNER, v);
+                            for (int r = 0; r < 4; ++r) {
+                                const int row = mt * 16 + quad * 4 + r;
+                                if (row < rows) {
+                                    const float v = acc[r] + bv;
+                                    dstl[row * LQ] = v;
+                                    st_ntg(dsts + (size_t)row * DFF_QKVW, v);
+                                }
                             }
-                        }
-                    });
+                        });
+                }
+                co_fill_x<HGS>(geo);
                 wg_sync<SPILL>();
                 pf.tick(3);
-                attn_softmax<HGS>(c, hg, l);
+                co_softmax<MT, HGS>(geo, sPl + (size_t)hg * HGS * RN * c.sl.PS, lane_, wave_);
                 wg_sync<SPILL>();
                 pf.tick(4);
-                attn_pv<HGS>(c, hg);
+                co_pv<MT, HGS>(geo, lane_, wave_);
                 wg_sync<SPILL>();
                 pf.tick(5);
-                gemm_tall<MT, NTW, 4>(acc_o, HGS,
-                    [&](int s, const float*& Ap, int& kb0) { Ap = c.Rg + 3 * RN * LQ + s * 64; kb0 = (hg * HGS + s) * 4; },
-                    LQ, RN, lw.Wo_p, DFF_INNER / 16, NT_H);
+                // attn_out += o_ext [W_o ; W_oc]   (K = 80 per head)
+                gemm_tall_kb<MT, NTW>(acc_o, 5 * HGS,
+                    [=](int i, int& aoff, int& wkb) {
+                        const int hh = i / 5, kb = i - 5 * hh;
+                        aoff = hh * 80 + 16 * kb;
+                        wkb = (hg * HGS + hh) * 5 + kb;
+                    },
+                    geo.Rg, LQ, RN, lw.Wox_p, DFF_HEADS * 5, NT_H);
+                wg_sync<SPILL>();
+                pf.tick(6);
             }
-            // + W_oc xrel  (K = 32, columns 24..31 of sbuf are zero)
-            gemm_tall<MT, NTW, 2>(acc_o, 1,
-                [&](int, const float*& Ap, int& kb0) { Ap = c.sbuf; kb0 = 0; },
-                DFF_SMALL_LD, RN, lw.Woc_p, 2, NT_H);
-            wg_sync<SPILL>();
-            pf.tick(6);
             store_tall<MT, NTW>(acc_o, tbuf, LH, rows, NT_H, lw.bo);
             wg_sync<SPILL>();
             row_gate1_ln2<H>(c, lw, l, tbuf);
@@ -1165,68 +1278,65 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             rowb_ln2_gate1<H>(c, lw, l, tbuf);
             wg_sync<SPILL>();
             pf.tick(14);
-            // r = dattn W_oc (dE/dxrel) -> sbuf ; u of this layer -> ubuf
-            gemm_wide<MT, NT_H, 1>(c.abuf, LH, RN, lw.WocT_p, NT_H, 0, 0, 2,
-                [&](int, float (&)[1]) {},
-                [&](int nt, int mt, const f32x4& acc, const float (&)[1]) {
-                    const int lane = tid & 63, quad = lane >> 4, col = 16 * nt + (lane & 15);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = mt * 16 + quad * 4 + r;
-                        if (row < rows) c.sbuf[row * DFF_SMALL_LD + col] = acc[r];
-                    }
-                });
-            for (int it = tid; it < rows * 32; it += DFF_NTHREADS)
-                c.ubuf[(it >> 5) * DFF_SMALL_LD + (it & 31)] = ld_nt(sb + c.sl.u + it);
+            const gfloat* const sqkv = (const gfloat*)sb + c.sl.qkvx;
+            const gfloat* const sPl = (const gfloat*)sb + c.sl.P;
             f32x4 acc_a[NTW][MT];
             acc_zero<MT, NTW>(acc_a);
             pf.tick(15);
             for (int hg = 0; hg < NHG; ++hg) {
-                reload_heads<HGS>(c, l, hg, l > 0);
-                // G = dattn W_o (dE/do) for the heads of this group -> R3
-                gemm_wide<MT, NT_H, 1>(c.abuf, LH, RN, lw.WoT_p, NT_H, 0, hg * HGS * 4, HGS * 4,
-                    [&](int, float (&)[1]) {},
-                    [&](int nt, int mt, const f32x4& acc, const float (&)[1]) {
-                        const int lane = tid & 63, quad = lane >> 4, cl = 16 * nt + (lane & 15);
+                co_reload<MT, HGS>(geo, sqkv + (size_t)hg * HGS * RN * DFF_QKVW, sPl + (size_t)hg * HGS * RN * c.sl.PS, true);
+                // G_ext = dattn [W_o ; W_oc]^T (dE/do | r = dE/dxrel) for the heads of this group -> R3 ;
+                // dE/dx_i -= r_i
+                {
+                    lfloat* const Gl = geo.Rg + 3 * RN * LQ;
+                    lfloat* const dxw = geo.dxw;
+                    gemm_wide<MT, NT_H, 1>(c.abuf, LH, RN, lw.WoxT_p, NT_H, 0, hg * HGS * 5, HGS * 5,
+                        [=](int, float (&)[1]) {},
+                        [=](int nt, int mt, const f32x4& acc, const float (&)[1]) {
+                            const int lane = tid & 63, quad = lane >> 4, cl = lane & 15;
+                            const int hh = nt / 5, tt = nt - 5 * hh;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = mt * 16 + quad * 4 + r;
-                            if (row < rows) c.Rg[3 * RN * LQ + row * LQ + cl] = acc[r];
-                        }
-                    });
+                            for (int r = 0; r < 4; ++r) {
+                                const int row = mt * 16 + quad * 4 + r;
+                                if (row < rows) {
+                                    Gl[row * LQ + hh * 80 + 16 * tt + cl] = acc[r];
+                                    if (tt == 4 && cl < 3) dxw[row * 4 + cl] -= acc[r];
+                                }
+                            }
+                        });
+                }
+                co_fill_x<HGS>(geo);
                 wg_sync<SPILL>();
                 pf.tick(16);
-                attnb_ds<HGS>(c, hg);
+                co_ds<MT, HGS>(geo, lane_, wave_);
                 wg_sync<SPILL>();
                 pf.tick(17);
-                attnb_dx<HGS>(c, hg);
                 if (l > 0) {
-                    attnb_dqkv<HGS, 0>(c);
+                    co_dqkv<MT, HGS, 0, false>(geo, lane_, wave_);
                     wg_sync<SPILL>();
-                    attnb_dqkv<HGS, 1>(c);
+                    co_dqkv<MT, HGS, 1, false>(geo, lane_, wave_);
                     wg_sync<SPILL>();
-                    attnb_dqkv<HGS, 2>(c);
+                    co_dqkv<MT, HGS, 2, false>(geo, lane_, wave_);
                     wg_sync<SPILL>();
                     pf.tick(18);
-                    // d(LN1 out) += dq Wq + dk Wk + dv Wv   (head-major K order [h][q|k|v][d])
-                    gemm_tall<MT, NTW, 4>(acc_a, 3 * HGS,
-                        [&](int s, const float*& Ap, int& kb0) {
-                            const int hh = s / 3, part = s - 3 * hh;
-                            const int reg = part == 0 ? 3 : part == 1 ? 1 : 2;  // dq in R3, dk in R1, dv in R2
-                            Ap = c.Rg + reg * RN * LQ + hh * 64;
-                            kb0 = ((hg * HGS + hh) * 3 + part) * 4;
+                    // d(LN1 out) += [dq|du] W_qu + dk W_k + dv W_v   (K order per head [q64|u16|k64|v64])
+                    gemm_tall_kb<MT, NTW>(acc_a, 13 * HGS,
+                        [=](int i, int& aoff, int& wkb) {
+                            const int hh = i / 13, tt = i - 13 * hh;
+                            const int part = (tt >= 5) + (tt >= 9);
+                            const int reg = part == 0 ? 3 : part;          // dQ_ext in R3, dK in R1, dV in R2
+                            aoff = reg * RN * LQ + hh * 80 + 16 * (tt - 5 * part + (part >> 1));
+                            wkb = (hg * HGS + hh) * 13 + tt;
                         },
-                        LQ, RN, lw.WqkvT_p, 3 * DFF_INNER / 16, NT_H);
+                        geo.Rg, LQ, RN, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
+                } else {
+                    co_dqkv<MT, HGS, 0, true>(geo, lane_, wave_);
+                    co_dqkv<MT, HGS, 2, true>(geo, lane_, wave_);
                 }
                 wg_sync<SPILL>();
                 pf.tick(19);
             }
             if (l > 0) {
-                // + du W_u   (K = 32)
-                gemm_tall<MT, NTW, 2>(acc_a, 1,
-                    [&](int, const float*& Ap, int& kb0) { Ap = c.dubuf; kb0 = 0; },
-                    DFF_SMALL_LD, RN, lw.WuT_p, 2, NT_H);
-                wg_sync<SPILL>();
                 store_tall<MT, NTW>(acc_a, tbuf, LH, rows, NT_H, nullptr);
                 wg_sync<SPILL>();
                 rowb_ln1<H>(c, lw, l, tbuf);
@@ -1234,6 +1344,14 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 pf.tick(20);
             }
         }
+        // dE/dx = sum of the per-wave partials
+        if (tid < rows * 4) {
+            float sdx = 0.f;
+#pragma unroll
+            for (int w = 0; w < DFF_NWAVES; ++w) sdx += (smem + ll.dxw)[w * RN * 4 + tid];
+            c.dxs[tid] = sdx;
+        }
+        wg_sync<SPILL>();
 
         // =============================== update ===============================
         // dxs = d(sum E)/dx ; the score op returns -dxs (graph_transformer.py:159)

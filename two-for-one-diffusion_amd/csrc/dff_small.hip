@@ -24,27 +24,6 @@
 #pragma once
 #include "dff_internal.h"
 
-// Explicitly address-space-typed pointers: the hot lambdas capture pointers by reference and some
-// closures end up in memory, where a plain `float*` loses its provenance and every access turns
-// into a FLAT op (which waits on BOTH counters and drains the weight ring).  Typed pointers keep
-// ds_* / global_* no matter how they travel.
-typedef __attribute__((address_space(3))) float lfloat;
-typedef __attribute__((address_space(1))) float gfloat;
-typedef f32x4 __attribute__((address_space(3))) lf32x4;
-typedef f32x4 __attribute__((address_space(1))) gf32x4;
-#ifndef DFF_STASH_NT
-#define DFF_STASH_NT 0   // 1: non-temporal stash traffic. Measured: default policy is 3% faster (stash stays in L2/MALL)
-#endif
-#if DFF_STASH_NT
-DEVI void st_ntg(gfloat* p, float v) { __builtin_nontemporal_store(v, p); }
-DEVI float ld_ntg(const gfloat* p) { return __builtin_nontemporal_load(p); }
-DEVI f32x4 ld_ntg4(const gfloat* p) { return __builtin_nontemporal_load((const gf32x4*)p); }
-#else
-DEVI void st_ntg(gfloat* p, float v) { *p = v; }
-DEVI float ld_ntg(const gfloat* p) { return *p; }
-DEVI f32x4 ld_ntg4(const gfloat* p) { return *(const gf32x4*)p; }
-#endif
-
 // GELU(erf) value and derivative in one go: the forward FFN epilogue stashes gelu'(h_pre) so that the
 // backward epilogue is a single multiply (one erf + one exp per element per step instead of two + one)
 // Branch-free erf: |x| <= 0.8: x * P5(x^2);  else 1 - exp(P8(|x|)) with P8 ~ log erfc on [0.8, 4.2]
@@ -80,7 +59,6 @@ DEVI void gelu_both(float x, float& g, float& gp) {
 #define DFF_XLD 84      // leading dim of the per-wave head buffers
 #define DFF_PLD 20      // leading dim of the per-wave P / dS tiles
 
-#define DFF_QKVW 208    // stash row of one head: [q_ext 80 | k 64 | v 64]
 struct SmallStash {
     unsigned nodes_in, attn_out, ff, h_pre, qkv, P;
     unsigned layer_stride, total;
