@@ -136,7 +136,7 @@ int dff_last_launch(const dff_model* m, const char** kernel_name, int* grid, int
 int dff_debug_gemm(int device, const float* A_host, const float* W_host, int M, int K, int Nout,
                    float* out_host);
 /* Copy one stashed forward intermediate of the LAST dff_score call for sample `b`, layer `l`
- * to out_host: what 0 nodes_in (N,H), 1 attn_out (N,H), 2 ff (N,H), 3 h_pre (N,4H; the rows<=16 kernel keeps gelu'(h_pre) there),
+ * to out_host: what 0 nodes_in (N,H), 1 attn_out (N,H), 2 ff (N,H), 3 gelu'(h_pre) (N,4H; what the backward needs),
  * 4 q (N,512), 5 k (N,512), 6 v (N,512), 7 P (8,N,N), 8 u (N,32). */
 int dff_debug_stash(dff_model* m, int b, int layer, int what, float* out_host, size_t n);
 

@@ -8,8 +8,10 @@
 #define DFF_HEADS 8
 #define DFF_DH 64
 #define DFF_INNER 512
-#define DFF_NTHREADS 256
-#define DFF_NWAVES 4
+#ifndef DFF_NTHREADS
+#define DFF_NTHREADS 512   // generic kernel: 8 waves = two per SIMD (epilogue VALU of one overlaps MFMA of the other)
+#define DFF_NWAVES 8
+#endif
 #define DFF_NPROF 24       // per-stage cycle counters (debug)
 #define DFF_SMALL_LD 36   // leading dim of the 32-column u / xrel / r / du buffers
 

@@ -134,6 +134,14 @@ template <int CTRL>
 DEVI float dpp_mov(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
+// thread index behind an opaque barrier: every stage re-derives its lane / row / address arithmetic from
+// a fresh copy, so LICM cannot hoist hundreds of per-stage invariants to the top of the kernel (where
+// they spill and come back through scratch loads that drain the weight rings).
+DEVI int tid_now() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
 DEVI float row16_sum(float v) {
     v += dpp_mov<0xB1>(v);
     v += dpp_mov<0x4E>(v);
@@ -162,6 +170,37 @@ DEVI float gelu_grad_f(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) +
            x * expf(-0.5f * x * x) * 0.39894228040143267794f;
 }
+// GELU(erf) value and derivative in one go: the forward FFN epilogue stashes gelu'(h_pre) so that the
+// backward epilogue is a single multiply (one erf + one exp per element per step instead of two + one)
+// Branch-free erf: |x| <= 0.8: x * P5(x^2);  else 1 - exp(P8(|x|)) with P8 ~ log erfc on [0.8, 4.2]
+// (least-squares fits on Chebyshev nodes; max abs error 1.2e-7 against scipy.special.erf over
+// [-6, 6] in float32 -- the same 1-2 ulp class as the library erff, at about half its instructions).
+#ifndef DFF_FAST_ERF
+#define DFF_FAST_ERF 0   // measured: no faster than the library erff here (the FFN epilogue is not erf-bound)
+#endif
+DEVI float erf_fast(float x) {
+#if DFF_FAST_ERF
+    const float t = fminf(fabsf(x), 4.2f), s = x * x;
+    float a = -6.546706740e-04f;
+    a = fmaf(a, s, 5.086977565e-03f); a = fmaf(a, s, -2.682184972e-02f); a = fmaf(a, s, 1.128313692e-01f);
+    a = fmaf(a, s, -3.761260335e-01f); a = fmaf(a, s, 1.128379164e+00f);
+    a *= x;
+    float b = 1.534366307e-06f;
+    b = fmaf(b, t, -4.404490910e-05f); b = fmaf(b, t, 5.800263089e-04f); b = fmaf(b, t, -4.682034248e-03f);
+    b = fmaf(b, t, 2.620414818e-02f); b = fmaf(b, t, -1.097046865e-01f); b = fmaf(b, t, -6.322175036e-01f);
+    b = fmaf(b, t, -1.130008818e+00f); b = fmaf(b, t, 2.658824129e-04f);
+    b = copysignf(1.0f - __expf(b), x);
+    return t <= 0.8f ? a : b;
+#else
+    return erff(x);
+#endif
+}
+DEVI void gelu_both(float x, float& g, float& gp) {
+    const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
+    g = x * cdf;
+    gp = cdf + x * expf(-0.5f * x * x) * 0.39894228040143267794f;
+}
+
 DEVI float sigmoid_f(float z) { return 1.0f / (1.0f + expf(-z)); }
 DEVI void st_nt(float* p, float v) { __builtin_nontemporal_store(v, p); }
 DEVI float ld_nt(const float* p) { return __builtin_nontemporal_load(p); }
@@ -211,34 +250,33 @@ DEVI void mfma4(f32x4& acc, const f32x4 a, const f32x4 b) {
 // Weight fetch latency out of L2 is ~1 us when all 256 CUs stream the same packed image, and a
 // workgroup has only 4 waves, so each wave keeps a ring of D tiles (wide) / segments (tall) of
 // B operands in flight in registers (Little: D * 4 KB * 4 waves per CU).
-#ifndef DFF_WIDE_DEPTH
-#define DFF_WIDE_DEPTH 4
-#endif
-#ifndef DFF_TALL_DEPTH
-#define DFF_TALL_DEPTH 3
-#endif
 
-// "wide" GEMM: K = 16*KB (small, compile time), many output tiles; the 4 waves take tiles
-// round-robin.  epi(nt_local, mt, acc) consumes one 16x16 output tile.
+// "wide" GEMM: K = 16*KB (small, compile time), many output tiles; the waves take tiles
+// round-robin.  epi(nt_local, mt, acc, aux) consumes one 16x16 output tile.
 // pre(nt_local, aux) issues the global loads the tile's epilogue needs (bias, stashed values)
 // together with the tile's weights, so their latency is hidden by the ring as well.
+// Register diet (two waves per SIMD share 512 registers): the ring holds D tiles with D * KB ~ 12-16
+// k-blocks in flight, and the A fragments are re-read from LDS for every tile unless they are few.
 template <int MT, int KB, int NAUX, class Pre, class Epi>
-DEVI void gemm_wide(const float* A, int lda, int rowsA, const float* __restrict__ Wp, int KBtot,
+DEVI void gemm_wide(const lfloat* A, int lda, int rowsA, const float* __restrict__ Wp, int KBtot,
                     int kb0, int nt0, int ntn, Pre pre, Epi epi) {
-    constexpr int D = DFF_WIDE_DEPTH;
-    static_assert(KB % 2 == 0, "KB must be even");
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid_ = tid_now();
+    constexpr int D = KB >= 6 ? 2 : 3;
+    constexpr bool HOLD = MT * KB <= 16;   // keep all A fragments in registers
+    constexpr int NC = MT == 1 ? 2 : 1;    // independent accumulator chains per output tile
+    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     const int kk = lane >> 4, mm = lane & 15;
-    f32x4 a[MT][KB];
+    int rowoff[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int row = mt * 16 + mm;
-        row = row < rowsA ? row : rowsA - 1;
-        const float* ap = A + row * lda + 4 * kk;
+    for (int mt = 0; mt < MT; ++mt) rowoff[mt] = min(mt * 16 + mm, rowsA - 1) * lda + 4 * kk;
+    f32x4 ah[HOLD ? MT : 1][HOLD ? KB : 1];
+    if (HOLD) {
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) a[mt][kb] = *(const f32x4*)(ap + 16 * kb);
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) ah[HOLD ? mt : 0][HOLD ? kb : 0] = *(const lf32x4*)(A + rowoff[mt] + 16 * kb);
     }
-    const f32x4* wp = (const f32x4*)Wp + lane + (size_t)kb0 * 64;
+    const gf32x4* wp = (const gf32x4*)Wp + lane + (size_t)kb0 * 64;
     const int cnt = wave < ntn ? (ntn - wave + DFF_NWAVES - 1) / DFF_NWAVES : 0;
     f32x4 b[D][KB];
     float aux[D][NAUX];
@@ -255,18 +293,23 @@ DEVI void gemm_wide(const float* A, int lda, int rowsA, const float* __restrict_
             const int i = i0 + d;
             if (i < cnt) {
                 const int nt = wave + DFF_NWAVES * i;
-                f32x4 acc[MT], acc2[MT];
+                f32x4 acc[MT][NC];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) { acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int kb = 0; kb < KB; kb += 2)
+                    for (int q = 0; q < NC; ++q) acc[mt][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    f32x4 a[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        a[mt] = HOLD ? ah[HOLD ? mt : 0][HOLD ? kb : 0] : *(const lf32x4*)(A + rowoff[mt] + 16 * kb);
 #pragma unroll
                     for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) {
-                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][kb][s4], b[d][kb][s4], acc[mt], 0, 0, 0);
-                            acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][kb + 1][s4], b[d][kb + 1][s4], acc2[mt], 0, 0, 0);
-                        }
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt][kb % NC] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s4], b[d][kb][s4], acc[mt][kb % NC], 0, 0, 0);
+                }
                 float auxc[NAUX];
 #pragma unroll
                 for (int q = 0; q < NAUX; ++q) auxc[q] = aux[d][q];
@@ -277,94 +320,10 @@ DEVI void gemm_wide(const float* A, int lda, int rowsA, const float* __restrict_
                     pre(nt + DFF_NWAVES * D, aux[d]);
                 }
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) epi(nt, mt, acc[mt] + acc2[mt], auxc);
+                for (int mt = 0; mt < MT; ++mt) epi(nt, mt, NC == 2 ? acc[mt][0] + acc[mt][NC - 1] : acc[mt][0], auxc);
             }
         }
     }
-}
-
-// "tall" GEMM: few output tiles (Nout = H: wave w owns tiles w, w+4), long K given as `nseg`
-// segments of SKB k-blocks each; segf(s, A_ptr&, kb0&) names segment s.  Accumulates into acc,
-// which lives in registers across calls (head groups / FFN chunks).
-template <int MT, int NTW, int SKB, class SegF>
-DEVI void gemm_tall(f32x4 (&acc)[NTW][MT], int nseg, SegF segf, int lda, int rowsA,
-                    const float* __restrict__ Wp, int KBtot, int ntiles) {
-    constexpr int D = DFF_TALL_DEPTH;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int kk = lane >> 4, mm = lane & 15;
-    int rowoff[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int row = mt * 16 + mm;
-        row = row < rowsA ? row : rowsA - 1;
-        rowoff[mt] = row * lda + 4 * kk;
-    }
-    const f32x4* wp = (const f32x4*)Wp + lane;
-    size_t tbase[NTW];
-    bool tok[NTW];
-#pragma unroll
-    for (int i = 0; i < NTW; ++i) {
-        const int nt = wave + DFF_NWAVES * i;
-        tok[i] = nt < ntiles;
-        tbase[i] = (size_t)(tok[i] ? nt : 0) * KBtot;
-    }
-    if (!tok[0]) return;
-    f32x4 b[D][NTW][SKB];
-    const float* Ap[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-        if (d < nseg) {
-            int kbn;
-            segf(d, Ap[d], kbn);
-#pragma unroll
-            for (int i = 0; i < NTW; ++i)
-#pragma unroll
-                for (int kb = 0; kb < SKB; ++kb) b[d][i][kb] = wp[(tbase[i] + kbn + kb) * 64];
-        }
-    // second accumulator set breaks the dependent-MFMA chain when a wave owns one tile row
-    f32x4 acc2[NTW][MT];
-#pragma unroll
-    for (int i = 0; i < NTW; ++i)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc2[i][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int s0 = 0; s0 < nseg; s0 += D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int s = s0 + d;
-            if (s < nseg) {
-                f32x4 a[MT][SKB];
-#pragma unroll
-                for (int kb = 0; kb < SKB; ++kb)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) a[mt][kb] = *(const f32x4*)(Ap[d] + rowoff[mt] + 16 * kb);
-#pragma unroll
-                for (int kb = 0; kb < SKB; kb += 2)
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-                        for (int i = 0; i < NTW; ++i)
-                            if (tok[i]) {
-#pragma unroll
-                                for (int mt = 0; mt < MT; ++mt) {
-                                    acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][kb][s4], b[d][i][kb][s4], acc[i][mt], 0, 0, 0);
-                                    acc2[i][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][kb + 1][s4], b[d][i][kb + 1][s4], acc2[i][mt], 0, 0, 0);
-                                }
-                            }
-                if (s + D < nseg) {
-                    int kbn;
-                    segf(s + D, Ap[d], kbn);
-#pragma unroll
-                    for (int i = 0; i < NTW; ++i)
-#pragma unroll
-                        for (int kb = 0; kb < SKB; ++kb) b[d][i][kb] = wp[(tbase[i] + kbn + kb) * 64];
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < NTW; ++i)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[i][mt] += acc2[i][mt];
 }
 
 // "tall" GEMM over an explicit list of 16-wide k-blocks: kf(i, aoff, wkb) names the i-th block (its A
@@ -372,8 +331,9 @@ DEVI void gemm_tall(f32x4 (&acc)[NTW][MT], int nseg, SegF segf, int lda, int row
 template <int MT, int NTW, class KF>
 DEVI void gemm_tall_kb(f32x4 (&acc)[NTW][MT], int nkb, KF kf, const lfloat* A, int lda, int rowsA,
                        const float* __restrict__ Wp, int KBtot, int ntiles) {
+    const int tid_ = tid_now();
     constexpr int D = 4;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     const int kk = lane >> 4, mm = lane & 15;
     int rowoff[MT];
 #pragma unroll
@@ -438,7 +398,8 @@ DEVI void acc_zero(f32x4 (&acc)[NTW][MT]) {
 template <int MT, int NTW>
 DEVI void store_tall(const f32x4 (&acc)[NTW][MT], float* out, int ld, int rows, int ntiles,
                      const float* __restrict__ bias) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid_ = tid_now();
+    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     const int quad = lane >> 4, col = lane & 15;
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
@@ -488,7 +449,8 @@ struct Ctx {
 // 91-92,100-103) -> resbuf, stashed as nodes_in of layer 0.
 template <int H>
 DEVI void node_embed(const Ctx& c, const DffModelDev& m) {
-    for (int idx = threadIdx.x; idx < c.rows * H; idx += DFF_NTHREADS) {
+    const int tid_ = tid_now();
+    for (int idx = tid_; idx < c.rows * H; idx += DFF_NTHREADS) {
         const int row = idx / H, col = idx - row * H;
         const int g = row / c.N, i = row - g * c.N;
         const float v = m.WnT[i * H + col] + c.tn[g] * m.WnT[c.N * H + col] + m.bn[col];
@@ -525,10 +487,11 @@ DEVI float gate_value(const float (&x)[H / 16], const float (&res)[H / 16], cons
 // R0: nodes (resbuf) -> stash nodes_in ; LN1 -> abuf
 template <int H>
 DEVI void row_ln1(const Ctx& c, const DffLayerDev& lw, int l) {
+    const int tid_ = tid_now();
     constexpr int HC = H / 16, LH = H + 4;
-    const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    const int grp = tid_ >> 4, sub = tid_ & 15;
     float* s_nodes = c.stash + (size_t)l * c.sl.layer_stride + c.sl.nodes_in;
-    for (int row = grp; row < c.rows; row += 16) {
+    for (int row = grp; row < c.rows; row += DFF_NTHREADS / 16) {
         float x[HC];
 #pragma unroll
         for (int i = 0; i < HC; ++i) {
@@ -548,10 +511,11 @@ DEVI void row_ln1(const Ctx& c, const DffLayerDev& lw, int l) {
 // R1: tbuf = attn_out, resbuf = nodes -> nodes1 (resbuf), stash attn_out, LN2 -> abuf
 template <int H>
 DEVI void row_gate1_ln2(const Ctx& c, const DffLayerDev& lw, int l, const float* tbuf) {
+    const int tid_ = tid_now();
     constexpr int HC = H / 16, LH = H + 4;
-    const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    const int grp = tid_ >> 4, sub = tid_ & 15;
     float* s_att = c.stash + (size_t)l * c.sl.layer_stride + c.sl.attn_out;
-    for (int row = grp; row < c.rows; row += 16) {
+    for (int row = grp; row < c.rows; row += DFF_NTHREADS / 16) {
         float x[HC], res[HC], n1[HC];
 #pragma unroll
         for (int i = 0; i < HC; ++i) {
@@ -579,10 +543,11 @@ DEVI void row_gate1_ln2(const Ctx& c, const DffLayerDev& lw, int l, const float*
 template <int H>
 DEVI void row_gate2(const Ctx& c, const DffModelDev& m, const DffLayerDev& lw, int l, const float* tbuf,
                     bool last, float* energy_out) {
+    const int tid_ = tid_now();
     constexpr int HC = H / 16, LH = H + 4;
-    const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    const int grp = tid_ >> 4, sub = tid_ & 15;
     float* s_ff = c.stash + (size_t)l * c.sl.layer_stride + c.sl.ff;
-    for (int row = grp; row < c.rows; row += 16) {
+    for (int row = grp; row < c.rows; row += DFF_NTHREADS / 16) {
         float x[HC], res[HC];
 #pragma unroll
         for (int i = 0; i < HC; ++i) {
@@ -613,10 +578,11 @@ DEVI void row_gate2(const Ctx& c, const DffModelDev& m, const DffLayerDev& lw, i
 // RB1: dn (resbuf) through gate2 -> dff (abuf), dn1 partial (resbuf)
 template <int H>
 DEVI void rowb_gate2(const Ctx& c, const DffLayerDev& lw, int l) {
+    const int tid_ = tid_now();
     constexpr int HC = H / 16, LH = H + 4;
-    const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    const int grp = tid_ >> 4, sub = tid_ & 15;
     const float* sb = c.stash + (size_t)l * c.sl.layer_stride;
-    for (int row = grp; row < c.rows; row += 16) {
+    for (int row = grp; row < c.rows; row += DFF_NTHREADS / 16) {
         float ao[HC], nin[HC], n1[HC], ff[HC], dn[HC];
 #pragma unroll
         for (int i = 0; i < HC; ++i) {
@@ -647,10 +613,11 @@ DEVI void rowb_gate2(const Ctx& c, const DffLayerDev& lw, int l) {
 // RB2: tbuf = df ; dn1 = resbuf + LN2bwd(df) ; gate1 bwd -> dattn (abuf), dn_in partial (resbuf)
 template <int H>
 DEVI void rowb_ln2_gate1(const Ctx& c, const DffLayerDev& lw, int l, const float* tbuf) {
+    const int tid_ = tid_now();
     constexpr int HC = H / 16, LH = H + 4;
-    const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    const int grp = tid_ >> 4, sub = tid_ & 15;
     const float* sb = c.stash + (size_t)l * c.sl.layer_stride;
-    for (int row = grp; row < c.rows; row += 16) {
+    for (int row = grp; row < c.rows; row += DFF_NTHREADS / 16) {
         float ao[HC], nin[HC], n1[HC], d1[HC];
 #pragma unroll
         for (int i = 0; i < HC; ++i) {
@@ -696,10 +663,11 @@ DEVI void rowb_ln2_gate1(const Ctx& c, const DffLayerDev& lw, int l, const float
 // RB3: tbuf = d(LN1 out) ; dn = resbuf + LN1bwd
 template <int H>
 DEVI void rowb_ln1(const Ctx& c, const DffLayerDev& lw, int l, const float* tbuf) {
+    const int tid_ = tid_now();
     constexpr int HC = H / 16, LH = H + 4;
-    const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    const int grp = tid_ >> 4, sub = tid_ & 15;
     const float* sb = c.stash + (size_t)l * c.sl.layer_stride;
-    for (int row = grp; row < c.rows; row += 16) {
+    for (int row = grp; row < c.rows; row += DFF_NTHREADS / 16) {
         float nin[HC];
 #pragma unroll
         for (int i = 0; i < HC; ++i) nin[i] = ld_nt(sb + c.sl.nodes_in + row * H + sub + 16 * i);
@@ -801,9 +769,10 @@ struct CoGeo {
 // K_ext / V_ext extension columns <- x (columns 3..15 zero)
 template <int HGS>
 DEVI void co_fill_x(const CoGeo& g) {
+    const int tid_ = tid_now();
     constexpr int LQ = 80 * HGS + 4;
     const int total = g.rows * HGS * 16;
-    for (int it = threadIdx.x; it < total; it += DFF_NTHREADS) {
+    for (int it = tid_; it < total; it += DFF_NTHREADS) {
         const int cc = it & 15, r2 = it >> 4;
         const int hh = r2 % HGS, row = r2 / HGS;
         const float v = cc < 3 ? g.xs[row * 4 + cc] : 0.f;
@@ -816,7 +785,8 @@ DEVI void co_fill_x(const CoGeo& g) {
 // logits + softmax:  a_ihj = softmax_j( scale (q_ih.k_jh + u_ih.x_j) ) over the beads j of i's own
 // protein (graph_transformer.py:247-255 with the j-constant terms dropped) -> Pbuf (+ stash)
 template <int MT, int HGS>
-DEVI void co_softmax(const CoGeo& g, gfloat* sP /* P block of head hg*HGS */, int lane, int wave) {
+DEVI void co_softmax(const CoGeo& g, gfloat* sP /* P block of head hg*HGS */) {
+    const int tid_ = tid_now(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     constexpr int LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL, PS = 16 * MT;
     const int quad = lane >> 4, col = lane & 15;
     int gj[MT];
@@ -861,7 +831,8 @@ DEVI void co_softmax(const CoGeo& g, gfloat* sP /* P block of head hg*HGS */, in
 
 // o_ext = P V_ext -> R0 (Q_ext is dead after the logits); extension tile: xrel_i = sum_j a_ij x_j - x_i
 template <int MT, int HGS>
-DEVI void co_pv(const CoGeo& g, int lane, int wave) {
+DEVI void co_pv(const CoGeo& g) {
+    const int tid_ = tid_now(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     constexpr int LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL;
     const int quad = lane >> 4, col = lane & 15;
     for (int item = wave; item < HGS * MT * 5; item += DFF_NWAVES) {
@@ -882,7 +853,8 @@ DEVI void co_pv(const CoGeo& g, int lane, int wave) {
 
 // backward: da = G_ext V_ext^T ; ds = scale a (da - sum_j a da) -> dSbuf
 template <int MT, int HGS>
-DEVI void co_ds(const CoGeo& g, int lane, int wave) {
+DEVI void co_ds(const CoGeo& g) {
+    const int tid_ = tid_now(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     constexpr int LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL;
     const int quad = lane >> 4, col = lane & 15;
     for (int item = wave; item < HGS * MT; item += DFF_NWAVES) {
@@ -913,7 +885,8 @@ DEVI void co_ds(const CoGeo& g, int lane, int wave) {
 // the extension tiles of dV_ext / dK_ext are dE/dx_j and go to this wave's dxw instead.
 // EXT_ONLY (layer 0: nothing upstream of q, k, v depends on x): only those two extension tiles.
 template <int MT, int HGS, int WHICH, bool EXT_ONLY>
-DEVI void co_dqkv(const CoGeo& g, int lane, int wave) {
+DEVI void co_dqkv(const CoGeo& g) {
+    const int tid_ = tid_now(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     constexpr int LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL;
     constexpr int SRC = WHICH == 0 ? 3 : WHICH == 1 ? 1 : 0;
     constexpr int DST = WHICH == 0 ? 2 : WHICH == 1 ? 3 : 1;
@@ -941,6 +914,7 @@ DEVI void co_dqkv(const CoGeo& g, int lane, int wave) {
 // reload Q_ext, K, V (-> R0, R1, R2) and optionally P (-> Pbuf) of layer l / head group hg from the stash
 template <int MT, int HGS>
 DEVI void co_reload(const CoGeo& g, const gfloat* sqkv /* head hg*HGS */, const gfloat* sP, bool need_p) {
+    const int tid_ = tid_now();
     constexpr int LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL, PS = 16 * MT;
     constexpr int U = 4;  // loads in flight per thread before the LDS writes
     constexpr int per_row = (DFF_QKVW / 4) * HGS;
@@ -949,7 +923,7 @@ DEVI void co_reload(const CoGeo& g, const gfloat* sqkv /* head hg*HGS */, const 
         f32x4 t[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int it = base + u * DFF_NTHREADS + threadIdx.x;
+            const int it = base + u * DFF_NTHREADS + tid_;
             if (it < total) {
                 const int row = it / per_row, r2 = it - row * per_row;
                 const int hh = r2 / (DFF_QKVW / 4), c4 = r2 - hh * (DFF_QKVW / 4);
@@ -958,7 +932,7 @@ DEVI void co_reload(const CoGeo& g, const gfloat* sqkv /* head hg*HGS */, const 
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int it = base + u * DFF_NTHREADS + threadIdx.x;
+            const int it = base + u * DFF_NTHREADS + tid_;
             if (it < total) {
                 const int row = it / per_row, r2 = it - row * per_row;
                 const int hh = r2 / (DFF_QKVW / 4), c4 = r2 - hh * (DFF_QKVW / 4);
@@ -976,7 +950,7 @@ DEVI void co_reload(const CoGeo& g, const gfloat* sqkv /* head hg*HGS */, const 
             f32x4 t[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int it = base + u * DFF_NTHREADS + threadIdx.x;
+                const int it = base + u * DFF_NTHREADS + tid_;
                 if (it < pn) {
                     const int hh = it / (g.rows * ppr), r2 = it - hh * (g.rows * ppr);
                     const int row = r2 / ppr, c4 = r2 - row * ppr;
@@ -985,7 +959,7 @@ DEVI void co_reload(const CoGeo& g, const gfloat* sqkv /* head hg*HGS */, const 
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int it = base + u * DFF_NTHREADS + threadIdx.x;
+                const int it = base + u * DFF_NTHREADS + tid_;
                 if (it < pn) {
                     const int hh = it / (g.rows * ppr), r2 = it - hh * (g.rows * ppr);
                     const int row = r2 / ppr, c4 = r2 - row * ppr;
@@ -1000,11 +974,12 @@ DEVI void co_reload(const CoGeo& g, const gfloat* sqkv /* head hg*HGS */, const 
 // centring helpers (utils.py:65-70): per-protein mean over beads
 // ------------------------------------------------------------------------------------------
 DEVI void bead_mean(const Ctx& c, const float* src, float* cm) {
-    if ((int)threadIdx.x < c.gcnt * 4) {
-        const int g = threadIdx.x >> 2, cc = threadIdx.x & 3;
+    const int tid_ = tid_now();
+    if (tid_ < c.gcnt * 4) {
+        const int g = tid_ >> 2, cc = tid_ & 3;
         float s = 0.f;
         for (int i = 0; i < c.N; ++i) s += src[(g * c.N + i) * 4 + cc];
-        cm[threadIdx.x] = s / (float)c.N;
+        cm[tid_] = s / (float)c.N;
     }
 }
 
@@ -1047,8 +1022,9 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
     c.resbuf = SPILL ? (c.stash + c.sl.dn_spill) : (smem + ll.resbuf);
     float* tbuf = c.Rg;  // GEMM outputs of width H alias the start of the head-group region
     const int tid = threadIdx.x;
-    const int lane_ = tid & 63, wave_ = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_ = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = c.N, RN = c.G * N, rows = c.rows;
+    const lfloat* const abufL = (const lfloat*)smem + ll.abuf;
     CoGeo geo;
     {
         lfloat* const sm = (lfloat*)smem;
@@ -1151,10 +1127,11 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 // [q|u|k|v] of HGS heads -> R0,R1,R2 (+ stash)
                 if (cached) co_reload<MT, HGS>(geo, sqkv + (size_t)hg * HGS * RN * DFF_QKVW, sPl, false);
                 else {
+                    const int tid = tid_now();
                     const gfloat* bq = (const gfloat*)lw.bqkvx + hg * HGS * DFF_QKVW;
                     gfloat* const sq = sqkv + (size_t)hg * HGS * RN * DFF_QKVW;
                     lfloat* const Rl = geo.Rg;
-                    gemm_wide<MT, NT_H, 1>(c.abuf, LH, RN, lw.Wqkvx_p, NT_H, 0, hg * HGS * 13, HGS * 13,
+                    gemm_wide<MT, NT_H, 1>(abufL, LH, RN, lw.Wqkvx_p, NT_H, 0, hg * HGS * 13, HGS * 13,
                         [=](int nt, float (&aux)[1]) { aux[0] = bq[nt * 16 + (tid & 15)]; },
                         [=](int nt, int mt, const f32x4& acc, const float (&aux)[1]) {
                             const int lane = tid & 63, quad = lane >> 4, cl = lane & 15;
@@ -1177,10 +1154,10 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 co_fill_x<HGS>(geo);
                 wg_sync<SPILL>();
                 pf.tick(3);
-                co_softmax<MT, HGS>(geo, sPl + (size_t)hg * HGS * RN * c.sl.PS, lane_, wave_);
+                co_softmax<MT, HGS>(geo, sPl + (size_t)hg * HGS * RN * c.sl.PS);
                 wg_sync<SPILL>();
                 pf.tick(4);
-                co_pv<MT, HGS>(geo, lane_, wave_);
+                co_pv<MT, HGS>(geo);
                 wg_sync<SPILL>();
                 pf.tick(5);
                 // attn_out += o_ext [W_o ; W_oc]   (K = 80 per head)
@@ -1203,27 +1180,33 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             f32x4 acc_f[NTW][MT];
             acc_zero<MT, NTW>(acc_f);
             for (int ch = 0; ch < NCH; ++ch) {
-                gemm_wide<MT, NT_H, 1>(c.abuf, LH, RN, lw.W1_p, NT_H, 0, ch * (FC / 16), FC / 16,
-                    [&](int nt, float (&aux)[1]) { aux[0] = lw.b1[ch * FC + 16 * nt + (tid & 15)]; },
-                    [&](int nt, int mt, const f32x4& acc, const float (&aux)[1]) {
-                        const int lane = tid & 63, quad = lane >> 4, cl = 16 * nt + (lane & 15);
-                        const int colg = ch * FC + cl;
-                        const float bv = aux[0];
+                {
+                    const int tid = tid_now();
+                    const gfloat* const b1g = (const gfloat*)lw.b1 + ch * FC;
+                    gfloat* const shp = (gfloat*)sb + c.sl.h_pre + ch * FC;
+                    lfloat* const hl = geo.Rg;
+                    gemm_wide<MT, NT_H, 1>(abufL, LH, RN, lw.W1_p, NT_H, 0, ch * (FC / 16), FC / 16,
+                        [=](int nt, float (&aux)[1]) { aux[0] = b1g[16 * nt + (tid & 15)]; },
+                        [=](int nt, int mt, const f32x4& acc, const float (&aux)[1]) {
+                            const int lane = tid & 63, quad = lane >> 4, cl = 16 * nt + (lane & 15);
+                            const float bv = aux[0];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = mt * 16 + quad * 4 + r;
-                            if (row < rows) {
-                                const float hp = acc[r] + bv;
-                                st_nt(sb + c.sl.h_pre + (size_t)row * F + colg, hp);
-                                c.Rg[row * LF + cl] = gelu_f(hp);
+                            for (int r = 0; r < 4; ++r) {
+                                const int row = mt * 16 + quad * 4 + r;
+                                if (row < rows) {
+                                    float gv, gp;
+                                    gelu_both(acc[r] + bv, gv, gp);
+                                    st_ntg(shp + (size_t)row * F + cl, gp);   // the slot "h_pre" holds gelu'(h_pre)
+                                    hl[row * LF + cl] = gv;
+                                }
                             }
-                        }
-                    });
+                        });
+                }
                 wg_sync<SPILL>();
                 pf.tick(8);
-                gemm_tall<MT, NTW, 4>(acc_f, FC / 64,
-                    [&](int s, const float*& Ap, int& kb0) { Ap = c.Rg + s * 64; kb0 = ch * (FC / 16) + s * 4; },
-                    LF, RN, lw.W2_p, F / 16, NT_H);
+                gemm_tall_kb<MT, NTW>(acc_f, FC / 16,
+                    [=](int i, int& aoff, int& wkb) { aoff = 16 * i; wkb = ch * (FC / 16) + i; },
+                    geo.Rg, LF, RN, lw.W2_p, F / 16, NT_H);
                 wg_sync<SPILL>();
                 pf.tick(9);
             }
@@ -1245,31 +1228,33 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             f32x4 acc_f[NTW][MT];
             acc_zero<MT, NTW>(acc_f);
             for (int ch = 0; ch < NCH; ++ch) {
-                gemm_wide<MT, NT_H, 4 * MT>(c.abuf, LH, RN, lw.W2T_p, NT_H, 0, ch * (FC / 16), FC / 16,
-                    [&](int nt, float (&aux)[4 * MT]) {
-                        const int lane = tid & 63, quad = lane >> 4, colg = ch * FC + 16 * nt + (lane & 15);
+                {
+                    const int tid = tid_now();
+                    const gfloat* const shp = (const gfloat*)sb + c.sl.h_pre + ch * FC;
+                    lfloat* const hl = geo.Rg;
+                    gemm_wide<MT, NT_H, 4 * MT>(abufL, LH, RN, lw.W2T_p, NT_H, 0, ch * (FC / 16), FC / 16,
+                        [=](int nt, float (&aux)[4 * MT]) {
+                            const int lane = tid & 63, quad = lane >> 4, cl = 16 * nt + (lane & 15);
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
+                            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    aux[mt * 4 + r] = ld_ntg(shp + (size_t)min(mt * 16 + quad * 4 + r, rows - 1) * F + cl);
+                        },
+                        [=](int nt, int mt, const f32x4& acc, const float (&aux)[4 * MT]) {
+                            const int lane = tid & 63, quad = lane >> 4, cl = 16 * nt + (lane & 15);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                int row = mt * 16 + quad * 4 + r;
-                                row = row < rows ? row : rows - 1;
-                                aux[mt * 4 + r] = ld_nt(sb + c.sl.h_pre + (size_t)row * F + colg);
+                                const int row = mt * 16 + quad * 4 + r;
+                                if (row < rows) hl[row * LF + cl] = acc[r] * aux[mt * 4 + r];
                             }
-                    },
-                    [&](int nt, int mt, const f32x4& acc, const float (&aux)[4 * MT]) {
-                        const int lane = tid & 63, quad = lane >> 4, cl = 16 * nt + (lane & 15);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = mt * 16 + quad * 4 + r;
-                            if (row < rows) c.Rg[row * LF + cl] = acc[r] * gelu_grad_f(aux[mt * 4 + r]);
-                        }
-                    });
+                        });
+                }
                 wg_sync<SPILL>();
                 pf.tick(12);
-                gemm_tall<MT, NTW, 4>(acc_f, FC / 64,
-                    [&](int s, const float*& Ap, int& kb0) { Ap = c.Rg + s * 64; kb0 = ch * (FC / 16) + s * 4; },
-                    LF, RN, lw.W1T_p, F / 16, NT_H);
+                gemm_tall_kb<MT, NTW>(acc_f, FC / 16,
+                    [=](int i, int& aoff, int& wkb) { aoff = 16 * i; wkb = ch * (FC / 16) + i; },
+                    geo.Rg, LF, RN, lw.W1T_p, F / 16, NT_H);
                 wg_sync<SPILL>();
                 pf.tick(13);
             }
@@ -1288,9 +1273,10 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 // G_ext = dattn [W_o ; W_oc]^T (dE/do | r = dE/dxrel) for the heads of this group -> R3 ;
                 // dE/dx_i -= r_i
                 {
+                    const int tid = tid_now();
                     lfloat* const Gl = geo.Rg + 3 * RN * LQ;
                     lfloat* const dxw = geo.dxw;
-                    gemm_wide<MT, NT_H, 1>(c.abuf, LH, RN, lw.WoxT_p, NT_H, 0, hg * HGS * 5, HGS * 5,
+                    gemm_wide<MT, NT_H, 1>(abufL, LH, RN, lw.WoxT_p, NT_H, 0, hg * HGS * 5, HGS * 5,
                         [=](int, float (&)[1]) {},
                         [=](int nt, int mt, const f32x4& acc, const float (&)[1]) {
                             const int lane = tid & 63, quad = lane >> 4, cl = lane & 15;
@@ -1308,15 +1294,15 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 co_fill_x<HGS>(geo);
                 wg_sync<SPILL>();
                 pf.tick(16);
-                co_ds<MT, HGS>(geo, lane_, wave_);
+                co_ds<MT, HGS>(geo);
                 wg_sync<SPILL>();
                 pf.tick(17);
                 if (l > 0) {
-                    co_dqkv<MT, HGS, 0, false>(geo, lane_, wave_);
+                    co_dqkv<MT, HGS, 0, false>(geo);
                     wg_sync<SPILL>();
-                    co_dqkv<MT, HGS, 1, false>(geo, lane_, wave_);
+                    co_dqkv<MT, HGS, 1, false>(geo);
                     wg_sync<SPILL>();
-                    co_dqkv<MT, HGS, 2, false>(geo, lane_, wave_);
+                    co_dqkv<MT, HGS, 2, false>(geo);
                     wg_sync<SPILL>();
                     pf.tick(18);
                     // d(LN1 out) += [dq|du] W_qu + dk W_k + dv W_v   (K order per head [q64|u16|k64|v64])
@@ -1330,8 +1316,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         },
                         geo.Rg, LQ, RN, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
                 } else {
-                    co_dqkv<MT, HGS, 0, true>(geo, lane_, wave_);
-                    co_dqkv<MT, HGS, 2, true>(geo, lane_, wave_);
+                    co_dqkv<MT, HGS, 0, true>(geo);
+                    co_dqkv<MT, HGS, 2, true>(geo);
                 }
                 wg_sync<SPILL>();
                 pf.tick(19);
@@ -1468,9 +1454,9 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_debug_gemm_kernel(const floa
     __syncthreads();
     for (int i = threadIdx.x; i < M * K; i += DFF_NTHREADS) smem[(i / K) * LD + (i % K)] = A[i];
     __syncthreads();
-    gemm_wide<4, KB, 1>(smem, LD, M, Wp, KB, 0, 0, Nout / 16,
-        [&](int, float (&)[1]) {},
-        [&](int nt, int mt, const f32x4& acc, const float (&)[1]) {
+    gemm_wide<4, KB, 1>((const lfloat*)smem, LD, M, Wp, KB, 0, 0, Nout / 16,
+        [=](int, float (&)[1]) {},
+        [=](int nt, int mt, const f32x4& acc, const float (&)[1]) {
             const int lane = threadIdx.x & 63, quad = lane >> 4, col = 16 * nt + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

@@ -24,37 +24,6 @@
 #pragma once
 #include "dff_internal.h"
 
-// GELU(erf) value and derivative in one go: the forward FFN epilogue stashes gelu'(h_pre) so that the
-// backward epilogue is a single multiply (one erf + one exp per element per step instead of two + one)
-// Branch-free erf: |x| <= 0.8: x * P5(x^2);  else 1 - exp(P8(|x|)) with P8 ~ log erfc on [0.8, 4.2]
-// (least-squares fits on Chebyshev nodes; max abs error 1.2e-7 against scipy.special.erf over
-// [-6, 6] in float32 -- the same 1-2 ulp class as the library erff, at about half its instructions).
-#ifndef DFF_FAST_ERF
-#define DFF_FAST_ERF 0   // measured: no faster than the library erff here (the FFN epilogue is not erf-bound)
-#endif
-DEVI float erf_fast(float x) {
-#if DFF_FAST_ERF
-    const float t = fminf(fabsf(x), 4.2f), s = x * x;
-    float a = -6.546706740e-04f;
-    a = fmaf(a, s, 5.086977565e-03f); a = fmaf(a, s, -2.682184972e-02f); a = fmaf(a, s, 1.128313692e-01f);
-    a = fmaf(a, s, -3.761260335e-01f); a = fmaf(a, s, 1.128379164e+00f);
-    a *= x;
-    float b = 1.534366307e-06f;
-    b = fmaf(b, t, -4.404490910e-05f); b = fmaf(b, t, 5.800263089e-04f); b = fmaf(b, t, -4.682034248e-03f);
-    b = fmaf(b, t, 2.620414818e-02f); b = fmaf(b, t, -1.097046865e-01f); b = fmaf(b, t, -6.322175036e-01f);
-    b = fmaf(b, t, -1.130008818e+00f); b = fmaf(b, t, 2.658824129e-04f);
-    b = copysignf(1.0f - __expf(b), x);
-    return t <= 0.8f ? a : b;
-#else
-    return erff(x);
-#endif
-}
-DEVI void gelu_both(float x, float& g, float& gp) {
-    const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
-    g = x * cdf;
-    gp = cdf + x * expf(-0.5f * x * x) * 0.39894228040143267794f;
-}
-
 #define DFF_XH 80       // extended head width
 #define DFF_XLD 84      // leading dim of the per-wave head buffers
 #define DFF_PLD 20      // leading dim of the per-wave P / dS tiles
