@@ -100,7 +100,8 @@ struct LdsLayout {
     static constexpr int F = 4 * H;
     static constexpr int FC = (F % 256 == 0) ? 256 : 128;
     static constexpr int LF = FC + 4;
-    unsigned xst, xs, dxs, vst, cm, tn, prof, dxw, abuf, resbuf, Pbuf, dSbuf, Rg, total;
+    static constexpr int NREG = MT < 4 ? 5 : 4;   // a fifth head-group buffer (backward: dQ_ext) where LDS allows
+    unsigned xst, xs, dxs, vst, cm, tn, prof, prow, dxw, abuf, resbuf, Pbuf, dSbuf, Rg, total;
     __host__ __device__ LdsLayout(int N, int G) {
         const unsigned R = (unsigned)(G * N);
         unsigned o = 0;
@@ -111,13 +112,14 @@ struct LdsLayout {
         cm = o;    o += 16 * 4 * 2;
         tn = o;    o += 16;
         prof = o;  o += 2 * DFF_NPROF;
+        prow = o;  o += 64;                    // protein index of each row (-1: pad row)
         dxw = o;   o += DFF_NWAVES * R * 4;   // per-wave partial dE/dx (summed once per step)
         abuf = o;  o += R * LH;
         resbuf = o; if (!SPILL) o += R * LH;
         Pbuf = o;  o += HGS * PT;
         dSbuf = o; o += HGS * PT;
         Rg = o;
-        unsigned rsz = 4u * R * LQ;
+        unsigned rsz = (unsigned)NREG * R * LQ;
         if (R * LF > rsz) rsz = R * LF;
         if (R * LH > rsz) rsz = R * LH;
         o += rsz + 64;  // slack: clamped A-fragment reads never leave the allocation
@@ -760,9 +762,39 @@ DEVI f32x4 co_mm(const lfloat* T, int mo, const lfloat* B, int ldb, int RN, int 
     return c0 + c1;
 }
 
+// the same for the five 16-column tiles of a head at once (B points at the head's column 0): the A
+// operand is read once and five independent accumulator chains keep the MFMA pipe busy while the
+// next operands arrive.
+template <int MT, bool TRANS>
+DEVI void co_mm5(f32x4 (&c)[5], const lfloat* T, int mo, const lfloat* B, int ldb, int RN, int lane) {
+    constexpr int PL = 16 * MT + 4;
+    const int kk = lane >> 4, mm = lane & 15;
+#pragma unroll
+    for (int nt = 0; nt < 5; ++nt) c[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < MT; ++kt) {
+        float as[4];
+        if (TRANS) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) as[s] = T[(16 * kt + 4 * kk + s) * PL + 16 * mo + mm];
+        } else {
+            const f32x4 t = *(const lf32x4*)(T + (16 * mo + mm) * PL + 16 * kt + 4 * kk);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) as[s] = t[s];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const lfloat* bp = B + min(16 * kt + 4 * kk + s, RN - 1) * ldb + mm;
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) c[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[s], bp[16 * nt], c[nt], 0, 0, 0);
+        }
+    }
+}
+
 // geometry every attention phase needs
 struct CoGeo {
     lfloat *Rg, *Pbuf, *dSbuf, *xs, *dxw;   // dxw: this wave's partial dE/dx
+    const int __attribute__((address_space(3))) * prow;   // protein index of each row, -1 for pad rows
     int N, RN, rows;
 };
 
@@ -783,119 +815,168 @@ DEVI void co_fill_x(const CoGeo& g) {
 }
 
 // logits + softmax:  a_ihj = softmax_j( scale (q_ih.k_jh + u_ih.x_j) ) over the beads j of i's own
-// protein (graph_transformer.py:247-255 with the j-constant terms dropped) -> Pbuf (+ stash)
+// protein (graph_transformer.py:247-255 with the j-constant terms dropped) -> Pbuf (+ stash); then, by
+// the same wave (its 16 probability rows are all it needs, so no barrier):
+// o_ext = P V_ext -> R0 rows of this tile (Q_ext rows of the tile are dead after its logits);
+// extension tile: xrel_i = sum_j a_ij x_j - x_i
 template <int MT, int HGS>
-DEVI void co_softmax(const CoGeo& g, gfloat* sP /* P block of head hg*HGS */) {
+DEVI void co_softmax_pv(const CoGeo& g, gfloat* sP /* P block of head hg*HGS */) {
     const int tid_ = tid_now(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     constexpr int LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL, PS = 16 * MT;
     const int quad = lane >> 4, col = lane & 15;
     int gj[MT];
 #pragma unroll
-    for (int jt = 0; jt < MT; ++jt) {
-        const int j = 16 * jt + col;
-        gj[jt] = j < g.rows ? j / g.N : -1;
-    }
+    for (int jt = 0; jt < MT; ++jt) gj[jt] = g.prow[16 * jt + col];
     for (int item = wave; item < HGS * MT; item += DFF_NWAVES) {
         const int hh = item / MT, it = item - hh * MT;
-        f32x4 acc[MT];
-        co_dot_rows<MT>(acc, g.Rg + hh * 80, g.Rg + g.RN * LQ + hh * 80, LQ, g.RN, it, lane);
+        {
+            f32x4 acc[MT];
+            co_dot_rows<MT>(acc, g.Rg + hh * 80, g.Rg + g.RN * LQ + hh * 80, LQ, g.RN, it, lane);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = 16 * it + 4 * quad + r;
-            const int gi = i < g.rows ? i / g.N : -2;
-            float s[MT], mx = -INFINITY;
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * it + 4 * quad + r;
+                const int gi0 = g.prow[i], gi = gi0 >= 0 ? gi0 : -2;   // a pad row matches nothing
+                float s[MT], mx = -INFINITY;
 #pragma unroll
-            for (int jt = 0; jt < MT; ++jt) {
-                s[jt] = gj[jt] == gi ? acc[jt][r] * 0.125f : -INFINITY;
-                mx = fmaxf(mx, s[jt]);
-            }
-            mx = row16_max(mx);
-            float e[MT], den = 0.f;
+                for (int jt = 0; jt < MT; ++jt) {
+                    s[jt] = gj[jt] == gi ? acc[jt][r] * 0.125f : -INFINITY;
+                    mx = fmaxf(mx, s[jt]);
+                }
+                mx = row16_max(mx);
+                float e[MT], den = 0.f;
 #pragma unroll
-            for (int jt = 0; jt < MT; ++jt) {
-                e[jt] = gj[jt] == gi ? expf(s[jt] - mx) : 0.f;
-                den += e[jt];
-            }
-            den = row16_sum(den);
-            lfloat* pl = g.Pbuf + hh * PT + i * PL + col;
-            gfloat* ps = sP + ((size_t)hh * g.RN + min(i, g.RN - 1)) * PS + col;
+                for (int jt = 0; jt < MT; ++jt) {
+                    e[jt] = gj[jt] == gi ? expf(s[jt] - mx) : 0.f;
+                    den += e[jt];
+                }
+                den = row16_sum(den);
+                lfloat* pl = g.Pbuf + hh * PT + i * PL + col;
+                gfloat* ps = sP + ((size_t)hh * g.RN + min(i, g.RN - 1)) * PS + col;
 #pragma unroll
-            for (int jt = 0; jt < MT; ++jt) {
-                const float p = gi >= 0 ? e[jt] / den : 0.f;
-                pl[16 * jt] = p;
-                if (gi >= 0) st_ntg(ps + 16 * jt, p);
+                for (int jt = 0; jt < MT; ++jt) {
+                    const float p = gi >= 0 ? e[jt] / den : 0.f;
+                    pl[16 * jt] = p;
+                    if (gi >= 0) st_ntg(ps + 16 * jt, p);
+                }
             }
         }
-    }
-}
-
-// o_ext = P V_ext -> R0 (Q_ext is dead after the logits); extension tile: xrel_i = sum_j a_ij x_j - x_i
-template <int MT, int HGS>
-DEVI void co_pv(const CoGeo& g) {
-    const int tid_ = tid_now(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
-    constexpr int LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL;
-    const int quad = lane >> 4, col = lane & 15;
-    for (int item = wave; item < HGS * MT * 5; item += DFF_NWAVES) {
-        const int hh = item / (MT * 5), rem = item - hh * (MT * 5);
-        const int it = rem / 5, nt = rem - it * 5;
-        const f32x4 acc = co_mm<MT, false>(g.Pbuf + hh * PT, it, g.Rg + 2 * g.RN * LQ + hh * 80 + 16 * nt, LQ, g.RN, lane);
+        f32x4 o[5];
+        co_mm5<MT, false>(o, g.Pbuf + hh * PT, it, g.Rg + 2 * g.RN * LQ + hh * 80, LQ, g.RN, lane);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * it + 4 * quad + r;
             if (row < g.rows) {
-                float v = acc[r];
-                if (nt == 4) v -= g.xs[row * 4 + min(col, 3)];
-                g.Rg[row * LQ + hh * 80 + 16 * nt + col] = v;
+                lfloat* d = g.Rg + row * LQ + hh * 80 + col;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) d[16 * nt] = o[nt][r];
+                d[64] = o[4][r] - g.xs[row * 4 + min(col, 3)];
             }
         }
     }
 }
 
-// backward: da = G_ext V_ext^T ; ds = scale a (da - sum_j a da) -> dSbuf
-template <int MT, int HGS>
+// backward: da = G_ext V_ext^T ; ds = scale a (da - sum_j a da) -> dSbuf.
+// DQ: the same wave goes on with dQ_ext = dS K_ext for its row tile -> buffer 4 (no barrier needed: it
+// only reads the dS rows it has just written).
+template <int MT, int HGS, bool DQ>
 DEVI void co_ds(const CoGeo& g) {
     const int tid_ = tid_now(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     constexpr int LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL;
     const int quad = lane >> 4, col = lane & 15;
     for (int item = wave; item < HGS * MT; item += DFF_NWAVES) {
         const int hh = item / MT, it = item - hh * MT;
-        f32x4 acc[MT];
-        co_dot_rows<MT>(acc, g.Rg + 3 * g.RN * LQ + hh * 80, g.Rg + 2 * g.RN * LQ + hh * 80, LQ, g.RN, it, lane);
+        {
+            f32x4 acc[MT];
+            co_dot_rows<MT>(acc, g.Rg + 3 * g.RN * LQ + hh * 80, g.Rg + 2 * g.RN * LQ + hh * 80, LQ, g.RN, it, lane);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = 16 * it + 4 * quad + r;
-            const lfloat* pl = g.Pbuf + hh * PT + i * PL + col;
-            float p[MT], sm = 0.f;
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * it + 4 * quad + r;
+                const lfloat* pl = g.Pbuf + hh * PT + i * PL + col;
+                float p[MT], sm = 0.f;
 #pragma unroll
-            for (int jt = 0; jt < MT; ++jt) {
-                p[jt] = pl[16 * jt];
-                sm += p[jt] * acc[jt][r];
+                for (int jt = 0; jt < MT; ++jt) {
+                    p[jt] = pl[16 * jt];
+                    sm += p[jt] * acc[jt][r];
+                }
+                sm = row16_sum(sm);
+                lfloat* dl = g.dSbuf + hh * PT + i * PL + col;
+#pragma unroll
+                for (int jt = 0; jt < MT; ++jt) dl[16 * jt] = 0.125f * (p[jt] * (acc[jt][r] - sm));
             }
-            sm = row16_sum(sm);
-            lfloat* dl = g.dSbuf + hh * PT + i * PL + col;
+        }
+        if (DQ) {
+            f32x4 dq[5];
+            co_mm5<MT, false>(dq, g.dSbuf + hh * PT, it, g.Rg + g.RN * LQ + hh * 80, LQ, g.RN, lane);
 #pragma unroll
-            for (int jt = 0; jt < MT; ++jt) dl[16 * jt] = 0.125f * (p[jt] * (acc[jt][r] - sm));
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * it + 4 * quad + r;
+                if (row < g.rows) {
+                    lfloat* d = g.Rg + 4 * g.RN * LQ + row * LQ + hh * 80 + col;
+#pragma unroll
+                    for (int nt = 0; nt < 5; ++nt) d[16 * nt] = dq[nt][r];
+                }
+            }
         }
     }
 }
 
-// backward tile products.  WHICH 0: dV_ext = P^T G_ext      (reads Pbuf, R3)  -> R2
-//                          WHICH 1: dQ_ext = dS K_ext       (reads dSbuf, R1) -> R3
-//                          WHICH 2: dK_ext = dS^T Q_ext     (reads dSbuf, R0) -> R1
+// backward, with the fifth buffer: dV_ext = P^T G_ext (-> R2) and dK_ext = dS^T Q_ext (-> R1) in ONE phase
+// (nothing reads R1 / R2 any more); their extension tiles are dE/dx_j -> this wave's dxw.
+// EXT_ONLY (layer 0: nothing upstream of q, k, v depends on x): only those extension tiles.
+template <int MT, int HGS, bool EXT_ONLY>
+DEVI void co_dv_dk(const CoGeo& g) {
+    const int tid_ = tid_now(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+    constexpr int LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL;
+    const int quad = lane >> 4, col = lane & 15;
+    if (EXT_ONLY) {
+        for (int item = wave; item < 2 * HGS * MT; item += DFF_NWAVES) {
+            const int which = item / (HGS * MT), r0 = item - which * (HGS * MT);   // 0: dV, 1: dK
+            const int hh = r0 / MT, mo = r0 - hh * MT;
+            const lfloat* T = (which ? g.dSbuf : g.Pbuf) + hh * PT;
+            const f32x4 acc = co_mm<MT, true>(T, mo, g.Rg + (which ? 0 : 3) * g.RN * LQ + hh * 80 + 64, LQ, g.RN, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * mo + 4 * quad + r;
+                if (row < g.rows && col < 3) g.dxw[row * 4 + col] += acc[r];
+            }
+        }
+    } else {
+        for (int item = wave; item < 2 * HGS * MT; item += DFF_NWAVES) {
+            const int which = item / (HGS * MT), r0 = item - which * (HGS * MT);
+            const int hh = r0 / MT, mo = r0 - hh * MT;
+            const lfloat* T = (which ? g.dSbuf : g.Pbuf) + hh * PT;
+            f32x4 acc[5];
+            co_mm5<MT, true>(acc, T, mo, g.Rg + (which ? 0 : 3) * g.RN * LQ + hh * 80, LQ, g.RN, lane);
+            lfloat* const dst = g.Rg + (which ? 1 : 2) * g.RN * LQ + hh * 80 + col;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * mo + 4 * quad + r;
+                if (row < g.rows) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) dst[row * LQ + 16 * nt] = acc[nt][r];
+                    if (col < 3) g.dxw[row * 4 + col] += acc[4][r];
+                }
+            }
+        }
+    }
+}
+
+// backward tile products without the fifth buffer (4 row tiles: LDS is full), one phase each:
+// WHICH 0: dV_ext = P^T G_ext      (reads Pbuf, R3)  -> R2
+// WHICH 1: dQ_ext = dS K_ext       (reads dSbuf, R1) -> R3
+// WHICH 2: dK_ext = dS^T Q_ext     (reads dSbuf, R0) -> R1
 // the extension tiles of dV_ext / dK_ext are dE/dx_j and go to this wave's dxw instead.
-// EXT_ONLY (layer 0: nothing upstream of q, k, v depends on x): only those two extension tiles.
-template <int MT, int HGS, int WHICH, bool EXT_ONLY>
+template <int MT, int HGS, int WHICH>
 DEVI void co_dqkv(const CoGeo& g) {
     const int tid_ = tid_now(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     constexpr int LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL;
     constexpr int SRC = WHICH == 0 ? 3 : WHICH == 1 ? 1 : 0;
     constexpr int DST = WHICH == 0 ? 2 : WHICH == 1 ? 3 : 1;
-    constexpr int NTI = EXT_ONLY ? 1 : 5;
     const int quad = lane >> 4, col = lane & 15;
     const lfloat* T = WHICH == 0 ? g.Pbuf : g.dSbuf;
-    for (int item = wave; item < HGS * MT * NTI; item += DFF_NWAVES) {
-        const int hh = item / (MT * NTI), rem = item - hh * (MT * NTI);
-        const int mo = rem / NTI, nt = EXT_ONLY ? 4 : rem - mo * NTI;
+    for (int item = wave; item < HGS * MT * 5; item += DFF_NWAVES) {
+        const int hh = item / (MT * 5), rem = item - hh * (MT * 5);
+        const int mo = rem / 5, nt = rem - mo * 5;
         const f32x4 acc = co_mm<MT, WHICH != 1>(T + hh * PT, mo, g.Rg + SRC * g.RN * LQ + hh * 80 + 16 * nt, LQ, g.RN, lane);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -911,61 +992,57 @@ DEVI void co_dqkv(const CoGeo& g) {
     }
 }
 
-// reload Q_ext, K, V (-> R0, R1, R2) and optionally P (-> Pbuf) of layer l / head group hg from the stash
+// reload Q_ext, K, V (-> R0, R1, R2) and optionally P (-> Pbuf) of layer l / head group hg from the stash,
+// split in two so that the loads fly while something else (the G_ext GEMM) runs:
+// issue: global -> registers ; commit: registers -> LDS.
 template <int MT, int HGS>
-DEVI void co_reload(const CoGeo& g, const gfloat* sqkv /* head hg*HGS */, const gfloat* sP, bool need_p) {
-    const int tid_ = tid_now();
-    constexpr int LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL, PS = 16 * MT;
-    constexpr int U = 4;  // loads in flight per thread before the LDS writes
-    constexpr int per_row = (DFF_QKVW / 4) * HGS;
-    const int total = g.rows * per_row;
-    for (int base = 0; base < total; base += DFF_NTHREADS * U) {
-        f32x4 t[U];
+struct CoReload {
+    static constexpr int NQ = (DFF_QKVW / 4) * HGS;          // float4 per row of the q|k|v blocks
+    static constexpr int NP = 4 * MT * HGS;                  // float4 per row of the P blocks
+    static constexpr int U = (16 * MT * (NQ + NP) + DFF_NTHREADS - 1) / DFF_NTHREADS;
+    f32x4 t[U];
+};
+template <int MT, int HGS>
+DEVI void co_reload_issue(CoReload<MT, HGS>& rl, const CoGeo& g, const gfloat* sqkv /* head hg*HGS */,
+                          const gfloat* sP, bool need_p, int tid) {
+    using RL = CoReload<MT, HGS>;
+    constexpr int PS = 16 * MT;
+    const int nq = g.rows * RL::NQ, total = nq + (need_p ? g.rows * RL::NP : 0);
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int it = base + u * DFF_NTHREADS + tid_;
-            if (it < total) {
-                const int row = it / per_row, r2 = it - row * per_row;
-                const int hh = r2 / (DFF_QKVW / 4), c4 = r2 - hh * (DFF_QKVW / 4);
-                t[u] = ld_ntg4(sqkv + ((size_t)hh * g.RN + row) * DFF_QKVW + 4 * c4);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int it = base + u * DFF_NTHREADS + tid_;
-            if (it < total) {
-                const int row = it / per_row, r2 = it - row * per_row;
-                const int hh = r2 / (DFF_QKVW / 4), c4 = r2 - hh * (DFF_QKVW / 4);
-                const int colq = 4 * c4;
-                const int reg = (colq >= 80) + (colq >= 144);
-                const int cl = colq - (reg == 0 ? 0 : reg == 1 ? 80 : 144);
-                *(lf32x4*)(g.Rg + reg * g.RN * LQ + row * LQ + hh * 80 + cl) = t[u];
-            }
+    for (int u = 0; u < RL::U; ++u) {
+        const int it = u * DFF_NTHREADS + tid;
+        if (it < nq) {
+            const int row = it / RL::NQ, r2 = it - row * RL::NQ;
+            const int hh = r2 / (DFF_QKVW / 4), c4 = r2 - hh * (DFF_QKVW / 4);
+            rl.t[u] = ld_ntg4(sqkv + ((size_t)hh * g.RN + row) * DFF_QKVW + 4 * c4);
+        } else if (it < total) {
+            const int ip = it - nq;
+            const int row = ip / RL::NP, r2 = ip - row * RL::NP;
+            const int hh = r2 / (4 * MT), c4 = r2 - hh * (4 * MT);
+            rl.t[u] = ld_ntg4(sP + ((size_t)hh * g.RN + row) * PS + 4 * c4);
         }
     }
-    if (need_p) {
-        constexpr int ppr = PS / 4;
-        const int pn = HGS * g.rows * ppr;
-        for (int base = 0; base < pn; base += DFF_NTHREADS * U) {
-            f32x4 t[U];
+}
+template <int MT, int HGS>
+DEVI void co_reload_commit(const CoReload<MT, HGS>& rl, const CoGeo& g, bool need_p, int tid) {
+    using RL = CoReload<MT, HGS>;
+    constexpr int LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL;
+    const int nq = g.rows * RL::NQ, total = nq + (need_p ? g.rows * RL::NP : 0);
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int it = base + u * DFF_NTHREADS + tid_;
-                if (it < pn) {
-                    const int hh = it / (g.rows * ppr), r2 = it - hh * (g.rows * ppr);
-                    const int row = r2 / ppr, c4 = r2 - row * ppr;
-                    t[u] = ld_ntg4(sP + ((size_t)hh * g.RN + row) * PS + 4 * c4);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int it = base + u * DFF_NTHREADS + tid_;
-                if (it < pn) {
-                    const int hh = it / (g.rows * ppr), r2 = it - hh * (g.rows * ppr);
-                    const int row = r2 / ppr, c4 = r2 - row * ppr;
-                    *(lf32x4*)(g.Pbuf + hh * PT + row * PL + 4 * c4) = t[u];
-                }
-            }
+    for (int u = 0; u < RL::U; ++u) {
+        const int it = u * DFF_NTHREADS + tid;
+        if (it < nq) {
+            const int row = it / RL::NQ, r2 = it - row * RL::NQ;
+            const int hh = r2 / (DFF_QKVW / 4), c4 = r2 - hh * (DFF_QKVW / 4);
+            const int colq = 4 * c4;
+            const int reg = (colq >= 80) + (colq >= 144);
+            const int cl = colq - 80 * reg + 16 * (reg >> 1);
+            *(lf32x4*)(g.Rg + reg * g.RN * LQ + row * LQ + hh * 80 + cl) = rl.t[u];
+        } else if (it < total) {
+            const int ip = it - nq;
+            const int row = ip / RL::NP, r2 = ip - row * RL::NP;
+            const int hh = r2 / (4 * MT), c4 = r2 - hh * (4 * MT);
+            *(lf32x4*)(g.Pbuf + hh * PT + row * PL + 4 * c4) = rl.t[u];
         }
     }
 }
@@ -1030,12 +1107,14 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
         lfloat* const sm = (lfloat*)smem;
         geo.Rg = sm + ll.Rg; geo.Pbuf = sm + ll.Pbuf; geo.dSbuf = sm + ll.dSbuf; geo.xs = sm + ll.xs;
         geo.dxw = sm + ll.dxw + wave_ * RN * 4;
+        geo.prow = (const int __attribute__((address_space(3)))*)(sm + ll.prow);
         geo.N = N; geo.RN = RN; geo.rows = rows;
     }
 
     // zero LDS once (pad columns of the 32-wide buffers must be 0; pad rows must be finite)
     for (int i = tid; i < (int)ll.total; i += DFF_NTHREADS) smem[i] = 0.f;
     wg_sync<SPILL>();
+    if (tid < 64) ((int*)smem)[ll.prow + tid] = tid < rows ? tid / N : -1;
 
     Prof pf;
     pf.on = (a.prof != nullptr) && blockIdx.x == 0 && tid == 0;
@@ -1125,7 +1204,12 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             acc_zero<MT, NTW>(acc_o);
             for (int hg = 0; hg < NHG; ++hg) {
                 // [q|u|k|v] of HGS heads -> R0,R1,R2 (+ stash)
-                if (cached) co_reload<MT, HGS>(geo, sqkv + (size_t)hg * HGS * RN * DFF_QKVW, sPl, false);
+                if (cached) {
+                    const int tid = tid_now();
+                    CoReload<MT, HGS> rl;
+                    co_reload_issue<MT, HGS>(rl, geo, sqkv + (size_t)hg * HGS * RN * DFF_QKVW, sPl, false, tid);
+                    co_reload_commit<MT, HGS>(rl, geo, false, tid);
+                }
                 else {
                     const int tid = tid_now();
                     const gfloat* bq = (const gfloat*)lw.bqkvx + hg * HGS * DFF_QKVW;
@@ -1154,12 +1238,9 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 co_fill_x<HGS>(geo);
                 wg_sync<SPILL>();
                 pf.tick(3);
-                co_softmax<MT, HGS>(geo, sPl + (size_t)hg * HGS * RN * c.sl.PS);
+                co_softmax_pv<MT, HGS>(geo, sPl + (size_t)hg * HGS * RN * c.sl.PS);
                 wg_sync<SPILL>();
                 pf.tick(4);
-                co_pv<MT, HGS>(geo);
-                wg_sync<SPILL>();
-                pf.tick(5);
                 // attn_out += o_ext [W_o ; W_oc]   (K = 80 per head)
                 gemm_tall_kb<MT, NTW>(acc_o, 5 * HGS,
                     [=](int i, int& aoff, int& wkb) {
@@ -1269,11 +1350,14 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             acc_zero<MT, NTW>(acc_a);
             pf.tick(15);
             for (int hg = 0; hg < NHG; ++hg) {
-                co_reload<MT, HGS>(geo, sqkv + (size_t)hg * HGS * RN * DFF_QKVW, sPl + (size_t)hg * HGS * RN * c.sl.PS, true);
                 // G_ext = dattn [W_o ; W_oc]^T (dE/do | r = dE/dxrel) for the heads of this group -> R3 ;
                 // dE/dx_i -= r_i
                 {
                     const int tid = tid_now();
+                    // the stash loads of this head group fly while the G_ext GEMM runs
+                    CoReload<MT, HGS> rl;
+                    co_reload_issue<MT, HGS>(rl, geo, sqkv + (size_t)hg * HGS * RN * DFF_QKVW,
+                                             sPl + (size_t)hg * HGS * RN * c.sl.PS, true, tid);
                     lfloat* const Gl = geo.Rg + 3 * RN * LQ;
                     lfloat* const dxw = geo.dxw;
                     gemm_wide<MT, NT_H, 1>(abufL, LH, RN, lw.WoxT_p, NT_H, 0, hg * HGS * 5, HGS * 5,
@@ -1290,19 +1374,25 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                                 }
                             }
                         });
+                    co_reload_commit<MT, HGS>(rl, geo, true, tid);
                 }
                 co_fill_x<HGS>(geo);
                 wg_sync<SPILL>();
                 pf.tick(16);
-                co_ds<MT, HGS>(geo);
-                wg_sync<SPILL>();
-                pf.tick(17);
+                constexpr bool FIVE = LL::NREG == 5;
                 if (l > 0) {
-                    co_dqkv<MT, HGS, 0, false>(geo);
+                    co_ds<MT, HGS, FIVE>(geo);
                     wg_sync<SPILL>();
-                    co_dqkv<MT, HGS, 1, false>(geo);
-                    wg_sync<SPILL>();
-                    co_dqkv<MT, HGS, 2, false>(geo);
+                    pf.tick(17);
+                    if (FIVE) {
+                        co_dv_dk<MT, HGS, false>(geo);
+                    } else {
+                        co_dqkv<MT, HGS, 0>(geo);
+                        wg_sync<SPILL>();
+                        co_dqkv<MT, HGS, 1>(geo);
+                        wg_sync<SPILL>();
+                        co_dqkv<MT, HGS, 2>(geo);
+                    }
                     wg_sync<SPILL>();
                     pf.tick(18);
                     // d(LN1 out) += [dq|du] W_qu + dk W_k + dv W_v   (K order per head [q64|u16|k64|v64])
@@ -1310,14 +1400,16 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         [=](int i, int& aoff, int& wkb) {
                             const int hh = i / 13, tt = i - 13 * hh;
                             const int part = (tt >= 5) + (tt >= 9);
-                            const int reg = part == 0 ? 3 : part;          // dQ_ext in R3, dK in R1, dV in R2
+                            const int reg = part == 0 ? (FIVE ? 4 : 3) : part;   // dQ_ext in buffer 4 (or R3), dK in R1, dV in R2
                             aoff = reg * RN * LQ + hh * 80 + 16 * (tt - 5 * part + (part >> 1));
                             wkb = (hg * HGS + hh) * 13 + tt;
                         },
                         geo.Rg, LQ, RN, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
                 } else {
-                    co_dqkv<MT, HGS, 0, true>(geo);
-                    co_dqkv<MT, HGS, 2, true>(geo);
+                    co_ds<MT, HGS, false>(geo);
+                    wg_sync<SPILL>();
+                    pf.tick(17);
+                    co_dv_dk<MT, HGS, true>(geo);
                 }
                 wg_sync<SPILL>();
                 pf.tick(19);
