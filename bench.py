@@ -51,7 +51,7 @@ def hbm_traffic_from_profile(kname, cfg, P, chunk):
             t = json.load(open(f))
         except Exception:
             continue
-        if t.get("kernel") == kname and t.get("workload") == f"{cfg} P={P} chunk={chunk}":
+        if t.get("kernel", "").replace(" ", "") == kname.replace(" ", "") and t.get("workload") == f"{cfg} P={P} chunk={chunk}":
             best = t
     return None if best is None else float(best["hbm_bytes_per_launch"])
 
