@@ -146,6 +146,24 @@ int dff_debug_stash(dff_model* m, int b, int layer, int what, float* out_host, s
 int dff_debug_profile(dff_model* m, int enable);
 int dff_debug_profile_read(dff_model* m, unsigned long long* out_host);
 
+/* ---- pairwise-distance (PWD) histograms for the Jensen-Shannon sample-quality metric ----
+ * Replaces, for structures already resident on the GPU, evaluate/evaluators.py: get_pwd_triu_batch
+ * (:934-948), the per-pair maximum (:239, :259) and the per-pair torch.histc (:241-247, :261-263) of
+ * PwdEvaluator -- without materialising the (n, n_pairs) distance matrix.  Pairs are (i, j >= i+offset)
+ * in torch.triu_indices order; distances and bin selection reproduce torch's float32 arithmetic, so
+ * the counts equal the reference's.  The (n_pairs x bins) JS reduction stays on the host
+ * (two-for-one-diffusion_amd/evaluate.py). */
+int dff_pwd_num_pairs(int n_beads, int offset);
+/* max_out_dev[p] = max over the n structures of d_p (0 when n == 0).  x_dev: (n, n_beads, 3) fp32. */
+int dff_pwd_max(int device, const float* x_dev, long long n, int n_beads, int offset,
+                float* max_out_dev, void* stream);
+/* hist_dev[p * ld + b], b < nbins_dev[p]: number of structures whose d_p falls into bin b of
+ * torch.histc(d_p, bins=nbins[p], min=0, max=hmax_dev[p]); the call zeroes hist_dev (n_pairs * ld)
+ * first.  max_bins >= every nbins[p]; ld >= max_bins. */
+int dff_pwd_hist(int device, const float* x_dev, long long n, int n_beads, int offset,
+                 const int32_t* nbins_dev, const float* hmax_dev, int max_bins, int ld,
+                 uint32_t* hist_dev, void* stream);
+
 const char* dff_last_error(void);
 const char* dff_version(void);
 

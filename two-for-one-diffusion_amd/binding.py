@@ -61,6 +61,9 @@ SYMBOLS = {
     "dff_debug_stash": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_size_t]),
     "dff_debug_profile": (C.c_int, [_P, C.c_int]),
     "dff_debug_profile_read": (C.c_int, [_P, _P]),
+    "dff_pwd_num_pairs": (C.c_int, [C.c_int, C.c_int]),
+    "dff_pwd_max": (C.c_int, [C.c_int, _P, C.c_longlong, C.c_int, C.c_int, _P, _P]),
+    "dff_pwd_hist": (C.c_int, [C.c_int, _P, C.c_longlong, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P]),
     "dff_last_error": (C.c_char_p, []),
     "dff_version": (C.c_char_p, []),
 }
@@ -247,4 +250,52 @@ def debug_gemm(A: np.ndarray, W: np.ndarray, device: int = 0) -> np.ndarray:
     rc = lib.dff_debug_gemm(device, A.ctypes.data_as(C.c_void_p), W.ctypes.data_as(C.c_void_p), M, K, Nout,
                             out.ctypes.data_as(C.c_void_p))
     _check(lib, rc, "dff_debug_gemm")
+    return out
+
+
+# ---- PWD histograms (dff_pwd_*): stateless entry points, no model handle ----
+def _coords(x):
+    import torch
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+            and x.dim() == 3 and x.shape[-1] == 3):
+        raise ValueError("structures must be a contiguous float32 CUDA tensor of shape (n, n_beads, 3)")
+    return x
+
+
+def pwd_num_pairs(n_beads: int, offset: int) -> int:
+    return int(load_library().dff_pwd_num_pairs(int(n_beads), int(offset)))
+
+
+def pwd_max(x, offset: int):
+    """Per-pair maximum distance over the structures x (n, N, 3) -> float32 CUDA tensor (n_pairs,)."""
+    import torch
+    lib = load_library()
+    x = _coords(x)
+    n, N = int(x.shape[0]), int(x.shape[1])
+    out = torch.empty(pwd_num_pairs(N, offset), dtype=torch.float32, device=x.device)
+    stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    _check(lib, lib.dff_pwd_max(x.device.index, _ptr(x), n, N, int(offset), _ptr(out), stream), "dff_pwd_max")
+    return out
+
+
+def pwd_hist(x, offset: int, nbins, hmax):
+    """Per-pair histograms (torch.histc semantics, min=0, max=hmax[p], bins=nbins[p]) of the
+    pairwise distances of x (n, N, 3) -> int32 CUDA tensor (n_pairs, max(nbins)) of counts."""
+    import torch
+    lib = load_library()
+    x = _coords(x)
+    n, N = int(x.shape[0]), int(x.shape[1])
+    npairs = pwd_num_pairs(N, offset)
+    nb = torch.as_tensor(nbins, dtype=torch.int32).reshape(-1)
+    hm = torch.as_tensor(hmax, dtype=torch.float32).reshape(-1)
+    if nb.numel() != npairs or hm.numel() != npairs:
+        raise ValueError(f"nbins / hmax must have {npairs} entries")
+    if int(nb.min()) < 1:
+        raise ValueError("nbins must be >= 1")
+    max_bins = int(nb.max())
+    nb_d, hm_d = nb.to(x.device), hm.to(x.device)
+    out = torch.empty((npairs, max_bins), dtype=torch.int32, device=x.device)
+    stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    _check(lib, lib.dff_pwd_hist(x.device.index, _ptr(x), n, N, int(offset), _ptr(nb_d), _ptr(hm_d), max_bins,
+                                 max_bins, _ptr(out), stream), "dff_pwd_hist")
     return out

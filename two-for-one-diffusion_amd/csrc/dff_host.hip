@@ -14,6 +14,7 @@
 // device code: one translation unit (kernel handles, layouts and templates are shared)
 #include "dff_kernels.hip"
 #include "dff_small.hip"
+#include "dff_pwd.hip"
 
 static thread_local std::string g_err;
 static int fail(int code, const char* fmt, ...) {
@@ -586,6 +587,88 @@ extern "C" int dff_debug_profile_read(dff_model* m, unsigned long long* out) {
     HIPCHK(hipSetDevice(m->device));
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, m->prof, DFF_NPROF * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return DFF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// PWD histograms (dff_pwd.hip)
+// ---------------------------------------------------------------------------------------------
+extern "C" int dff_pwd_num_pairs(int n_beads, int offset) {
+    if (n_beads < 1 || offset < 0) return 0;
+    int np = 0;
+    for (int i = 0; i < n_beads; ++i) np += (n_beads - i - offset > 0) ? n_beads - i - offset : 0;
+    return np;
+}
+
+static int pwd_check(int device, const float* x, long long n, int N, int offset, int& npairs) {
+    if ((!x && n > 0) || n < 0) return fail(DFF_EINVAL, "pwd: null input / negative count");
+    if (N < 2 || N > 255) return fail(DFF_EINVAL, "pwd: n_beads must be 2..255");
+    npairs = dff_pwd_num_pairs(N, offset);
+    if (npairs <= 0) return fail(DFF_EINVAL, "pwd: no bead pairs at offset %d", offset);
+    HIPCHK(hipSetDevice(device));
+    return DFF_OK;
+}
+
+// structures per workgroup: a multiple of the tile, enough workgroups to fill the chip, and long
+// enough that the per-workgroup flush stays small next to the streaming part
+static long long pwd_chunk(long long n, long long want_wgs, long long min_chunk) {
+    long long chunk = (n + want_wgs - 1) / want_wgs;
+    if (chunk < min_chunk) chunk = min_chunk;
+    chunk = (chunk + DFF_PWD_TILE - 1) / DFF_PWD_TILE * DFF_PWD_TILE;
+    return chunk;
+}
+
+extern "C" int dff_pwd_max(int device, const float* x, long long n, int N, int offset, float* max_out, void* stream_) {
+    int npairs;
+    int rc = pwd_check(device, x, n, N, offset, npairs);
+    if (rc) return rc;
+    if (!max_out) return fail(DFF_EINVAL, "pwd: null output");
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(hipMemsetAsync(max_out, 0, (size_t)npairs * sizeof(float), stream));
+    if (n == 0) return DFF_OK;
+    const long long chunk = pwd_chunk(n, 2048, DFF_PWD_TILE);
+    const int grid = (int)((n + chunk - 1) / chunk);
+    const unsigned lds = (unsigned)(DFF_PWD_TILE * 3 * N * sizeof(float) + npairs * sizeof(unsigned) + 2 * npairs + 16);
+    if (lds > 160 * 1024) return fail(DFF_EINVAL, "pwd: LDS budget exceeded (%u bytes)", lds);
+    HIPCHK(hipFuncSetAttribute((const void*)&dff_pwd_max_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int vec4 = ((uintptr_t)x % 16) == 0;
+    hipLaunchKernelGGL(dff_pwd_max_kernel, dim3(grid), dim3(DFF_PWD_THREADS), lds, stream, x, n, N, offset, npairs, chunk,
+                       (unsigned*)max_out, vec4);
+    HIPCHK(hipGetLastError());
+    return DFF_OK;
+}
+
+extern "C" int dff_pwd_hist(int device, const float* x, long long n, int N, int offset, const int32_t* nbins,
+                            const float* hmax, int max_bins, int ld, uint32_t* hist, void* stream_) {
+    int npairs;
+    int rc = pwd_check(device, x, n, N, offset, npairs);
+    if (rc) return rc;
+    if (!nbins || !hmax || !hist) return fail(DFF_EINVAL, "pwd: null argument");
+    if (max_bins < 1 || ld < max_bins) return fail(DFF_EINVAL, "pwd: need 1 <= max_bins <= ld");
+    if (max_bins > DFF_PWD_LDS_BINS) return fail(DFF_EINVAL, "pwd: more than %d bins per pair", DFF_PWD_LDS_BINS);
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(hipMemsetAsync(hist, 0, (size_t)npairs * ld * sizeof(uint32_t), stream));
+    if (n == 0) return DFF_OK;
+    const int ldl = max_bins | 1;   // odd leading dimension: pairs land in different LDS banks
+    int PC = DFF_PWD_LDS_BINS / ldl;
+    if (PC > npairs) PC = npairs;
+    if (PC > 256) PC = 256;
+    const int npc = (npairs + PC - 1) / PC;
+    // each workgroup flushes up to PC * ldl bins: give it at least ~8x that many (pair, structure) items
+    const long long min_chunk = (8LL * ldl + DFF_PWD_TILE - 1) / DFF_PWD_TILE * DFF_PWD_TILE;
+    const long long chunk = pwd_chunk(n, (2048 + npc - 1) / npc, min_chunk);
+    long long nsc = (n + chunk - 1) / chunk;
+    nsc = (nsc + 7) / 8 * 8;       // whole XCD rounds (empty chunks return at once)
+    const long long grid = nsc * npc;
+    if (grid > 0x7fffffffLL) return fail(DFF_EINVAL, "pwd: grid too large");
+    const unsigned lds = (unsigned)(DFF_PWD_TILE * 3 * N * sizeof(float) + (size_t)PC * ldl * sizeof(unsigned) +
+                                    PC * (sizeof(int) + sizeof(float) + 2) + 16);
+    if (lds > 160 * 1024) return fail(DFF_EINVAL, "pwd: LDS budget exceeded (%u bytes)", lds);
+    HIPCHK(hipFuncSetAttribute((const void*)&dff_pwd_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int vec4 = ((uintptr_t)x % 16) == 0;
+    hipLaunchKernelGGL(dff_pwd_hist_kernel, dim3((unsigned)grid), dim3(DFF_PWD_THREADS), lds, stream, x, n, N, offset,
+                       npairs, nbins, hmax, ld, PC, npc, chunk, ldl, hist, vec4);
+    HIPCHK(hipGetLastError());
     return DFF_OK;
 }
 
