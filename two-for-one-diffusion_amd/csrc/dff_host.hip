@@ -602,7 +602,7 @@ extern "C" int dff_pwd_num_pairs(int n_beads, int offset) {
 
 static int pwd_check(int device, const float* x, long long n, int N, int offset, int& npairs) {
     if ((!x && n > 0) || n < 0) return fail(DFF_EINVAL, "pwd: null input / negative count");
-    if (N < 2 || N > 255) return fail(DFF_EINVAL, "pwd: n_beads must be 2..255");
+    if (N < 2 || N > DFF_MAX_BEADS) return fail(DFF_EINVAL, "pwd: n_beads must be 2..%d", DFF_MAX_BEADS);
     npairs = dff_pwd_num_pairs(N, offset);
     if (npairs <= 0) return fail(DFF_EINVAL, "pwd: no bead pairs at offset %d", offset);
     HIPCHK(hipSetDevice(device));
@@ -626,14 +626,15 @@ extern "C" int dff_pwd_max(int device, const float* x, long long n, int N, int o
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(hipMemsetAsync(max_out, 0, (size_t)npairs * sizeof(float), stream));
     if (n == 0) return DFF_OK;
-    const long long chunk = pwd_chunk(n, 2048, DFF_PWD_TILE);
+    const long long chunk = pwd_chunk(n, 1024, 4 * DFF_PWD_TILE);
     const int grid = (int)((n + chunk - 1) / chunk);
-    const unsigned lds = (unsigned)(DFF_PWD_TILE * 3 * N * sizeof(float) + npairs * sizeof(unsigned) + 2 * npairs + 16);
-    if (lds > 160 * 1024) return fail(DFF_EINVAL, "pwd: LDS budget exceeded (%u bytes)", lds);
-    HIPCHK(hipFuncSetAttribute((const void*)&dff_pwd_max_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned lds = (unsigned)(DFF_PWD_TILE * 3 * N * sizeof(float) + 16);
+    int pc_log2 = 0;
+    while ((1 << pc_log2) < npairs && pc_log2 < 8) ++pc_log2;
+    if (npairs > (DFF_PWD_MAXG << pc_log2)) return fail(DFF_EINVAL, "pwd: too many pairs (%d)", npairs);
     const int vec4 = ((uintptr_t)x % 16) == 0;
-    hipLaunchKernelGGL(dff_pwd_max_kernel, dim3(grid), dim3(DFF_PWD_THREADS), lds, stream, x, n, N, offset, npairs, chunk,
-                       (unsigned*)max_out, vec4);
+    hipLaunchKernelGGL(dff_pwd_max_kernel, dim3(grid), dim3(DFF_PWD_THREADS), lds, stream, x, n, N, offset, npairs,
+                       pc_log2, chunk, (unsigned*)max_out, vec4);
     HIPCHK(hipGetLastError());
     return DFF_OK;
 }
@@ -645,29 +646,32 @@ extern "C" int dff_pwd_hist(int device, const float* x, long long n, int N, int 
     if (rc) return rc;
     if (!nbins || !hmax || !hist) return fail(DFF_EINVAL, "pwd: null argument");
     if (max_bins < 1 || ld < max_bins) return fail(DFF_EINVAL, "pwd: need 1 <= max_bins <= ld");
-    if (max_bins > DFF_PWD_LDS_BINS) return fail(DFF_EINVAL, "pwd: more than %d bins per pair", DFF_PWD_LDS_BINS);
+    // LDS: one tile of structures + the privatised histograms
+    const int tile_bytes = DFF_PWD_TILE * 3 * N * (int)sizeof(float);
+    int slots = (160 * 1024 - 64 - tile_bytes) / (int)sizeof(unsigned);
+    if (slots > DFF_PWD_LDS_BINS) slots = DFF_PWD_LDS_BINS;
+    if ((max_bins | 1) > slots) return fail(DFF_EINVAL, "pwd: more than %d bins per pair", slots - 1);
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(hipMemsetAsync(hist, 0, (size_t)npairs * ld * sizeof(uint32_t), stream));
     if (n == 0) return DFF_OK;
     const int ldl = max_bins | 1;   // odd leading dimension: pairs land in different LDS banks
-    int PC = DFF_PWD_LDS_BINS / ldl;
-    if (PC > npairs) PC = npairs;
-    if (PC > 256) PC = 256;
+    int pc_log2 = 8;                // pair lanes per workgroup: the largest power of two whose histograms fit
+    while (pc_log2 > 0 && ((1 << pc_log2) * ldl > slots || (1 << (pc_log2 - 1)) >= npairs)) --pc_log2;
+    const int PC = 1 << pc_log2;
     const int npc = (npairs + PC - 1) / PC;
-    // each workgroup flushes up to PC * ldl bins: give it at least ~8x that many (pair, structure) items
-    const long long min_chunk = (8LL * ldl + DFF_PWD_TILE - 1) / DFF_PWD_TILE * DFF_PWD_TILE;
+    // each workgroup flushes up to PC * ldl bins: give it at least ~2x that many (pair, structure) items
+    const long long min_chunk = (2LL * ldl + DFF_PWD_TILE - 1) / DFF_PWD_TILE * DFF_PWD_TILE;
     const long long chunk = pwd_chunk(n, (2048 + npc - 1) / npc, min_chunk);
     long long nsc = (n + chunk - 1) / chunk;
     nsc = (nsc + 7) / 8 * 8;       // whole XCD rounds (empty chunks return at once)
     const long long grid = nsc * npc;
     if (grid > 0x7fffffffLL) return fail(DFF_EINVAL, "pwd: grid too large");
-    const unsigned lds = (unsigned)(DFF_PWD_TILE * 3 * N * sizeof(float) + (size_t)PC * ldl * sizeof(unsigned) +
-                                    PC * (sizeof(int) + sizeof(float) + 2) + 16);
+    const unsigned lds = (unsigned)(DFF_PWD_TILE * 3 * N * sizeof(float) + (size_t)PC * ldl * sizeof(unsigned) + 16);
     if (lds > 160 * 1024) return fail(DFF_EINVAL, "pwd: LDS budget exceeded (%u bytes)", lds);
     HIPCHK(hipFuncSetAttribute((const void*)&dff_pwd_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int vec4 = ((uintptr_t)x % 16) == 0;
-    hipLaunchKernelGGL(dff_pwd_hist_kernel, dim3((unsigned)grid), dim3(DFF_PWD_THREADS), lds, stream, x, n, N, offset,
-                       npairs, nbins, hmax, ld, PC, npc, chunk, ldl, hist, vec4);
+    hipLaunchKernelGGL(dff_pwd_hist_kernel, dim3((unsigned)grid), dim3(DFF_PWD_HIST_THREADS), lds, stream, x, n, N, offset,
+                       npairs, nbins, hmax, ld, pc_log2, npc, chunk, ldl, hist, vec4);
     HIPCHK(hipGetLastError());
     return DFF_OK;
 }

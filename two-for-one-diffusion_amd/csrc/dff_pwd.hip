@@ -22,8 +22,11 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define DFF_PWD_THREADS 256
+// the histogram kernel owns the whole CU's LDS (one workgroup per CU), so it brings 16 waves of its own:
+// 4 per SIMD hide the LDS-read -> sqrt -> divide -> LDS-atomic chain of each evaluation
+#define DFF_PWD_HIST_THREADS 1024
 #define DFF_PWD_TILE 64          // structures per LDS tile (multiple of 4: float4-aligned tiles)
-#define DFF_PWD_LDS_BINS 24576   // uint32 histogram slots per workgroup (96 KB)
+#define DFF_PWD_LDS_BINS 30720   // uint32 histogram slots per workgroup (120 KB)
 
 // (i, j) of pair p in torch.triu_indices(N, N, offset) order
 __device__ __forceinline__ void pwd_pair(int p, int N, int offset, int& i, int& j) {
@@ -39,71 +42,92 @@ __device__ __forceinline__ void pwd_pair(int p, int N, int offset, int& i, int& 
 }
 
 // cooperative, coalesced load of `cnt` structures starting at s0 into LDS
+template <int NT>
 __device__ __forceinline__ void pwd_load_tile(float* tile, const float* __restrict__ x, long long s0, int cnt,
                                               int N3, bool vec4) {
     const float* src = x + s0 * N3;
     const int nf = cnt * N3;
     if (vec4) {
         const int n4 = nf >> 2;
-        for (int k = threadIdx.x; k < n4; k += DFF_PWD_THREADS)
+        for (int k = threadIdx.x; k < n4; k += NT)
             ((f32x4*)tile)[k] = __builtin_nontemporal_load((const f32x4*)src + k);
-        for (int k = (n4 << 2) + threadIdx.x; k < nf; k += DFF_PWD_THREADS) tile[k] = src[k];
+        for (int k = (n4 << 2) + threadIdx.x; k < nf; k += NT) tile[k] = src[k];
     } else {
-        for (int k = threadIdx.x; k < nf; k += DFF_PWD_THREADS) tile[k] = src[k];
+        for (int k = threadIdx.x; k < nf; k += NT) tile[k] = src[k];
     }
 }
 
-__device__ __forceinline__ float pwd_dist(const float* tile, int s, int N3, int i, int j) {
-    const float* a = tile + s * N3 + 3 * i;
-    const float* b = tile + s * N3 + 3 * j;
+__device__ __forceinline__ float pwd_dist2(const float* xs, int oi, int oj) {
+    const float* a = xs + oi;
+    const float* b = xs + oj;
     const float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
     // sqrtf and '/' are correctly rounded here (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt);
     // the __fsqrt_rn / __fdiv_rn intrinsics are NOT (they lower to the fast native ops)
     return sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
 }
 
+// Thread layout of both kernels: PC (a power of two <= 256) pair lanes x threads/PC structure groups.  A
+// thread keeps ITS pair's constants (bead indices, bin count, range, LDS histogram row) in registers and
+// walks the structures of the tile with stride threads/PC: no index arithmetic per evaluation, the lanes of a
+// wave read the same structure (LDS broadcast for shared beads) and update different histogram rows.
+
 // per-pair maximum distance: max_out[p] = max_s d_p(s)   (bit pattern max: distances are >= 0)
+#define DFF_PWD_MAXG 16   // pair groups per thread: n_pairs <= 16 * PC
 __global__ __launch_bounds__(DFF_PWD_THREADS) void dff_pwd_max_kernel(const float* __restrict__ x, long long n,
-                                                                       int N, int offset, int npairs,
+                                                                       int N, int offset, int npairs, int pc_log2,
                                                                        long long chunk, unsigned* max_out, int vec4) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int N3 = 3 * N;
     float* tile = smem;                                      // DFF_PWD_TILE * N3
-    unsigned* mx = (unsigned*)(smem + DFF_PWD_TILE * N3);    // npairs
-    unsigned char* pij = (unsigned char*)(mx + npairs);      // 2 * npairs
-    for (int p = threadIdx.x; p < npairs; p += DFF_PWD_THREADS) {
-        int i, j;
-        pwd_pair(p, N, offset, i, j);
-        pij[2 * p] = (unsigned char)i;
-        pij[2 * p + 1] = (unsigned char)j;
-        mx[p] = 0u;
+    const int PC = 1 << pc_log2, lane_p = threadIdx.x & (PC - 1), sgrp = threadIdx.x >> pc_log2;
+    const int sstride = DFF_PWD_THREADS >> pc_log2;
+    const int ngrp = (npairs + PC - 1) >> pc_log2;
+    int oi[DFF_PWD_MAXG], oj[DFF_PWD_MAXG];
+    float mx[DFF_PWD_MAXG];
+#pragma unroll
+    for (int g = 0; g < DFF_PWD_MAXG; ++g) {
+        const int p = (g << pc_log2) + lane_p;
+        int i = 0, j = 0;
+        if (g < ngrp && p < npairs) pwd_pair(p, N, offset, i, j);
+        oi[g] = 3 * i;
+        oj[g] = 3 * j;
+        mx[g] = 0.f;
     }
     const long long s_begin = (long long)blockIdx.x * chunk;
     const long long s_end = s_begin + chunk < n ? s_begin + chunk : n;
     for (long long s0 = s_begin; s0 < s_end; s0 += DFF_PWD_TILE) {
         const int cnt = (int)(s_end - s0 < DFF_PWD_TILE ? s_end - s0 : DFF_PWD_TILE);
         __syncthreads();
-        pwd_load_tile(tile, x, s0, cnt, N3, vec4 != 0);
+        pwd_load_tile<DFF_PWD_THREADS>(tile, x, s0, cnt, N3, vec4 != 0);
         __syncthreads();
-        // thread -> (structure, pair), pair fastest: the lanes of a wave hit different LDS words
-        const int items = npairs * cnt;
-        for (int it = threadIdx.x; it < items; it += DFF_PWD_THREADS) {
-            const int s = it / npairs, p = it - s * npairs;
-            const float d = pwd_dist(tile, s, N3, pij[2 * p], pij[2 * p + 1]);
-            atomicMax(&mx[p], __float_as_uint(d));
+        for (int s = sgrp; s < cnt; s += sstride) {
+            const float* xs = tile + s * N3;
+#pragma unroll
+            for (int g = 0; g < DFF_PWD_MAXG; ++g)
+                if (g < ngrp) mx[g] = fmaxf(mx[g], pwd_dist2(xs, oi[g], oj[g]));
         }
+    }
+    // structure groups -> one value per pair in LDS (the tile is dead), then ONE global atomic per pair
+    __syncthreads();
+    unsigned* red = (unsigned*)tile;   // npairs <= N (N + 1) / 2 < 192 N words
+    for (int p = threadIdx.x; p < npairs; p += DFF_PWD_THREADS) red[p] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < DFF_PWD_MAXG; ++g) {
+        const int p = (g << pc_log2) + lane_p;
+        if (g < ngrp && p < npairs && mx[g] > 0.f) atomicMax(&red[p], __float_as_uint(mx[g]));
     }
     __syncthreads();
     for (int p = threadIdx.x; p < npairs; p += DFF_PWD_THREADS)
-        if (mx[p]) atomicMax(&max_out[p], mx[p]);
+        if (red[p]) atomicMax(&max_out[p], red[p]);
 }
 
-// histograms of a chunk of pairs over a chunk of structures.  LDS: tile | hist[pc][ldl] | tables
-__global__ __launch_bounds__(DFF_PWD_THREADS) void dff_pwd_hist_kernel(const float* __restrict__ x, long long n,
+// histograms of a chunk of PC pairs over a chunk of structures.  LDS: tile | hist[PC][ldl]
+__global__ __launch_bounds__(DFF_PWD_HIST_THREADS) void dff_pwd_hist_kernel(const float* __restrict__ x, long long n,
                                                                         int N, int offset, int npairs,
                                                                         const int* __restrict__ nbins,
                                                                         const float* __restrict__ hmax, int ld,
-                                                                        int PC, int npc, long long chunk, int ldl,
+                                                                        int pc_log2, int npc, long long chunk, int ldl,
                                                                         unsigned* hist, int vec4) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int N3 = 3 * N;
@@ -111,44 +135,44 @@ __global__ __launch_bounds__(DFF_PWD_THREADS) void dff_pwd_hist_kernel(const flo
     const int w = blockIdx.x, xcd = w & 7, q = w >> 3;
     const int pchunk = q % npc;
     const long long schunk = (long long)(q / npc) * 8 + xcd;
-    const int p0 = pchunk * PC;
+    const int PC = 1 << pc_log2, lane_p = threadIdx.x & (PC - 1), sgrp = threadIdx.x >> pc_log2;
+    const int sstride = DFF_PWD_HIST_THREADS >> pc_log2;
+    const int p0 = pchunk << pc_log2;
     const int pc = npairs - p0 < PC ? npairs - p0 : PC;
     float* tile = smem;
-    unsigned* hl = (unsigned*)(smem + DFF_PWD_TILE * N3);    // pc * ldl
-    int* nb = (int*)(hl + PC * ldl);
-    float* hm = (float*)(nb + PC);
-    unsigned char* pij = (unsigned char*)(hm + PC);
-    for (int k = threadIdx.x; k < pc * ldl; k += DFF_PWD_THREADS) hl[k] = 0u;
-    for (int p = threadIdx.x; p < pc; p += DFF_PWD_THREADS) {
-        int i, j;
-        pwd_pair(p0 + p, N, offset, i, j);
-        pij[2 * p] = (unsigned char)i;
-        pij[2 * p + 1] = (unsigned char)j;
-        nb[p] = nbins[p0 + p];
-        hm[p] = hmax[p0 + p];
+    unsigned* hl = (unsigned*)(smem + DFF_PWD_TILE * N3);    // PC * ldl
+    for (int k = threadIdx.x; k < pc * ldl; k += DFF_PWD_HIST_THREADS) hl[k] = 0u;
+    const bool live = lane_p < pc;
+    int i = 0, j = 0, b = 1;
+    float m = 0.f;
+    if (live) {
+        pwd_pair(p0 + lane_p, N, offset, i, j);
+        b = nbins[p0 + lane_p];
+        m = hmax[p0 + lane_p];
     }
+    const int oi = 3 * i, oj = 3 * j;
+    const float bf = (float)b;
+    unsigned* row = hl + lane_p * ldl;
     const long long s_begin = schunk * chunk;
     const long long s_end = s_begin + chunk < n ? s_begin + chunk : n;
     for (long long s0 = s_begin; s0 < s_end; s0 += DFF_PWD_TILE) {
         const int cnt = (int)(s_end - s0 < DFF_PWD_TILE ? s_end - s0 : DFF_PWD_TILE);
         __syncthreads();
-        pwd_load_tile(tile, x, s0, cnt, N3, vec4 != 0);
+        pwd_load_tile<DFF_PWD_HIST_THREADS>(tile, x, s0, cnt, N3, vec4 != 0);
         __syncthreads();
-        const int items = pc * cnt;
-        for (int it = threadIdx.x; it < items; it += DFF_PWD_THREADS) {
-            const int s = it / pc, p = it - s * pc;
-            const float d = pwd_dist(tile, s, N3, pij[2 * p], pij[2 * p + 1]);
-            const float m = hm[p];
-            const int b = nb[p];
-            if (d >= 0.0f && d <= m) {
-                int pos = (int)(long long)((d * (float)b) / m);
-                pos = pos < b ? pos : b - 1;
-                atomicAdd(&hl[p * ldl + pos], 1u);
+        if (live)
+#pragma unroll 4
+            for (int s = sgrp; s < cnt; s += sstride) {
+                const float d = pwd_dist2(tile + s * N3, oi, oj);
+                if (d <= m) {   // NaN fails the test, d >= 0 always: histc's range check
+                    int pos = (int)(long long)((d * bf) / m);
+                    pos = pos < b ? pos : b - 1;
+                    atomicAdd(&row[pos], 1u);
+                }
             }
-        }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < pc * ldl; k += DFF_PWD_THREADS) {
+    for (int k = threadIdx.x; k < pc * ldl; k += DFF_PWD_HIST_THREADS) {
         const unsigned v = hl[k];
         if (v) {
             const int p = k / ldl, bin = k - p * ldl;
