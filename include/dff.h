@@ -129,6 +129,9 @@ int dff_set_group(dff_model* m, int proteins_per_workgroup);
 int dff_debug_force_generic(dff_model* m, int on);
 /* Debugging: waves per workgroup of the rows<=16 kernel: 0 auto (8 where it applies), 4 or 8. */
 int dff_debug_small_waves(dff_model* m, int waves);
+/* Debugging: on == 0 makes the sampling loops recompute layer 0 every step instead of reading the
+ * precomputed per-noise-level table of layer-0 inputs (results are bit-identical either way). */
+int dff_debug_l0_table(dff_model* m, int on);
 /* Name of the kernel the last call launched, grid size and dynamic LDS bytes. */
 int dff_last_launch(const dff_model* m, const char** kernel_name, int* grid, int* lds_bytes);
 /* Run one MFMA GEMM stage out(M,Nout) = A(M,K) W(K,Nout) through the same device routine and

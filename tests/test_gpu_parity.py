@@ -384,3 +384,38 @@ def test_small_kernel_wave_variants(dff, golden):
         tr[w] = LangevinDiffusion(diff, init, **kw).sample().numpy()
     diff.model.native.small_waves(0)
     np.testing.assert_allclose(tr[8], tr[4], rtol=2e-4, atol=2e-4 * np.abs(tr[4]).max())
+
+
+@pytest.mark.parametrize("cfg,G", [("chignolin", 0), ("ala2", 3)])
+def test_layer0_table_is_bit_identical(dff, cfg, G):
+    """The sampling loops read layer 0's x-independent inputs from a table precomputed per noise level
+    (rows<=16 kernel); switching the table off recomputes them every step.  Same arithmetic either way:
+    trajectories and samples must agree bit for bit -- Langevin (one entry), DDPM (one entry per t),
+    several proteins per workgroup, chunked launches, and a change of noise level between runs."""
+    from dff_amd.langevin import LangevinDiffusion
+    _, N, H, L = synth.SHIPPED_CONFIGS[cfg]
+    diff, _ = _diffusion(dff, cfg, decoder_scale=1e-2, norm=NORM_STD[cfg])
+    nat = diff.model.native
+    nat.set_group(G)
+    init = torch.from_numpy(synth.normal((7, N, 3), 3, 19).astype(np.float32)) * 2.0
+    out = {}
+    try:
+        for on in (True, False):
+            nat.l0_table(on)
+            res = []
+            for t_level in (20, 8):
+                kw = dict(n_timesteps=24, save_interval=6, t=t_level, temp_data=300, temp_sim=300, dt=None,
+                          masses=[12.0] * N, friction=1.0, verbose=False, seed=5)
+                res.append(LangevinDiffusion(diff, init, **kw).sample().numpy())
+            x = torch.from_numpy(synth.normal((7, N, 3), 4, 23).astype(np.float32)).cuda()
+            x = x - x.mean(1, keepdim=True)
+            res.append(diff.p_sample_loop_from(x.clone(), 40).cpu().numpy())
+            res.append(diff.p_sample_loop_from(x.clone(), 999, t_end=990).cpu().numpy())
+            out[on] = res
+            assert "small" in nat.last_launch()[0]
+    finally:
+        nat.l0_table(True)
+        nat.set_group(0)
+    for a, b in zip(out[True], out[False]):
+        assert np.isfinite(a).all()
+        assert np.array_equal(a, b)

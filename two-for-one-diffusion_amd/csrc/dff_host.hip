@@ -86,6 +86,12 @@ struct dff_model {
     const char* last_kernel = "";
     int last_grid = 0, last_lds = 0, last_G = 0, last_B = 0;
     unsigned long long last_stride = 0;
+    // precomputed layer-0 table (see ensure_l0_table)
+    float* l0_tab = nullptr;
+    size_t l0_floats = 0;
+    int l0_kind = 0, l0_G = 0, l0_waves = -1;   // kind 1: one entry at l0_tnorm (Langevin), 2: one per t (DDPM)
+    float l0_tnorm = 0.f;
+    bool l0_off = false;                       // debugging: never use the table
 };
 
 static int upload(dff_model* m, const std::vector<float>& h, const float** out) {
@@ -310,6 +316,7 @@ extern "C" void dff_model_destroy(dff_model* m) {
     for (void* p : m->allocs) (void)hipFree(p);
     if (m->stash) (void)hipFree(m->stash);
     if (m->prof) (void)hipFree(m->prof);
+    if (m->l0_tab) (void)hipFree(m->l0_tab);
     delete m;
 }
 
@@ -328,6 +335,12 @@ extern "C" int dff_set_group(dff_model* m, int g) {
 extern "C" int dff_debug_force_generic(dff_model* m, int on) {
     if (!m) return fail(DFF_EINVAL, "null model");
     m->force_generic = on != 0;
+    return DFF_OK;
+}
+
+extern "C" int dff_debug_l0_table(dff_model* m, int on) {
+    if (!m) return fail(DFF_EINVAL, "null model");
+    m->l0_off = on == 0;
     return DFF_OK;
 }
 
@@ -384,6 +397,55 @@ static int launch_small(dff_model* m, DffRunArgs& a, int G, hipStream_t stream) 
     return DFF_OK;
 }
 
+// Layer-0 inputs do not depend on x (node features are [one-hot, t]): nodes_in and the
+// [q|u|k|v] rows of layer 0 are functions of the noise level only.  They are computed ONCE per noise
+// level by running the rows<=16 kernel itself in score mode (one workgroup per level, x = 0) and
+// copying the layer-0 slot of each workgroup's stash into a table, which the sampling loops then read
+// instead of running layer 0's QKV GEMM: bit-identical values (same code produced them), one shared
+// L2-resident copy instead of one per workgroup.  Langevin: one entry (its fixed t); DDPM: T entries.
+static int ensure_l0_table(dff_model* m, int kind, float t_norm, int G, hipStream_t stream) {
+    const int N = m->cfg.n_beads, H = m->cfg.hidden, L = m->cfg.n_layers, T = m->cfg.timesteps;
+    if (m->l0_tab && m->l0_kind == kind && m->l0_G == G && m->l0_waves == m->small_waves &&
+        (kind == 2 || m->l0_tnorm == t_norm))
+        return DFF_OK;
+    const int nent = kind == 2 ? T : 1;
+    const SmallStash sl = dff_small_stash(N, G, H, L);
+    const size_t need = (size_t)nent * sl.layer_stride;
+    if (need > m->l0_floats) {
+        if (m->l0_tab) HIPCHK(hipFree(m->l0_tab));
+        m->l0_tab = nullptr; m->l0_floats = 0;
+        HIPCHK(hipMalloc((void**)&m->l0_tab, need * sizeof(float)));
+        m->l0_floats = need;
+    }
+    m->l0_kind = 0;   // invalid until filled
+    const int B = nent * G;
+    std::vector<float> tn((size_t)B);
+    for (int e = 0; e < nent; ++e)
+        for (int g = 0; g < G; ++g) tn[(size_t)e * G + g] = kind == 2 ? (1.0f * (float)e) / (float)T : t_norm;  // as the kernel forms t/T
+    float *xz = nullptr, *tnd = nullptr, *fo = nullptr;
+    HIPCHK(hipMalloc((void**)&xz, (size_t)B * N * 3 * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&fo, (size_t)B * N * 3 * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&tnd, (size_t)B * sizeof(float)));
+    HIPCHK(hipMemsetAsync(xz, 0, (size_t)B * N * 3 * sizeof(float), stream));
+    HIPCHK(hipMemcpyAsync(tnd, tn.data(), (size_t)B * sizeof(float), hipMemcpyHostToDevice, stream));
+    DffRunArgs a;
+    memset(&a, 0, sizeof(a));
+    a.mode = DFF_MODE_SCORE; a.B = B; a.n_steps = 1; a.save_interval = 1;
+    a.x_in = xz; a.tnorm = tnd; a.force_out = fo;
+    int rc = launch_small(m, a, G, stream);
+    if (!rc) {
+        hipError_t e = hipMemcpy2DAsync(m->l0_tab, (size_t)sl.layer_stride * sizeof(float), m->stash,
+                                        (size_t)sl.total * sizeof(float), (size_t)sl.layer_stride * sizeof(float),
+                                        (size_t)nent, hipMemcpyDeviceToDevice, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) rc = fail(DFF_EHIP, "layer-0 table copy: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(xz); (void)hipFree(fo); (void)hipFree(tnd);
+    if (rc) return rc;
+    m->l0_kind = kind; m->l0_G = G; m->l0_waves = m->small_waves; m->l0_tnorm = t_norm;
+    return DFF_OK;
+}
+
 // choose proteins-per-workgroup and the kernel variant, make sure scratch is large enough, launch
 static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
     const int N = m->cfg.n_beads, H = m->cfg.hidden, L = m->cfg.n_layers;
@@ -400,7 +462,16 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
     if (G > 16) G = 16;
     int mt = (G * N + 15) / 16;
     if (mt > 4) { G = 64 / N; mt = (G * N + 15) / 16; }
-    if (G * N <= 16 && !m->force_generic) return launch_small(m, a, G, stream);
+    if (G * N <= 16 && !m->force_generic) {
+        a.l0_tab = nullptr;
+        if (a.mode != DFF_MODE_SCORE && !m->l0_off) {
+            int rc = ensure_l0_table(m, a.mode == DFF_MODE_DDPM ? 2 : 1, a.t_norm, G, stream);
+            if (rc) return rc;
+            a.l0_tab = m->l0_tab;
+        }
+        return launch_small(m, a, G, stream);
+    }
+    a.l0_tab = nullptr;
     const Variant* v = nullptr;
     for (const Variant& c : g_variants)
         if (c.H == H && c.MT == mt) { v = &c; break; }

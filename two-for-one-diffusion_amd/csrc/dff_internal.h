@@ -92,4 +92,7 @@ struct DffRunArgs {
     unsigned long long* prof;   // optional: DFF_NPROF per-stage cycle totals of block 0
     float* stash;               // per-workgroup stash slots
     unsigned long long stash_stride; // floats per workgroup
+    // optional table of precomputed layer-0 inputs (nodes_in, q|u|k|v), one stash-layer-shaped entry per
+    // noise level: entry 0 (Langevin, fixed t) or entry t (DDPM).  Rows-<=16 kernel only.
+    const float* l0_tab;
 };

@@ -460,11 +460,18 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             t_int = a.t_start - step;
             if (tid < gcnt) tn[tid] = (1.0f * (float)t_int) / (float)m.T;
         }
-        const bool cached0 = (a.mode == DFF_MODE_LANGEVIN) && step > 0;
+        // Layer-0 inputs are x-independent: with a precomputed table entry for this step's t
+        // (one entry per noise level, shared by all workgroups and L2-resident; built by the host with this
+        // very kernel, see ensure_l0_table) layer 0 never runs its QKV GEMM.  Without a table, Langevin
+        // (fixed t) still re-reads what step 0 left in this workgroup's own stash.
+        const bool tab = a.l0_tab != nullptr;
+        const gfloat* const l0e = tab ? (const gfloat*)a.l0_tab + (size_t)(a.mode == DFF_MODE_DDPM ? t_int : 0) * sl.layer_stride
+                                      : (const gfloat*)stash;
+        const bool cached0 = tab || ((a.mode == DFF_MODE_LANGEVIN) && step > 0);
         // first weights of the first block (hidden behind the centring below)
         { const int lane = lane_id();
         if (cached0) {
-            const gfloat* sb0 = stash;
+            const gfloat* sb0 = l0e;
             if constexpr (HPW == 2) head_fetch(hr, sb0 + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
             ring_prefetch<E>(ring, s_wox(m.layer[0], wave), lane);
         } else {
@@ -499,6 +506,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         for (int l = 0; l < m.L; ++l) {
             const DffLayerDev& lw = m.layer[l];
             gfloat* const sb = stash + (size_t)l * sl.layer_stride;
+            const gfloat* const sbq = l == 0 ? l0e : (const gfloat*)sb;   // where this layer's nodes_in / q|k|v are read from
             const bool cached = cached0 && l == 0;
             // ---- row stage A (layer 0 only; later layers get LN1 fused into stage C) ----
             if (l == 0) {
@@ -506,7 +514,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 if (cached) {
                     if (ract) {
 #pragma unroll
-                        for (int i = 0; i < HC; ++i) resbuf[rrow * LH + sub + 16 * i] = ld_ntg(sb + sl.nodes_in + rrow * H + sub + 16 * i);
+                        for (int i = 0; i < HC; ++i) resbuf[rrow * LH + sub + 16 * i] = ld_ntg(sbq + sl.nodes_in + rrow * H + sub + 16 * i);
                     }
                 } else if (ract) {
                     float x[HC];
@@ -565,14 +573,14 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     // layer-0 q_ext / k / v are x-independent and t is fixed: re-read, no GEMM
                     if constexpr (HPW == 2) {
                         head_commit(hr, Qx, Kx, Vx, pb, true, false, lane, RLA);
-                        head_fetch(hr, sb + sl.qkv + (size_t)(wave + 4) * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
+                        head_fetch(hr, sbq + sl.qkv + (size_t)(wave + 4) * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
                         head_math(wave);
                         tall_run<0, 5, E>(ring, acc_o, wox_fa, s_wox(lw, wave), s_wox(lw, wave + 4), lane);
                         head_commit(hr, Qx, Kx, Vx, pb, true, false, lane, RLA);
                         head_math(wave + 4);
                         tall_run<1, 5, E>(ring, acc_o, wox_fa, s_wox(lw, wave + 4), after, lane);
                     } else {
-                        head_fetch(hr, sb + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
+                        head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
                         head_commit(hr, Qx, Kx, Vx, pb, true, false, lane, RLA);
                         head_math(wave);
                         tall_run<0, 5, E>(ring, acc_o, wox_fa, s_wox(lw, wave), after, lane);
@@ -741,7 +749,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #pragma unroll
                     for (int i = 0; i < HC; ++i) { ro[6][i] = ro[1][i]; ro[7][i] = ro[2][i]; ro[8][i] = ro[3][i]; ro[2][i] = x[i]; }
                     ro_load(0, (const float*)(sb + sl.attn_out + rrow * H), sub);
-                    ro_load(1, (const float*)(sb + sl.nodes_in + rrow * H), sub);
+                    ro_load(1, (const float*)(sbq + sl.nodes_in + rrow * H), sub);
                     ro_load3(3, lw.g1, sub);
                 } else {
                     gfloat* const sbn = stash + (size_t)(l + 1) * sl.layer_stride;
@@ -767,6 +775,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         for (int l = m.L - 1; l >= 0; --l) {
             const DffLayerDev& lw = m.layer[l];
             const gfloat* const sb = stash + (size_t)l * sl.layer_stride;
+            const gfloat* const sbq = l == 0 ? l0e : sb;
             // ---- row stage D: gate2 backward: dn (resbuf) -> dff (abuf), dn1 partial (resbuf) ----
             // operands (prefetched): ro[0] attn_out, ro[1] nodes_in, ro[2] ff, ro[3..5] g1, ro[6..8] g2
             { DFF_ROW_CONSTS
@@ -832,7 +841,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             // first head of this layer's attention backward: start the stash read (hidden by row stage E)
             if constexpr (HPW == 2) {
                 const int lane = lane_id();
-                head_fetch(hr, sb + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, l > 0, lane);
+                head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, l > 0, lane);
             }
             // ---- row stage E: df = sum_w part ; LN2 backward ; gate1 backward -> dattn (abuf), dn_in partial (resbuf) ----
             // operands: ro[0] attn_out, ro[1] nodes_in, ro[2] ln2 gamma, ro[3..5] g1
@@ -955,7 +964,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 if (l > 0) {
                     if constexpr (HPW == 2) {
                         head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
-                        head_fetch(hr, sb + sl.qkv + (size_t)h1 * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)h1 * 256, RA, true, lane);
+                        head_fetch(hr, sbq + sl.qkv + (size_t)h1 * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)h1 * 256, RA, true, lane);
                         pf.tick(8);
                         gext(std::integral_constant<int, 0>{}, wave, s_qkvt(lw, wave));
                         pf.tick(15);
@@ -975,7 +984,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         tall_run<3, 13, E>(ring, acc_a, qkvt_fa, s_qkvt(lw, h1), after, lane);   // ends at phase 0
                         pf.tick(18);
                     } else {
-                        head_fetch(hr, sb + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, true, lane);
+                        head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, true, lane);
                         head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
                         pf.tick(8);
                         gext(std::integral_constant<int, 0>{}, wave, s_qkvt(lw, wave));
@@ -993,7 +1002,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     // layer 0 needs q_ext (for the dS^T u term) but not k
                     head_commit(hr, Qx, Kx, Vx, pb, false, true, lane, RLA);
                     {   // q_ext of head `wave`
-                        const gfloat* sq = sb + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW;
+                        const gfloat* sq = sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW;
 #pragma unroll
                         for (int u = 0; u < 5; ++u) {
                             const int it = lane + 64 * u, row = it / 20, c4 = it % 20;
@@ -1005,7 +1014,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                             if (row < RLA) *(lf32x4*)(Qx + row * DFF_XLD + 4 * c4) = hr.q[u];
                         }
                     }
-                    head_fetch(hr, sb + sl.qkv + (size_t)h1 * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)h1 * 256, RA, true, lane);
+                    head_fetch(hr, sbq + sl.qkv + (size_t)h1 * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)h1 * 256, RA, true, lane);
                     gext(std::integral_constant<int, 0>{}, wave, s_woxt(lw, h1));
                     ds_math();
                     dx_only();
@@ -1015,7 +1024,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     dx_only();
                     // the next step (if any) re-stages its own first entries at phase 0
                 } else {
-                    head_fetch(hr, sb + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, true, lane);
+                    head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, true, lane);
                     head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
                     gext(std::integral_constant<int, 0>{}, wave, after);
                     ds_math();
@@ -1049,7 +1058,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     const DffLayerDev& lp = m.layer[l - 1];
                     const gfloat* const sp = stash + (size_t)(l - 1) * sl.layer_stride;
                     ro_load(0, (const float*)(sp + sl.attn_out + rrow * H), sub);
-                    ro_load(1, (const float*)(sp + sl.nodes_in + rrow * H), sub);
+                    ro_load(1, (const float*)((l == 1 ? l0e : sp) + sl.nodes_in + rrow * H), sub);
                     ro_load(2, (const float*)(sp + sl.ff + rrow * H), sub);
                     ro_load3(3, lp.g1, sub); ro_load3(6, lp.g2, sub);
                 }
