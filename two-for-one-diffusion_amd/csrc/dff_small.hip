@@ -343,11 +343,24 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     lfloat* const pb = wr + 4 * RS; lfloat* const dsb = pb + 16 * DFF_PLD;
     lfloat* const hbuf = wr;          // FFN hidden slice of this wave (aliases the head buffers)
     lfloat* const mypart = wr;        // this wave's partial H-wide output (ditto; summed by the row stages)
-    auto psum = [=](int o) {          // sum of the NW waves' partial outputs at offset o
-        float t = 0.f;
+    // sum of the NW waves' partial outputs for this lane's HC columns of a row: ALL NW x HC LDS reads are
+    // issued first (one latency), then added in wave order (left to itself the compiler issues one read,
+    // waits, adds, issues the next: NW/2 serial LDS latencies inside a stage every other wave waits for)
+    auto psum_all = [=](float (&out)[(H / (NW == 8 ? 32 : 16))], int o0) {
+        constexpr int HC_ = H / (NW == 8 ? 32 : 16), LPR_ = NW == 8 ? 32 : 16;
+        float pv[NW][HC_];
 #pragma unroll
-        for (int w = 0; w < NW; ++w) t += sm[LL::wreg + w * LL::WREG + o];
-        return t;
+        for (int w = 0; w < NW; ++w)
+#pragma unroll
+            for (int i = 0; i < HC_; ++i) pv[w][i] = sm[LL::wreg + w * LL::WREG + o0 + LPR_ * i];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < HC_; ++i) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += pv[w][i];
+            out[i] = t;
+        }
     };
     const SmallStash sl = dff_small_stash(N, G, H, m.L);
     gfloat* const stash = (gfloat*)a.stash + (size_t)blockIdx.x * a.stash_stride;
@@ -376,7 +389,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     (void)srow; (void)dxi; (void)pj; (void)lro;
 #define DFF_ROW_CONSTS                                  \
     const int tq_ = tid_id();                           \
-    const int rrow = tq_ >> 4, sub = tq_ & 15;          \
+    const int rrow = tq_ / LPR, sub = tq_ % LPR;        \
     const bool ract = rrow < rows;
 
     // ---- load state (as dff_fused_kernel) ----
@@ -405,7 +418,31 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             __syncthreads();
         }
     }
-    constexpr int HC = H / 16;   // row stages: 16 lanes per row, HC columns per lane
+    // Row stages: LPR lanes per row, HC columns per lane.  They run between barriers while every other
+    // wave waits, so their critical path is pure loss: the 8-wave variant spreads a row over 32 lanes
+    // (all 16 possible rows then use the 512 threads) and halves the per-lane work of the 4-wave layout.
+    constexpr int LPR = NW == 8 ? 32 : 16;
+    constexpr int HC = H / LPR;
+    static_assert(H % LPR == 0, "row layout");
+    auto rsum = [](float v) {   // all-reduce over the LPR lanes of a row
+        if constexpr (LPR == 32) {
+            // lanes l and l^16 first (gfx950 v_permlane16_swap: [0] + [1] = v[l] + v[l^16]), then the 16-lane rows
+            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+            v = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
+        return row16_sum(v);
+    };
+    auto ln_stats_row = [&](const float (&x)[HC], float& mean, float& rstd) {   // LayerNorm statistics of one row
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < HC; ++i) t += x[i];
+        mean = rsum(t) * (1.0f / H);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < HC; ++i) { const float d = x[i] - mean; q += d * d; }
+        const float var = rsum(q) * (1.0f / H);
+        rstd = 1.0f / sqrtf(var + 1e-5f);
+    };
 
     Ring<E, DR> ring;
     HeadRegs hr;
@@ -417,7 +454,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     auto ro_load = [&](int k, const float* src, int sub) {
         const gfloat* g = (const gfloat*)src;
 #pragma unroll
-        for (int i = 0; i < HC; ++i) ro[k][i] = g[sub + 16 * i];
+        for (int i = 0; i < HC; ++i) ro[k][i] = g[sub + LPR * i];
     };
     auto ro_load3 = [&](int k, const float* w, int sub) {   // gate weights [x | res | x-res]
         ro_load(k, w, sub); ro_load(k + 1, w + H, sub); ro_load(k + 2, w + 2 * H, sub);
@@ -426,7 +463,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         float z = 0.f;
 #pragma unroll
         for (int i = 0; i < HC; ++i) z += x[i] * ro[k][i] + res[i] * ro[k + 1][i] + (x[i] - res[i]) * ro[k + 2][i];
-        return sigmoid_f(row16_sum(z));
+        return sigmoid_f(rsum(z));
     };
     // stage B operands: bo, g1 (3), ln2 gamma, ln2 beta
     auto pre_B = [&](const DffLayerDev& w, int sub) {
@@ -514,20 +551,20 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 if (cached) {
                     if (ract) {
 #pragma unroll
-                        for (int i = 0; i < HC; ++i) resbuf[rrow * LH + sub + 16 * i] = ld_ntg(sbq + sl.nodes_in + rrow * H + sub + 16 * i);
+                        for (int i = 0; i < HC; ++i) resbuf[rrow * LH + sub + LPR * i] = ld_ntg(sbq + sl.nodes_in + rrow * H + sub + LPR * i);
                     }
                 } else if (ract) {
                     float x[HC];
 #pragma unroll
                     for (int i = 0; i < HC; ++i) {
-                        x[i] = resbuf[rrow * LH + sub + 16 * i];
-                        st_ntg(sb + sl.nodes_in + rrow * H + sub + 16 * i, x[i]);
+                        x[i] = resbuf[rrow * LH + sub + LPR * i];
+                        st_ntg(sb + sl.nodes_in + rrow * H + sub + LPR * i, x[i]);
                     }
                     float mean, rstd;
-                    ln_stats<H>(x, mean, rstd);
+                    ln_stats_row(x, mean, rstd);
 #pragma unroll
                     for (int i = 0; i < HC; ++i) {
-                        const int cl = sub + 16 * i;
+                        const int cl = sub + LPR * i;
                         abuf[rrow * LH + cl] = (x[i] - mean) * rstd * lw.ln1_g[cl] + lw.ln1_b[cl];
                     }
                 }
@@ -653,10 +690,12 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             { DFF_ROW_CONSTS
             if (ract) {
                 float x[HC], res[HC], n1[HC];
+                float ps[HC];
+                psum_all(ps, rrow * LH + sub);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
-                    const int cl = sub + 16 * i, o = rrow * LH + cl;
-                    x[i] = psum(o) + ro[0][i];
+                    const int cl = sub + LPR * i, o = rrow * LH + cl;
+                    x[i] = ps[i] + ro[0][i];
                     res[i] = resbuf[o];
                     st_ntg(sb + sl.attn_out + rrow * H + cl, x[i]);
                 }
@@ -664,12 +703,12 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
                     n1[i] = x[i] * g + res[i] * (1.0f - g);
-                    resbuf[rrow * LH + sub + 16 * i] = n1[i];
+                    resbuf[rrow * LH + sub + LPR * i] = n1[i];
                 }
                 float mean, rstd;
-                ln_stats<H>(n1, mean, rstd);
+                ln_stats_row(n1, mean, rstd);
 #pragma unroll
-                for (int i = 0; i < HC; ++i) abuf[rrow * LH + sub + 16 * i] = (n1[i] - mean) * rstd * ro[4][i] + ro[5][i];
+                for (int i = 0; i < HC; ++i) abuf[rrow * LH + sub + LPR * i] = (n1[i] - mean) * rstd * ro[4][i] + ro[5][i];
                 // stage C operands: b2, g2 (3), and the next layer's LN1 gamma / beta
                 ro_load(0, lw.b2, sub); ro_load3(1, lw.g2, sub);
                 if (l + 1 < m.L) { ro_load(4, m.layer[l + 1].ln1_g, sub); ro_load(5, m.layer[l + 1].ln1_b, sub); }
@@ -721,10 +760,12 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             if (ract) {
                 const bool last = l == m.L - 1;
                 float x[HC], res[HC], n2[HC];
+                float ps[HC];
+                psum_all(ps, rrow * LH + sub);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
-                    const int cl = sub + 16 * i, o = rrow * LH + cl;
-                    x[i] = psum(o) + ro[0][i];
+                    const int cl = sub + LPR * i, o = rrow * LH + cl;
+                    x[i] = ps[i] + ro[0][i];
                     res[i] = resbuf[o];
                     st_ntg(sb + sl.ff + rrow * H + cl, x[i]);
                 }
@@ -735,13 +776,13 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     float e = 0.f;
 #pragma unroll
                     for (int i = 0; i < HC; ++i) {
-                        const int cl = sub + 16 * i;
+                        const int cl = sub + LPR * i;
                         const float wd = m.wdec[cl];
                         e += n2[i] * wd;
                         resbuf[rrow * LH + cl] = wd;   // dn = d(sum e)/d nodes_L
                     }
                     if (a.energy_out) {
-                        e = row16_sum(e);
+                        e = rsum(e);
                         if (sub == 0) a.energy_out[(size_t)b0 * N + rrow] = e + m.bdec;
                     }
                     // stage D operands of this (last) layer: attn_out, nodes_in from the stash, ff (kept),
@@ -754,10 +795,10 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 } else {
                     gfloat* const sbn = stash + (size_t)(l + 1) * sl.layer_stride;
                     float mean, rstd;
-                    ln_stats<H>(n2, mean, rstd);
+                    ln_stats_row(n2, mean, rstd);
 #pragma unroll
                     for (int i = 0; i < HC; ++i) {
-                        const int cl = sub + 16 * i;
+                        const int cl = sub + LPR * i;
                         resbuf[rrow * LH + cl] = n2[i];
                         st_ntg(sbn + sl.nodes_in + rrow * H + cl, n2[i]);
                         abuf[rrow * LH + cl] = (n2[i] - mean) * rstd * ro[4][i] + ro[5][i];
@@ -782,7 +823,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             if (ract) {
                 float n1[HC], dn[HC];
 #pragma unroll
-                for (int i = 0; i < HC; ++i) dn[i] = resbuf[rrow * LH + sub + 16 * i];
+                for (int i = 0; i < HC; ++i) dn[i] = resbuf[rrow * LH + sub + LPR * i];
                 const float g1 = ro_gate(ro[0], ro[1], 3);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) n1[i] = ro[0][i] * g1 + ro[1][i] * (1.0f - g1);
@@ -790,11 +831,11 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 float dg = 0.f;
 #pragma unroll
                 for (int i = 0; i < HC; ++i) dg += dn[i] * (ro[2][i] - n1[i]);
-                dg = row16_sum(dg);
+                dg = rsum(dg);
                 const float dz = dg * g2 * (1.0f - g2);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
-                    const int cl = sub + 16 * i;
+                    const int cl = sub + LPR * i;
                     abuf[rrow * LH + cl] = dn[i] * g2 + dz * (ro[6][i] + ro[8][i]);
                     resbuf[rrow * LH + cl] = dn[i] * (1.0f - g2) + dz * (ro[7][i] - ro[8][i]);
                 }
@@ -847,34 +888,35 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             // operands: ro[0] attn_out, ro[1] nodes_in, ro[2] ln2 gamma, ro[3..5] g1
             { DFF_ROW_CONSTS
             if (ract) {
-                float n1[HC], d1[HC], dyg[HC], xh[HC];
+                float n1[HC], d1[HC], dyg[HC], xh[HC], ps[HC];
+                psum_all(ps, rrow * LH + sub);
                 const float g1 = ro_gate(ro[0], ro[1], 3);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) n1[i] = ro[0][i] * g1 + ro[1][i] * (1.0f - g1);
                 float mean, rstd;
-                ln_stats<H>(n1, mean, rstd);
+                ln_stats_row(n1, mean, rstd);
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
-                    const int o = rrow * LH + sub + 16 * i;
+                    const int o = rrow * LH + sub + LPR * i;
                     xh[i] = (n1[i] - mean) * rstd;
-                    dyg[i] = (psum(o)) * ro[2][i];
+                    dyg[i] = ps[i] * ro[2][i];
                     s1 += dyg[i];
                     s2 += dyg[i] * xh[i];
                 }
-                s1 = row16_sum(s1) * (1.0f / H);
-                s2 = row16_sum(s2) * (1.0f / H);
+                s1 = rsum(s1) * (1.0f / H);
+                s2 = rsum(s2) * (1.0f / H);
                 float dg = 0.f;
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
-                    d1[i] = resbuf[rrow * LH + sub + 16 * i] + rstd * (dyg[i] - s1 - xh[i] * s2);
+                    d1[i] = resbuf[rrow * LH + sub + LPR * i] + rstd * (dyg[i] - s1 - xh[i] * s2);
                     dg += d1[i] * (ro[0][i] - ro[1][i]);
                 }
-                dg = row16_sum(dg);
+                dg = rsum(dg);
                 const float dz = dg * g1 * (1.0f - g1);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
-                    const int cl = sub + 16 * i;
+                    const int cl = sub + LPR * i;
                     abuf[rrow * LH + cl] = d1[i] * g1 + dz * (ro[3][i] + ro[5][i]);
                     resbuf[rrow * LH + cl] = d1[i] * (1.0f - g1) + dz * (ro[4][i] - ro[5][i]);
                 }
@@ -1038,22 +1080,23 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             if (l > 0) {
                 DFF_ROW_CONSTS
                 if (ract) {
-                    float dyg[HC], xh[HC];
+                    float dyg[HC], xh[HC], ps[HC];
+                    psum_all(ps, rrow * LH + sub);
                     float mean, rstd;
-                    ln_stats<H>(ro[1], mean, rstd);
+                    ln_stats_row(ro[1], mean, rstd);
                     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                     for (int i = 0; i < HC; ++i) {
-                        const int o = rrow * LH + sub + 16 * i;
+                        const int o = rrow * LH + sub + LPR * i;
                         xh[i] = (ro[1][i] - mean) * rstd;
-                        dyg[i] = (psum(o)) * ro[2][i];
+                        dyg[i] = ps[i] * ro[2][i];
                         s1 += dyg[i];
                         s2 += dyg[i] * xh[i];
                     }
-                    s1 = row16_sum(s1) * (1.0f / H);
-                    s2 = row16_sum(s2) * (1.0f / H);
+                    s1 = rsum(s1) * (1.0f / H);
+                    s2 = rsum(s2) * (1.0f / H);
 #pragma unroll
-                    for (int i = 0; i < HC; ++i) resbuf[rrow * LH + sub + 16 * i] += rstd * (dyg[i] - s1 - xh[i] * s2);
+                    for (int i = 0; i < HC; ++i) resbuf[rrow * LH + sub + LPR * i] += rstd * (dyg[i] - s1 - xh[i] * s2);
                     // stage D operands of layer l-1
                     const DffLayerDev& lp = m.layer[l - 1];
                     const gfloat* const sp = stash + (size_t)(l - 1) * sl.layer_stride;
