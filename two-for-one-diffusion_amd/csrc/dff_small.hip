@@ -1112,9 +1112,13 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         // dxs = sum of the 4 waves' partial x-gradients
         if (tid < 64) {
             const lfloat* d0 = sm + LL::dxw;
+            float pv[NW];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) pv[w] = d0[w * 128 + tid];
+            __builtin_amdgcn_sched_barrier(0);   // all reads in flight before the first add
             float t = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) t += d0[w * 128 + tid];
+            for (int w = 0; w < NW; ++w) t += pv[w];
             dxs[tid] = t;
         }
         __syncthreads();
