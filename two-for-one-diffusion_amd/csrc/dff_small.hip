@@ -446,6 +446,10 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 
     Ring<E, DR> ring;
     HeadRegs hr;
+    // GELU'(h_pre) slice of the NEXT backward layer, fetched a whole layer ahead (the stash is HBM-resident:
+    // its latency is several times the weight ring's run-ahead).  Only when the slice is one ring revolution.
+    constexpr bool HP_EARLY = NTS == DR;
+    float hpn[DR][4];
     // Row-stage operand registers: every row stage ends by issuing the (global) loads of the NEXT
     // row stage's per-column parameters and stashed activations -- the thread<->(row, column)
     // mapping is the same in all row stages -- so they are in flight during the wave-private block
@@ -813,6 +817,15 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         }
 
         // =============================== backward ===============================
+        auto hp_prefetch = [&](int l) {
+            DFF_LANE_CONSTS
+            const gfloat* const shp = stash + (size_t)l * sl.layer_stride + sl.h_pre + wave * FS + col;
+#pragma unroll
+            for (int d = 0; d < DR; ++d)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hpn[d][r] = ld_ntg(shp + srow[r] * F + 16 * d);
+        };
+        if constexpr (HP_EARLY) hp_prefetch(m.L - 1);
         for (int l = m.L - 1; l >= 0; --l) {
             const DffLayerDev& lw = m.layer[l];
             const gfloat* const sb = stash + (size_t)l * sl.layer_stride;
@@ -857,8 +870,16 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     ax[0] = ld_ntg(shp + s0 + 16 * t); ax[1] = ld_ntg(shp + s1 + 16 * t);
                     ax[2] = ld_ntg(shp + s2 + 16 * t); ax[3] = ld_ntg(shp + s3 + 16 * t);
                 };
+                if constexpr (HP_EARLY) {
 #pragma unroll
-                for (int d = 0; d < DR; ++d) hp_load(d, hp[d]);
+                    for (int d = 0; d < DR; ++d)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) hp[d][r] = hpn[d][r];
+                    if (l > 0) hp_prefetch(l - 1);      // the next backward layer's slice, a whole layer ahead
+                } else {
+#pragma unroll
+                    for (int d = 0; d < DR; ++d) hp_load(d, hp[d]);
+                }
                 {
                     lfloat* const hb = hbuf + quad * 4 * LF + col;
                     wide_run<0, NTS, E, 4>(ring, hp, afr, s_w2t(lw), s_w1t(lw), lane, hp_load,
