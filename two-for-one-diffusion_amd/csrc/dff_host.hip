@@ -91,6 +91,7 @@ struct dff_model {
     size_t l0_floats = 0;
     int l0_kind = 0, l0_G = 0, l0_waves = -1;   // kind 1: one entry at l0_tnorm (Langevin), 2: one per t (DDPM)
     float l0_tnorm = 0.f;
+    const void* l0_variant = nullptr;
     bool l0_off = false;                       // debugging: never use the table
 };
 
@@ -397,20 +398,45 @@ static int launch_small(dff_model* m, DffRunArgs& a, int G, hipStream_t stream) 
     return DFF_OK;
 }
 
+// generic kernel (rows <= 64), variant already chosen
+static int launch_generic(dff_model* m, DffRunArgs& a, int G, const Variant* v, hipStream_t stream) {
+    const int N = m->cfg.n_beads, H = m->cfg.hidden, L = m->cfg.n_layers;
+    const unsigned lds = v->lds_floats(N, G) * (unsigned)sizeof(float);
+    if (lds > 160 * 1024) return fail(DFF_EINVAL, "LDS budget exceeded (%u bytes) for N=%d G=%d H=%d", lds, N, G, H);
+    const int grid = (a.B + G - 1) / G;
+    const StashLayout sl = dff_stash_layout(N, G, H, L);
+    { int rc = ensure_stash(m, (size_t)grid * sl.total); if (rc) return rc; }
+    m->last_small = false;
+    a.G = G;
+    a.prof = m->prof_on ? m->prof : nullptr;
+    a.stash = m->stash;
+    a.stash_stride = sl.total;
+    HIPCHK(hipFuncSetAttribute(v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    void* args[] = {(void*)&m->dev, (void*)&a};
+    HIPCHK(hipLaunchKernel(v->fn, dim3(grid), dim3(DFF_NTHREADS), args, lds, stream));
+    m->last_kernel = v->name; m->last_grid = grid; m->last_lds = (int)lds; m->last_G = G; m->last_B = a.B;
+    m->last_stride = sl.total;
+    return DFF_OK;
+}
+
 // Layer-0 inputs do not depend on x (node features are [one-hot, t]): nodes_in and the
 // [q|u|k|v] rows of layer 0 are functions of the noise level only.  They are computed ONCE per noise
-// level by running the rows<=16 kernel itself in score mode (one workgroup per level, x = 0) and
+// level by running the sampling kernel itself in score mode (one workgroup per level, x = 0) and
 // copying the layer-0 slot of each workgroup's stash into a table, which the sampling loops then read
 // instead of running layer 0's QKV GEMM: bit-identical values (same code produced them), one shared
-// L2-resident copy instead of one per workgroup.  Langevin: one entry (its fixed t); DDPM: T entries.
-static int ensure_l0_table(dff_model* m, int kind, float t_norm, int G, hipStream_t stream) {
+// L2-resident copy instead of one per workgroup.  Langevin: one entry (its fixed t); DDPM: T entries,
+// built in chunks so that the stash does not grow beyond what sampling needs anyway.
+// v == nullptr: rows<=16 kernel, else that variant of the generic kernel.
+static int ensure_l0_table(dff_model* m, int kind, float t_norm, int G, const Variant* v, hipStream_t stream) {
     const int N = m->cfg.n_beads, H = m->cfg.hidden, L = m->cfg.n_layers, T = m->cfg.timesteps;
-    if (m->l0_tab && m->l0_kind == kind && m->l0_G == G && m->l0_waves == m->small_waves &&
+    if (m->l0_tab && m->l0_kind == kind && m->l0_G == G && m->l0_waves == m->small_waves && m->l0_variant == (const void*)v &&
         (kind == 2 || m->l0_tnorm == t_norm))
         return DFF_OK;
     const int nent = kind == 2 ? T : 1;
-    const SmallStash sl = dff_small_stash(N, G, H, L);
-    const size_t need = (size_t)nent * sl.layer_stride;
+    size_t layer_stride, total;
+    if (v) { const StashLayout sl = dff_stash_layout(N, G, H, L); layer_stride = sl.layer_stride; total = sl.total; }
+    else   { const SmallStash sl = dff_small_stash(N, G, H, L); layer_stride = sl.layer_stride; total = sl.total; }
+    const size_t need = (size_t)nent * layer_stride;
     if (need > m->l0_floats) {
         if (m->l0_tab) HIPCHK(hipFree(m->l0_tab));
         m->l0_tab = nullptr; m->l0_floats = 0;
@@ -418,31 +444,38 @@ static int ensure_l0_table(dff_model* m, int kind, float t_norm, int G, hipStrea
         m->l0_floats = need;
     }
     m->l0_kind = 0;   // invalid until filled
-    const int B = nent * G;
-    std::vector<float> tn((size_t)B);
-    for (int e = 0; e < nent; ++e)
-        for (int g = 0; g < G; ++g) tn[(size_t)e * G + g] = kind == 2 ? (1.0f * (float)e) / (float)T : t_norm;  // as the kernel forms t/T
+    const int CH = nent < 256 ? nent : 256;   // noise levels (= workgroups) per build launch
+    const int Bmax = CH * G;
     float *xz = nullptr, *tnd = nullptr, *fo = nullptr;
-    HIPCHK(hipMalloc((void**)&xz, (size_t)B * N * 3 * sizeof(float)));
-    HIPCHK(hipMalloc((void**)&fo, (size_t)B * N * 3 * sizeof(float)));
-    HIPCHK(hipMalloc((void**)&tnd, (size_t)B * sizeof(float)));
-    HIPCHK(hipMemsetAsync(xz, 0, (size_t)B * N * 3 * sizeof(float), stream));
-    HIPCHK(hipMemcpyAsync(tnd, tn.data(), (size_t)B * sizeof(float), hipMemcpyHostToDevice, stream));
-    DffRunArgs a;
-    memset(&a, 0, sizeof(a));
-    a.mode = DFF_MODE_SCORE; a.B = B; a.n_steps = 1; a.save_interval = 1;
-    a.x_in = xz; a.tnorm = tnd; a.force_out = fo;
-    int rc = launch_small(m, a, G, stream);
-    if (!rc) {
-        hipError_t e = hipMemcpy2DAsync(m->l0_tab, (size_t)sl.layer_stride * sizeof(float), m->stash,
-                                        (size_t)sl.total * sizeof(float), (size_t)sl.layer_stride * sizeof(float),
-                                        (size_t)nent, hipMemcpyDeviceToDevice, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        if (e != hipSuccess) rc = fail(DFF_EHIP, "layer-0 table copy: %s", hipGetErrorString(e));
+    HIPCHK(hipMalloc((void**)&xz, (size_t)Bmax * N * 3 * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&fo, (size_t)Bmax * N * 3 * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&tnd, (size_t)Bmax * sizeof(float)));
+    HIPCHK(hipMemsetAsync(xz, 0, (size_t)Bmax * N * 3 * sizeof(float), stream));
+    int rc = DFF_OK;
+    std::vector<float> tn((size_t)Bmax);
+    for (int e0 = 0; e0 < nent && !rc; e0 += CH) {
+        const int ne = nent - e0 < CH ? nent - e0 : CH;
+        for (int e = 0; e < ne; ++e)
+            for (int g = 0; g < G; ++g)
+                tn[(size_t)e * G + g] = kind == 2 ? (1.0f * (float)(e0 + e)) / (float)T : t_norm;   // as the kernel forms t/T
+        hipError_t er = hipMemcpyAsync(tnd, tn.data(), (size_t)ne * G * sizeof(float), hipMemcpyHostToDevice, stream);
+        if (er == hipSuccess) er = hipStreamSynchronize(stream);   // tn is reused by the next chunk
+        if (er != hipSuccess) { rc = fail(DFF_EHIP, "layer-0 table: %s", hipGetErrorString(er)); break; }
+        DffRunArgs a;
+        memset(&a, 0, sizeof(a));
+        a.mode = DFF_MODE_SCORE; a.B = ne * G; a.n_steps = 1; a.save_interval = 1;
+        a.x_in = xz; a.tnorm = tnd; a.force_out = fo;
+        rc = v ? launch_generic(m, a, G, v, stream) : launch_small(m, a, G, stream);
+        if (rc) break;
+        er = hipMemcpy2DAsync(m->l0_tab + (size_t)e0 * layer_stride, layer_stride * sizeof(float), m->stash,
+                              total * sizeof(float), layer_stride * sizeof(float), (size_t)ne,
+                              hipMemcpyDeviceToDevice, stream);
+        if (er == hipSuccess) er = hipStreamSynchronize(stream);
+        if (er != hipSuccess) rc = fail(DFF_EHIP, "layer-0 table copy: %s", hipGetErrorString(er));
     }
     (void)hipFree(xz); (void)hipFree(fo); (void)hipFree(tnd);
     if (rc) return rc;
-    m->l0_kind = kind; m->l0_G = G; m->l0_waves = m->small_waves; m->l0_tnorm = t_norm;
+    m->l0_kind = kind; m->l0_G = G; m->l0_waves = m->small_waves; m->l0_tnorm = t_norm; m->l0_variant = (const void*)v;
     return DFF_OK;
 }
 
@@ -462,16 +495,16 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
     if (G > 16) G = 16;
     int mt = (G * N + 15) / 16;
     if (mt > 4) { G = 64 / N; mt = (G * N + 15) / 16; }
+    const bool want_tab = a.mode != DFF_MODE_SCORE && !m->l0_off;
+    a.l0_tab = nullptr;
     if (G * N <= 16 && !m->force_generic) {
-        a.l0_tab = nullptr;
-        if (a.mode != DFF_MODE_SCORE && !m->l0_off) {
-            int rc = ensure_l0_table(m, a.mode == DFF_MODE_DDPM ? 2 : 1, a.t_norm, G, stream);
+        if (want_tab) {
+            int rc = ensure_l0_table(m, a.mode == DFF_MODE_DDPM ? 2 : 1, a.t_norm, G, nullptr, stream);
             if (rc) return rc;
             a.l0_tab = m->l0_tab;
         }
         return launch_small(m, a, G, stream);
     }
-    a.l0_tab = nullptr;
     const Variant* v = nullptr;
     for (const Variant& c : g_variants)
         if (c.H == H && c.MT == mt) { v = &c; break; }
@@ -481,22 +514,12 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
             if (c.H == H && c.MT == mt) { v = &c; break; }
     }
     if (!v) return fail(DFF_EINVAL, "no kernel variant for hidden=%d rows=%d", H, G * N);
-    const unsigned lds = v->lds_floats(N, G) * (unsigned)sizeof(float);
-    if (lds > 160 * 1024) return fail(DFF_EINVAL, "LDS budget exceeded (%u bytes) for N=%d G=%d H=%d", lds, N, G, H);
-    const int grid = (a.B + G - 1) / G;
-    const StashLayout sl = dff_stash_layout(N, G, H, L);
-    { int rc = ensure_stash(m, (size_t)grid * sl.total); if (rc) return rc; }
-    m->last_small = false;
-    a.G = G;
-    a.prof = m->prof_on ? m->prof : nullptr;
-    a.stash = m->stash;
-    a.stash_stride = sl.total;
-    HIPCHK(hipFuncSetAttribute(v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    void* args[] = {(void*)&m->dev, (void*)&a};
-    HIPCHK(hipLaunchKernel(v->fn, dim3(grid), dim3(DFF_NTHREADS), args, lds, stream));
-    m->last_kernel = v->name; m->last_grid = grid; m->last_lds = (int)lds; m->last_G = G; m->last_B = a.B;
-    m->last_stride = sl.total;
-    return DFF_OK;
+    if (want_tab) {
+        int rc = ensure_l0_table(m, a.mode == DFF_MODE_DDPM ? 2 : 1, a.t_norm, G, v, stream);
+        if (rc) return rc;
+        a.l0_tab = m->l0_tab;
+    }
+    return launch_generic(m, a, G, v, stream);
 }
 
 extern "C" int dff_score(dff_model* m, const float* x, const float* tnorm, int batch, float* force,

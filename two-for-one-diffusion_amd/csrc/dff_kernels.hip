@@ -444,6 +444,7 @@ struct Ctx {
     int b0;
     float *xst, *xs, *dxs, *vst, *cm, *tn, *abuf, *resbuf, *Pbuf, *dSbuf, *Rg;
     float* stash;  // this workgroup's slot
+    const float* l0;   // layer-0 slot the x-independent nodes_in / q|u|k|v are READ from (table entry or own stash)
     StashLayout sl;
 };
 
@@ -590,7 +591,7 @@ DEVI void rowb_gate2(const Ctx& c, const DffLayerDev& lw, int l) {
         for (int i = 0; i < HC; ++i) {
             const int col = sub + 16 * i;
             ao[i] = ld_nt(sb + c.sl.attn_out + row * H + col);
-            nin[i] = ld_nt(sb + c.sl.nodes_in + row * H + col);
+            nin[i] = ld_nt((l == 0 ? c.l0 : sb) + c.sl.nodes_in + row * H + col);
             ff[i] = ld_nt(sb + c.sl.ff + row * H + col);
             dn[i] = c.resbuf[row * LH + col];
         }
@@ -625,7 +626,7 @@ DEVI void rowb_ln2_gate1(const Ctx& c, const DffLayerDev& lw, int l, const float
         for (int i = 0; i < HC; ++i) {
             const int col = sub + 16 * i;
             ao[i] = ld_nt(sb + c.sl.attn_out + row * H + col);
-            nin[i] = ld_nt(sb + c.sl.nodes_in + row * H + col);
+            nin[i] = ld_nt((l == 0 ? c.l0 : sb) + c.sl.nodes_in + row * H + col);
         }
         const float g1 = gate_value<H>(ao, nin, lw.g1, sub);
 #pragma unroll
@@ -672,7 +673,7 @@ DEVI void rowb_ln1(const Ctx& c, const DffLayerDev& lw, int l, const float* tbuf
     for (int row = grp; row < c.rows; row += DFF_NTHREADS / 16) {
         float nin[HC];
 #pragma unroll
-        for (int i = 0; i < HC; ++i) nin[i] = ld_nt(sb + c.sl.nodes_in + row * H + sub + 16 * i);
+        for (int i = 0; i < HC; ++i) nin[i] = ld_nt((l == 0 ? c.l0 : sb) + c.sl.nodes_in + row * H + sub + 16 * i);
         float mean, rstd;
         ln_stats<H>(nin, mean, rstd);
         float s1 = 0.f, s2 = 0.f, dyg[HC], xh[HC];
@@ -1179,7 +1180,11 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
         // =============================== forward ===============================
         // Langevin: t is fixed, so the x-independent layer-0 inputs (node features, LN1, u, q, k, v)
         // are the same every step: computed on step 0, re-read from the stash afterwards.
-        const bool cached0 = (a.mode == DFF_MODE_LANGEVIN) && step > 0;
+        // with a precomputed table entry for this step's noise level (ensure_l0_table) layer 0 never runs its
+        // QKV GEMM; without one, Langevin (fixed t) re-reads what step 0 left in this workgroup's own stash
+        const bool tab = a.l0_tab != nullptr;
+        c.l0 = tab ? a.l0_tab + (size_t)(a.mode == DFF_MODE_DDPM ? t_int : 0) * c.sl.layer_stride : c.stash;
+        const bool cached0 = tab || ((a.mode == DFF_MODE_LANGEVIN) && step > 0);
         if (!cached0) {
             node_embed<H>(c, m);
             wg_sync<SPILL>();
@@ -1189,11 +1194,12 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             float* sb = c.stash + (size_t)l * c.sl.layer_stride;
             const bool cached = cached0 && l == 0;
             gfloat* const sqkv = (gfloat*)sb + c.sl.qkvx;
+            const gfloat* const sqkv_r = (const gfloat*)(l == 0 ? c.l0 : sb) + c.sl.qkvx;   // cached reads
             gfloat* const sPl = (gfloat*)sb + c.sl.P;
             if (cached) {
                 for (int it = tid; it < rows * H; it += DFF_NTHREADS) {
                     const int row = it / H, col = it - row * H;
-                    c.resbuf[row * LH + col] = ld_nt(sb + c.sl.nodes_in + it);
+                    c.resbuf[row * LH + col] = ld_nt(c.l0 + c.sl.nodes_in + it);
                 }
             } else {
                 row_ln1<H>(c, lw, l);
@@ -1207,7 +1213,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 if (cached) {
                     const int tid = tid_now();
                     CoReload<MT, HGS> rl;
-                    co_reload_issue<MT, HGS>(rl, geo, sqkv + (size_t)hg * HGS * RN * DFF_QKVW, sPl, false, tid);
+                    co_reload_issue<MT, HGS>(rl, geo, sqkv_r + (size_t)hg * HGS * RN * DFF_QKVW, sPl, false, tid);
                     co_reload_commit<MT, HGS>(rl, geo, false, tid);
                 }
                 else {
@@ -1344,7 +1350,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             rowb_ln2_gate1<H>(c, lw, l, tbuf);
             wg_sync<SPILL>();
             pf.tick(14);
-            const gfloat* const sqkv = (const gfloat*)sb + c.sl.qkvx;
+            const gfloat* const sqkv = (const gfloat*)(l == 0 ? c.l0 : sb) + c.sl.qkvx;
             const gfloat* const sPl = (const gfloat*)sb + c.sl.P;
             f32x4 acc_a[NTW][MT];
             acc_zero<MT, NTW>(acc_a);
