@@ -125,7 +125,11 @@ def main():
     if "SQ_LDS_BANK_CONFLICT" in C:
         lines.append(f"- LDS: bank-conflict cycles / active cycles = "
                      f"{C['SQ_LDS_BANK_CONFLICT'] / max(C.get('SQ_LDS_IDX_ACTIVE', 1.0), 1.0):.2f}")
-    open(os.path.join(dst, "README.md"), "w").write("\n".join(lines) + "\n")
+    extra = ""
+    old = os.path.join(dst, "README.md")
+    if os.path.exists(old) and "## other kernels" in open(old).read():
+        extra = "\n" + open(old).read()[open(old).read().index("## other kernels"):]
+    open(old, "w").write("\n".join(lines) + "\n" + extra)
     print("\n".join(lines))
 
 
