@@ -109,7 +109,7 @@ def energy(p: Dict[str, torch.Tensor], x: torch.Tensor, t: torch.Tensor, n_layer
 
 
 def score(p: Dict[str, torch.Tensor], x: torch.Tensor, t: torch.Tensor, n_layers: int,
-          return_energy: bool = False):
+          return_energy: bool = False, conservative: bool = True):
     """GraphTransformer.forward: graph_transformer.py:77-114 + compute_forces :143-159.
 
     x (B,N,3) need not be centred; returns -d(sum E)/d(x_centred), detached (eval mode:
@@ -118,6 +118,9 @@ def score(p: Dict[str, torch.Tensor], x: torch.Tensor, t: torch.Tensor, n_layers
     xc = center_zero(x.detach()).requires_grad_(True)
     if t.numel() == 1:
         t = t.reshape(1).repeat(x.shape[0])
+    if not conservative:   # force head: node_decoder is Linear(H, 3), forces = output (:62-65, :112-113)
+        with torch.no_grad():
+            return energy(p, xc.detach(), t, n_layers)
     with torch.enable_grad():
         e = energy(p, xc, t, n_layers)
         (grad,) = torch.autograd.grad(e, xc, grad_outputs=torch.ones_like(e))

@@ -63,7 +63,7 @@ def normal(shape, seed: int, stream: int) -> np.ndarray:
     return np.sqrt(-2.0 * np.log(1.0 - u1)) * np.cos(2.0 * math.pi * u2)
 
 
-def param_specs(n_beads: int, hidden: int, n_layers: int):
+def param_specs(n_beads: int, hidden: int, n_layers: int, decoder_out: int = 1):
     """[(state-dict key under 'model.', shape, kind)] in the reference's registration order.
 
     kinds: 'w' Linear weight (fan_in = shape[1]), 'b' Linear bias (fan_in given), 'g' LN gamma,
@@ -75,8 +75,8 @@ def param_specs(n_beads: int, hidden: int, n_layers: int):
         ("node_embedding.bias", (H,), "b", N + 1),
         ("edge_embedding.weight", (H, 3), "w", 3),
         ("edge_embedding.bias", (H,), "b", 3),
-        ("node_decoder.weight", (1, H), "w", H),
-        ("node_decoder.bias", (1,), "b", H),
+        ("node_decoder.weight", (decoder_out, H), "w", H),   # 1: energy head (conservative), 3: force head
+        ("node_decoder.bias", (decoder_out,), "b", H),
     ]
     for l in range(n_layers):
         p = f"graphtransformer.layers.{l}."
@@ -104,10 +104,10 @@ def param_specs(n_beads: int, hidden: int, n_layers: int):
 
 
 def synth_gnn_params(n_beads: int, hidden: int, n_layers: int, seed: int = 1234,
-                     decoder_scale: float = 1.0) -> "OrderedDict[str, np.ndarray]":
+                     decoder_scale: float = 1.0, decoder_out: int = 1) -> "OrderedDict[str, np.ndarray]":
     """float32 GraphTransformer parameters keyed as in the reference state-dict (no prefix)."""
     out = OrderedDict()
-    for stream, (key, shape, kind, fan_in) in enumerate(param_specs(n_beads, hidden, n_layers)):
+    for stream, (key, shape, kind, fan_in) in enumerate(param_specs(n_beads, hidden, n_layers, decoder_out)):
         bound = 1.0 / math.sqrt(fan_in)
         if kind in ("w", "b"):
             a = uniform(shape, seed, stream, -bound, bound)

@@ -112,7 +112,8 @@ static int upload(dff_model* m, const std::vector<float>& h, const float** out) 
 extern "C" size_t dff_weight_count(const dff_config* c) {
     if (!c) return 0;
     const size_t H = c->hidden, N = c->n_beads, I = DFF_INNER, F = 4 * H;
-    size_t n = H * (N + 1) + H + H * 3 + H + H + 1;
+    const size_t dec = c->conservative ? 1 : 3;   // node_decoder: Linear(H, 1) or Linear(H, 3)
+    size_t n = H * (N + 1) + H + H * 3 + H + dec * H + dec;
     const size_t per_layer = I * H + I + 2 * I * H + 2 * I + I * H + I + H * I + H + H + H + 3 * H +
                              F * H + F + H * F + H + H + H + 3 * H;
     return n + per_layer * c->n_layers;
@@ -158,8 +159,8 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
                                 dff_model** out) {
     if (!cfg || !w || !out) return fail(DFF_EINVAL, "null argument");
     if (!(cfg->use_intrinsic_coords == 1 && cfg->use_distances == 0 && cfg->use_abs_coords == 0 &&
-          cfg->conservative == 1))
-        return fail(DFF_EINVAL, "only use_intrinsic_coords=1,use_distances=0,use_abs_coords=0,conservative=1 is implemented");
+          (cfg->conservative == 0 || cfg->conservative == 1)))
+        return fail(DFF_EINVAL, "only use_intrinsic_coords=1,use_distances=0,use_abs_coords=0 (conservative 0 or 1) is implemented");
     const int H = cfg->hidden, N = cfg->n_beads, L = cfg->n_layers, I = DFF_INNER, F = 4 * H;
     if (!(H == 64 || H == 96 || H == 128)) return fail(DFF_EINVAL, "hidden must be 64, 96 or 128 (got %d)", H);
     if (N < 2 || N > DFF_MAX_BEADS) return fail(DFF_EINVAL, "n_beads must be in [2,%d] (got %d)", DFF_MAX_BEADS, N);
@@ -181,16 +182,19 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
     const float* bn = take(H);
     const float* We = take((size_t)H * 3);
     const float* be = take(H);
-    const float* wd = take(H);
-    const float* bd = take(1);
+    const int dec = cfg->conservative ? 1 : 3;
+    const float* wd = take((size_t)dec * H);
+    const float* bd = take(dec);
     {
         std::vector<float> WnT((size_t)(N + 1) * H);
         for (int c = 0; c < H; ++c)
             for (int i = 0; i <= N; ++i) WnT[(size_t)i * H + c] = Wn[(size_t)c * (N + 1) + i];
         UP(WnT, m->dev.WnT);
         UP(std::vector<float>(bn, bn + H), m->dev.bn);
-        UP(std::vector<float>(wd, wd + H), m->dev.wdec);
+        UP(std::vector<float>(wd, wd + (size_t)dec * H), m->dev.wdec);
+        m->dev.conservative = cfg->conservative;
         m->dev.bdec = bd[0];
+        for (int c2 = 0; c2 < 3; ++c2) m->dev.bdec3[c2] = dec == 3 ? bd[c2] : 0.f;
     }
     for (int l = 0; l < L; ++l) {
         const float* Wq = take((size_t)I * H);  const float* bq = take(I);
@@ -526,6 +530,7 @@ extern "C" int dff_score(dff_model* m, const float* x, const float* tnorm, int b
                          float* energy, void* stream) {
     if (!m || !x || !tnorm || !force) return fail(DFF_EINVAL, "null argument");
     if (batch <= 0) return batch == 0 ? DFF_OK : fail(DFF_EINVAL, "negative batch");
+    if (energy && !m->cfg.conservative) return fail(DFF_EINVAL, "a non-conservative model has no energy (graph_transformer.py:106-113)");
     DffRunArgs a;
     memset(&a, 0, sizeof a);
     a.mode = DFF_MODE_SCORE; a.B = batch; a.n_steps = 1;

@@ -53,8 +53,10 @@ struct DffModelDev {
     int N, H, L, T;
     const float *WnT;   // (N+1, H): node_embedding.weight transposed (one-hot columns, then t)
     const float *bn;    // (H)
-    const float *wdec;  // (H)
-    float bdec;
+    const float *wdec;  // (H) conservative: energy head ; (3,H) otherwise: force head
+    float bdec;         // conservative
+    float bdec3[3];     // non-conservative
+    int conservative;   // 1: forces = -dE/dx (hand-written VJP) ; 0: forces = node_decoder(nodes) (forward only)
     DffLayerDev layer[DFF_MAX_LAYERS];
     // schedule tables, float32 (T each)
     const float *sqrt_recip_ac, *sqrt_recipm1_ac, *post_c1, *post_c2, *post_logvar;

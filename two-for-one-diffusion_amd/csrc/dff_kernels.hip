@@ -559,6 +559,24 @@ DEVI void row_gate2(const Ctx& c, const DffModelDev& m, const DffLayerDev& lw, i
             st_nt(s_ff + row * H + sub + 16 * i, x[i]);
         }
         const float g = gate_value<H>(x, res, lw.g2, sub);
+        if (last && !m.conservative) {
+            // force head (graph_transformer.py:62-63,112-113): forces = node_decoder(nodes), no VJP;
+            // the update stage takes dE/dx, so the negated forces go there
+            float f[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < HC; ++i) {
+                const int col = sub + 16 * i;
+                const float n2 = x[i] * g + res[i] * (1.0f - g);
+#pragma unroll
+                for (int c3 = 0; c3 < 3; ++c3) f[c3] += n2 * m.wdec[c3 * H + col];
+            }
+#pragma unroll
+            for (int c3 = 0; c3 < 3; ++c3) {
+                f[c3] = grp16_sum(f[c3]);
+                if (sub == 0) c.dxs[row * 4 + c3] = -(f[c3] + m.bdec3[c3]);
+            }
+            continue;
+        }
         float e = 0.f;
 #pragma unroll
         for (int i = 0; i < HC; ++i) {
@@ -1305,7 +1323,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
         }
 
         // =============================== backward ===============================
-        for (int l = m.L - 1; l >= 0; --l) {
+        for (int l = m.conservative ? m.L - 1 : -1; l >= 0; --l) {
             const DffLayerDev& lw = m.layer[l];
             const float* sb = c.stash + (size_t)l * c.sl.layer_stride;
             rowb_gate2<H>(c, lw, l);
@@ -1428,8 +1446,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 pf.tick(20);
             }
         }
-        // dE/dx = sum of the per-wave partials
-        if (tid < rows * 4) {
+        // dE/dx = sum of the per-wave partials (the force head wrote dxs itself)
+        if (tid < rows * 4 && m.conservative) {
             float sdx = 0.f;
 #pragma unroll
             for (int w = 0; w < DFF_NWAVES; ++w) sdx += (smem + ll.dxw)[w * RN * 4 + tid];

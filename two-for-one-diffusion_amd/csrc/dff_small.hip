@@ -776,7 +776,22 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 const float g = ro_gate(x, res, 1);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) n2[i] = x[i] * g + res[i] * (1.0f - g);
-                if (last) {
+                if (last && !m.conservative) {
+                    // force head (graph_transformer.py:62-63,112-113): forces = node_decoder(nodes), no VJP.
+                    // The update stage takes dE/dx, so store the negated forces there.
+                    float f[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < HC; ++i) {
+                        const int cl = sub + LPR * i;
+#pragma unroll
+                        for (int c3 = 0; c3 < 3; ++c3) f[c3] += n2[i] * m.wdec[c3 * H + cl];
+                    }
+#pragma unroll
+                    for (int c3 = 0; c3 < 3; ++c3) {
+                        f[c3] = rsum(f[c3]);
+                        if (sub == 0) dxs[rrow * 4 + c3] = -(f[c3] + m.bdec3[c3]);
+                    }
+                } else if (last) {
                     float e = 0.f;
 #pragma unroll
                     for (int i = 0; i < HC; ++i) {
@@ -825,8 +840,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #pragma unroll
                 for (int r = 0; r < 4; ++r) hpn[d][r] = ld_ntg(shp + srow[r] * F + 16 * d);
         };
-        if constexpr (HP_EARLY) hp_prefetch(m.L - 1);
-        for (int l = m.L - 1; l >= 0; --l) {
+        if constexpr (HP_EARLY) { if (m.conservative) hp_prefetch(m.L - 1); }
+        for (int l = m.conservative ? m.L - 1 : -1; l >= 0; --l) {
             const DffLayerDev& lw = m.layer[l];
             const gfloat* const sb = stash + (size_t)l * sl.layer_stride;
             const gfloat* const sbq = l == 0 ? l0e : sb;
@@ -1130,8 +1145,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             }
             pf.tick(10);
         }
-        // dxs = sum of the 4 waves' partial x-gradients
-        if (tid < 64) {
+        // dxs = sum of the waves' partial x-gradients (the force head wrote dxs itself)
+        if (tid < 64 && m.conservative) {
             const lfloat* d0 = sm + LL::dxw;
             float pv[NW];
 #pragma unroll

@@ -31,7 +31,7 @@ class GraphTransformer:
         if dev.type != "cuda":
             raise binding.DffLibraryError("the HIP score network needs a GPU device ('cuda[:i]'); there is no CPU path")
         self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
-        flat = weights.flatten_gnn_params(state_dict, num_beads, hidden_nf, n_layers)
+        flat = weights.flatten_gnn_params(state_dict, num_beads, hidden_nf, n_layers, conservative)
         self.native = binding.Model(num_beads, hidden_nf, n_layers, flat, timesteps=timesteps,
                                     device=self.device.index, use_intrinsic_coords=use_intrinsic_coords,
                                     use_distances=use_distances, use_abs_coords=use_abs_coords,
@@ -58,6 +58,8 @@ class GraphTransformer:
             t = t.repeat(x.shape[0])
         t = t.contiguous()
         if return_energy:
+            if not self.conservative:
+                raise ValueError("a non-conservative model has no energy (graph_transformer.py:106-113)")
             _, e = self.native.score(x, t, return_energy=True)
             return e.unsqueeze(-1)
         return self.native.score(x, t)

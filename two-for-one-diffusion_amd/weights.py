@@ -30,10 +30,11 @@ def abi_key_order(n_layers: int) -> List[str]:
     return keys
 
 
-def expected_shapes(n_beads: int, hidden: int, n_layers: int) -> Dict[str, Tuple[int, ...]]:
+def expected_shapes(n_beads: int, hidden: int, n_layers: int, conservative: bool = True) -> Dict[str, Tuple[int, ...]]:
     H, N, I, F = hidden, n_beads, INNER, 4 * hidden
+    D = 1 if conservative else 3     # node_decoder: energy head or force head (graph_transformer.py:62-65)
     s = {"node_embedding.weight": (H, N + 1), "node_embedding.bias": (H,), "edge_embedding.weight": (H, 3),
-         "edge_embedding.bias": (H,), "node_decoder.weight": (1, H), "node_decoder.bias": (1,)}
+         "edge_embedding.bias": (H,), "node_decoder.weight": (D, H), "node_decoder.bias": (D,)}
     for l in range(n_layers):
         p = f"graphtransformer.layers.{l}."
         s.update({p + "0.0.fn.to_q.weight": (I, H), p + "0.0.fn.to_q.bias": (I,),
@@ -53,9 +54,10 @@ def _np(v) -> np.ndarray:
     return np.asarray(v, dtype=np.float32)
 
 
-def flatten_gnn_params(params: Mapping[str, object], n_beads: int, hidden: int, n_layers: int) -> np.ndarray:
+def flatten_gnn_params(params: Mapping[str, object], n_beads: int, hidden: int, n_layers: int,
+                       conservative: bool = True) -> np.ndarray:
     """GraphTransformer state-dict (keys without prefix) -> flat float32 array, shape-checked."""
-    shapes = expected_shapes(n_beads, hidden, n_layers)
+    shapes = expected_shapes(n_beads, hidden, n_layers, conservative)
     chunks = []
     for k in abi_key_order(n_layers):
         if k not in params:
