@@ -132,6 +132,10 @@ int dff_set_group(dff_model* m, int proteins_per_workgroup);
 int dff_debug_force_generic(dff_model* m, int on);
 /* Debugging: waves per workgroup of the rows<=16 kernel: 0 auto (8 where it applies), 4 or 8. */
 int dff_debug_small_waves(dff_model* m, int waves);
+/* Workgroups per kernel launch (default 2048).  Proteins are independent, so a batch that needs more
+ * workgroups runs as consecutive launches over one bounded scratch "stash" (n x stash slot) instead
+ * of a scratch allocation that grows with the batch.  Results do not depend on the limit. */
+int dff_debug_max_workgroups(dff_model* m, int n);
 /* Debugging: on == 0 makes the sampling loops recompute layer 0 every step instead of reading the
  * precomputed per-noise-level table of layer-0 inputs (results are bit-identical either way). */
 int dff_debug_l0_table(dff_model* m, int on);

@@ -419,3 +419,36 @@ def test_layer0_table_is_bit_identical(dff, cfg, G):
     for a, b in zip(out[True], out[False]):
         assert np.isfinite(a).all()
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("cfg", ["chignolin", "trp_cage"])
+def test_batch_split_over_launches_is_invisible(dff, cfg):
+    """Proteins are independent: a batch that needs more than `max_workgroups` workgroups runs as consecutive
+    launches over one bounded stash.  Forces, energies, trajectories (frames, x, v, KE) and samples must not
+    depend on the limit."""
+    from dff_amd.langevin import LangevinDiffusion
+    _, N, H, L = synth.SHIPPED_CONFIGS[cfg]
+    diff, _ = _diffusion(dff, cfg, decoder_scale=1e-2, norm=NORM_STD.get(cfg, 5.0))
+    nat = diff.model.native
+    B = 11
+    x = torch.from_numpy(synth.normal((B, N, 3), 7, 31).astype(np.float32)).cuda()
+    t = torch.linspace(0.01, 0.9, B).cuda()
+    init = torch.from_numpy(synth.normal((B, N, 3), 8, 32).astype(np.float32)) * 2.0
+    kw = dict(n_timesteps=12, save_interval=4, t=20, temp_data=300, temp_sim=300, dt=None, masses=[12.0] * N,
+              friction=1.0, verbose=False, seed=5)
+    out = {}
+    try:
+        for lim in (2048, 3):
+            nat.max_workgroups(lim)
+            f, e = nat.score(x, t, return_energy=True)
+            ld = LangevinDiffusion(diff, init, **kw)
+            traj = ld.sample().numpy()
+            xc = x - x.mean(1, keepdim=True)
+            s = diff.p_sample_loop_from(xc.clone(), 30, t_end=26).cpu().numpy()
+            out[lim] = [f.cpu().numpy(), e.cpu().numpy(), traj, ld.x.cpu().numpy(), ld.v.cpu().numpy(),
+                        np.asarray(ld.kinetic_energies), s]
+            assert nat.last_launch()[1] == (B if lim == 2048 else B - 3 * ((B - 1) // 3))   # grid of the last launch
+    finally:
+        nat.max_workgroups(2048)
+    for a, b in zip(out[2048], out[3]):
+        assert np.isfinite(a).all() and np.array_equal(a, b)

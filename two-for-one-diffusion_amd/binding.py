@@ -57,6 +57,7 @@ SYMBOLS = {
     "dff_debug_force_generic": (C.c_int, [_P, C.c_int]),
     "dff_debug_small_waves": (C.c_int, [_P, C.c_int]),
     "dff_debug_l0_table": (C.c_int, [_P, C.c_int]),
+    "dff_debug_max_workgroups": (C.c_int, [_P, C.c_int]),
     "dff_last_launch": (C.c_int, [_P, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dff_debug_gemm": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "dff_debug_stash": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_size_t]),
@@ -168,6 +169,9 @@ class Model:
 
     def small_waves(self, waves: int = 0):
         _check(self.lib, self.lib.dff_debug_small_waves(self.handle, int(waves)), "dff_debug_small_waves")
+
+    def max_workgroups(self, n: int = 2048):
+        _check(self.lib, self.lib.dff_debug_max_workgroups(self.handle, int(n)), "dff_debug_max_workgroups")
 
     def l0_table(self, on: bool = True):
         _check(self.lib, self.lib.dff_debug_l0_table(self.handle, int(on)), "dff_debug_l0_table")

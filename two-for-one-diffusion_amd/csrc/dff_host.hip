@@ -93,6 +93,8 @@ struct dff_model {
     float l0_tnorm = 0.f;
     const void* l0_variant = nullptr;
     bool l0_off = false;                       // debugging: never use the table
+    int max_wgs = 2048;                        // workgroups per launch: bounds the stash (grid x stash slot) for big batches
+    int last_base = 0;
 };
 
 static int upload(dff_model* m, const std::vector<float>& h, const float** out) {
@@ -343,6 +345,12 @@ extern "C" int dff_debug_force_generic(dff_model* m, int on) {
     return DFF_OK;
 }
 
+extern "C" int dff_debug_max_workgroups(dff_model* m, int n) {
+    if (!m || n < 1) return fail(DFF_EINVAL, "bad workgroup limit");
+    m->max_wgs = n;
+    return DFF_OK;
+}
+
 extern "C" int dff_debug_l0_table(dff_model* m, int on) {
     if (!m) return fail(DFF_EINVAL, "null model");
     m->l0_off = on == 0;
@@ -386,18 +394,27 @@ static int launch_small(dff_model* m, DffRunArgs& a, int G, hipStream_t stream) 
     else              { fn = (const void*)&dff_small_kernel<128, 4>; lds = SmallLds<128, 4>::total; name = "dff_small_kernel<128,4>"; }
     lds *= (unsigned)sizeof(float);
     if (lds > 160 * 1024) return fail(DFF_EINVAL, "LDS budget exceeded (%u bytes)", lds);
-    const int grid = (a.B + G - 1) / G;
+    const int grid_all = (a.B + G - 1) / G;
+    const int grid_max = grid_all < m->max_wgs ? grid_all : m->max_wgs;
     const SmallStash sl = dff_small_stash(N, G, H, L);
-    int rc = ensure_stash(m, (size_t)grid * sl.total);
+    int rc = ensure_stash(m, (size_t)grid_max * sl.total);
     if (rc) return rc;
     a.G = G;
     a.prof = m->prof_on ? m->prof : nullptr;
     a.stash = m->stash;
     a.stash_stride = sl.total;
     HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    void* args[] = {(void*)&m->dev, (void*)&a};
-    HIPCHK(hipLaunchKernel(fn, dim3(grid), dim3(nthreads), args, lds, stream));
-    m->last_kernel = name; m->last_grid = grid; m->last_lds = (int)lds; m->last_G = G; m->last_B = a.B;
+    // independent proteins: a batch larger than max_wgs workgroups runs as consecutive launches (same stream,
+    // same stash), each over the whole step range
+    for (int w0 = 0; w0 < grid_all; w0 += grid_max) {
+        const int grid = grid_all - w0 < grid_max ? grid_all - w0 : grid_max;
+        a.b_base = w0 * G;
+        void* args[] = {(void*)&m->dev, (void*)&a};
+        HIPCHK(hipLaunchKernel(fn, dim3(grid), dim3(nthreads), args, lds, stream));
+        m->last_grid = grid; m->last_base = a.b_base;
+        a.prof = nullptr;   // per-stage cycles: first launch only
+    }
+    m->last_kernel = name; m->last_lds = (int)lds; m->last_G = G; m->last_B = a.B;
     m->last_stride = sl.total; m->last_small = true;
     return DFF_OK;
 }
@@ -407,18 +424,25 @@ static int launch_generic(dff_model* m, DffRunArgs& a, int G, const Variant* v, 
     const int N = m->cfg.n_beads, H = m->cfg.hidden, L = m->cfg.n_layers;
     const unsigned lds = v->lds_floats(N, G) * (unsigned)sizeof(float);
     if (lds > 160 * 1024) return fail(DFF_EINVAL, "LDS budget exceeded (%u bytes) for N=%d G=%d H=%d", lds, N, G, H);
-    const int grid = (a.B + G - 1) / G;
+    const int grid_all = (a.B + G - 1) / G;
+    const int grid_max = grid_all < m->max_wgs ? grid_all : m->max_wgs;
     const StashLayout sl = dff_stash_layout(N, G, H, L);
-    { int rc = ensure_stash(m, (size_t)grid * sl.total); if (rc) return rc; }
+    { int rc = ensure_stash(m, (size_t)grid_max * sl.total); if (rc) return rc; }
     m->last_small = false;
     a.G = G;
     a.prof = m->prof_on ? m->prof : nullptr;
     a.stash = m->stash;
     a.stash_stride = sl.total;
     HIPCHK(hipFuncSetAttribute(v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    void* args[] = {(void*)&m->dev, (void*)&a};
-    HIPCHK(hipLaunchKernel(v->fn, dim3(grid), dim3(DFF_NTHREADS), args, lds, stream));
-    m->last_kernel = v->name; m->last_grid = grid; m->last_lds = (int)lds; m->last_G = G; m->last_B = a.B;
+    for (int w0 = 0; w0 < grid_all; w0 += grid_max) {   // see launch_small
+        const int grid = grid_all - w0 < grid_max ? grid_all - w0 : grid_max;
+        a.b_base = w0 * G;
+        void* args[] = {(void*)&m->dev, (void*)&a};
+        HIPCHK(hipLaunchKernel(v->fn, dim3(grid), dim3(DFF_NTHREADS), args, lds, stream));
+        m->last_grid = grid; m->last_base = a.b_base;
+        a.prof = nullptr;
+    }
+    m->last_kernel = v->name; m->last_lds = (int)lds; m->last_G = G; m->last_B = a.B;
     m->last_stride = sl.total;
     return DFF_OK;
 }
@@ -448,7 +472,8 @@ static int ensure_l0_table(dff_model* m, int kind, float t_norm, int G, const Va
         m->l0_floats = need;
     }
     m->l0_kind = 0;   // invalid until filled
-    const int CH = nent < 256 ? nent : 256;   // noise levels (= workgroups) per build launch
+    int CH = nent < 256 ? nent : 256;         // noise levels (= workgroups) per build launch ...
+    if (CH > m->max_wgs) CH = m->max_wgs;     // ... each of which must be ONE kernel launch (its stash is copied out)
     const int Bmax = CH * G;
     float *xz = nullptr, *tnd = nullptr, *fo = nullptr;
     HIPCHK(hipMalloc((void**)&xz, (size_t)Bmax * N * 3 * sizeof(float)));
@@ -609,7 +634,8 @@ extern "C" int dff_debug_stash(dff_model* m, int b, int layer, int what, float* 
     if (b < 0 || b >= m->last_B || layer < 0 || layer >= L) return fail(DFF_EINVAL, "bad sample / layer");
     HIPCHK(hipSetDevice(m->device));
     HIPCHK(hipDeviceSynchronize());
-    const int wg = b / G, g = b % G;
+    if (b < m->last_base) return fail(DFF_EINVAL, "sample %d was not part of the last launch (it started at %d)", b, m->last_base);
+    const int wg = (b - m->last_base) / G, g = (b - m->last_base) % G;
     // both kernels stash the same per-head blocks; they differ in offsets, allocated rows and P stride
     unsigned o_nodes, o_attn, o_ff, o_hpre, o_qkv, o_P, lstride, total;
     int R, PS;

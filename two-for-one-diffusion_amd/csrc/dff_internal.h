@@ -66,7 +66,8 @@ enum DffMode { DFF_MODE_SCORE = 0, DFF_MODE_LANGEVIN = 1, DFF_MODE_DDPM = 2 };
 
 struct DffRunArgs {
     int mode;
-    int B;            // proteins (samples / trajectories) in this launch
+    int B;            // proteins (samples / trajectories) of the whole call (stride of noise / frames / ke)
+    int b_base;       // first protein of this launch: big batches run as several launches over one bounded stash
     int G;            // proteins per workgroup
     int n_steps;
     // state

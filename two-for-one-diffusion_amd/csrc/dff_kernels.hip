@@ -1103,7 +1103,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
 
     Ctx c;
     c.N = m.N; c.G = a.G; c.L = m.L;
-    c.b0 = blockIdx.x * a.G;
+    c.b0 = a.b_base + blockIdx.x * a.G;
     c.gcnt = min(a.G, a.B - c.b0);
     if (c.gcnt <= 0) return;
     c.rows = c.gcnt * c.N;

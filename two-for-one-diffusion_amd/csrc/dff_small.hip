@@ -328,7 +328,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     // weight-stream base lives in SGPRs and its arithmetic runs on the scalar unit
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = m.N, G = a.G;
-    const int b0 = blockIdx.x * G;
+    const int b0 = a.b_base + blockIdx.x * G;
     const int gcnt = min(G, a.B - b0);
     if (gcnt <= 0) return;
     const int rows = gcnt * N, RA = G * N;   // real rows of this workgroup / dummy stash row index
