@@ -776,29 +776,14 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 const float g = ro_gate(x, res, 1);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) n2[i] = x[i] * g + res[i] * (1.0f - g);
-                if (last && !m.conservative) {
-                    // force head (graph_transformer.py:62-63,112-113): forces = node_decoder(nodes), no VJP.
-                    // The update stage takes dE/dx, so store the negated forces there.
-                    float f[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int i = 0; i < HC; ++i) {
-                        const int cl = sub + LPR * i;
-#pragma unroll
-                        for (int c3 = 0; c3 < 3; ++c3) f[c3] += n2[i] * m.wdec[c3 * H + cl];
-                    }
-#pragma unroll
-                    for (int c3 = 0; c3 < 3; ++c3) {
-                        f[c3] = rsum(f[c3]);
-                        if (sub == 0) dxs[rrow * 4 + c3] = -(f[c3] + m.bdec3[c3]);
-                    }
-                } else if (last) {
+                if (last) {
                     float e = 0.f;
 #pragma unroll
                     for (int i = 0; i < HC; ++i) {
                         const int cl = sub + LPR * i;
                         const float wd = m.wdec[cl];
                         e += n2[i] * wd;
-                        resbuf[rrow * LH + cl] = wd;   // dn = d(sum e)/d nodes_L
+                        resbuf[rrow * LH + cl] = m.conservative ? wd : n2[i];   // dn = d(sum e)/d nodes_L (or nodes_L for the force head)
                     }
                     if (a.energy_out) {
                         e = rsum(e);
@@ -840,6 +825,27 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #pragma unroll
                 for (int r = 0; r < 4; ++r) hpn[d][r] = ld_ntg(shp + srow[r] * F + 16 * d);
         };
+        if (!m.conservative) {
+            // force head (graph_transformer.py:62-63,112-113): node_decoder is Linear(H, 3) and forces = its output,
+            // no VJP.  nodes_L is in resbuf; the update stage takes dE/dx, so the negated forces go to dxs.
+            DFF_ROW_CONSTS
+            if (ract) {
+                float f[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < HC; ++i) {
+                    const int cl = sub + LPR * i;
+                    const float nv = resbuf[rrow * LH + cl];
+#pragma unroll
+                    for (int c3 = 0; c3 < 3; ++c3) f[c3] += nv * m.wdec[c3 * H + cl];
+                }
+#pragma unroll
+                for (int c3 = 0; c3 < 3; ++c3) {
+                    f[c3] = rsum(f[c3]);
+                    if (sub == 0) dxs[rrow * 4 + c3] = -(f[c3] + m.bdec3[c3]);
+                }
+            }
+            __syncthreads();
+        }
         if constexpr (HP_EARLY) { if (m.conservative) hp_prefetch(m.L - 1); }
         for (int l = m.conservative ? m.L - 1 : -1; l >= 0; --l) {
             const DffLayerDev& lw = m.layer[l];
