@@ -63,18 +63,19 @@ def normal(shape, seed: int, stream: int) -> np.ndarray:
     return np.sqrt(-2.0 * np.log(1.0 - u1)) * np.cos(2.0 * math.pi * u2)
 
 
-def param_specs(n_beads: int, hidden: int, n_layers: int, decoder_out: int = 1):
+def param_specs(n_beads: int, hidden: int, n_layers: int, decoder_out: int = 1, node_in: int = 0, edge_in: int = 3):
     """[(state-dict key under 'model.', shape, kind)] in the reference's registration order.
 
     kinds: 'w' Linear weight (fan_in = shape[1]), 'b' Linear bias (fan_in given), 'g' LN gamma,
     'be' LN beta.  Shapes: SURVEY.md section 5 (probe of the reference's own state_dict()).
     """
     H, N, I, F = hidden, n_beads, INNER, 4 * hidden
+    NI = node_in if node_in else N + 1      # N + 1 + 3 * use_abs_coords
     specs = [
-        ("node_embedding.weight", (H, N + 1), "w", N + 1),
-        ("node_embedding.bias", (H,), "b", N + 1),
-        ("edge_embedding.weight", (H, 3), "w", 3),
-        ("edge_embedding.bias", (H,), "b", 3),
+        ("node_embedding.weight", (H, NI), "w", NI),
+        ("node_embedding.bias", (H,), "b", NI),
+        ("edge_embedding.weight", (H, edge_in), "w", edge_in),
+        ("edge_embedding.bias", (H,), "b", edge_in),
         ("node_decoder.weight", (decoder_out, H), "w", H),   # 1: energy head (conservative), 3: force head
         ("node_decoder.bias", (decoder_out,), "b", H),
     ]
@@ -104,10 +105,11 @@ def param_specs(n_beads: int, hidden: int, n_layers: int, decoder_out: int = 1):
 
 
 def synth_gnn_params(n_beads: int, hidden: int, n_layers: int, seed: int = 1234,
-                     decoder_scale: float = 1.0, decoder_out: int = 1) -> "OrderedDict[str, np.ndarray]":
+                     decoder_scale: float = 1.0, decoder_out: int = 1, node_in: int = 0,
+                     edge_in: int = 3) -> "OrderedDict[str, np.ndarray]":
     """float32 GraphTransformer parameters keyed as in the reference state-dict (no prefix)."""
     out = OrderedDict()
-    for stream, (key, shape, kind, fan_in) in enumerate(param_specs(n_beads, hidden, n_layers, decoder_out)):
+    for stream, (key, shape, kind, fan_in) in enumerate(param_specs(n_beads, hidden, n_layers, decoder_out, node_in, edge_in)):
         bound = 1.0 / math.sqrt(fan_in)
         if kind in ("w", "b"):
             a = uniform(shape, seed, stream, -bound, bound)
