@@ -37,19 +37,21 @@ extern "C" {
 typedef struct dff_model dff_model; /* opaque */
 
 /* Hyper-parameters of GraphTransformer.__init__ as sample.py passes them
- * (models/__init__.py:4-15, models/graph_transformer.py:23-75).  Only the branch every shipped
- * checkpoint uses is implemented: use_intrinsic_coords=1, use_distances=0, use_abs_coords=0,
- * conservative=1 (saved_models/<mol>/args.pickle), plus conservative=0 (the force head of
- * graph_transformer.py:62-65,112-113: node_decoder is Linear(H,3), forces = its output, no energy and no
- * VJP); anything else returns DFF_EINVAL. */
+ * (models/__init__.py:4-15, models/graph_transformer.py:23-75).  Every combination of the 0/1 input
+ * flags is implemented: use_intrinsic_coords (edge features x_j - x_i), use_distances (edge feature
+ * |x_j - x_i|^2), use_abs_coords (node features include x) -- :53-58,99-102,116-140 -- and
+ * conservative (1: forces = -dE/dx through the hand-written VJP; 0: the force head of :62-65,112-113,
+ * node_decoder = Linear(H,3), forces = its output, no energy).  All shipped checkpoints are
+ * (1, 0, 0, conservative 1) and run the specialised kernels; main_train.py's defaults (0, 1, 1) and the
+ * other combinations run the general ("gen") variants of the <= 64-row kernel. */
 typedef struct {
     int32_t n_beads;              /* num_beads, 2..DFF_MAX_BEADS */
     int32_t hidden;               /* hidden_features_gnn: 64, 96 or 128 */
     int32_t n_layers;             /* num_layers_gnn, 1..8 */
     int32_t timesteps;            /* diffusion_steps (GaussianDiffusion timesteps), e.g. 1000 */
-    int32_t use_intrinsic_coords; /* must be 1 */
-    int32_t use_distances;        /* must be 0 */
-    int32_t use_abs_coords;       /* must be 0 */
+    int32_t use_intrinsic_coords; /* 0 / 1 */
+    int32_t use_distances;        /* 0 / 1 */
+    int32_t use_abs_coords;       /* 0 / 1 */
     int32_t conservative;         /* 1: forces = -dE/dx ; 0: forces = node_decoder(nodes) */
 } dff_config;
 
@@ -57,8 +59,8 @@ typedef struct {
 size_t dff_weight_count(const dff_config* cfg);
 
 /* Build a model from the GraphTransformer parameters, given as ONE flat host fp32 array in the
- * reference's state_dict() order: node_embedding.{weight (H,N+1), bias},
- * edge_embedding.{weight (H,3), bias}, node_decoder.{weight (D,H), bias (D)} with D = 1
+ * reference's state_dict() order: node_embedding.{weight (H, N+1+3*abs), bias},
+ * edge_embedding.{weight (H, 3*intrinsic+distances, or 1 if neither), bias}, node_decoder.{weight (D,H), bias (D)} with D = 1
  * (conservative) or 3, then per layer
  * l: attn to_q.{weight (512,H), bias}, to_kv.{weight (1024,H), bias}, edges_to_kv.{weight
  * (512,H), bias}, to_out.{weight (H,512), bias}, norm.{weight, bias}, gate proj.0.weight

@@ -35,12 +35,20 @@ def test_weight_count_and_bad_configs_without_gpu():
     for cfg, (_, N, H, L) in synth.SHIPPED_CONFIGS.items():
         c = binding.DffConfig(N, H, L, 1000, 1, 0, 0, 1)
         assert lib.dff_weight_count(ctypes.byref(c)) == synth.count_params(N, H, L)
-    # unsupported branch (use_distances) is rejected before any device work
-    c = binding.DffConfig(10, 64, 3, 1000, 1, 1, 0, 1)
+    # the other input branches change the embedding shapes: node (H, N+1+3 abs), edge (H, 3 intr + dist)
+    for intr, dist, ab in [(0, 1, 1), (1, 1, 1), (1, 0, 1), (1, 1, 0), (0, 1, 0), (0, 0, 0)]:
+        c = binding.DffConfig(10, 64, 3, 1000, intr, dist, ab, 1)
+        want = sum(int(np.prod(sh)) for _, sh, _, _ in synth.param_specs(10, 64, 3, 1, 11 + 3 * ab, (3 * intr + dist) or 1))
+        assert lib.dff_weight_count(ctypes.byref(c)) == want
+    # flag values other than 0 / 1 and a wrong weight count are rejected before any device work
     w = np.zeros(synth.count_params(10, 64, 3), np.float32)
     h = ctypes.c_void_p()
+    c = binding.DffConfig(10, 64, 3, 1000, 1, 2, 0, 1)
     rc = lib.dff_model_create(ctypes.byref(c), w.ctypes.data_as(ctypes.c_void_p), w.size, 0, ctypes.byref(h))
-    assert rc == 1 and b"use_intrinsic_coords" in lib.dff_last_error()
+    assert rc == 1 and b"must be 0 or 1" in lib.dff_last_error()
+    c = binding.DffConfig(10, 64, 3, 1000, 1, 1, 0, 1)
+    rc = lib.dff_model_create(ctypes.byref(c), w.ctypes.data_as(ctypes.c_void_p), w.size, 0, ctypes.byref(h))
+    assert rc == 1 and b"expected" in lib.dff_last_error()
     c = binding.DffConfig(10, 80, 3, 1000, 1, 0, 0, 1)
     rc = lib.dff_model_create(ctypes.byref(c), w.ctypes.data_as(ctypes.c_void_p), w.size, 0, ctypes.byref(h))
     assert rc == 1 and b"hidden" in lib.dff_last_error()

@@ -17,7 +17,7 @@ SEED = 2468
 
 def params_for(cfg, intr, dist, ab):
     _, N, H, L = synth.SHIPPED_CONFIGS[cfg]
-    return synth.synth_gnn_params(N, H, L, seed=SEED, node_in=N + 1 + 3 * ab, edge_in=3 * intr + dist), (N, H, L)
+    return synth.synth_gnn_params(N, H, L, seed=SEED, node_in=N + 1 + 3 * ab, edge_in=(3 * intr + dist) or 1), (N, H, L)
 
 
 def rel(a, b):
@@ -45,3 +45,87 @@ def test_general_model_reduces_to_the_shipped_branch(golden):
     f1, e1 = km.score(p, g["x"], g["t"], L)
     f2, e2 = kg.score(p, g["x"], g["t"], L, True, False, False)
     assert np.abs(f1 - f2).max() < 1e-13 and np.abs(e1 - e2).max() < 1e-13
+
+
+# ------------------------------------------------------------------ GPU: the HIP path (GEN variants of the generic kernel)
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", CFGS)
+@pytest.mark.parametrize("flags", COMBOS)
+def test_hip_forces_vs_reference(cfg, flags, golden):
+    from dff_amd.score import GraphTransformer
+    intr, dist, ab = flags
+    g = golden(f"score_in_{cfg}_{intr}{dist}{ab}.npz")
+    p, (N, H, L) = params_for(cfg, intr, dist, ab)
+    model = GraphTransformer(N, H, device="cuda:0", n_layers=L, use_intrinsic_coords=bool(intr), use_abs_coords=bool(ab),
+                             use_distances=bool(dist), conservative=True, state_dict=p)
+    x, t = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["t"]).cuda()
+    f = model(x, None, t).cpu().numpy()
+    e = model(x, None, t, return_energy=True).cpu().numpy()
+    r64 = rel(f, g["forces64"])
+    a32 = np.abs(f - g["forces32"]).max() / np.abs(g["forces32"]).max()
+    print(f"{cfg} intr={intr} dist={dist} abs={ab} {model.native.last_launch()[0]}: rel64 {r64:.2e} abs32 {a32:.2e}")
+    assert "gen" in model.native.last_launch()[0]
+    np.testing.assert_allclose(e, g["energy32"], rtol=0, atol=2e-5 * max(1.0, np.abs(g["energy32"]).max()))
+    assert r64 <= 2e-5 and a32 <= 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,flags,G", [("villin", (0, 1, 1), 0), ("protein_g", (0, 1, 1), 0), ("protein_g", (1, 1, 0), 0),
+                                         ("ala2", (0, 1, 1), 3), ("bba", (1, 1, 1), 2), ("villin", (0, 0, 1), 0)])
+def test_hip_vs_factorised_model_other_sizes(cfg, flags, G):
+    """Row-tile counts 3 and 4 (the latter without the fifth LDS buffer), several proteins per workgroup and the
+    degenerate no-edge-feature branch, against the float64 model the golden vectors pin."""
+    from dff_amd.score import GraphTransformer
+    intr, dist, ab = flags
+    p, (N, H, L) = params_for(cfg, intr, dist, ab)
+    model = GraphTransformer(N, H, device="cuda:0", n_layers=L, use_intrinsic_coords=bool(intr), use_abs_coords=bool(ab),
+                             use_distances=bool(dist), conservative=True, state_dict=p)
+    model.native.set_group(G)
+    B = 5
+    x = (synth.normal((B, N, 3), 31, N) * 1.3).astype(np.float32)
+    t = np.linspace(0.01, 0.8, B).astype(np.float32)
+    f = model(torch.from_numpy(x).cuda(), None, torch.from_numpy(t).cuda()).cpu().numpy()
+    fr, er = kg.score(p, x, t, L, bool(intr), bool(dist), bool(ab))
+    print(f"{cfg} {flags} G={G} {model.native.last_launch()}: rel {rel(f, fr):.2e}")
+    assert "gen" in model.native.last_launch()[0]
+    assert rel(f, fr) <= 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [(0, 1, 1), (0, 1, 0), (1, 1, 1)])
+def test_sampling_loops_with_other_inputs(flags):
+    """Fused Langevin / DDPM launches of a GEN model: equal to stepping the score op by hand with the same noise
+    (absolute coordinates: layer 0 is recomputed every step; otherwise it comes from the layer-0 table, which must
+    not change a bit)."""
+    from dff_amd.score import GraphTransformer
+    from dff_amd.ddpm import GaussianDiffusion
+    from dff_amd.langevin import LangevinDiffusion
+    intr, dist, ab = flags
+    cfg = "chignolin"
+    _, N, H, L = synth.SHIPPED_CONFIGS[cfg]
+    p = synth.synth_gnn_params(N, H, L, seed=SEED, decoder_scale=1e-2, node_in=N + 1 + 3 * ab, edge_in=3 * intr + dist)
+    model = GraphTransformer(N, H, device="cuda:0", n_layers=L, use_intrinsic_coords=bool(intr), use_abs_coords=bool(ab),
+                             use_distances=bool(dist), conservative=True, state_dict=p)
+    diff = GaussianDiffusion(model, num_atoms=N, timesteps=1000, norm_factor=3.0)
+    x = torch.from_numpy(synth.normal((4, N, 3), 5, 77).astype(np.float32)).cuda()
+    x = x - x.mean(1, keepdim=True)
+    nz = torch.from_numpy(synth.normal((3, 4, N, 3), 5, 78).astype(np.float32)).cuda()
+    fused = diff.p_sample_loop_from(x.clone(), 300, t_end=298, noises=nz).cpu().numpy()
+    xs = x.clone()
+    for k, tt in enumerate((300, 299, 298)):
+        xs = diff.p_sample(xs, torch.full((4,), tt, dtype=torch.long, device="cuda"), noise=nz[k])
+        xs = xs - xs.mean(1, keepdim=True)
+    np.testing.assert_allclose(fused, xs.cpu().numpy(), rtol=1e-4, atol=1e-4 * np.abs(fused).max())
+    kw = dict(n_timesteps=12, save_interval=4, t=20, temp_data=340, temp_sim=340, dt=None, masses=[12.0] * N, friction=1.0,
+              verbose=False, seed=3)
+    init = torch.from_numpy(synth.normal((4, N, 3), 5, 79).astype(np.float32)) * 2.0
+    out = {}
+    for on in (True, False):
+        model.native.l0_table(on)
+        out[on] = LangevinDiffusion(diff, init, **kw).sample().numpy()
+    model.native.l0_table(True)
+    assert np.isfinite(out[True]).all() and np.array_equal(out[True], out[False])
+    # chunked launches == one launch
+    ld = LangevinDiffusion(diff, init, **kw)
+    ld.chunk_steps = 4 if hasattr(ld, "chunk_steps") else None
+    assert np.array_equal(LangevinDiffusion(diff, init, **kw).sample().numpy(), out[True])

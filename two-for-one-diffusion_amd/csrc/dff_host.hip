@@ -53,16 +53,18 @@ static std::vector<float> pack_b(int K, int Nout, const std::function<double(int
 // ------------------------------------------------------------------------------------------
 struct Variant {
     int H, MT, HGS;
-    bool spill;
+    bool spill, gen;
     const void* fn;
     unsigned (*lds_floats)(int N, int G);
     const char* name;
 };
 template <int H, int MT, int HGS, bool SP>
 static unsigned lds_floats_of(int N, int G) { return LdsLayout<H, MT, HGS, SP>(N, G).total; }
-#define VAR(H, MT, HGS, SP)                                                                       \
-    { H, MT, HGS, SP, (const void*)&dff_fused_kernel<H, MT, HGS, SP>, &lds_floats_of<H, MT, HGS, SP>, \
-      "dff_fused_kernel<" #H "," #MT "," #HGS "," #SP ">" }
+#define VAR(H, MT, HGS, SP)                                                                                     \
+    { H, MT, HGS, SP, false, (const void*)&dff_fused_kernel<H, MT, HGS, SP, false>, &lds_floats_of<H, MT, HGS, SP>,  \
+      "dff_fused_kernel<" #H "," #MT "," #HGS "," #SP ">" },                                                    \
+    { H, MT, HGS, SP, true, (const void*)&dff_fused_kernel<H, MT, HGS, SP, true>, &lds_floats_of<H, MT, HGS, SP>,    \
+      "dff_fused_kernel<" #H "," #MT "," #HGS "," #SP ",gen>" }
 static const Variant g_variants[] = {
     VAR(64, 1, 4, false),  VAR(64, 2, 2, false),  VAR(96, 1, 4, false),  VAR(96, 2, 2, false),
     VAR(128, 1, 4, false), VAR(128, 2, 2, false), VAR(128, 3, 1, false), VAR(128, 4, 1, true),
@@ -115,7 +117,10 @@ extern "C" size_t dff_weight_count(const dff_config* c) {
     if (!c) return 0;
     const size_t H = c->hidden, N = c->n_beads, I = DFF_INNER, F = 4 * H;
     const size_t dec = c->conservative ? 1 : 3;   // node_decoder: Linear(H, 1) or Linear(H, 3)
-    size_t n = H * (N + 1) + H + H * 3 + H + dec * H + dec;
+    const size_t nin = N + 1 + (c->use_abs_coords ? 3 : 0);                                  // graph_transformer.py:53
+    size_t nfe = (c->use_intrinsic_coords ? 3 : 0) + (c->use_distances ? 1 : 0);             // :54-58
+    if (nfe == 0) nfe = 1;
+    size_t n = H * nin + H + H * nfe + H + dec * H + dec;
     const size_t per_layer = I * H + I + 2 * I * H + 2 * I + I * H + I + H * I + H + H + H + 3 * H +
                              F * H + F + H * F + H + H + H + 3 * H;
     return n + per_layer * c->n_layers;
@@ -160,9 +165,9 @@ static void build_schedule(int T, std::vector<std::vector<float>>& out) {
 extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_weights, int device,
                                 dff_model** out) {
     if (!cfg || !w || !out) return fail(DFF_EINVAL, "null argument");
-    if (!(cfg->use_intrinsic_coords == 1 && cfg->use_distances == 0 && cfg->use_abs_coords == 0 &&
-          (cfg->conservative == 0 || cfg->conservative == 1)))
-        return fail(DFF_EINVAL, "only use_intrinsic_coords=1,use_distances=0,use_abs_coords=0 (conservative 0 or 1) is implemented");
+    auto is01 = [](int v) { return v == 0 || v == 1; };
+    if (!(is01(cfg->use_intrinsic_coords) && is01(cfg->use_distances) && is01(cfg->use_abs_coords) && is01(cfg->conservative)))
+        return fail(DFF_EINVAL, "use_intrinsic_coords, use_distances, use_abs_coords and conservative must be 0 or 1");
     const int H = cfg->hidden, N = cfg->n_beads, L = cfg->n_layers, I = DFF_INNER, F = 4 * H;
     if (!(H == 64 || H == 96 || H == 128)) return fail(DFF_EINVAL, "hidden must be 64, 96 or 128 (got %d)", H);
     if (N < 2 || N > DFF_MAX_BEADS) return fail(DFF_EINVAL, "n_beads must be in [2,%d] (got %d)", DFF_MAX_BEADS, N);
@@ -180,17 +185,23 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
 
     const float* p = w;
     auto take = [&](size_t n) { const float* r = p; p += n; return r; };
-    const float* Wn = take((size_t)H * (N + 1));
+    const int intr = cfg->use_intrinsic_coords, dist = cfg->use_distances, ab = cfg->use_abs_coords;
+    const int NI = N + 1 + 3 * ab;                 // node inputs: one-hot (N) | x (3, with abs coords) | t
+    const int nfe_used = 3 * intr + dist;          // edge inputs: x_j - x_i (3) | |x_j - x_i|^2 ; neither -> one zero feature
+    const int nfe = nfe_used ? nfe_used : 1;
+    const float* Wn = take((size_t)H * NI);
     const float* bn = take(H);
-    const float* We = take((size_t)H * 3);
+    const float* We = take((size_t)H * nfe);
     const float* be = take(H);
     const int dec = cfg->conservative ? 1 : 3;
     const float* wd = take((size_t)dec * H);
     const float* bd = take(dec);
     {
-        std::vector<float> WnT((size_t)(N + 1) * H);
+        std::vector<float> WnT((size_t)NI * H);
         for (int c = 0; c < H; ++c)
-            for (int i = 0; i <= N; ++i) WnT[(size_t)i * H + c] = Wn[(size_t)c * (N + 1) + i];
+            for (int i = 0; i < NI; ++i) WnT[(size_t)i * H + c] = Wn[(size_t)c * NI + i];
+        m->dev.in_intr = intr; m->dev.in_dist = dist; m->dev.in_abs = ab;
+        m->dev.wn_t = NI - 1;
         UP(WnT, m->dev.WnT);
         UP(std::vector<float>(bn, bn + H), m->dev.bn);
         UP(std::vector<float>(wd, wd + (size_t)dec * H), m->dev.wdec);
@@ -211,16 +222,35 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
         const float* g2 = take(3 * H);
         DffLayerDev& d = m->dev.layer[l];
         // ---- fold edge_embedding into edges_to_kv (float64): W_c (512x3), b_c (512) ----
-        std::vector<double> Wc((size_t)I * 3), bc(I);
+        // W_c3 (512x3): the intrinsic-coordinate columns (zero without them); cd (512): the distance column
+        std::vector<double> Wc((size_t)I * 3, 0.0), cd(I, 0.0), bc(I);
         for (int r = 0; r < I; ++r) {
-            double s0 = 0, s1 = 0, s2 = 0, sb = 0;
+            double s0 = 0, s1 = 0, s2 = 0, sd = 0, sb = 0;
             for (int c = 0; c < H; ++c) {
                 const double e = Wek[(size_t)r * H + c];
-                s0 += e * We[c * 3 + 0]; s1 += e * We[c * 3 + 1]; s2 += e * We[c * 3 + 2];
+                if (intr) { s0 += e * We[c * nfe + 0]; s1 += e * We[c * nfe + 1]; s2 += e * We[c * nfe + 2]; }
+                if (dist) sd += e * We[c * nfe + 3 * intr];
                 sb += e * be[c];
             }
             Wc[r * 3 + 0] = s0; Wc[r * 3 + 1] = s1; Wc[r * 3 + 2] = s2;
+            cd[r] = sd;
             bc[r] = sb + bek[r];
+        }
+        // distance term: s_ih = c_h . q_ih -> W_s (8xH), b_s (8) ; D_ih feeds the output through w_od,h = W_o,h c_h (Hx8)
+        std::vector<double> Wsd((size_t)8 * H, 0.0), bsd(8, 0.0), Wod((size_t)H * 8, 0.0);
+        for (int h = 0; h < DFF_HEADS; ++h) {
+            for (int c = 0; c < H; ++c) {
+                double s = 0, t = 0;
+                for (int dd = 0; dd < DFF_DH; ++dd) {
+                    s += cd[h * 64 + dd] * Wq[(size_t)(h * 64 + dd) * H + c];
+                    t += (double)Wo[(size_t)c * I + h * 64 + dd] * cd[h * 64 + dd];
+                }
+                Wsd[(size_t)h * H + c] = s;
+                Wod[(size_t)c * 8 + h] = t;
+            }
+            double s = 0;
+            for (int dd = 0; dd < DFF_DH; ++dd) s += cd[h * 64 + dd] * bq[h * 64 + dd];
+            bsd[h] = s;
         }
         // W_u (24xH), b_u (24): u_ih = W_c,h^T q_ih ; W_oc (Hx24) = W_o,h W_c,h ; b_o' = b_o + W_o b_c
         std::vector<double> Wu((size_t)24 * H, 0.0), bu(24, 0.0), Woc((size_t)H * 24, 0.0), bof(H);
@@ -285,21 +315,21 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
         auto wqkvx = [&](int col, int c) -> double {
             const int h = col / 208, e = col % 208;
             if (e < 64) return Wq[(size_t)(h * 64 + e) * H + c];
-            if (e < 80) return e < 67 ? Wu[(size_t)(3 * h + e - 64) * H + c] : 0.0;
+            if (e < 80) return e < 67 ? Wu[(size_t)(3 * h + e - 64) * H + c] : e == 67 ? Wsd[(size_t)h * H + c] : 0.0;
             if (e < 144) return Wkv[(size_t)(h * 64 + e - 80) * H + c];
             return Wkv[(size_t)(I + h * 64 + e - 144) * H + c];
         };
         std::vector<float> bqkvx(8 * 208, 0.f);
         for (int col = 0; col < 8 * 208; ++col) {
             const int h = col / 208, e = col % 208;
-            bqkvx[col] = e < 64 ? bq[h * 64 + e] : e < 67 ? (float)bu[3 * h + e - 64] : e < 80 ? 0.f
+            bqkvx[col] = e < 64 ? bq[h * 64 + e] : e < 67 ? (float)bu[3 * h + e - 64] : e == 67 ? (float)bsd[h] : e < 80 ? 0.f
                          : e < 144 ? bkv[h * 64 + e - 80] : bkv[I + h * 64 + e - 144];
         }
         // output projection with the xrel rows: row e of head h: [0,64) W_o[:, h*64+e], [64,67) W_oc[:, 3h+e-64]
         auto wox = [&](int krow, int c) -> double {
             const int h = krow / 80, e = krow % 80;
             if (e < 64) return Wo[(size_t)c * I + h * 64 + e];
-            return e < 67 ? Woc[(size_t)c * 24 + 3 * h + e - 64] : 0.0;
+            return e < 67 ? Woc[(size_t)c * 24 + 3 * h + e - 64] : e == 67 ? Wod[(size_t)c * 8 + h] : 0.0;
         };
         UP(pack_b(H, 8 * 208, [&](int k, int n) { return wqkvx(n, k); }), d.Wqkvx_p);
         UP(bqkvx, d.bqkvx);
@@ -524,9 +554,12 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
     if (G > 16) G = 16;
     int mt = (G * N + 15) / 16;
     if (mt > 4) { G = 64 / N; mt = (G * N + 15) / 16; }
-    const bool want_tab = a.mode != DFF_MODE_SCORE && !m->l0_off;
+    // input branches other than the shipped one run the GEN variants of the generic kernel; with absolute
+    // coordinates layer 0 depends on x, so there is no layer-0 table
+    const bool gen = !(m->cfg.use_intrinsic_coords == 1 && m->cfg.use_distances == 0 && m->cfg.use_abs_coords == 0);
+    const bool want_tab = a.mode != DFF_MODE_SCORE && !m->l0_off && !m->cfg.use_abs_coords;
     a.l0_tab = nullptr;
-    if (G * N <= 16 && !m->force_generic) {
+    if (G * N <= 16 && !m->force_generic && !gen) {
         if (want_tab) {
             int rc = ensure_l0_table(m, a.mode == DFF_MODE_DDPM ? 2 : 1, a.t_norm, G, nullptr, stream);
             if (rc) return rc;
@@ -536,11 +569,11 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
     }
     const Variant* v = nullptr;
     for (const Variant& c : g_variants)
-        if (c.H == H && c.MT == mt) { v = &c; break; }
+        if (c.H == H && c.MT == mt && c.gen == gen) { v = &c; break; }
     if (!v) {  // fall back to one protein per workgroup
         G = 1; mt = mt_min;
         for (const Variant& c : g_variants)
-            if (c.H == H && c.MT == mt) { v = &c; break; }
+            if (c.H == H && c.MT == mt && c.gen == gen) { v = &c; break; }
     }
     if (!v) return fail(DFF_EINVAL, "no kernel variant for hidden=%d rows=%d", H, G * N);
     if (want_tab) {

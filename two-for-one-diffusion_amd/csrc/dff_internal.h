@@ -57,6 +57,10 @@ struct DffModelDev {
     float bdec;         // conservative
     float bdec3[3];     // non-conservative
     int conservative;   // 1: forces = -dE/dx (hand-written VJP) ; 0: forces = node_decoder(nodes) (forward only)
+    // input branches (graph_transformer.py:53-58,99-102,116-140).  The shipped checkpoints are intr=1, dist=0,
+    // abs=0; anything else runs the GEN variants of the generic kernel.
+    int in_intr, in_dist, in_abs;
+    int wn_t;           // row of WnT that multiplies t: N, or N + 3 with absolute coordinates (rows N..N+2 multiply x)
     DffLayerDev layer[DFF_MAX_LAYERS];
     // schedule tables, float32 (T each)
     const float *sqrt_recip_ac, *sqrt_recipm1_ac, *post_c1, *post_c2, *post_logvar;

@@ -58,7 +58,7 @@ DEVI f32x4 ld_ntg4(const gfloat* p) { return *(const gf32x4*)p; }
 // Stash layout (floats, per workgroup).  R = G*N allocated rows, F = 4H.
 // ------------------------------------------------------------------------------------------
 struct StashLayout {
-    unsigned nodes_in, attn_out, ff, h_pre, qkvx, P;  // offsets inside a layer slot
+    unsigned nodes_in, attn_out, ff, h_pre, qkvx, P, m12;  // offsets inside a layer slot
     unsigned PS;          // leading dimension of a stashed probability row (16 * row tiles)
     unsigned layer_stride;
     unsigned dn_spill;   // offset of the (R,H) spill slot for nodes / dn (after all layers)
@@ -79,6 +79,7 @@ __host__ __device__ inline StashLayout dff_stash_layout(int N, int G, int H, int
     s.h_pre = o;    o += R * F;
     s.qkvx = o;     o += (unsigned)DFF_HEADS * R * DFF_QKVW;
     s.P = o;        o += (unsigned)DFF_HEADS * R * s.PS;
+    s.m12 = o;      o += (unsigned)DFF_HEADS * R * 4;   // GEN: [sum_j a x_j (3) | sum_j a |x_j|^2] per head and row
     s.layer_stride = o;
     s.dn_spill = o * (unsigned)L;
     s.total = s.dn_spill + R * (H + 4);   // indexed with the LDS leading dimension H + 4
@@ -101,7 +102,7 @@ struct LdsLayout {
     static constexpr int FC = (F % 256 == 0) ? 256 : 128;
     static constexpr int LF = FC + 4;
     static constexpr int NREG = MT < 4 ? 5 : 4;   // a fifth head-group buffer (backward: dQ_ext) where LDS allows
-    unsigned xst, xs, dxs, vst, cm, tn, prof, prow, dxw, abuf, resbuf, Pbuf, dSbuf, Rg, total;
+    unsigned xst, xs, dxs, vst, cm, tn, prof, prow, dxw, m12, abuf, resbuf, Pbuf, dSbuf, Rg, total;
     __host__ __device__ LdsLayout(int N, int G) {
         const unsigned R = (unsigned)(G * N);
         unsigned o = 0;
@@ -114,6 +115,7 @@ struct LdsLayout {
         prof = o;  o += 2 * DFF_NPROF;
         prow = o;  o += 64;                    // protein index of each row (-1: pad row)
         dxw = o;   o += DFF_NWAVES * R * 4;   // per-wave partial dE/dx (summed once per step)
+        m12 = o;   o += HGS * R * 4;          // GEN: reloaded [m1 | m2] of the head group (backward)
         abuf = o;  o += R * LH;
         resbuf = o; if (!SPILL) o += R * LH;
         Pbuf = o;  o += HGS * PT;
@@ -450,14 +452,40 @@ struct Ctx {
 
 // x-independent layer-0 node features: node_embedding([one_hot(i), t])  (graph_transformer.py:
 // 91-92,100-103) -> resbuf, stashed as nodes_in of layer 0.
-template <int H>
+template <int H, bool GEN>
 DEVI void node_embed(const Ctx& c, const DffModelDev& m) {
     const int tid_ = tid_now();
     for (int idx = tid_; idx < c.rows * H; idx += DFF_NTHREADS) {
         const int row = idx / H, col = idx - row * H;
         const int g = row / c.N, i = row - g * c.N;
-        const float v = m.WnT[i * H + col] + c.tn[g] * m.WnT[c.N * H + col] + m.bn[col];
+        float v = m.WnT[i * H + col] + c.tn[g] * m.WnT[(GEN ? m.wn_t : c.N) * H + col] + m.bn[col];
+        if (GEN && m.in_abs) {   // nodes = [one-hot, x, t]  (graph_transformer.py:99-102)
+#pragma unroll
+            for (int c3 = 0; c3 < 3; ++c3) v += c.xs[row * 4 + c3] * m.WnT[(c.N + c3) * H + col];
+        }
         c.resbuf[row * (H + 4) + col] = v;
+    }
+}
+// absolute coordinates: dE/dx_i += d(nodes_0)_i . W_node[:, x columns]   (dn_0 is in resbuf after layer 0's backward)
+template <int H>
+DEVI void node_embed_bwd(const Ctx& c, const DffModelDev& m) {
+    const int tid_ = tid_now();
+    constexpr int HC = H / 16, LH = H + 4;
+    const int grp = tid_ >> 4, sub = tid_ & 15;
+    for (int row = grp; row < c.rows; row += DFF_NTHREADS / 16) {
+        float f[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < HC; ++i) {
+            const int col = sub + 16 * i;
+            const float dn = c.resbuf[row * LH + col];
+#pragma unroll
+            for (int c3 = 0; c3 < 3; ++c3) f[c3] += dn * m.WnT[(c.N + c3) * H + col];
+        }
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) {
+            f[c3] = grp16_sum(f[c3]);
+            if (sub == 0) c.dxs[row * 4 + c3] += f[c3];
+        }
     }
 }
 
@@ -811,14 +839,27 @@ DEVI void co_mm5(f32x4 (&c)[5], const lfloat* T, int mo, const lfloat* B, int ld
 }
 
 // geometry every attention phase needs
+DEVI float quad_sum(float v) {        // all-reduce over the 4 lanes of a DPP quad
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    return v;
+}
+DEVI float quad_bcast3(float v) { return dpp_mov<0xFF>(v); }   // lane 3 of the quad to all four
+
+// GEN variants (other input branches, oracle/kernel_model_gen.py): the 16-column head extension carries
+//   Q_ext: [u - 2 s x_i (3) | s]    K_ext, V_ext: [x_j (3) | |x_j|^2]    o_ext: [xrel (3) | D]
+//   G_ext: [r - 2 gD x_i (3) | gD]  with s = c_h.q (distance term of the logits), D = sum_j a_ij |x_i - x_j|^2.
+// The GEMMs produce the x-independent parts ([u | s], [r | gD]); the x_i-dependent fix-ups are applied in LDS
+// by the wave that owns the row tile, right before it uses them.
 struct CoGeo {
     lfloat *Rg, *Pbuf, *dSbuf, *xs, *dxw;   // dxw: this wave's partial dE/dx
+    lfloat* m12;                            // GEN: [m1 | m2] rows of the head group (backward)
     const int __attribute__((address_space(3))) * prow;   // protein index of each row, -1 for pad rows
     int N, RN, rows;
 };
 
 // K_ext / V_ext extension columns <- x (columns 3..15 zero)
-template <int HGS>
+template <int HGS, bool GEN>
 DEVI void co_fill_x(const CoGeo& g) {
     const int tid_ = tid_now();
     constexpr int LQ = 80 * HGS + 4;
@@ -826,10 +867,43 @@ DEVI void co_fill_x(const CoGeo& g) {
     for (int it = tid_; it < total; it += DFF_NTHREADS) {
         const int cc = it & 15, r2 = it >> 4;
         const int hh = r2 % HGS, row = r2 / HGS;
-        const float v = cc < 3 ? g.xs[row * 4 + cc] : 0.f;
+        float v = cc < 3 ? g.xs[row * 4 + cc] : 0.f;
+        if (GEN && cc == 3) {
+            const float x0 = g.xs[row * 4], x1 = g.xs[row * 4 + 1], x2 = g.xs[row * 4 + 2];
+            v = x0 * x0 + x1 * x1 + x2 * x2;
+        }
         lfloat* d = g.Rg + g.RN * LQ + row * LQ + hh * 80 + 64 + cc;
         d[0] = v;
         d[g.RN * LQ] = v;
+    }
+}
+
+// GEN fix-ups of one row tile (lanes 0..15 take one row each)
+template <int HGS>
+DEVI void co_fix_q(const CoGeo& g, int hh, int it, int lane) {   // Q_ext ext: [u | s] -> [u - 2 s x_i | s]
+    constexpr int LQ = 80 * HGS + 4;
+    const int row = 16 * it + lane;
+    if (lane < 16 && row < g.rows) {
+        lfloat* q = g.Rg + row * LQ + hh * 80 + 64;
+        const float sv = q[3];
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) q[c3] = q[c3] - 2.0f * sv * g.xs[row * 4 + c3];
+    }
+}
+template <int HGS>
+DEVI void co_fix_g(const CoGeo& g, int hh, int it, int lane) {   // G_ext ext: [r | gD] -> [r - 2 gD x_i | gD]; dE/dx_i += gD (2 x_i - 2 m1_i)
+    constexpr int LQ = 80 * HGS + 4;
+    const int row = 16 * it + lane;
+    if (lane < 16 && row < g.rows) {
+        lfloat* gp = g.Rg + 3 * g.RN * LQ + row * LQ + hh * 80 + 64;
+        const lfloat* mp = g.m12 + (hh * g.RN + row) * 4;
+        const float gD = gp[3];
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) {
+            const float xc = g.xs[row * 4 + c3];
+            g.dxw[row * 4 + c3] += gD * (2.0f * xc - 2.0f * mp[c3]);
+            gp[c3] = gp[c3] - 2.0f * gD * xc;
+        }
     }
 }
 
@@ -838,8 +912,8 @@ DEVI void co_fill_x(const CoGeo& g) {
 // the same wave (its 16 probability rows are all it needs, so no barrier):
 // o_ext = P V_ext -> R0 rows of this tile (Q_ext rows of the tile are dead after its logits);
 // extension tile: xrel_i = sum_j a_ij x_j - x_i
-template <int MT, int HGS>
-DEVI void co_softmax_pv(const CoGeo& g, gfloat* sP /* P block of head hg*HGS */) {
+template <int MT, int HGS, bool GEN>
+DEVI void co_softmax_pv(const CoGeo& g, gfloat* sP /* P block of head hg*HGS */, gfloat* sM /* m12 block of head hg*HGS (GEN) */) {
     const int tid_ = tid_now(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     constexpr int LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL, PS = 16 * MT;
     const int quad = lane >> 4, col = lane & 15;
@@ -848,6 +922,7 @@ DEVI void co_softmax_pv(const CoGeo& g, gfloat* sP /* P block of head hg*HGS */)
     for (int jt = 0; jt < MT; ++jt) gj[jt] = g.prow[16 * jt + col];
     for (int item = wave; item < HGS * MT; item += DFF_NWAVES) {
         const int hh = item / MT, it = item - hh * MT;
+        if (GEN) co_fix_q<HGS>(g, hh, it, lane);
         {
             f32x4 acc[MT];
             co_dot_rows<MT>(acc, g.Rg + hh * 80, g.Rg + g.RN * LQ + hh * 80, LQ, g.RN, it, lane);
@@ -888,22 +963,55 @@ DEVI void co_softmax_pv(const CoGeo& g, gfloat* sP /* P block of head hg*HGS */)
                 lfloat* d = g.Rg + row * LQ + hh * 80 + col;
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) d[16 * nt] = o[nt][r];
-                d[64] = o[4][r] - g.xs[row * 4 + min(col, 3)];
+                if (!GEN) d[64] = o[4][r] - g.xs[row * 4 + min(col, 3)];
+            }
+            if (GEN) {
+                // extension tile [m1 (3) | m2]: xrel = m1 - x_i ; D = |x_i|^2 - 2 x_i.m1 + m2  (columns 0..3 = one DPP quad)
+                const int rw = min(row, g.rows - 1);
+                const float x0 = g.xs[rw * 4], x1 = g.xs[rw * 4 + 1], x2 = g.xs[rw * 4 + 2];
+                const float xr = col == 0 ? x0 : col == 1 ? x1 : col == 2 ? x2 : 0.f;
+                const float e = o[4][r];
+                const float tq = col < 3 ? -2.0f * xr * e : col == 3 ? e + (x0 * x0 + x1 * x1 + x2 * x2) : 0.f;
+                const float D = quad_sum(tq);
+                if (row < g.rows) {
+                    g.Rg[row * LQ + hh * 80 + 64 + col] = col < 3 ? e - xr : col == 3 ? D : 0.f;
+                    if (col < 4) st_ntg(sM + ((size_t)hh * g.RN + row) * 4 + col, e);
+                }
             }
         }
     }
 }
 
+// GEN: extension tile of dQ_ext = dS K_ext holds [A (3) | B] = [sum_j dS x_j | sum_j dS |x_j|^2] in the columns
+// 0..3 of a row: du = A ; ds = -2 x_i.A + B ; dE/dx_i += -2 s_i A.  Returns the value to store.
+template <int HGS>
+DEVI float co_dq_ext(const CoGeo& g, int hh, int row, int col, float e) {
+    constexpr int LQ = 80 * HGS + 4;
+    const int rw = min(row, g.rows - 1);
+    const float xr = col < 3 ? g.xs[rw * 4 + col] : 0.f;
+    const float tq = col < 3 ? -2.0f * xr * e : col == 3 ? e : 0.f;
+    const float dsv = quad_sum(tq);
+    if (row < g.rows && col < 3) g.dxw[row * 4 + col] += -2.0f * g.Rg[row * LQ + hh * 80 + 67] * e;
+    return col == 3 ? dsv : e;
+}
+// GEN: extension tile of dV_ext / dK_ext holds [c (3) | w]: dE/dx_j += c + 2 x_j w
+DEVI float co_dx_ext(const CoGeo& g, int row, int col, float e) {
+    const float w = quad_bcast3(e);
+    const int rw = min(row, g.rows - 1);
+    return e + 2.0f * (col < 3 ? g.xs[rw * 4 + col] : 0.f) * w;
+}
+
 // backward: da = G_ext V_ext^T ; ds = scale a (da - sum_j a da) -> dSbuf.
 // DQ: the same wave goes on with dQ_ext = dS K_ext for its row tile -> buffer 4 (no barrier needed: it
 // only reads the dS rows it has just written).
-template <int MT, int HGS, bool DQ>
+template <int MT, int HGS, bool DQ, bool GEN>
 DEVI void co_ds(const CoGeo& g) {
     const int tid_ = tid_now(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     constexpr int LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL;
     const int quad = lane >> 4, col = lane & 15;
     for (int item = wave; item < HGS * MT; item += DFF_NWAVES) {
         const int hh = item / MT, it = item - hh * MT;
+        if (GEN) { co_fix_q<HGS>(g, hh, it, lane); co_fix_g<HGS>(g, hh, it, lane); }
         {
             f32x4 acc[MT];
             co_dot_rows<MT>(acc, g.Rg + 3 * g.RN * LQ + hh * 80, g.Rg + 2 * g.RN * LQ + hh * 80, LQ, g.RN, it, lane);
@@ -929,6 +1037,7 @@ DEVI void co_ds(const CoGeo& g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * it + 4 * quad + r;
+                if (GEN) dq[4][r] = co_dq_ext<HGS>(g, hh, row, col, dq[4][r]);
                 if (row < g.rows) {
                     lfloat* d = g.Rg + 4 * g.RN * LQ + row * LQ + hh * 80 + col;
 #pragma unroll
@@ -942,7 +1051,7 @@ DEVI void co_ds(const CoGeo& g) {
 // backward, with the fifth buffer: dV_ext = P^T G_ext (-> R2) and dK_ext = dS^T Q_ext (-> R1) in ONE phase
 // (nothing reads R1 / R2 any more); their extension tiles are dE/dx_j -> this wave's dxw.
 // EXT_ONLY (layer 0: nothing upstream of q, k, v depends on x): only those extension tiles.
-template <int MT, int HGS, bool EXT_ONLY>
+template <int MT, int HGS, bool EXT_ONLY, bool GEN>
 DEVI void co_dv_dk(const CoGeo& g) {
     const int tid_ = tid_now(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     constexpr int LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL;
@@ -956,7 +1065,16 @@ DEVI void co_dv_dk(const CoGeo& g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * mo + 4 * quad + r;
-                if (row < g.rows && col < 3) g.dxw[row * 4 + col] += acc[r];
+                const float e = GEN ? co_dx_ext(g, row, col, acc[r]) : acc[r];
+                if (row < g.rows && col < 3) g.dxw[row * 4 + col] += e;
+            }
+        }
+        if (GEN) {   // the logits' distance term reaches x_i through Q_ext as well: dE/dx_i += -2 s_i sum_j dS_ij x_j
+            for (int item = wave; item < HGS * MT; item += DFF_NWAVES) {
+                const int hh = item / MT, it = item - hh * MT;
+                const f32x4 acc = co_mm<MT, false>(g.dSbuf + hh * PT, it, g.Rg + g.RN * LQ + hh * 80 + 64, LQ, g.RN, lane);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) (void)co_dq_ext<HGS>(g, hh, 16 * it + 4 * quad + r, col, acc[r]);
             }
         }
     } else {
@@ -973,8 +1091,9 @@ DEVI void co_dv_dk(const CoGeo& g) {
                 if (row < g.rows) {
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) dst[row * LQ + 16 * nt] = acc[nt][r];
-                    if (col < 3) g.dxw[row * 4 + col] += acc[4][r];
                 }
+                const float e = GEN ? co_dx_ext(g, row, col, acc[4][r]) : acc[4][r];
+                if (row < g.rows && col < 3) g.dxw[row * 4 + col] += e;
             }
         }
     }
@@ -985,7 +1104,7 @@ DEVI void co_dv_dk(const CoGeo& g) {
 // WHICH 1: dQ_ext = dS K_ext       (reads dSbuf, R1) -> R3
 // WHICH 2: dK_ext = dS^T Q_ext     (reads dSbuf, R0) -> R1
 // the extension tiles of dV_ext / dK_ext are dE/dx_j and go to this wave's dxw instead.
-template <int MT, int HGS, int WHICH>
+template <int MT, int HGS, int WHICH, bool GEN>
 DEVI void co_dqkv(const CoGeo& g) {
     const int tid_ = tid_now(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     constexpr int LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL;
@@ -1000,11 +1119,13 @@ DEVI void co_dqkv(const CoGeo& g) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * mo + 4 * quad + r;
+            float e = acc[r];
+            if (GEN && nt == 4) e = WHICH == 1 ? co_dq_ext<HGS>(g, hh, row, col, e) : co_dx_ext(g, row, col, e);
             if (row < g.rows) {
                 if (WHICH != 1 && nt == 4) {
-                    if (col < 3) g.dxw[row * 4 + col] += acc[r];
+                    if (col < 3) g.dxw[row * 4 + col] += e;
                 } else {
-                    g.Rg[DST * g.RN * LQ + row * LQ + hh * 80 + 16 * nt + col] = acc[r];
+                    g.Rg[DST * g.RN * LQ + row * LQ + hh * 80 + 16 * nt + col] = e;
                 }
             }
         }
@@ -1091,7 +1212,7 @@ DEVI void wg_sync() {
     __syncthreads();
 }
 
-template <int H, int MT, int HGS, bool SPILL>
+template <int H, int MT, int HGS, bool SPILL, bool GEN>
 __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelDev m, const DffRunArgs a) {
     using LL = LdsLayout<H, MT, HGS, SPILL>;
     constexpr int LH = LL::LH, LQ = LL::LQ, F = LL::F, FC = LL::FC, LF = LL::LF;
@@ -1126,6 +1247,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
         lfloat* const sm = (lfloat*)smem;
         geo.Rg = sm + ll.Rg; geo.Pbuf = sm + ll.Pbuf; geo.dSbuf = sm + ll.dSbuf; geo.xs = sm + ll.xs;
         geo.dxw = sm + ll.dxw + wave_ * RN * 4;
+        geo.m12 = sm + ll.m12;
         geo.prow = (const int __attribute__((address_space(3)))*)(sm + ll.prow);
         geo.N = N; geo.RN = RN; geo.rows = rows;
     }
@@ -1202,9 +1324,11 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
         // QKV GEMM; without one, Langevin (fixed t) re-reads what step 0 left in this workgroup's own stash
         const bool tab = a.l0_tab != nullptr;
         c.l0 = tab ? a.l0_tab + (size_t)(a.mode == DFF_MODE_DDPM ? t_int : 0) * c.sl.layer_stride : c.stash;
-        const bool cached0 = tab || ((a.mode == DFF_MODE_LANGEVIN) && step > 0);
+        // absolute coordinates make layer 0 x-dependent: no caching, and the VJP runs through layer 0 and the embedding
+        const bool full0 = GEN && m.in_abs;
+        const bool cached0 = !full0 && (tab || ((a.mode == DFF_MODE_LANGEVIN) && step > 0));
         if (!cached0) {
-            node_embed<H>(c, m);
+            node_embed<H, GEN>(c, m);
             wg_sync<SPILL>();
         }
         for (int l = 0; l < m.L; ++l) {
@@ -1259,10 +1383,11 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                             }
                         });
                 }
-                co_fill_x<HGS>(geo);
+                co_fill_x<HGS, GEN>(geo);
                 wg_sync<SPILL>();
                 pf.tick(3);
-                co_softmax_pv<MT, HGS>(geo, sPl + (size_t)hg * HGS * RN * c.sl.PS);
+                co_softmax_pv<MT, HGS, GEN>(geo, sPl + (size_t)hg * HGS * RN * c.sl.PS,
+                                            (gfloat*)sb + c.sl.m12 + (size_t)hg * HGS * RN * 4);
                 wg_sync<SPILL>();
                 pf.tick(4);
                 // attn_out += o_ext [W_o ; W_oc]   (K = 80 per head)
@@ -1399,23 +1524,27 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                             }
                         });
                     co_reload_commit<MT, HGS>(rl, geo, true, tid);
+                    if (GEN) {   // [m1 | m2] rows of this head group (contiguous in the stash and in LDS)
+                        const gfloat* const sM = (const gfloat*)sb + c.sl.m12 + (size_t)hg * HGS * RN * 4;
+                        for (int i2 = tid; i2 < HGS * RN * 4; i2 += DFF_NTHREADS) geo.m12[i2] = ld_ntg(sM + i2);
+                    }
                 }
-                co_fill_x<HGS>(geo);
+                co_fill_x<HGS, GEN>(geo);
                 wg_sync<SPILL>();
                 pf.tick(16);
                 constexpr bool FIVE = LL::NREG == 5;
-                if (l > 0) {
-                    co_ds<MT, HGS, FIVE>(geo);
+                if (l > 0 || full0) {
+                    co_ds<MT, HGS, FIVE, GEN>(geo);
                     wg_sync<SPILL>();
                     pf.tick(17);
                     if (FIVE) {
-                        co_dv_dk<MT, HGS, false>(geo);
+                        co_dv_dk<MT, HGS, false, GEN>(geo);
                     } else {
-                        co_dqkv<MT, HGS, 0>(geo);
+                        co_dqkv<MT, HGS, 0, GEN>(geo);
                         wg_sync<SPILL>();
-                        co_dqkv<MT, HGS, 1>(geo);
+                        co_dqkv<MT, HGS, 1, GEN>(geo);
                         wg_sync<SPILL>();
-                        co_dqkv<MT, HGS, 2>(geo);
+                        co_dqkv<MT, HGS, 2, GEN>(geo);
                     }
                     wg_sync<SPILL>();
                     pf.tick(18);
@@ -1430,15 +1559,15 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         },
                         geo.Rg, LQ, RN, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
                 } else {
-                    co_ds<MT, HGS, false>(geo);
+                    co_ds<MT, HGS, false, GEN>(geo);
                     wg_sync<SPILL>();
                     pf.tick(17);
-                    co_dv_dk<MT, HGS, true>(geo);
+                    co_dv_dk<MT, HGS, true, GEN>(geo);
                 }
                 wg_sync<SPILL>();
                 pf.tick(19);
             }
-            if (l > 0) {
+            if (l > 0 || full0) {
                 store_tall<MT, NTW>(acc_a, tbuf, LH, rows, NT_H, nullptr);
                 wg_sync<SPILL>();
                 rowb_ln1<H>(c, lw, l, tbuf);
@@ -1454,6 +1583,10 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             c.dxs[tid] = sdx;
         }
         wg_sync<SPILL>();
+        if (full0 && m.conservative) {
+            node_embed_bwd<H>(c, m);
+            wg_sync<SPILL>();
+        }
 
         // =============================== update ===============================
         // dxs = d(sum E)/dx ; the score op returns -dxs (graph_transformer.py:159)
@@ -1584,7 +1717,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_debug_gemm_kernel(const floa
 
 // explicit instantiations used by the host dispatcher
 #define DFF_INST(H, MT, HGS, SPILL) \
-    template __global__ void dff_fused_kernel<H, MT, HGS, SPILL>(const DffModelDev, const DffRunArgs);
+    template __global__ void dff_fused_kernel<H, MT, HGS, SPILL, false>(const DffModelDev, const DffRunArgs); \
+    template __global__ void dff_fused_kernel<H, MT, HGS, SPILL, true>(const DffModelDev, const DffRunArgs);
 DFF_INST(64, 1, 4, false)
 DFF_INST(64, 2, 2, false)
 DFF_INST(96, 1, 4, false)

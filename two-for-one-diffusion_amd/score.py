@@ -31,7 +31,8 @@ class GraphTransformer:
         if dev.type != "cuda":
             raise binding.DffLibraryError("the HIP score network needs a GPU device ('cuda[:i]'); there is no CPU path")
         self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
-        flat = weights.flatten_gnn_params(state_dict, num_beads, hidden_nf, n_layers, conservative)
+        flat = weights.flatten_gnn_params(state_dict, num_beads, hidden_nf, n_layers, conservative,
+                                          use_intrinsic_coords, use_distances, use_abs_coords)
         self.native = binding.Model(num_beads, hidden_nf, n_layers, flat, timesteps=timesteps,
                                     device=self.device.index, use_intrinsic_coords=use_intrinsic_coords,
                                     use_distances=use_distances, use_abs_coords=use_abs_coords,

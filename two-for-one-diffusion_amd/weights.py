@@ -30,10 +30,14 @@ def abi_key_order(n_layers: int) -> List[str]:
     return keys
 
 
-def expected_shapes(n_beads: int, hidden: int, n_layers: int, conservative: bool = True) -> Dict[str, Tuple[int, ...]]:
+def expected_shapes(n_beads: int, hidden: int, n_layers: int, conservative: bool = True,
+                    use_intrinsic_coords: bool = True, use_distances: bool = False,
+                    use_abs_coords: bool = False) -> Dict[str, Tuple[int, ...]]:
     H, N, I, F = hidden, n_beads, INNER, 4 * hidden
     D = 1 if conservative else 3     # node_decoder: energy head or force head (graph_transformer.py:62-65)
-    s = {"node_embedding.weight": (H, N + 1), "node_embedding.bias": (H,), "edge_embedding.weight": (H, 3),
+    NI = N + 1 + 3 * bool(use_abs_coords)                                       # :53
+    NE = 3 * bool(use_intrinsic_coords) + bool(use_distances) or 1              # :54-58
+    s = {"node_embedding.weight": (H, NI), "node_embedding.bias": (H,), "edge_embedding.weight": (H, NE),
          "edge_embedding.bias": (H,), "node_decoder.weight": (D, H), "node_decoder.bias": (D,)}
     for l in range(n_layers):
         p = f"graphtransformer.layers.{l}."
@@ -55,9 +59,11 @@ def _np(v) -> np.ndarray:
 
 
 def flatten_gnn_params(params: Mapping[str, object], n_beads: int, hidden: int, n_layers: int,
-                       conservative: bool = True) -> np.ndarray:
+                       conservative: bool = True, use_intrinsic_coords: bool = True, use_distances: bool = False,
+                       use_abs_coords: bool = False) -> np.ndarray:
     """GraphTransformer state-dict (keys without prefix) -> flat float32 array, shape-checked."""
-    shapes = expected_shapes(n_beads, hidden, n_layers, conservative)
+    shapes = expected_shapes(n_beads, hidden, n_layers, conservative, use_intrinsic_coords, use_distances,
+                             use_abs_coords)
     chunks = []
     for k in abi_key_order(n_layers):
         if k not in params:
