@@ -275,27 +275,10 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
             for (int r = 0; r < I; ++r) s += (double)Wo[(size_t)c * I + r] * bc[r];
             bof[c] = s;
         }
-        // head-major q|k|v column order: col = h*192 + part*64 + d
-        auto wqkv = [&](int col, int c) -> double {
-            const int h = col / 192, part = (col % 192) / 64, dd = col % 64;
-            const int r = h * 64 + dd;
-            return part == 0 ? Wq[(size_t)r * H + c] : part == 1 ? Wkv[(size_t)r * H + c] : Wkv[(size_t)(I + r) * H + c];
-        };
-        std::vector<float> bqkv(3 * I), bu32(32, 0.f), bo32(H);
-        for (int col = 0; col < 3 * I; ++col) {
-            const int h = col / 192, part = (col % 192) / 64, dd = col % 64, r = h * 64 + dd;
-            bqkv[col] = part == 0 ? bq[r] : part == 1 ? bkv[r] : bkv[I + r];
-        }
-        for (int i = 0; i < 24; ++i) bu32[i] = (float)bu[i];
+        std::vector<float> bo32(H);
         for (int c = 0; c < H; ++c) bo32[c] = (float)bof[c];
 
         UP(std::vector<float>(ln1g, ln1g + H), d.ln1_g); UP(std::vector<float>(ln1b, ln1b + H), d.ln1_b);
-        UP(pack_b(H, 3 * I, [&](int k, int n) { return wqkv(n, k); }), d.Wqkv_p);
-        UP(bqkv, d.bqkv);
-        UP(pack_b(H, 32, [&](int k, int n) { return n < 24 ? Wu[(size_t)n * H + k] : 0.0; }), d.Wu_p);
-        UP(bu32, d.bu);
-        UP(pack_b(I, H, [&](int k, int n) { return (double)Wo[(size_t)n * I + k]; }), d.Wo_p);
-        UP(pack_b(32, H, [&](int k, int n) { return k < 24 ? Woc[(size_t)n * 24 + k] : 0.0; }), d.Woc_p);
         UP(bo32, d.bo);
         UP(std::vector<float>(g1, g1 + 3 * H), d.g1);
         UP(std::vector<float>(ln2g, ln2g + H), d.ln2_g); UP(std::vector<float>(ln2b, ln2b + H), d.ln2_b);
@@ -307,10 +290,6 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
         // transposed orientation for the VJP
         UP(pack_b(H, F, [&](int k, int n) { return (double)W2[(size_t)k * F + n]; }), d.W2T_p);
         UP(pack_b(F, H, [&](int k, int n) { return (double)W1[(size_t)k * H + n]; }), d.W1T_p);
-        UP(pack_b(H, I, [&](int k, int n) { return (double)Wo[(size_t)k * I + n]; }), d.WoT_p);
-        UP(pack_b(H, 32, [&](int k, int n) { return n < 24 ? Woc[(size_t)k * 24 + n] : 0.0; }), d.WocT_p);
-        UP(pack_b(3 * I, H, [&](int k, int n) { return wqkv(k, n); }), d.WqkvT_p);
-        UP(pack_b(32, H, [&](int k, int n) { return k < 24 ? Wu[(size_t)k * H + n] : 0.0; }), d.WuT_p);
         // extended-head images: column e of head h: [0,64) q, [64,67) u, [67,80) 0, [80,144) k, [144,208) v
         auto wqkvx = [&](int col, int c) -> double {
             const int h = col / 208, e = col % 208;

@@ -25,10 +25,6 @@
 struct DffLayerDev {
     // forward
     const float *ln1_g, *ln1_b;
-    const float *Wqkv_p, *bqkv;   // K=H, Nout=1536 head-major columns [h][q|k|v][d]
-    const float *Wu_p, *bu;       // K=H, Nout=32 (24 used: [h][c])
-    const float *Wo_p;            // K=512, Nout=H
-    const float *Woc_p;           // K=32 (24 used), Nout=H
     const float *bo;              // folded: bo + Wo b_c
     const float *g1;              // (3H) gate weights [x | res | x-res]
     const float *ln2_g, *ln2_b;
@@ -38,13 +34,9 @@ struct DffLayerDev {
     // backward (transposed orientation)
     const float *W2T_p;           // K=H, Nout=4H   dh  = dff  W2
     const float *W1T_p;           // K=4H, Nout=H   df  = dhp  W1
-    const float *WoT_p;           // K=H, Nout=512  G   = dattn Wo
-    const float *WocT_p;          // K=H, Nout=32   r   = dattn Woc
-    const float *WqkvT_p;         // K=1536 (head-major), Nout=H
-    const float *WuT_p;           // K=32, Nout=H
-    // "extended head" images of the rows<=16 fast path (dff_small.hip): per head 80 = 64 + 16
-    const float *Wqkvx_p, *bqkvx; // K=H, Nout=8*208, per head [q 64 | u 16 | k 64 | v 64]
-    const float *Wox_p;           // K=8*80 per head [o 64 | xrel 16], Nout=H
+    // "extended head" images: per head 80 = 64 + 16 extension columns / rows ([u (3) | s | 0...], [xrel (3) | D | 0...])
+    const float *Wqkvx_p, *bqkvx; // K=H, Nout=8*208, per head [q 64 | ext 16 | k 64 | v 64]
+    const float *Wox_p;           // K=8*80 per head [o 64 | ext 16], Nout=H
     const float *WoxT_p;          // K=H, Nout=8*80
     const float *WqkvxT_p;        // K=8*208, Nout=H
 };
