@@ -783,32 +783,38 @@ extern "C" int dff_pwd_hist(int device, const float* x, long long n, int N, int 
     if (rc) return rc;
     if (!nbins || !hmax || !hist) return fail(DFF_EINVAL, "pwd: null argument");
     if (max_bins < 1 || ld < max_bins) return fail(DFF_EINVAL, "pwd: need 1 <= max_bins <= ld");
-    // LDS: one tile of structures + the privatised histograms
-    const int tile_bytes = DFF_PWD_TILE * 3 * N * (int)sizeof(float);
-    int slots = (160 * 1024 - 64 - tile_bytes) / (int)sizeof(unsigned);
-    if (slots > DFF_PWD_LDS_BINS) slots = DFF_PWD_LDS_BINS;
-    if ((max_bins | 1) > slots) return fail(DFF_EINVAL, "pwd: more than %d bins per pair", slots - 1);
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(hipMemsetAsync(hist, 0, (size_t)npairs * ld * sizeof(uint32_t), stream));
     if (n == 0) return DFF_OK;
+    // LDS: one tile of structures + the privatised histograms.  The tile shrinks (64 -> 32 -> 16 structures) when
+    // that lets twice as many pairs keep their histograms in LDS (fewer passes over the structures).
     const int ldl = max_bins | 1;   // odd leading dimension: pairs land in different LDS banks
-    int pc_log2 = 8;                // pair lanes per workgroup: the largest power of two whose histograms fit
-    while (pc_log2 > 0 && ((1 << pc_log2) * ldl > slots || (1 << (pc_log2 - 1)) >= npairs)) --pc_log2;
+    int tile_n = DFF_PWD_TILE, pc_log2 = -1, tile_bytes = 0;
+    for (int tn = DFF_PWD_TILE; tn >= 16; tn >>= 1) {
+        const int tb = tn * 3 * N * (int)sizeof(float);
+        int slots = (160 * 1024 - 64 - tb) / (int)sizeof(unsigned);
+        if (slots > DFF_PWD_LDS_BINS) slots = DFF_PWD_LDS_BINS;
+        if (ldl > slots) continue;
+        int lg = 8;                 // pair lanes per workgroup: the largest power of two whose histograms fit
+        while (lg > 0 && ((1 << lg) * ldl > slots || (1 << (lg - 1)) >= npairs)) --lg;
+        if (lg > pc_log2) { pc_log2 = lg; tile_n = tn; tile_bytes = tb; }
+    }
+    if (pc_log2 < 0) return fail(DFF_EINVAL, "pwd: %d bins per pair do not fit in LDS", max_bins);
     const int PC = 1 << pc_log2;
     const int npc = (npairs + PC - 1) / PC;
     // each workgroup flushes up to PC * ldl bins: give it at least ~2x that many (pair, structure) items
-    const long long min_chunk = (2LL * ldl + DFF_PWD_TILE - 1) / DFF_PWD_TILE * DFF_PWD_TILE;
+    const long long min_chunk = (2LL * ldl + DFF_PWD_TILE - 1) / DFF_PWD_TILE * DFF_PWD_TILE;   // multiple of every tile size
     const long long chunk = pwd_chunk(n, (2048 + npc - 1) / npc, min_chunk);
     long long nsc = (n + chunk - 1) / chunk;
     nsc = (nsc + 7) / 8 * 8;       // whole XCD rounds (empty chunks return at once)
     const long long grid = nsc * npc;
     if (grid > 0x7fffffffLL) return fail(DFF_EINVAL, "pwd: grid too large");
-    const unsigned lds = (unsigned)(DFF_PWD_TILE * 3 * N * sizeof(float) + (size_t)PC * ldl * sizeof(unsigned) + 16);
+    const unsigned lds = (unsigned)(tile_bytes + (size_t)PC * ldl * sizeof(unsigned) + 16);
     if (lds > 160 * 1024) return fail(DFF_EINVAL, "pwd: LDS budget exceeded (%u bytes)", lds);
     HIPCHK(hipFuncSetAttribute((const void*)&dff_pwd_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int vec4 = ((uintptr_t)x % 16) == 0;
     hipLaunchKernelGGL(dff_pwd_hist_kernel, dim3((unsigned)grid), dim3(DFF_PWD_HIST_THREADS), lds, stream, x, n, N, offset,
-                       npairs, nbins, hmax, ld, pc_log2, npc, chunk, ldl, hist, vec4);
+                       npairs, nbins, hmax, ld, pc_log2, npc, chunk, ldl, hist, vec4, tile_n);
     HIPCHK(hipGetLastError());
     return DFF_OK;
 }

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(DFF_PWD_HIST_THREADS) void dff_pwd_hist_kernel(cons
                                                                         const int* __restrict__ nbins,
                                                                         const float* __restrict__ hmax, int ld,
                                                                         int pc_log2, int npc, long long chunk, int ldl,
-                                                                        unsigned* hist, int vec4) {
+                                                                        unsigned* hist, int vec4, int tile_n) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int N3 = 3 * N;
     // XCD-aware placement: the npc workgroups of one structure chunk sit on one XCD, back to back
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(DFF_PWD_HIST_THREADS) void dff_pwd_hist_kernel(cons
     const int p0 = pchunk << pc_log2;
     const int pc = npairs - p0 < PC ? npairs - p0 : PC;
     float* tile = smem;
-    unsigned* hl = (unsigned*)(smem + DFF_PWD_TILE * N3);    // PC * ldl
+    unsigned* hl = (unsigned*)(smem + tile_n * N3);          // PC * ldl  (tile_n structures per LDS tile: 64, 32 or 16)
     for (int k = threadIdx.x; k < pc * ldl; k += DFF_PWD_HIST_THREADS) hl[k] = 0u;
     const bool live = lane_p < pc;
     int i = 0, j = 0, b = 1;
@@ -155,8 +155,8 @@ __global__ __launch_bounds__(DFF_PWD_HIST_THREADS) void dff_pwd_hist_kernel(cons
     unsigned* row = hl + lane_p * ldl;
     const long long s_begin = schunk * chunk;
     const long long s_end = s_begin + chunk < n ? s_begin + chunk : n;
-    for (long long s0 = s_begin; s0 < s_end; s0 += DFF_PWD_TILE) {
-        const int cnt = (int)(s_end - s0 < DFF_PWD_TILE ? s_end - s0 : DFF_PWD_TILE);
+    for (long long s0 = s_begin; s0 < s_end; s0 += tile_n) {
+        const int cnt = (int)(s_end - s0 < tile_n ? s_end - s0 : tile_n);
         __syncthreads();
         pwd_load_tile<DFF_PWD_HIST_THREADS>(tile, x, s0, cnt, N3, vec4 != 0);
         __syncthreads();
