@@ -59,14 +59,21 @@ def test_hip_forces_vs_reference(cfg, flags, golden):
     model = GraphTransformer(N, H, device="cuda:0", n_layers=L, use_intrinsic_coords=bool(intr), use_abs_coords=bool(ab),
                              use_distances=bool(dist), conservative=True, state_dict=p)
     x, t = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["t"]).cuda()
-    f = model(x, None, t).cpu().numpy()
-    e = model(x, None, t, return_energy=True).cpu().numpy()
-    r64 = rel(f, g["forces64"])
-    a32 = np.abs(f - g["forces32"]).max() / np.abs(g["forces32"]).max()
-    print(f"{cfg} intr={intr} dist={dist} abs={ab} {model.native.last_launch()[0]}: rel64 {r64:.2e} abs32 {a32:.2e}")
-    assert "gen" in model.native.last_launch()[0]
-    np.testing.assert_allclose(e, g["energy32"], rtol=0, atol=2e-5 * max(1.0, np.abs(g["energy32"]).max()))
-    assert r64 <= 2e-5 and a32 <= 1e-4
+    variants = [("default", lambda: None)]
+    if N <= 16:   # the rows<=16 fast path (8- and 4-wave) and the generic kernel
+        variants += [("4 waves", lambda: model.native.small_waves(4)), ("generic", lambda: model.native.force_generic(True))]
+    for name, setup in variants:
+        model.native.small_waves(0); model.native.force_generic(False)
+        setup()
+        f = model(x, None, t).cpu().numpy()
+        e = model(x, None, t, return_energy=True).cpu().numpy()
+        r64 = rel(f, g["forces64"])
+        a32 = np.abs(f - g["forces32"]).max() / np.abs(g["forces32"]).max()
+        print(f"{cfg} intr={intr} dist={dist} abs={ab} [{name}] {model.native.last_launch()[0]}: rel64 {r64:.2e} abs32 {a32:.2e}")
+        assert "gen" in model.native.last_launch()[0]
+        np.testing.assert_allclose(e, g["energy32"], rtol=0, atol=2e-5 * max(1.0, np.abs(g["energy32"]).max()))
+        assert r64 <= 2e-5 and a32 <= 1e-4
+    model.native.small_waves(0); model.native.force_generic(False)
 
 
 @pytest.mark.gpu

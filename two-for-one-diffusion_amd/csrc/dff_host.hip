@@ -396,11 +396,20 @@ static int launch_small(dff_model* m, DffRunArgs& a, int G, hipStream_t stream) 
     const void* fn; unsigned lds; const char* name; int nthreads = 256;
     // 8 waves (two per SIMD, one head per wave) when the rows fit its 11-row head buffers
     const bool eight = (H == 64 || H == 96) && G * N <= 10 && m->small_waves != 4;
-    if (eight && H == 64) { fn = (const void*)&dff_small_kernel<64, 8>; lds = SmallLds<64, 8>::total; name = "dff_small_kernel<64,8>"; nthreads = 512; }
-    else if (eight)       { fn = (const void*)&dff_small_kernel<96, 8>; lds = SmallLds<96, 8>::total; name = "dff_small_kernel<96,8>"; nthreads = 512; }
-    else if (H == 64) { fn = (const void*)&dff_small_kernel<64, 4>;  lds = SmallLds<64, 4>::total;  name = "dff_small_kernel<64,4>"; }
-    else if (H == 96) { fn = (const void*)&dff_small_kernel<96, 4>;  lds = SmallLds<96, 4>::total;  name = "dff_small_kernel<96,4>"; }
-    else              { fn = (const void*)&dff_small_kernel<128, 4>; lds = SmallLds<128, 4>::total; name = "dff_small_kernel<128,4>"; }
+    const bool gen = !(m->cfg.use_intrinsic_coords == 1 && m->cfg.use_distances == 0 && m->cfg.use_abs_coords == 0);
+#define SMALL_PICK(H_, NW_)                                                                                         \
+    do {                                                                                                            \
+        fn = gen ? (const void*)&dff_small_kernel<H_, NW_, true> : (const void*)&dff_small_kernel<H_, NW_, false>;  \
+        lds = SmallLds<H_, NW_>::total;                                                                             \
+        name = gen ? "dff_small_kernel<" #H_ "," #NW_ ",gen>" : "dff_small_kernel<" #H_ "," #NW_ ">";               \
+        nthreads = NW_ * 64;                                                                                        \
+    } while (0)
+    if (eight && H == 64) SMALL_PICK(64, 8);
+    else if (eight)       SMALL_PICK(96, 8);
+    else if (H == 64)     SMALL_PICK(64, 4);
+    else if (H == 96)     SMALL_PICK(96, 4);
+    else                  SMALL_PICK(128, 4);
+#undef SMALL_PICK
     lds *= (unsigned)sizeof(float);
     if (lds > 160 * 1024) return fail(DFF_EINVAL, "LDS budget exceeded (%u bytes)", lds);
     const int grid_all = (a.B + G - 1) / G;
@@ -538,7 +547,7 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
     const bool gen = !(m->cfg.use_intrinsic_coords == 1 && m->cfg.use_distances == 0 && m->cfg.use_abs_coords == 0);
     const bool want_tab = a.mode != DFF_MODE_SCORE && !m->l0_off && !m->cfg.use_abs_coords;
     a.l0_tab = nullptr;
-    if (G * N <= 16 && !m->force_generic && !gen) {
+    if (G * N <= 16 && !m->force_generic) {
         if (want_tab) {
             int rc = ensure_l0_table(m, a.mode == DFF_MODE_DDPM ? 2 : 1, a.t_norm, G, nullptr, stream);
             if (rc) return rc;

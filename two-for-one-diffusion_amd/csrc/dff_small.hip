@@ -29,7 +29,7 @@
 #define DFF_PLD 20      // leading dim of the per-wave P / dS tiles
 
 struct SmallStash {
-    unsigned nodes_in, attn_out, ff, h_pre, qkv, P;
+    unsigned nodes_in, attn_out, ff, h_pre, qkv, P, m12;
     unsigned layer_stride, total;
 };
 __host__ __device__ inline SmallStash dff_small_stash(int N, int G, int H, int L) {
@@ -45,6 +45,7 @@ __host__ __device__ inline SmallStash dff_small_stash(int N, int G, int H, int L
     s.h_pre = o;    o += R * F;
     s.qkv = o;      o += DFF_HEADS * R * DFF_QKVW;
     s.P = o;        o += DFF_HEADS * 16 * 16;
+    s.m12 = o;      o += DFF_HEADS * 16 * 4;   // GEN: [sum_j a x_j (3) | sum_j a |x_j|^2] per head and row
     s.layer_stride = o;
     s.total = (o * (unsigned)L + 63u) & ~63u;
     return s;
@@ -273,8 +274,11 @@ DEVI void wv_mm(const lfloat* T, const lfloat* B, int lane, Epi epi) {
 // rows beyond the real ones come from the dummy stash row: finite, and P's are exact zeros)
 struct HeadRegs {
     f32x4 q[5], k[4], v[4], p;
+    float m;   // GEN: element (row = lane >> 2, c = lane & 3) of the head's [m1 | m2] rows
 };
-DEVI void head_fetch(HeadRegs& r, const gfloat* sqkv, const gfloat* sp, int RA, bool need_qk, int lane) {
+DEVI void head_fetch(HeadRegs& r, const gfloat* sqkv, const gfloat* sp, int RA, bool need_qk, int lane,
+                     const gfloat* sm12 = nullptr) {
+    if (sm12) r.m = ld_ntg(sm12 + lane);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int it = lane + 64 * u, row = min(it >> 4, RA), c4 = it & 15;
@@ -311,7 +315,7 @@ DEVI void head_commit(const HeadRegs& r, lfloat* Qx, lfloat* Kx, lfloat* Vx, lfl
 }
 
 // ---------------------------------------------------------------- the kernel
-template <int H, int NW>
+template <int H, int NW, bool GEN>
 __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m, const DffRunArgs a) {
     using LL = SmallLds<H, NW>;
     constexpr int LH = LL::LH, F = 4 * H, E = H / 16;
@@ -487,12 +491,52 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int idx = lane + 64 * e, row = idx >> 4, cc = idx & 15;
-            const float xv = (cc < 3 && row < rows) ? xs[row * 4 + cc] : 0.f;
+            float xv = (cc < 3 && row < rows) ? xs[row * 4 + cc] : 0.f;
+            if constexpr (GEN) {
+                if (cc == 3 && row < rows) {
+                    const float x0 = xs[row * 4], x1 = xs[row * 4 + 1], x2 = xs[row * 4 + 2];
+                    xv = x0 * x0 + x1 * x1 + x2 * x2;
+                }
+            }
             if (row < RLA) {
                 Kx[row * DFF_XLD + 64 + cc] = xv;
                 Vx[row * DFF_XLD + 64 + cc] = xv;
             }
         }
+    };
+    // ---- GEN variants (other input branches, see dff_kernels.hip / oracle/kernel_model_gen.py): extension columns
+    //   Q_ext [u - 2 s x_i | s]   K_ext, V_ext [x_j | |x_j|^2]   o_ext [xrel | D]   G_ext [r - 2 gD x_i | gD]
+    // the GEMMs give the x-independent parts; the fix-ups run on this wave's own 16-row buffers, lane = (row, c).
+    auto fix_q = [&](int lane) {
+        const int row = lane >> 2, c3 = lane & 3;
+        if (row < rows && c3 < 3) {
+            lfloat* q = Qx + row * DFF_XLD + 64;
+            q[c3] = q[c3] - 2.0f * q[3] * xs[row * 4 + c3];
+        }
+    };
+    auto fix_g = [&](int lane, float mv) {   // mv = [m1 | m2] element of this lane; dE/dx_i += gD (2 x_i - 2 m1_i)
+        const int row = lane >> 2, c3 = lane & 3;
+        if (row < rows && c3 < 3) {
+            lfloat* gp = Gx + row * DFF_XLD + 64;
+            const float gD = gp[3], xc = xs[row * 4 + c3];
+            dxw[row * 4 + c3] += gD * (2.0f * xc - 2.0f * mv);
+            gp[c3] = gp[c3] - 2.0f * gD * xc;
+        }
+    };
+    // extension tile of dQ_ext = dS K_ext: [A | B] -> du = A, ds = -2 x_i.A + B (column 3), dE/dx_i += -2 s_i A
+    auto dq_ext = [&](int row, int col, float e) {
+        const int rw = min(row, rows - 1);
+        const float xr = col < 3 ? xs[rw * 4 + col] : 0.f;
+        const float tq = col < 3 ? -2.0f * xr * e : col == 3 ? e : 0.f;
+        const float dsv = quad_sum(tq);
+        if (row < rows && col < 3) dxw[row * 4 + col] += -2.0f * Qx[row * DFF_XLD + 67] * e;
+        return col == 3 ? dsv : e;
+    };
+    // extension tile of dV_ext / dK_ext: [c | w] -> dE/dx_j += c + 2 x_j w
+    auto dx_ext = [&](int row, int col, float e) {
+        const float w = quad_bcast3(e);
+        const int rw = min(row, rows - 1);
+        return e + 2.0f * (col < 3 ? xs[rw * 4 + col] : 0.f) * w;
     };
 
     for (int step = 0; step < a.n_steps; ++step) {
@@ -508,7 +552,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         const bool tab = a.l0_tab != nullptr;
         const gfloat* const l0e = tab ? (const gfloat*)a.l0_tab + (size_t)(a.mode == DFF_MODE_DDPM ? t_int : 0) * sl.layer_stride
                                       : (const gfloat*)stash;
-        const bool cached0 = tab || ((a.mode == DFF_MODE_LANGEVIN) && step > 0);
+        const bool full0 = GEN && m.in_abs;   // absolute coordinates: layer 0 depends on x (no caching, VJP through layer 0)
+        const bool cached0 = !full0 && (tab || ((a.mode == DFF_MODE_LANGEVIN) && step > 0));
         // first weights of the first block (hidden behind the centring below)
         { const int lane = lane_id();
         if (cached0) {
@@ -540,7 +585,12 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             for (int idx = tid; idx < rows * H; idx += NTHR) {
                 const int row = idx / H, cl = idx - row * H;
                 const int g = row / N, i = row - g * N;
-                resbuf[row * LH + cl] = m.WnT[i * H + cl] + tn[g] * m.WnT[N * H + cl] + m.bn[cl];
+                float nv = m.WnT[i * H + cl] + tn[g] * m.WnT[(GEN ? m.wn_t : N) * H + cl] + m.bn[cl];
+                if constexpr (GEN) {
+                    if (m.in_abs) nv += xs[row * 4] * m.WnT[N * H + cl] + xs[row * 4 + 1] * m.WnT[(N + 1) * H + cl] +
+                                        xs[row * 4 + 2] * m.WnT[(N + 2) * H + cl];
+                }
+                resbuf[row * LH + cl] = nv;
             }
             __syncthreads();
         }
@@ -585,6 +635,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 const WStream after = s_w1(lw);   // the FFN block follows
                 auto head_math = [&](int h) {
                     write_xext(lane);
+                    if constexpr (GEN) fix_q(lane);
                     const f32x4 S = wv_dot_rows(Qx, Kx, lane);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -603,7 +654,19 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             float v = acc[r];
-                            if (nt == 4) v -= (col < 3) ? xs[(quad * 4 + r) * 4 + col] : 0.f;
+                            if constexpr (GEN) {
+                                if (nt == 4) {   // [m1 | m2] -> xrel = m1 - x_i ; D = |x_i|^2 - 2 x_i.m1 + m2 ; stash [m1 | m2]
+                                    const int row = quad * 4 + r;
+                                    const float x0 = xs[row * 4], x1 = xs[row * 4 + 1], x2 = xs[row * 4 + 2];
+                                    const float xr = col == 0 ? x0 : col == 1 ? x1 : col == 2 ? x2 : 0.f;
+                                    const float tq = col < 3 ? -2.0f * xr * v : col == 3 ? v + (x0 * x0 + x1 * x1 + x2 * x2) : 0.f;
+                                    const float D = quad_sum(tq);
+                                    if (col < 4) st_ntg(sb + sl.m12 + (h * 16 + row) * 4 + col, v);
+                                    v = col < 3 ? v - xr : col == 3 ? D : 0.f;
+                                }
+                            } else {
+                                if (nt == 4) v -= (col < 3) ? xs[(quad * 4 + r) * 4 + col] : 0.f;
+                            }
                             Qx[lro[r] + 16 * nt + col] = v;
                         }
                     });
@@ -924,7 +987,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             // first head of this layer's attention backward: start the stash read (hidden by row stage E)
             if constexpr (HPW == 2) {
                 const int lane = lane_id();
-                head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, l > 0, lane);
+                head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, l > 0 || full0, lane,
+                           GEN ? sb + sl.m12 + wave * 64 : nullptr);
             }
             // ---- row stage E: df = sum_w part ; LN2 backward ; gate1 backward -> dattn (abuf), dn_in partial (resbuf) ----
             // operands: ro[0] attn_out, ro[1] nodes_in, ro[2] ln2 gamma, ro[3..5] g1
@@ -963,7 +1027,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     resbuf[rrow * LH + cl] = d1[i] * (1.0f - g1) + dz * (ro[4][i] - ro[5][i]);
                 }
                 // stage F operands: nodes_in stays in ro[1]; LN1 gamma -> ro[2]
-                if (l > 0) ro_load(2, lw.ln1_g, sub);
+                if (l > 0 || full0) ro_load(2, lw.ln1_g, sub);
             } }
             __syncthreads();
             pf.tick(8);
@@ -1019,38 +1083,61 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             Vx[lro[r] + 16 * nt + col] = acc[r];
-                            if (nt == 4) dxw[dxi[r]] += acc[r];
+                            if (nt == 4) dxw[dxi[r]] += GEN ? dx_ext(quad * 4 + r, col, acc[r]) : acc[r];
                         }
                     });
-                    // dQ_ext = dS K_ext -> G region (ext columns: du)
-                    wv_mm<0, 5, false>(dsb, Kx, lane, [&](int nt, const f32x4& acc) { c_store_all(Gx, DFF_XLD, 16 * nt, acc, lane, RLA - 1); });
+                    // dQ_ext = dS K_ext -> G region (ext columns: du, and ds in the GEN variants)
+                    wv_mm<0, 5, false>(dsb, Kx, lane, [&](int nt, const f32x4& acc) {
+                        f32x4 v = acc;
+                        if constexpr (GEN) {
+                            if (nt == 4) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] = dq_ext(quad * 4 + r, col, acc[r]);
+                            }
+                        }
+                        c_store_all(Gx, DFF_XLD, 16 * nt, v, lane, RLA - 1);
+                    });
                     // dK_ext = dS^T Q_ext -> K region (ext columns: dx term sum_i dS_ij u_i)
                     wv_mm<0, 5, true>(dsb, Qx, lane, [&](int nt, const f32x4& acc) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             Kx[lro[r] + 16 * nt + col] = acc[r];
-                            if (nt == 4) dxw[dxi[r]] += acc[r];
+                            if (nt == 4) dxw[dxi[r]] += GEN ? dx_ext(quad * 4 + r, col, acc[r]) : acc[r];
                         }
                     });
                 };
                 auto dx_only = [&]() {   // layer 0: node inputs do not depend on x
                     wv_mm<4, 5, true>(pb, Gx, lane, [&](int, const f32x4& acc) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) dxw[dxi[r]] += acc[r];
+                        for (int r = 0; r < 4; ++r) dxw[dxi[r]] += GEN ? dx_ext(quad * 4 + r, col, acc[r]) : acc[r];
                     });
                     wv_mm<4, 5, true>(dsb, Qx, lane, [&](int, const f32x4& acc) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) dxw[dxi[r]] += acc[r];
+                        for (int r = 0; r < 4; ++r) dxw[dxi[r]] += GEN ? dx_ext(quad * 4 + r, col, acc[r]) : acc[r];
                     });
+                    if constexpr (GEN) {   // the distance term of the logits reaches x_i through Q_ext: -2 s_i sum_j dS_ij x_j
+                        wv_mm<4, 5, false>(dsb, Kx, lane, [&](int, const f32x4& acc) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) (void)dq_ext(quad * 4 + r, col, acc[r]);
+                        });
+                    }
                 };
                 const int h1 = wave + 4;
                 (void)h1;
-                if (l > 0) {
+                // GEN: [m1 | m2] of the head whose buffers are live (hr.m is overwritten by the next head's prefetch),
+                // and the x_i fix-ups of Q_ext (after every commit that brings q_ext) and G_ext (after every gext)
+                float m_cur = 0.f;
+                auto m12p = [&](int h) -> const gfloat* { return GEN ? sb + sl.m12 + h * 64 : nullptr; };
+                auto committed = [&]() { if constexpr (GEN) { m_cur = hr.m; fix_q(lane); } };
+                auto gfix = [&]() { if constexpr (GEN) fix_g(lane, m_cur); };
+                if (l > 0 || full0) {
                     if constexpr (HPW == 2) {
                         head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
-                        head_fetch(hr, sbq + sl.qkv + (size_t)h1 * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)h1 * 256, RA, true, lane);
+                        committed();
+                        head_fetch(hr, sbq + sl.qkv + (size_t)h1 * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)h1 * 256, RA, true, lane, m12p(h1));
                         pf.tick(8);
                         gext(std::integral_constant<int, 0>{}, wave, s_qkvt(lw, wave));
+                        gfix();
                         pf.tick(15);
                         ds_math();
                         pf.tick(16);
@@ -1059,7 +1146,9 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         tall_run<1, 13, E>(ring, acc_a, qkvt_fa, s_qkvt(lw, wave), s_woxt(lw, h1), lane);
                         pf.tick(18);
                         head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
+                        committed();
                         gext(std::integral_constant<int, 2>{}, h1, s_qkvt(lw, h1));
+                        gfix();
                         pf.tick(15);
                         ds_math();
                         pf.tick(16);
@@ -1068,10 +1157,12 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         tall_run<3, 13, E>(ring, acc_a, qkvt_fa, s_qkvt(lw, h1), after, lane);   // ends at phase 0
                         pf.tick(18);
                     } else {
-                        head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, true, lane);
+                        head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, true, lane, m12p(wave));
                         head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
+                        committed();
                         pf.tick(8);
                         gext(std::integral_constant<int, 0>{}, wave, s_qkvt(lw, wave));
+                        gfix();
                         pf.tick(15);
                         ds_math();
                         pf.tick(16);
@@ -1098,19 +1189,25 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                             if (row < RLA) *(lf32x4*)(Qx + row * DFF_XLD + 4 * c4) = hr.q[u];
                         }
                     }
-                    head_fetch(hr, sbq + sl.qkv + (size_t)h1 * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)h1 * 256, RA, true, lane);
+                    committed();
+                    head_fetch(hr, sbq + sl.qkv + (size_t)h1 * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)h1 * 256, RA, true, lane, m12p(h1));
                     gext(std::integral_constant<int, 0>{}, wave, s_woxt(lw, h1));
+                    gfix();
                     ds_math();
                     dx_only();
                     head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
+                    committed();
                     gext(std::integral_constant<int, 1>{}, h1, after);
+                    gfix();
                     ds_math();
                     dx_only();
                     // the next step (if any) re-stages its own first entries at phase 0
                 } else {
-                    head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, true, lane);
+                    head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, true, lane, m12p(wave));
                     head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
+                    committed();
                     gext(std::integral_constant<int, 0>{}, wave, after);
+                    gfix();
                     ds_math();
                     dx_only();
                 }
@@ -1119,7 +1216,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             pf.tick(9);
             // ---- row stage F: dn = dn_in partial + LN1 backward(sum_w part)  (l > 0) ----
             // operands: ro[1] nodes_in, ro[2] ln1 gamma
-            if (l > 0) {
+            if (l > 0 || full0) {
                 DFF_ROW_CONSTS
                 if (ract) {
                     float dyg[HC], xh[HC], ps[HC];
@@ -1139,13 +1236,14 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     s2 = rsum(s2) * (1.0f / H);
 #pragma unroll
                     for (int i = 0; i < HC; ++i) resbuf[rrow * LH + sub + LPR * i] += rstd * (dyg[i] - s1 - xh[i] * s2);
-                    // stage D operands of layer l-1
-                    const DffLayerDev& lp = m.layer[l - 1];
-                    const gfloat* const sp = stash + (size_t)(l - 1) * sl.layer_stride;
-                    ro_load(0, (const float*)(sp + sl.attn_out + rrow * H), sub);
-                    ro_load(1, (const float*)((l == 1 ? l0e : sp) + sl.nodes_in + rrow * H), sub);
-                    ro_load(2, (const float*)(sp + sl.ff + rrow * H), sub);
-                    ro_load3(3, lp.g1, sub); ro_load3(6, lp.g2, sub);
+                    if (l > 0) {   // stage D operands of layer l-1
+                        const DffLayerDev& lp = m.layer[l - 1];
+                        const gfloat* const sp = stash + (size_t)(l - 1) * sl.layer_stride;
+                        ro_load(0, (const float*)(sp + sl.attn_out + rrow * H), sub);
+                        ro_load(1, (const float*)((l == 1 ? l0e : sp) + sl.nodes_in + rrow * H), sub);
+                        ro_load(2, (const float*)(sp + sl.ff + rrow * H), sub);
+                        ro_load3(3, lp.g1, sub); ro_load3(6, lp.g2, sub);
+                    }
                 }
                 __syncthreads();
             }
@@ -1164,6 +1262,27 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             dxs[tid] = t;
         }
         __syncthreads();
+        if constexpr (GEN) {
+            if (full0 && m.conservative) {   // absolute coordinates: dE/dx_i += d(nodes_0)_i . W_node[:, x columns]
+                DFF_ROW_CONSTS
+                if (ract) {
+                    float f3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < HC; ++i) {
+                        const int cl = sub + LPR * i;
+                        const float dn = resbuf[rrow * LH + cl];
+#pragma unroll
+                        for (int c3 = 0; c3 < 3; ++c3) f3[c3] += dn * m.WnT[(N + c3) * H + cl];
+                    }
+#pragma unroll
+                    for (int c3 = 0; c3 < 3; ++c3) {
+                        f3[c3] = rsum(f3[c3]);
+                        if (sub == 0) dxs[rrow * 4 + c3] += f3[c3];
+                    }
+                }
+                __syncthreads();
+            }
+        }
 
         // =============================== update (as dff_fused_kernel) ===============================
         if (a.mode == DFF_MODE_SCORE) {
@@ -1263,8 +1382,11 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     }
 }
 
-template __global__ void dff_small_kernel<64, 4>(const DffModelDev, const DffRunArgs);
-template __global__ void dff_small_kernel<96, 4>(const DffModelDev, const DffRunArgs);
-template __global__ void dff_small_kernel<128, 4>(const DffModelDev, const DffRunArgs);
-template __global__ void dff_small_kernel<64, 8>(const DffModelDev, const DffRunArgs);
-template __global__ void dff_small_kernel<96, 8>(const DffModelDev, const DffRunArgs);
+#define DFF_SMALL_INST(H, NW) \
+    template __global__ void dff_small_kernel<H, NW, false>(const DffModelDev, const DffRunArgs); \
+    template __global__ void dff_small_kernel<H, NW, true>(const DffModelDev, const DffRunArgs);
+DFF_SMALL_INST(64, 4)
+DFF_SMALL_INST(96, 4)
+DFF_SMALL_INST(128, 4)
+DFF_SMALL_INST(64, 8)
+DFF_SMALL_INST(96, 8)
