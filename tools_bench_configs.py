@@ -12,13 +12,17 @@ from oracle import synth
 MF = {"ala2": 11.27, "chignolin": 22.00, "trp_cage": 102.97, "bba": 107.19, "villin": 190.40, "protein_g": 327.47}
 ap = argparse.ArgumentParser(); ap.add_argument("--cfgs", default="ala2,chignolin,trp_cage,bba,villin,protein_g")
 ap.add_argument("--P", type=int, default=256); ap.add_argument("--steps", type=int, default=100)
+ap.add_argument("--flags", default="100", help="use_intrinsic_coords, use_distances, use_abs_coords as three digits (shipped: 100; main_train.py default: 011)")
 a = ap.parse_args()
 out = []
 for cfg in a.cfgs.split(","):
     _, N, H, L = synth.SHIPPED_CONFIGS[cfg]
     P = a.P if cfg != "protein_g" else min(a.P, 128)
-    model = GraphTransformer(N, H, device="cuda:0", n_layers=L, use_intrinsic_coords=True, use_abs_coords=False,
-                             use_distances=False, conservative=True, state_dict=synth.synth_gnn_params(N, H, L, decoder_scale=1e-2))
+    intr, dist, ab = (int(ch) for ch in a.flags)
+    model = GraphTransformer(N, H, device="cuda:0", n_layers=L, use_intrinsic_coords=bool(intr), use_abs_coords=bool(ab),
+                             use_distances=bool(dist), conservative=True,
+                             state_dict=synth.synth_gnn_params(N, H, L, decoder_scale=1e-2, node_in=N + 1 + 3 * ab,
+                                                               edge_in=(3 * intr + dist) or 1))
     diff = GaussianDiffusion(model, num_atoms=N, norm_factor=3.0)
     x0 = torch.randn(P, N, 3); x0 = (x0 - x0.mean(1, keepdim=True)) * 3.0
     def lang():
@@ -27,7 +31,7 @@ for cfg in a.cfgs.split(","):
         ld.simulate()
     def ddpm():
         diff.p_sample_loop_from(x0 / 3.0, 500, 500 - a.steps + 1)
-    res = {"cfg": cfg, "N": N, "H": H, "L": L, "P": P}
+    res = {"cfg": cfg, "flags": a.flags, "N": N, "H": H, "L": L, "P": P}
     for name, fn in (("langevin", lang), ("ddpm", ddpm)):
         fn(); torch.cuda.synchronize()
         t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
