@@ -171,10 +171,12 @@ DEVI void wide_run(Ring<E, DR>& ring, float (&aux)[DR][NAUX], const f32x4 (&a)[E
 }
 
 // tall GEMM of one wave: acc[nt] += A(:, k-block kb) . W(entry kb, tile nt), kb = 0..N-1
+// The A fragment of k-block kb + 1 is read from LDS BEFORE the MFMAs of k-block kb are issued (`a` is the
+// fragment of this step, loaded one step ago): otherwise every step starts with an exposed LDS round trip.
 template <int SLOT, int N, int E, int DR, class FA>
-DEVI void tall_step(Ring<E, DR>& ring, f32x4 (&acc)[E], const FA& fa, const WStream& w, const WStream& wn, int lane, int kb) {
+DEVI void tall_step(Ring<E, DR>& ring, f32x4 (&acc)[E], f32x4& a, const FA& fa, const WStream& w, const WStream& wn, int lane, int kb) {
     f32x4 (&b)[E] = ring.b[SLOT];
-    const f32x4 a = *(const lf32x4*)fa(kb);
+    const f32x4 an = *(const lf32x4*)fa(kb + 1 < N ? kb + 1 : N - 1);
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -182,23 +184,25 @@ DEVI void tall_step(Ring<E, DR>& ring, f32x4 (&acc)[E], const FA& fa, const WStr
             acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[nt][s], acc[nt], 0, 0, 0);
     if (kb + DR < N) ring_fill<E>(b, w, kb + DR, lane);
     else ring_fill<E>(b, wn, kb + DR - N, lane);
+    a = an;
 }
 template <int PH, int N, int E, int DR, class FA>
 DEVI void tall_run(Ring<E, DR>& ring, f32x4 (&acc)[E], const FA fa, const WStream& w, const WStream& wn, int lane) {
     constexpr int NREV = N / DR, REM = N % DR;
+    f32x4 a = *(const lf32x4*)fa(0);
 #pragma unroll 1
     for (int rev = 0; rev < NREV; ++rev) {
         const int k0 = rev * DR;
-        tall_step<(PH + 0) % DR, N, E>(ring, acc, fa, w, wn, lane, k0);
-        tall_step<(PH + 1) % DR, N, E>(ring, acc, fa, w, wn, lane, k0 + 1);
+        tall_step<(PH + 0) % DR, N, E>(ring, acc, a, fa, w, wn, lane, k0);
+        tall_step<(PH + 1) % DR, N, E>(ring, acc, a, fa, w, wn, lane, k0 + 1);
         if constexpr (DR == 4) {
-            tall_step<(PH + 2) % DR, N, E>(ring, acc, fa, w, wn, lane, k0 + 2);
-            tall_step<(PH + 3) % DR, N, E>(ring, acc, fa, w, wn, lane, k0 + 3);
+            tall_step<(PH + 2) % DR, N, E>(ring, acc, a, fa, w, wn, lane, k0 + 2);
+            tall_step<(PH + 3) % DR, N, E>(ring, acc, a, fa, w, wn, lane, k0 + 3);
         }
     }
-    if constexpr (REM > 0) tall_step<(PH + 0) % DR, N, E>(ring, acc, fa, w, wn, lane, NREV * DR);
-    if constexpr (REM > 1) tall_step<(PH + 1) % DR, N, E>(ring, acc, fa, w, wn, lane, NREV * DR + 1);
-    if constexpr (REM > 2) tall_step<(PH + 2) % DR, N, E>(ring, acc, fa, w, wn, lane, NREV * DR + 2);
+    if constexpr (REM > 0) tall_step<(PH + 0) % DR, N, E>(ring, acc, a, fa, w, wn, lane, NREV * DR);
+    if constexpr (REM > 1) tall_step<(PH + 1) % DR, N, E>(ring, acc, a, fa, w, wn, lane, NREV * DR + 1);
+    if constexpr (REM > 2) tall_step<(PH + 2) % DR, N, E>(ring, acc, a, fa, w, wn, lane, NREV * DR + 2);
 }
 
 // C layout: acc[r] <-> (row 4*(lane>>4)+r, col lane&15); unconditional (pad rows hold finite junk)
