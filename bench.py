@@ -51,7 +51,11 @@ def hbm_traffic_from_profile(kname, cfg, P, chunk):
             t = json.load(open(f))
         except Exception:
             continue
-        if t.get("kernel", "").replace(" ", "") == kname.replace(" ", "") and t.get("workload") == f"{cfg} P={P} chunk={chunk}":
+        # rocprofv3 prints the full template argument list ("<64, 8, false>"), the library the short name ("<64,8>")
+        def norm(n):
+            n = n.replace(" ", "")
+            return n[:-len(",false>")] + ">" if n.endswith(",false>") and n.count(",") in (2, 4) else n
+        if norm(t.get("kernel", "")) == norm(kname) and t.get("workload") == f"{cfg} P={P} chunk={chunk}":
             best = t
     return None if best is None else float(best["hbm_bytes_per_launch"])
 
