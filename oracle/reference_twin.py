@@ -76,7 +76,7 @@ def _gated_residual(w, x, res):
 
 
 def energy(p: Dict[str, torch.Tensor], x: torch.Tensor, t: torch.Tensor, n_layers: int,
-           intermediates: Optional[dict] = None) -> torch.Tensor:
+           intermediates: Optional[dict] = None, flags=(True, False, False)) -> torch.Tensor:
     """Per-bead energy (B,N,1) of an ALREADY centred x; graph_transformer.py:90-108,318-329.
 
     Shipped branch only: use_intrinsic_coords=True, use_distances=False, use_abs_coords=False
@@ -86,9 +86,19 @@ def energy(p: Dict[str, torch.Tensor], x: torch.Tensor, t: torch.Tensor, n_layer
     H = p["node_embedding.bias"].shape[0]
     tt = t.reshape(-1, 1, 1).to(x.dtype).repeat(1, n, 1)
     h = torch.eye(n, dtype=x.dtype).unsqueeze(0).repeat(b, 1, 1)
+    intr, dist, abs_ = flags   # use_intrinsic_coords, use_distances, use_abs_coords (:53-58, :99-102, :116-140)
     diff = x.unsqueeze(1) - x.unsqueeze(2)  # diff[b,i,j] = x[b,j]-x[b,i]  (:125-129)
-    edges = F.linear(diff, p["edge_embedding.weight"], p["edge_embedding.bias"])
-    nodes = F.linear(torch.cat((h, tt), dim=2), p["node_embedding.weight"], p["node_embedding.bias"])
+    if intr and dist:
+        attr = torch.cat([diff, torch.sum(diff ** 2, dim=3, keepdim=True)], dim=3)
+    elif dist:
+        attr = torch.sum(diff ** 2, dim=3, keepdim=True)
+    elif intr:
+        attr = diff
+    else:
+        attr = torch.zeros(b, n, n, 1, dtype=x.dtype)
+    edges = F.linear(attr, p["edge_embedding.weight"], p["edge_embedding.bias"])
+    nodes_in = torch.cat((h, x, tt), dim=2) if abs_ else torch.cat((h, tt), dim=2)
+    nodes = F.linear(nodes_in, p["node_embedding.weight"], p["node_embedding.bias"])
     for l in range(n_layers):
         pre = f"graphtransformer.layers.{l}."
         a = F.layer_norm(nodes, (H,), p[pre + "0.0.norm.weight"], p[pre + "0.0.norm.bias"], 1e-5)
@@ -109,7 +119,7 @@ def energy(p: Dict[str, torch.Tensor], x: torch.Tensor, t: torch.Tensor, n_layer
 
 
 def score(p: Dict[str, torch.Tensor], x: torch.Tensor, t: torch.Tensor, n_layers: int,
-          return_energy: bool = False, conservative: bool = True):
+          return_energy: bool = False, conservative: bool = True, flags=(True, False, False)):
     """GraphTransformer.forward: graph_transformer.py:77-114 + compute_forces :143-159.
 
     x (B,N,3) need not be centred; returns -d(sum E)/d(x_centred), detached (eval mode:
@@ -120,9 +130,9 @@ def score(p: Dict[str, torch.Tensor], x: torch.Tensor, t: torch.Tensor, n_layers
         t = t.reshape(1).repeat(x.shape[0])
     if not conservative:   # force head: node_decoder is Linear(H, 3), forces = output (:62-65, :112-113)
         with torch.no_grad():
-            return energy(p, xc.detach(), t, n_layers)
+            return energy(p, xc.detach(), t, n_layers, flags=flags)
     with torch.enable_grad():
-        e = energy(p, xc, t, n_layers)
+        e = energy(p, xc, t, n_layers, flags=flags)
         (grad,) = torch.autograd.grad(e, xc, grad_outputs=torch.ones_like(e))
     if return_energy:
         return -grad.detach(), e.detach()

@@ -36,6 +36,19 @@ def test_factorised_model_matches_reference_float64(cfg, flags, golden):
     assert np.abs(e - g["energy32"][..., 0]).max() < 1e-4 * max(1.0, np.abs(e).max())   # float32 reference energies
 
 
+@pytest.mark.parametrize("cfg", CFGS)
+@pytest.mark.parametrize("flags", COMBOS)
+def test_float32_twin_is_bit_identical_to_the_reference(cfg, flags, golden):
+    """oracle/reference_twin.py (the op-for-op torch twin, materialised formulation + autograd) with the input flags."""
+    from oracle import reference_twin as twin
+    intr, dist, ab = flags
+    g = golden(f"score_in_{cfg}_{intr}{dist}{ab}.npz")
+    p, (N, H, L) = params_for(cfg, intr, dist, ab)
+    f, e = twin.score(twin.to_torch(p), torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), L, return_energy=True,
+                      flags=(bool(intr), bool(dist), bool(ab)))
+    assert np.array_equal(f.numpy(), g["forces32"]) and np.array_equal(e.numpy(), g["energy32"])
+
+
 def test_general_model_reduces_to_the_shipped_branch(golden):
     """flags (1, 0, 0) through the general model == the dedicated model of the shipped checkpoints."""
     from oracle import kernel_model as km
