@@ -220,7 +220,7 @@ def main():
                          "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
                          "note": "fp32-compute bound: algorithmic HBM bytes are only 600 B per trajectory-step "
                                  "(x, v in/out + noise); measured traffic is dominated by the L2-spilling "
-                                 "activation stash and is ~16% of HBM peak, not the binding roof"},
+                                 "activation stash and is ~18% of HBM peak, not the binding roof"},
         }
         if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(cfg, P, args.noise_level)
