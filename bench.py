@@ -105,6 +105,51 @@ def cpu_baseline(cfg, P, t_level, budget_s=12.0, max_steps=40):
                       f"oracle/reference_twin.py on {torch.get_num_threads()} threads of {os.cpu_count()} logical cores"}
 
 
+def north_star_extras(dev, rank, world, P):
+    """The other figures BASELINE.json's north_star names, measured AFTER the timed region and reported
+    under `also` (never part of `value`): i.i.d. samples/s (full 1000-step DDPM reverse chains, the layer-0
+    table build included) and Langevin MD-steps/s on chignolin and villin at batch P per GPU."""
+    import torch.distributed as dist
+    from dff_amd.ddpm import GaussianDiffusion
+    from dff_amd.langevin import LangevinDiffusion
+    from dff_amd.score import GraphTransformer
+    from oracle import synth
+    out = {}
+    for cfg in ("chignolin", "villin"):
+        _, N, H, L = synth.SHIPPED_CONFIGS[cfg]
+        model = GraphTransformer(N, H, device=dev, n_layers=L, use_intrinsic_coords=True, use_abs_coords=False,
+                                 use_distances=False, conservative=True,
+                                 state_dict=synth.synth_gnn_params(N, H, L, seed=1234, decoder_scale=1e-2))
+        diff = GaussianDiffusion(model, num_atoms=N, timesteps=1000, norm_factor=NORM_STD[cfg])
+        diff.seed(77 + rank)
+        x0 = torch.randn(P, N, 3, generator=torch.Generator().manual_seed(2024 + rank))
+        x0 = (x0 - x0.mean(1, keepdim=True)) * NORM_STD[cfg]
+
+        def iid():
+            return diff.sample(P)
+
+        def md():
+            LangevinDiffusion(diff, x0, 1000, save_interval=250, t=20 if cfg == "chignolin" else 5, temp_data=TEMP[cfg],
+                              temp_sim=TEMP[cfg], dt=None, masses=[12.0] * N, friction=1.0, seed=1234,
+                              verbose=False).simulate(traj_offset=rank * P)
+
+        for name, fn, units in (("iid_samples_per_s", iid, P), ("md_steps_per_s", md, 1000)):
+            fn()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            out[f"{cfg}_{name}"] = world * units / dt.item()
+    out["note"] = (f"whole job, batch {P} per GPU; iid = complete 1000-step DDPM chains; md = 1000 Langevin steps, save_interval 250 "
+                   f"(chignolin t=20, villin t=5), host set-up of each call included")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,6 +161,7 @@ def main():
     ap.add_argument("--noise_level", type=int, default=20)
     ap.add_argument("--group", type=int, default=0, help="proteins per workgroup (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary north-star figures (`also`)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -194,6 +240,7 @@ def main():
         torch.cuda.synchronize()
         gather_ms = 1e3 * (time.perf_counter() - t1)
     ok = bool(torch.isfinite(frames).all().item()) and bool(torch.isfinite(ld.x).all().item())
+    also = None if args.no_extras else north_star_extras(dev, rank, world, P)
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / K
@@ -222,6 +269,8 @@ def main():
                                  "(x, v in/out + noise); measured traffic is dominated by the L2-spilling "
                                  "activation stash and is ~18% of HBM peak, not the binding roof"},
         }
+        if also is not None:
+            res["also"] = also
         if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(cfg, P, args.noise_level)
             res["speedup_vs_cpu_port"] = value / res["cpu_baseline"]["value"]
