@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=250)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=250)
+    ap.add_argument("--beads", type=int, default=10)
+    ap.add_argument("--bench-args", default="", help="extra bench.py arguments the profile was taken with")
     a = ap.parse_args()
     src = os.path.join(ROOT, "gpurun_out", f"prof_{a.tag}")
     dst = os.path.join(ROOT, "profiles", a.round)
@@ -84,7 +86,7 @@ def main():
     mfma_util = C.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024 * gui / 8) if gui else float("nan")
     wc = C.get("SQ_WAVE_CYCLES", 1.0)
     lines = []
-    lines.append(f"# profiles/{a.round} -- rocprofv3 of `python bench.py --steps {a.steps} --warmup {a.warmup} --no-cpu` "
+    lines.append(f"# profiles/{a.round} -- rocprofv3 of `python bench.py --steps {a.steps} --warmup {a.warmup} --no-cpu --no-extras{(' ' + a.bench_args) if a.bench_args else ''}` "
                  f"({a.cfg}, P={a.P}, 1 x MI355X)")
     lines.append("Collected by tools_rocprof.sh on the GPU box (kernel trace + stats in one run, each PMC set in its own "
                  "run) and condensed by tools_profile_report.py.")
@@ -117,7 +119,7 @@ def main():
                      f"{C.get('SQ_WAIT_INST_ANY', 0) / wc:.2f}, issuing {C.get('SQ_ACTIVE_INST_ANY', 0) / wc:.2f}")
     if "TCC_HIT_sum" in C:
         lines.append(f"- L2 hit rate = {C['TCC_HIT_sum'] / (C['TCC_HIT_sum'] + C['TCC_MISS_sum']):.3f}")
-    state = a.chunk * a.P * 600
+    state = a.chunk * a.P * 60 * a.beads
     lines.append(f"- HBM traffic per launch: read {fetch / 1e9:.2f} GB (FETCH_SIZE x 1024 x 2, gfx950 correction of "
                  f"MI355X_MICROARCH.md) + write {write / 1e9:.2f} GB = {(fetch + write) / 1e9:.2f} GB -> "
                  f"{(fetch + write) / (avg_ms * 1e-3) / 1e12:.2f} TB/s; algorithmic state traffic is only "
@@ -127,7 +129,7 @@ def main():
                      f"{C['SQ_LDS_BANK_CONFLICT'] / max(C.get('SQ_LDS_IDX_ACTIVE', 1.0), 1.0):.2f}")
     extra = ""
     old = os.path.join(dst, "README.md")
-    if os.path.exists(old) and "## other kernels" in open(old).read():
+    if os.path.exists(old) and "## other kernels" in open(old).read() and "/" not in a.round:
         extra = "\n" + open(old).read()[open(old).read().index("## other kernels"):]
     open(old, "w").write("\n".join(lines) + "\n" + extra)
     print("\n".join(lines))

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
-BENCH="python $ROOT/bench.py --steps 1000 --warmup 250 --no-cpu $*"
+BENCH="python $ROOT/bench.py --steps 1000 --warmup 250 --no-cpu --no-extras $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 i=0
 for set in "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE" \
