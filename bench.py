@@ -46,7 +46,7 @@ def hbm_traffic_from_profile(kname, cfg, P, chunk):
     gfx950 x2 read correction) for this exact kernel + workload: profiles/<round>/traffic.json."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "**", "traffic.json"), recursive=True)):
         try:
             t = json.load(open(f))
         except Exception:

@@ -252,8 +252,8 @@ DEVI void mfma4(f32x4& acc, const f32x4 a, const f32x4 b) {
 }
 
 // Weight fetch latency out of L2 is ~1 us when all 256 CUs stream the same packed image, and a
-// workgroup has only 4 waves, so each wave keeps a ring of D tiles (wide) / segments (tall) of
-// B operands in flight in registers (Little: D * 4 KB * 4 waves per CU).
+// workgroup has only 8 waves, so each wave keeps a ring of D tiles (wide) / k-blocks (tall) of
+// B operands in flight in registers (Little: D tiles * KB KiB * 8 waves per CU).
 
 // "wide" GEMM: K = 16*KB (small, compile time), many output tiles; the waves take tiles
 // round-robin.  epi(nt_local, mt, acc, aux) consumes one 16x16 output tile.
@@ -744,12 +744,13 @@ DEVI void rowb_ln1(const Ctx& c, const DffLayerDev& lw, int l, const float* tbuf
 // ------------------------------------------------------------------------------------------
 // attention stages on MFMA.  Head-group buffers (R x LQ each, a head = 80 columns [64 | 16 ext]):
 //   R0 = Q_ext = [q | u]   (u = W_c,h^T q: the edge term of the logits, 3 of 16 columns used)
-//   R1 = K_ext = [k | x]   R2 = V_ext = [v | x]   R3 = o_ext (forward) / G_ext = [dE/do | r] (backward)
+//   R1 = K_ext = [k | x]   R2 = V_ext = [v | x]   R3 = G_ext = [dE/do | r] (backward)
+//   (forward: o_ext overwrites the row tile's own Q_ext rows in R0 once its logits are done)
 // so that logits = Q_ext K_ext^T, o_ext = P V_ext = [o | sum_j a_ij x_j], da = G_ext V_ext^T, and the
 // extension columns of dQ_ext / dK_ext / dV_ext are du / dE/dx_j / dE/dx_j: every N x N contraction is
 // a 16x16x4 tile product.  A workgroup's G proteins share the tiles; pairs from different proteins are
 // masked in the softmax (exact zeros in P, hence in dS).
-// The phases are cooperative: tiles go round-robin over the 4 waves, barriers between phases.
+// The phases are cooperative: tiles go round-robin over the 8 waves, barriers between phases.
 // ------------------------------------------------------------------------------------------
 // acc[jt] = A[rows of tile it] . B[rows of tile jt]^T over K = 80
 template <int MT>

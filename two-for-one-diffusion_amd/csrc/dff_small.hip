@@ -5,10 +5,10 @@
 // work decomposition, chosen so that nothing but the row-wise LayerNorm / gate stages needs a
 // workgroup barrier:
 //
-//   * ONE ATTENTION HEAD PER WAVE.  Wave w owns heads {w, w+4}: it computes that head's q|u|k|v
-//     tiles, the logits, softmax, the P.V product and the head's slice of the output projection
-//     entirely out of its private LDS region; the 4 waves' partial output projections (a K-split
-//     by head) are summed by the next row stage.  The FFN is split the same way (each wave owns
+//   * HEADS ARE WAVE-PRIVATE.  With NW = 8 waves wave w owns head w, with NW = 4 heads {w, w+4}: it
+//     computes that head's q|u|k|v tiles, the logits, softmax, the P.V product and the head's slice of
+//     the output projection entirely out of its private LDS region; the waves' partial output
+//     projections (a K-split by head) are summed by the next row stage.  The FFN is split the same way (each wave owns
 //     H of the 4H hidden columns: W1 slice -> GELU -> partial W2).
 //   * x RIDES ALONG AS A 16-COLUMN HEAD EXTENSION.  Each 64-wide head is widened to 80 columns:
 //         Q_ext = [q | u 0..]   K_ext = [k | x 0..]   V_ext = [v | x 0..]
