@@ -13,6 +13,7 @@ MF = {"ala2": 11.27, "chignolin": 22.00, "trp_cage": 102.97, "bba": 107.19, "vil
 ap = argparse.ArgumentParser(); ap.add_argument("--cfgs", default="ala2,chignolin,trp_cage,bba,villin,protein_g")
 ap.add_argument("--P", type=int, default=256); ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--flags", default="100", help="use_intrinsic_coords, use_distances, use_abs_coords as three digits (shipped: 100; main_train.py default: 011)")
+ap.add_argument("--group", type=int, default=0, help="proteins per workgroup (0 = the library's choice)")
 a = ap.parse_args()
 out = []
 for cfg in a.cfgs.split(","):
@@ -23,6 +24,8 @@ for cfg in a.cfgs.split(","):
                              use_distances=bool(dist), conservative=True,
                              state_dict=synth.synth_gnn_params(N, H, L, decoder_scale=1e-2, node_in=N + 1 + 3 * ab,
                                                                edge_in=(3 * intr + dist) or 1))
+    if a.group:
+        model.native.set_group(a.group)
     diff = GaussianDiffusion(model, num_atoms=N, norm_factor=3.0)
     x0 = torch.randn(P, N, 3); x0 = (x0 - x0.mean(1, keepdim=True)) * 3.0
     def lang():
@@ -31,7 +34,7 @@ for cfg in a.cfgs.split(","):
         ld.simulate()
     def ddpm():
         diff.p_sample_loop_from(x0 / 3.0, 500, 500 - a.steps + 1)
-    res = {"cfg": cfg, "flags": a.flags, "N": N, "H": H, "L": L, "P": P}
+    res = {"cfg": cfg, "group": a.group, "flags": a.flags, "N": N, "H": H, "L": L, "P": P}
     for name, fn in (("langevin", lang), ("ddpm", ddpm)):
         fn(); torch.cuda.synchronize()
         t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps

@@ -35,16 +35,21 @@ static int fail(int code, const char* fmt, ...) {
 // ------------------------------------------------------------------------------------------
 // packing for the v_mfma_f32_16x16x4_f32 B operand (layout: dff_internal.h)
 // ------------------------------------------------------------------------------------------
-static std::vector<float> pack_b(int K, int Nout, const std::function<double(int, int)>& w) {
+// xper > 0: k-blocks with kb % xper == 4 are head EXTENSION blocks, of which only rows 0..3 are ever non-zero
+// (u | s, xrel | D, du | ds): they are packed with row (lane >> 4) in k-step 0 and zeros in k-steps 1..3, and the
+// kernels issue one MFMA for them instead of four (A operand: column lane >> 4 of the block).
+static std::vector<float> pack_b(int K, int Nout, const std::function<double(int, int)>& w, int xper = 0) {
     const int KB = (K + 15) / 16, NT = (Nout + 15) / 16;
     std::vector<float> out((size_t)KB * NT * 256, 0.f);
     for (int nt = 0; nt < NT; ++nt)
-        for (int kb = 0; kb < KB; ++kb)
+        for (int kb = 0; kb < KB; ++kb) {
+            const bool ext = xper > 0 && kb % xper == 4;
             for (int lane = 0; lane < 64; ++lane)
-                for (int s = 0; s < 4; ++s) {
-                    const int k = 16 * kb + 4 * (lane >> 4) + s, n = 16 * nt + (lane & 15);
+                for (int s = 0; s < (ext ? 1 : 4); ++s) {
+                    const int k = 16 * kb + (ext ? lane >> 4 : 4 * (lane >> 4) + s), n = 16 * nt + (lane & 15);
                     if (k < K && n < Nout) out[(((size_t)nt * KB + kb) * 64 + lane) * 4 + s] = (float)w(k, n);
                 }
+        }
     return out;
 }
 
@@ -312,9 +317,9 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
         };
         UP(pack_b(H, 8 * 208, [&](int k, int n) { return wqkvx(n, k); }), d.Wqkvx_p);
         UP(bqkvx, d.bqkvx);
-        UP(pack_b(8 * 80, H, [&](int k, int n) { return wox(k, n); }), d.Wox_p);
+        UP(pack_b(8 * 80, H, [&](int k, int n) { return wox(k, n); }, 5), d.Wox_p);
         UP(pack_b(H, 8 * 80, [&](int k, int n) { return wox(n, k); }), d.WoxT_p);
-        UP(pack_b(8 * 208, H, [&](int k, int n) { return wqkvx(k, n); }), d.WqkvxT_p);
+        UP(pack_b(8 * 208, H, [&](int k, int n) { return wqkvx(k, n); }, 13), d.WqkvxT_p);
     }
     build_schedule(cfg->timesteps, m->sched);
     UP(m->sched[6], m->dev.sqrt_recip_ac);

@@ -332,7 +332,9 @@ DEVI void gemm_wide(const lfloat* A, int lda, int rowsA, const float* __restrict
 
 // "tall" GEMM over an explicit list of 16-wide k-blocks: kf(i, aoff, wkb) names the i-th block (its A
 // columns start at A + aoff, its weights are k-block wkb of the packed image).  Ring of D k-blocks.
-template <int MT, int NTW, class KF>
+// XPER > 0: weight k-blocks with wkb % XPER == 4 are head extension blocks (rows 4..15 zero): one k-step over
+// columns 0..3 instead of four (packed with row lane >> 4 in k-step 0, dff_host.hip pack_b).
+template <int MT, int NTW, int XPER, class KF>
 DEVI void gemm_tall_kb(f32x4 (&acc)[NTW][MT], int nkb, KF kf, const lfloat* A, int lda, int rowsA,
                        const float* __restrict__ Wp, int KBtot, int ntiles) {
     const int tid_ = tid_now();
@@ -354,11 +356,13 @@ DEVI void gemm_tall_kb(f32x4 (&acc)[NTW][MT], int nkb, KF kf, const lfloat* A, i
     if (!tok[0]) return;
     f32x4 b[D][NTW];
     int aoff[D];
+    bool ext[D];
 #pragma unroll
     for (int d = 0; d < D; ++d)
         if (d < nkb) {
             int wkb;
             kf(d, aoff[d], wkb);
+            ext[d] = XPER > 0 && wkb % (XPER > 0 ? XPER : 1) == 4;
 #pragma unroll
             for (int i = 0; i < NTW; ++i) b[d][i] = wp[(tbase[i] + wkb) * 64];
         }
@@ -367,21 +371,35 @@ DEVI void gemm_tall_kb(f32x4 (&acc)[NTW][MT], int nkb, KF kf, const lfloat* A, i
         for (int d = 0; d < D; ++d) {
             const int ib = i0 + d;
             if (ib < nkb) {
-                f32x4 a[MT];
+                if (XPER > 0 && ext[d]) {
+                    float ax[MT];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) a[mt] = *(const lf32x4*)(A + aoff[d] + rowoff[mt]);
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4)
+                    for (int mt = 0; mt < MT; ++mt) ax[mt] = A[aoff[d] + rowoff[mt] - 3 * kk];
 #pragma unroll
                     for (int i = 0; i < NTW; ++i)
                         if (tok[i]) {
 #pragma unroll
                             for (int mt = 0; mt < MT; ++mt)
-                                acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s4], b[d][i][s4], acc[i][mt], 0, 0, 0);
+                                acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[mt], b[d][i][0], acc[i][mt], 0, 0, 0);
                         }
+                } else {
+                    f32x4 a[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) a[mt] = *(const lf32x4*)(A + aoff[d] + rowoff[mt]);
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                        for (int i = 0; i < NTW; ++i)
+                            if (tok[i]) {
+#pragma unroll
+                                for (int mt = 0; mt < MT; ++mt)
+                                    acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s4], b[d][i][s4], acc[i][mt], 0, 0, 0);
+                            }
+                }
                 if (ib + D < nkb) {
                     int wkb;
                     kf(ib + D, aoff[d], wkb);
+                    ext[d] = XPER > 0 && wkb % (XPER > 0 ? XPER : 1) == 4;
 #pragma unroll
                     for (int i = 0; i < NTW; ++i) b[d][i] = wp[(tbase[i] + wkb) * 64];
                 }
@@ -757,15 +775,18 @@ template <int MT>
 DEVI void co_dot_rows(f32x4 (&acc)[MT], const lfloat* A, const lfloat* B, int ld, int RN, int it, int lane) {
     const int kk = lane >> 4, mm = lane & 15;
     const lfloat* ap = A + min(16 * it + mm, RN - 1) * ld + 4 * kk;
-    f32x4 av[5];
+    f32x4 av[4];
 #pragma unroll
-    for (int kb = 0; kb < 5; ++kb) av[kb] = *(const lf32x4*)(ap + 16 * kb);
+    for (int kb = 0; kb < 4; ++kb) av[kb] = *(const lf32x4*)(ap + 16 * kb);
+    // extension block: only its first 4 columns are ever non-zero (u | s, x | |x|^2, r | g_D): one k-step, exact
+    const float ax = ap[64 - 3 * kk];
 #pragma unroll
     for (int jt = 0; jt < MT; ++jt) {
         const lfloat* bp = B + min(16 * jt + mm, RN - 1) * ld + 4 * kk;
-        f32x4 bv[5];
+        f32x4 bv[4];
 #pragma unroll
-        for (int kb = 0; kb < 5; ++kb) bv[kb] = *(const lf32x4*)(bp + 16 * kb);
+        for (int kb = 0; kb < 4; ++kb) bv[kb] = *(const lf32x4*)(bp + 16 * kb);
+        const float bx = bp[64 - 3 * kk];
         f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 4; kb += 2)
@@ -774,8 +795,7 @@ DEVI void co_dot_rows(f32x4 (&acc)[MT], const lfloat* A, const lfloat* B, int ld
                 c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb][s], bv[kb][s], c0, 0, 0, 0);
                 c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb + 1][s], bv[kb + 1][s], c1, 0, 0, 0);
             }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4][s], bv[4][s], c0, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, bx, c0, 0, 0, 0);
         acc[jt] = c0 + c1;
     }
 }
@@ -784,28 +804,26 @@ DEVI void co_dot_rows(f32x4 (&acc)[MT], const lfloat* A, const lfloat* B, int ld
 // TRANS = false: Aop[i][k] = T[i][k] ; true: Aop[i][k] = T[k][i]   (T = a head's (16MT x PL) tile array)
 // B points at column 0 of the wanted 16-column slice of a head-group buffer (rows clamped to RN-1:
 // the matching T entries are exact zeros).
+// k-step (kt, s) covers k = 16 kt + 4 s .. + 3 (lane: + kk); T's rows and columns at or beyond the workgroup's real
+// `rows` are exact zeros (P, dS), so the k-steps that start there are skipped.
 template <int MT, bool TRANS>
-DEVI f32x4 co_mm(const lfloat* T, int mo, const lfloat* B, int ldb, int RN, int lane) {
+DEVI f32x4 co_mm(const lfloat* T, int mo, const lfloat* B, int ldb, int RN, int rows, int lane) {
     constexpr int PL = 16 * MT + 4;
     const int kk = lane >> 4, mm = lane & 15;
     f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < MT; ++kt) {
         float as[4], bs[4];
-        if (TRANS) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) as[s] = T[(16 * kt + 4 * kk + s) * PL + 16 * mo + mm];
-        } else {
-            const f32x4 t = *(const lf32x4*)(T + (16 * mo + mm) * PL + 16 * kt + 4 * kk);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) as[s] = t[s];
+        for (int s = 0; s < 4; ++s) {
+            const int k = 16 * kt + 4 * s + kk;
+            as[s] = TRANS ? T[k * PL + 16 * mo + mm] : T[(16 * mo + mm) * PL + k];
+            bs[s] = B[min(k, RN - 1) * ldb + mm];
         }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) bs[s] = B[min(16 * kt + 4 * kk + s, RN - 1) * ldb + mm];
         c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(as[0], bs[0], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(as[1], bs[1], c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(as[2], bs[2], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(as[3], bs[3], c1, 0, 0, 0);
+        if (16 * kt + 4 < rows) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(as[1], bs[1], c1, 0, 0, 0);
+        if (16 * kt + 8 < rows) c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(as[2], bs[2], c0, 0, 0, 0);
+        if (16 * kt + 12 < rows) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(as[3], bs[3], c1, 0, 0, 0);
     }
     return c0 + c1;
 }
@@ -814,7 +832,7 @@ DEVI f32x4 co_mm(const lfloat* T, int mo, const lfloat* B, int ldb, int RN, int 
 // operand is read once and five independent accumulator chains keep the MFMA pipe busy while the
 // next operands arrive.
 template <int MT, bool TRANS>
-DEVI void co_mm5(f32x4 (&c)[5], const lfloat* T, int mo, const lfloat* B, int ldb, int RN, int lane) {
+DEVI void co_mm5(f32x4 (&c)[5], const lfloat* T, int mo, const lfloat* B, int ldb, int RN, int rows, int lane) {
     constexpr int PL = 16 * MT + 4;
     const int kk = lane >> 4, mm = lane & 15;
 #pragma unroll
@@ -822,20 +840,18 @@ DEVI void co_mm5(f32x4 (&c)[5], const lfloat* T, int mo, const lfloat* B, int ld
 #pragma unroll
     for (int kt = 0; kt < MT; ++kt) {
         float as[4];
-        if (TRANS) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) as[s] = T[(16 * kt + 4 * kk + s) * PL + 16 * mo + mm];
-        } else {
-            const f32x4 t = *(const lf32x4*)(T + (16 * mo + mm) * PL + 16 * kt + 4 * kk);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) as[s] = t[s];
-        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const lfloat* bp = B + min(16 * kt + 4 * kk + s, RN - 1) * ldb + mm;
-#pragma unroll
-            for (int nt = 0; nt < 5; ++nt) c[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[s], bp[16 * nt], c[nt], 0, 0, 0);
+            const int k = 16 * kt + 4 * s + kk;
+            as[s] = TRANS ? T[k * PL + 16 * mo + mm] : T[(16 * mo + mm) * PL + k];
         }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            if (s == 0 || 16 * kt + 4 * s < rows) {
+                const lfloat* bp = B + min(16 * kt + 4 * s + kk, RN - 1) * ldb + mm;
+#pragma unroll
+                for (int nt = 0; nt < 5; ++nt) c[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[s], bp[16 * nt], c[nt], 0, 0, 0);
+            }
     }
 }
 
@@ -956,7 +972,7 @@ DEVI void co_softmax_pv(const CoGeo& g, gfloat* sP /* P block of head hg*HGS */,
             }
         }
         f32x4 o[5];
-        co_mm5<MT, false>(o, g.Pbuf + hh * PT, it, g.Rg + 2 * g.RN * LQ + hh * 80, LQ, g.RN, lane);
+        co_mm5<MT, false>(o, g.Pbuf + hh * PT, it, g.Rg + 2 * g.RN * LQ + hh * 80, LQ, g.RN, g.rows, lane);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * it + 4 * quad + r;
@@ -1034,7 +1050,7 @@ DEVI void co_ds(const CoGeo& g) {
         }
         if (DQ) {
             f32x4 dq[5];
-            co_mm5<MT, false>(dq, g.dSbuf + hh * PT, it, g.Rg + g.RN * LQ + hh * 80, LQ, g.RN, lane);
+            co_mm5<MT, false>(dq, g.dSbuf + hh * PT, it, g.Rg + g.RN * LQ + hh * 80, LQ, g.RN, g.rows, lane);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * it + 4 * quad + r;
@@ -1062,7 +1078,7 @@ DEVI void co_dv_dk(const CoGeo& g) {
             const int which = item / (HGS * MT), r0 = item - which * (HGS * MT);   // 0: dV, 1: dK
             const int hh = r0 / MT, mo = r0 - hh * MT;
             const lfloat* T = (which ? g.dSbuf : g.Pbuf) + hh * PT;
-            const f32x4 acc = co_mm<MT, true>(T, mo, g.Rg + (which ? 0 : 3) * g.RN * LQ + hh * 80 + 64, LQ, g.RN, lane);
+            const f32x4 acc = co_mm<MT, true>(T, mo, g.Rg + (which ? 0 : 3) * g.RN * LQ + hh * 80 + 64, LQ, g.RN, g.rows, lane);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * mo + 4 * quad + r;
@@ -1073,7 +1089,7 @@ DEVI void co_dv_dk(const CoGeo& g) {
         if (GEN) {   // the logits' distance term reaches x_i through Q_ext as well: dE/dx_i += -2 s_i sum_j dS_ij x_j
             for (int item = wave; item < HGS * MT; item += DFF_NWAVES) {
                 const int hh = item / MT, it = item - hh * MT;
-                const f32x4 acc = co_mm<MT, false>(g.dSbuf + hh * PT, it, g.Rg + g.RN * LQ + hh * 80 + 64, LQ, g.RN, lane);
+                const f32x4 acc = co_mm<MT, false>(g.dSbuf + hh * PT, it, g.Rg + g.RN * LQ + hh * 80 + 64, LQ, g.RN, g.rows, lane);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) (void)co_dq_ext<HGS>(g, hh, 16 * it + 4 * quad + r, col, acc[r]);
             }
@@ -1084,7 +1100,7 @@ DEVI void co_dv_dk(const CoGeo& g) {
             const int hh = r0 / MT, mo = r0 - hh * MT;
             const lfloat* T = (which ? g.dSbuf : g.Pbuf) + hh * PT;
             f32x4 acc[5];
-            co_mm5<MT, true>(acc, T, mo, g.Rg + (which ? 0 : 3) * g.RN * LQ + hh * 80, LQ, g.RN, lane);
+            co_mm5<MT, true>(acc, T, mo, g.Rg + (which ? 0 : 3) * g.RN * LQ + hh * 80, LQ, g.RN, g.rows, lane);
             lfloat* const dst = g.Rg + (which ? 1 : 2) * g.RN * LQ + hh * 80 + col;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1116,7 +1132,7 @@ DEVI void co_dqkv(const CoGeo& g) {
     for (int item = wave; item < HGS * MT * 5; item += DFF_NWAVES) {
         const int hh = item / (MT * 5), rem = item - hh * (MT * 5);
         const int mo = rem / 5, nt = rem - mo * 5;
-        const f32x4 acc = co_mm<MT, WHICH != 1>(T + hh * PT, mo, g.Rg + SRC * g.RN * LQ + hh * 80 + 16 * nt, LQ, g.RN, lane);
+        const f32x4 acc = co_mm<MT, WHICH != 1>(T + hh * PT, mo, g.Rg + SRC * g.RN * LQ + hh * 80 + 16 * nt, LQ, g.RN, g.rows, lane);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * mo + 4 * quad + r;
@@ -1392,7 +1408,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 wg_sync<SPILL>();
                 pf.tick(4);
                 // attn_out += o_ext [W_o ; W_oc]   (K = 80 per head)
-                gemm_tall_kb<MT, NTW>(acc_o, 5 * HGS,
+                gemm_tall_kb<MT, NTW, 5>(acc_o, 5 * HGS,
                     [=](int i, int& aoff, int& wkb) {
                         const int hh = i / 5, kb = i - 5 * hh;
                         aoff = hh * 80 + 16 * kb;
@@ -1435,7 +1451,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 }
                 wg_sync<SPILL>();
                 pf.tick(8);
-                gemm_tall_kb<MT, NTW>(acc_f, FC / 16,
+                gemm_tall_kb<MT, NTW, 0>(acc_f, FC / 16,
                     [=](int i, int& aoff, int& wkb) { aoff = 16 * i; wkb = ch * (FC / 16) + i; },
                     geo.Rg, LF, RN, lw.W2_p, F / 16, NT_H);
                 wg_sync<SPILL>();
@@ -1483,7 +1499,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 }
                 wg_sync<SPILL>();
                 pf.tick(12);
-                gemm_tall_kb<MT, NTW>(acc_f, FC / 16,
+                gemm_tall_kb<MT, NTW, 0>(acc_f, FC / 16,
                     [=](int i, int& aoff, int& wkb) { aoff = 16 * i; wkb = ch * (FC / 16) + i; },
                     geo.Rg, LF, RN, lw.W1T_p, F / 16, NT_H);
                 wg_sync<SPILL>();
@@ -1550,7 +1566,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     wg_sync<SPILL>();
                     pf.tick(18);
                     // d(LN1 out) += [dq|du] W_qu + dk W_k + dv W_v   (K order per head [q64|u16|k64|v64])
-                    gemm_tall_kb<MT, NTW>(acc_a, 13 * HGS,
+                    gemm_tall_kb<MT, NTW, 13>(acc_a, 13 * HGS,
                         [=](int i, int& aoff, int& wkb) {
                             const int hh = i / 13, tt = i - 13 * hh;
                             const int part = (tt >= 5) + (tt >= 9);

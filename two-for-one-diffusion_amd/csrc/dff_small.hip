@@ -173,36 +173,45 @@ DEVI void wide_run(Ring<E, DR>& ring, float (&aux)[DR][NAUX], const f32x4 (&a)[E
 // tall GEMM of one wave: acc[nt] += A(:, k-block kb) . W(entry kb, tile nt), kb = 0..N-1
 // The A fragment of k-block kb + 1 is read from LDS BEFORE the MFMAs of k-block kb are issued (`a` is the
 // fragment of this step, loaded one step ago): otherwise every step starts with an exposed LDS round trip.
-template <int SLOT, int N, int E, int DR, class FA>
+// XKB >= 0: k-block XKB (> 0) is a head's extension block, whose weight rows 4..15 are zero: one k-step over its
+// columns 0..3 instead of four (the packed image holds row lane >> 4 in k-step 0, dff_host.hip pack_b).
+template <int SLOT, int N, int E, int XKB, int DR, class FA>
 DEVI void tall_step(Ring<E, DR>& ring, f32x4 (&acc)[E], f32x4& a, const FA& fa, const WStream& w, const WStream& wn, int lane, int kb) {
     f32x4 (&b)[E] = ring.b[SLOT];
-    const f32x4 an = *(const lf32x4*)fa(kb + 1 < N ? kb + 1 : N - 1);
+    const lfloat* const pn = fa(kb + 1 < N ? kb + 1 : N - 1);
+    f32x4 an;
+    if (XKB >= 0 && kb + 1 == XKB) an[0] = pn[-3 * (lane >> 4)];   // extension block: column lane >> 4 (see pack_b)
+    else an = *(const lf32x4*)pn;
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int nt = 0; nt < E; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[nt][0], acc[nt], 0, 0, 0);
+    if (XKB < 0 || kb != XKB) {
 #pragma unroll
-        for (int nt = 0; nt < E; ++nt)
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[nt][s], acc[nt], 0, 0, 0);
+        for (int s = 1; s < 4; ++s)
+#pragma unroll
+            for (int nt = 0; nt < E; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[nt][s], acc[nt], 0, 0, 0);
+    }
     if (kb + DR < N) ring_fill<E>(b, w, kb + DR, lane);
     else ring_fill<E>(b, wn, kb + DR - N, lane);
     a = an;
 }
-template <int PH, int N, int E, int DR, class FA>
+template <int PH, int N, int E, int XKB, int DR, class FA>
 DEVI void tall_run(Ring<E, DR>& ring, f32x4 (&acc)[E], const FA fa, const WStream& w, const WStream& wn, int lane) {
     constexpr int NREV = N / DR, REM = N % DR;
     f32x4 a = *(const lf32x4*)fa(0);
 #pragma unroll 1
     for (int rev = 0; rev < NREV; ++rev) {
         const int k0 = rev * DR;
-        tall_step<(PH + 0) % DR, N, E>(ring, acc, a, fa, w, wn, lane, k0);
-        tall_step<(PH + 1) % DR, N, E>(ring, acc, a, fa, w, wn, lane, k0 + 1);
+        tall_step<(PH + 0) % DR, N, E, XKB>(ring, acc, a, fa, w, wn, lane, k0);
+        tall_step<(PH + 1) % DR, N, E, XKB>(ring, acc, a, fa, w, wn, lane, k0 + 1);
         if constexpr (DR == 4) {
-            tall_step<(PH + 2) % DR, N, E>(ring, acc, a, fa, w, wn, lane, k0 + 2);
-            tall_step<(PH + 3) % DR, N, E>(ring, acc, a, fa, w, wn, lane, k0 + 3);
+            tall_step<(PH + 2) % DR, N, E, XKB>(ring, acc, a, fa, w, wn, lane, k0 + 2);
+            tall_step<(PH + 3) % DR, N, E, XKB>(ring, acc, a, fa, w, wn, lane, k0 + 3);
         }
     }
-    if constexpr (REM > 0) tall_step<(PH + 0) % DR, N, E>(ring, acc, a, fa, w, wn, lane, NREV * DR);
-    if constexpr (REM > 1) tall_step<(PH + 1) % DR, N, E>(ring, acc, a, fa, w, wn, lane, NREV * DR + 1);
-    if constexpr (REM > 2) tall_step<(PH + 2) % DR, N, E>(ring, acc, a, fa, w, wn, lane, NREV * DR + 2);
+    if constexpr (REM > 0) tall_step<(PH + 0) % DR, N, E, XKB>(ring, acc, a, fa, w, wn, lane, NREV * DR);
+    if constexpr (REM > 1) tall_step<(PH + 1) % DR, N, E, XKB>(ring, acc, a, fa, w, wn, lane, NREV * DR + 1);
+    if constexpr (REM > 2) tall_step<(PH + 2) % DR, N, E, XKB>(ring, acc, a, fa, w, wn, lane, NREV * DR + 2);
 }
 
 // C layout: acc[r] <-> (row 4*(lane>>4)+r, col lane&15); unconditional (pad rows hold finite junk)
@@ -224,9 +233,11 @@ DEVI void load_afrag(f32x4 (&a)[KB], const lfloat* A, int lda, int lane) {
 DEVI f32x4 wv_dot_rows(const lfloat* A, const lfloat* B, int lane) {
     const lfloat* ap = A + (lane & 15) * DFF_XLD + 4 * (lane >> 4);
     const lfloat* bp = B + (lane & 15) * DFF_XLD + 4 * (lane >> 4);
-    f32x4 av[5], bv[5];
+    f32x4 av[4], bv[4];
 #pragma unroll
-    for (int kb = 0; kb < 5; ++kb) { av[kb] = *(const lf32x4*)(ap + 16 * kb); bv[kb] = *(const lf32x4*)(bp + 16 * kb); }
+    for (int kb = 0; kb < 4; ++kb) { av[kb] = *(const lf32x4*)(ap + 16 * kb); bv[kb] = *(const lf32x4*)(bp + 16 * kb); }
+    // extension block: only its first 4 columns are ever non-zero (u | s, x | |x|^2, r | g_D): one k-step, exact
+    const float ax = ap[64 - 3 * (lane >> 4)], bx = bp[64 - 3 * (lane >> 4)];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -238,38 +249,35 @@ DEVI f32x4 wv_dot_rows(const lfloat* A, const lfloat* B, int lane) {
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2][s], bv[2][s], acc, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3][s], bv[3][s], acc2, 0, 0, 0);
     }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4][s], bv[4][s], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, bx, acc, 0, 0, 0);
     return acc + acc2;
 }
 
 // C[m][16nt+n] = sum_{k<16} Aop[m][k] B[k][16nt+n] for tiles nt in [NT0, NT1).
 // TRANS = false: Aop[m][k] = T[m][k] (T = 16x16 tile, ld DFF_PLD);  true: Aop[m][k] = T[k][m].
+// ks = k-steps that can be non-zero: columns / rows of T at or beyond the real rows are exact zeros (P, dS).
 template <int NT0, int NT1, bool TRANS, class Epi>
-DEVI void wv_mm(const lfloat* T, const lfloat* B, int lane, Epi epi) {
+DEVI void wv_mm(const lfloat* T, const lfloat* B, int lane, int ks, Epi epi) {
     const int kk = lane >> 4, mm = lane & 15;
+    // k-step s covers k = 4 s .. 4 s + 3 (lane: k = 4 s + kk), so trailing all-zero k-steps can be dropped
     float as[4];
-    if (TRANS) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) as[s] = T[(4 * kk + s) * DFF_PLD + mm];
-    } else {
-        const f32x4 t = *(const lf32x4*)(T + mm * DFF_PLD + 4 * kk);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) as[s] = t[s];
-    }
+    for (int s = 0; s < 4; ++s) as[s] = TRANS ? T[(4 * s + kk) * DFF_PLD + mm] : T[mm * DFF_PLD + 4 * s + kk];
     float bv[NT1 - NT0][4];
 #pragma unroll
     for (int nt = NT0; nt < NT1; ++nt)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) bv[nt - NT0][s] = B[(4 * kk + s) * DFF_XLD + 16 * nt + mm];
+        for (int s = 0; s < 4; ++s) bv[nt - NT0][s] = B[(4 * s + kk) * DFF_XLD + 16 * nt + mm];
     f32x4 acc[NT1 - NT0];
 #pragma unroll
     for (int nt = 0; nt < NT1 - NT0; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 4; ++s)
+        if (s == 0 || s < ks) {
 #pragma unroll
-        for (int nt = 0; nt < NT1 - NT0; ++nt)
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[s], bv[nt][s], acc[nt], 0, 0, 0);
+            for (int nt = 0; nt < NT1 - NT0; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[s], bv[nt][s], acc[nt], 0, 0, 0);
+        }
 #pragma unroll
     for (int nt = NT0; nt < NT1; ++nt) epi(nt, acc[nt - NT0]);
 }
@@ -340,6 +348,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     const int gcnt = min(G, a.B - b0);
     if (gcnt <= 0) return;
     const int rows = gcnt * N, RA = G * N;   // real rows of this workgroup / dummy stash row index
+    const int ks4 = __builtin_amdgcn_readfirstlane((rows + 3) >> 2);   // k-steps of a P / dS tile that can be non-zero
     lfloat* const sm = (lfloat*)smem;
     lfloat* const xst = sm + LL::xst; lfloat* const xs = sm + LL::xs; lfloat* const dxs = sm + LL::dxs;
     lfloat* const vst = sm + LL::vst; lfloat* const cm = sm + LL::cm; lfloat* const tn = sm + LL::tn;
@@ -654,7 +663,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         st_ntg(sb + sl.P + ((size_t)h * 16 + i) * 16 + col, p);
                     }
                     // O_ext = P V_ext (5 tiles) -> Q region; extension columns become xrel = xbar - x_i
-                    wv_mm<0, 5, false>(pb, Vx, lane, [&](int nt, const f32x4& acc) {
+                    wv_mm<0, 5, false>(pb, Vx, lane, ks4, [&](int nt, const f32x4& acc) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             float v = acc[r];
@@ -683,15 +692,15 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         head_commit(hr, Qx, Kx, Vx, pb, true, false, lane, RLA);
                         head_fetch(hr, sbq + sl.qkv + (size_t)(wave + 4) * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
                         head_math(wave);
-                        tall_run<0, 5, E>(ring, acc_o, wox_fa, s_wox(lw, wave), s_wox(lw, wave + 4), lane);
+                        tall_run<0, 5, E, 4>(ring, acc_o, wox_fa, s_wox(lw, wave), s_wox(lw, wave + 4), lane);
                         head_commit(hr, Qx, Kx, Vx, pb, true, false, lane, RLA);
                         head_math(wave + 4);
-                        tall_run<1, 5, E>(ring, acc_o, wox_fa, s_wox(lw, wave + 4), after, lane);
+                        tall_run<1, 5, E, 4>(ring, acc_o, wox_fa, s_wox(lw, wave + 4), after, lane);
                     } else {
                         head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
                         head_commit(hr, Qx, Kx, Vx, pb, true, false, lane, RLA);
                         head_math(wave);
-                        tall_run<0, 5, E>(ring, acc_o, wox_fa, s_wox(lw, wave), after, lane);
+                        tall_run<0, 5, E, 4>(ring, acc_o, wox_fa, s_wox(lw, wave), after, lane);
                     }
                     // the ring did not end on phase 0: re-stage the next block's first entries
                     ring_prefetch<E>(ring, after, lane);
@@ -734,20 +743,20 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         qkv_bias(std::integral_constant<int, 2>{}, wave + 4, bq);
                         head_math(wave);
                         pf.tick(13);
-                        tall_run<1, 5, E>(ring, acc_o, wox_fa, s_wox(lw, wave), s_qkv(lw, wave + 4), lane);
+                        tall_run<1, 5, E, 4>(ring, acc_o, wox_fa, s_wox(lw, wave), s_qkv(lw, wave + 4), lane);
                         pf.tick(14);
                         qkv(std::integral_constant<int, 2>{}, wave + 4, bq, s_wox(lw, wave + 4));
                         pf.tick(12);
                         head_math(wave + 4);
                         pf.tick(13);
-                        tall_run<3, 5, E>(ring, acc_o, wox_fa, s_wox(lw, wave + 4), after, lane);   // ends at phase 0
+                        tall_run<3, 5, E, 4>(ring, acc_o, wox_fa, s_wox(lw, wave + 4), after, lane);   // ends at phase 0
                         pf.tick(14);
                     } else {
                         qkv(std::integral_constant<int, 0>{}, wave, bq, s_wox(lw, wave));
                         pf.tick(12);
                         head_math(wave);
                         pf.tick(13);
-                        tall_run<13 % DR, 5, E>(ring, acc_o, wox_fa, s_wox(lw, wave), after, lane);       // 18 entries: phase 0
+                        tall_run<13 % DR, 5, E, 4>(ring, acc_o, wox_fa, s_wox(lw, wave), after, lane);       // 18 entries: phase 0
                         pf.tick(14);
                         static_assert(18 % DR == 0, "ring phase");
                     }
@@ -818,7 +827,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 for (int nt = 0; nt < E; ++nt) acc_f[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 {
                     const lfloat* const ha = hbuf + col * LF + 4 * quad;
-                    tall_run<NTS % DR, NTS, E>(ring, acc_f, [=](int kb) { return ha + 16 * kb; }, s_w2(lw), after, lane);
+                    tall_run<NTS % DR, NTS, E, -1>(ring, acc_f, [=](int kb) { return ha + 16 * kb; }, s_w2(lw), after, lane);
                 }
                 static_assert((2 * NTS) % DR == 0, "ring phase");
 #pragma unroll
@@ -981,7 +990,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 for (int nt = 0; nt < E; ++nt) acc_f[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 {
                     const lfloat* const ha = hbuf + col * LF + 4 * quad;
-                    tall_run<NTS % DR, NTS, E>(ring, acc_f, [=](int kb) { return ha + 16 * kb; }, s_w1t(lw), after, lane);
+                    tall_run<NTS % DR, NTS, E, -1>(ring, acc_f, [=](int kb) { return ha + 16 * kb; }, s_w1t(lw), after, lane);
                 }
 #pragma unroll
                 for (int nt = 0; nt < E; ++nt) c_store_all(mypart, LH, 16 * nt, acc_f[nt], lane);
@@ -1083,7 +1092,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 };
                 auto dqkv = [&]() {
                     // dV_ext = P^T G_ext -> V region (ext columns: dx term sum_i a_ij r_i)
-                    wv_mm<0, 5, true>(pb, Gx, lane, [&](int nt, const f32x4& acc) {
+                    wv_mm<0, 5, true>(pb, Gx, lane, ks4, [&](int nt, const f32x4& acc) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             Vx[lro[r] + 16 * nt + col] = acc[r];
@@ -1091,7 +1100,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         }
                     });
                     // dQ_ext = dS K_ext -> G region (ext columns: du, and ds in the GEN variants)
-                    wv_mm<0, 5, false>(dsb, Kx, lane, [&](int nt, const f32x4& acc) {
+                    wv_mm<0, 5, false>(dsb, Kx, lane, ks4, [&](int nt, const f32x4& acc) {
                         f32x4 v = acc;
                         if constexpr (GEN) {
                             if (nt == 4) {
@@ -1102,7 +1111,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         c_store_all(Gx, DFF_XLD, 16 * nt, v, lane, RLA - 1);
                     });
                     // dK_ext = dS^T Q_ext -> K region (ext columns: dx term sum_i dS_ij u_i)
-                    wv_mm<0, 5, true>(dsb, Qx, lane, [&](int nt, const f32x4& acc) {
+                    wv_mm<0, 5, true>(dsb, Qx, lane, ks4, [&](int nt, const f32x4& acc) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             Kx[lro[r] + 16 * nt + col] = acc[r];
@@ -1111,16 +1120,16 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     });
                 };
                 auto dx_only = [&]() {   // layer 0: node inputs do not depend on x
-                    wv_mm<4, 5, true>(pb, Gx, lane, [&](int, const f32x4& acc) {
+                    wv_mm<4, 5, true>(pb, Gx, lane, ks4, [&](int, const f32x4& acc) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) dxw[dxi[r]] += GEN ? dx_ext(quad * 4 + r, col, acc[r]) : acc[r];
                     });
-                    wv_mm<4, 5, true>(dsb, Qx, lane, [&](int, const f32x4& acc) {
+                    wv_mm<4, 5, true>(dsb, Qx, lane, ks4, [&](int, const f32x4& acc) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) dxw[dxi[r]] += GEN ? dx_ext(quad * 4 + r, col, acc[r]) : acc[r];
                     });
                     if constexpr (GEN) {   // the distance term of the logits reaches x_i through Q_ext: -2 s_i sum_j dS_ij x_j
-                        wv_mm<4, 5, false>(dsb, Kx, lane, [&](int, const f32x4& acc) {
+                        wv_mm<4, 5, false>(dsb, Kx, lane, ks4, [&](int, const f32x4& acc) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) (void)dq_ext(quad * 4 + r, col, acc[r]);
                         });
@@ -1147,7 +1156,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         pf.tick(16);
                         dqkv();
                         pf.tick(17);
-                        tall_run<1, 13, E>(ring, acc_a, qkvt_fa, s_qkvt(lw, wave), s_woxt(lw, h1), lane);
+                        tall_run<1, 13, E, 4>(ring, acc_a, qkvt_fa, s_qkvt(lw, wave), s_woxt(lw, h1), lane);
                         pf.tick(18);
                         head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
                         committed();
@@ -1158,7 +1167,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         pf.tick(16);
                         dqkv();
                         pf.tick(17);
-                        tall_run<3, 13, E>(ring, acc_a, qkvt_fa, s_qkvt(lw, h1), after, lane);   // ends at phase 0
+                        tall_run<3, 13, E, 4>(ring, acc_a, qkvt_fa, s_qkvt(lw, h1), after, lane);   // ends at phase 0
                         pf.tick(18);
                     } else {
                         head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, true, lane, m12p(wave));
@@ -1172,7 +1181,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         pf.tick(16);
                         dqkv();
                         pf.tick(17);
-                        tall_run<5 % DR, 13, E>(ring, acc_a, qkvt_fa, s_qkvt(lw, wave), after, lane);   // 18 entries: phase 0
+                        tall_run<5 % DR, 13, E, 4>(ring, acc_a, qkvt_fa, s_qkvt(lw, wave), after, lane);   // 18 entries: phase 0
                         pf.tick(18);
                     }
 #pragma unroll
