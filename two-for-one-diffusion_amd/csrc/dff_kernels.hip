@@ -261,9 +261,16 @@ DEVI void mfma4(f32x4& acc, const f32x4 a, const f32x4 b) {
 // together with the tile's weights, so their latency is hidden by the ring as well.
 // Register diet (two waves per SIMD share 512 registers): the ring holds D tiles with D * KB ~ 12-16
 // k-blocks in flight, and the A fragments are re-read from LDS for every tile unless they are few.
-template <int MT, int KB, int NAUX, class Pre, class Epi>
+// hook() runs right after the first ring loads are issued: the place to start long-latency loads (stash rows out of
+// HBM) that must NOT be older than the weight loads -- vmcnt retires in order, so a wave that issued them first would
+// wait for the HBM round trip before its first MFMA.
+struct NoHook { DEVI void operator()() const {} };
+// NTN_MAX > 0: the caller guarantees ntn <= NTN_MAX; when that fits the ring (no refills) the tile loop is
+// unrolled away, which also lets the compiler count the loads in flight exactly (a loop with refills makes it wait
+// for everything younger, hook loads included).
+template <int MT, int KB, int NAUX, int NTN_MAX = 0, class Pre, class Epi, class Hook = NoHook>
 DEVI void gemm_wide(const lfloat* A, int lda, int rowsA, const float* __restrict__ Wp, int KBtot,
-                    int kb0, int nt0, int ntn, Pre pre, Epi epi) {
+                    int kb0, int nt0, int ntn, Pre pre, Epi epi, Hook hook = Hook()) {
     const int tid_ = tid_now();
     constexpr int D = KB >= 6 ? 2 : 3;
     constexpr bool HOLD = MT * KB <= 16;   // keep all A fragments in registers
@@ -291,7 +298,9 @@ DEVI void gemm_wide(const lfloat* A, int lda, int rowsA, const float* __restrict
             for (int kb = 0; kb < KB; ++kb) b[d][kb] = wp[((size_t)(nt0 + wave + DFF_NWAVES * d) * KBtot + kb) * 64];
             pre(wave + DFF_NWAVES * d, aux[d]);
         }
-    for (int i0 = 0; i0 < cnt; i0 += D) {
+    hook();
+    constexpr bool ONCE = NTN_MAX > 0 && NTN_MAX <= D * DFF_NWAVES;
+    for (int i0 = 0; i0 < (ONCE ? 1 : cnt); i0 += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const int i = i0 + d;
@@ -317,7 +326,7 @@ DEVI void gemm_wide(const lfloat* A, int lda, int rowsA, const float* __restrict
                 float auxc[NAUX];
 #pragma unroll
                 for (int q = 0; q < NAUX; ++q) auxc[q] = aux[d][q];
-                if (i + D < cnt) {
+                if (!ONCE && i + D < cnt) {
 #pragma unroll
                     for (int kb = 0; kb < KB; ++kb)
                         b[d][kb] = wp[((size_t)(nt0 + nt + DFF_NWAVES * D) * KBtot + kb) * 64];
@@ -326,6 +335,49 @@ DEVI void gemm_wide(const lfloat* A, int lda, int rowsA, const float* __restrict
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) epi(nt, mt, NC == 2 ? acc[mt][0] + acc[mt][NC - 1] : acc[mt][0], auxc);
             }
+        }
+    }
+}
+
+// wide GEMM with few output tiles (NTN * MT (tile, row-tile) units <= a few per wave): the UNITS, not the tiles, go
+// round-robin over the waves, so that all four SIMDs carry the same MFMA load; loop-free, all weights loaded up
+// front, hook() as in gemm_wide.  epi(nt_local, mt, acc).
+template <int MT, int KB, int NTN, class Epi, class Hook>
+DEVI void gemm_wide_units(const lfloat* A, int lda, int rowsA, const float* __restrict__ Wp, int KBtot,
+                          int kb0, int nt0, Epi epi, Hook hook) {
+    const int tid_ = tid_now();
+    constexpr int NU = NTN * MT, DU = (NU + DFF_NWAVES - 1) / DFF_NWAVES;
+    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+    const int kk = lane >> 4, mm = lane & 15;
+    const gf32x4* wp = (const gf32x4*)Wp + lane + (size_t)kb0 * 64;
+    f32x4 b[DU][KB];
+#pragma unroll
+    for (int d = 0; d < DU; ++d) {
+        const int u = wave + DFF_NWAVES * d;
+        if (u < NU) {
+            const int nt = u / MT;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) b[d][kb] = wp[((size_t)(nt0 + nt) * KBtot + kb) * 64];
+        }
+    }
+    hook();
+#pragma unroll
+    for (int d = 0; d < DU; ++d) {
+        const int u = wave + DFF_NWAVES * d;
+        if (u < NU) {
+            const int nt = u / MT, mt = u - nt * MT;
+            const lfloat* ap = A + min(mt * 16 + mm, rowsA - 1) * lda + 4 * kk;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < KB; kb += 2) {
+                const f32x4 a0 = *(const lf32x4*)(ap + 16 * kb), a1 = *(const lf32x4*)(ap + 16 * kb + 16);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s4], b[d][kb][s4], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s4], b[d][kb + 1][s4], acc1, 0, 0, 0);
+                }
+            }
+            epi(nt, mt, acc0 + acc1);
         }
     }
 }
@@ -1158,49 +1210,63 @@ struct CoReload {
     static constexpr int NP = 4 * MT * HGS;                  // float4 per row of the P blocks
     static constexpr int U = (16 * MT * (NQ + NP) + DFF_NTHREADS - 1) / DFF_NTHREADS;
     f32x4 t[U];
+    // per item: [0,14) source offset (float4 units, from the head group's q|k|v or P block), [14,28) LDS offset
+    // (float4 units, from Rg or Pbuf), bit 28: q|k|v item (else P), bit 29: in range
+    unsigned code[U];
 };
+// The item -> address maps depend on the thread and the workgroup's row count only: planned once per hg loop
+// (the divisions are the expensive part), then every issue / commit is an unpack and an add.
 template <int MT, int HGS>
-DEVI void co_reload_issue(CoReload<MT, HGS>& rl, const CoGeo& g, const gfloat* sqkv /* head hg*HGS */,
-                          const gfloat* sP, bool need_p, int tid) {
+DEVI void co_reload_plan(CoReload<MT, HGS>& rl, const CoGeo& g, bool need_p, int tid) {
     using RL = CoReload<MT, HGS>;
-    constexpr int PS = 16 * MT;
+    constexpr int PS = 16 * MT, LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL;
     const int nq = g.rows * RL::NQ, total = nq + (need_p ? g.rows * RL::NP : 0);
 #pragma unroll
     for (int u = 0; u < RL::U; ++u) {
-        const int it = u * DFF_NTHREADS + tid;
-        if (it < nq) {
-            const int row = it / RL::NQ, r2 = it - row * RL::NQ;
-            const int hh = r2 / (DFF_QKVW / 4), c4 = r2 - hh * (DFF_QKVW / 4);
-            rl.t[u] = ld_ntg4(sqkv + ((size_t)hh * g.RN + row) * DFF_QKVW + 4 * c4);
-        } else if (it < total) {
-            const int ip = it - nq;
-            const int row = ip / RL::NP, r2 = ip - row * RL::NP;
-            const int hh = r2 / (4 * MT), c4 = r2 - hh * (4 * MT);
-            rl.t[u] = ld_ntg4(sP + ((size_t)hh * g.RN + row) * PS + 4 * c4);
-        }
-    }
-}
-template <int MT, int HGS>
-DEVI void co_reload_commit(const CoReload<MT, HGS>& rl, const CoGeo& g, bool need_p, int tid) {
-    using RL = CoReload<MT, HGS>;
-    constexpr int LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL;
-    const int nq = g.rows * RL::NQ, total = nq + (need_p ? g.rows * RL::NP : 0);
-#pragma unroll
-    for (int u = 0; u < RL::U; ++u) {
-        const int it = u * DFF_NTHREADS + tid;
+        const int it0 = u * DFF_NTHREADS + tid;
+        const int it = min(it0, total - 1);       // out-of-range items re-read the last one and store nothing
+        unsigned code;
         if (it < nq) {
             const int row = it / RL::NQ, r2 = it - row * RL::NQ;
             const int hh = r2 / (DFF_QKVW / 4), c4 = r2 - hh * (DFF_QKVW / 4);
             const int colq = 4 * c4;
             const int reg = (colq >= 80) + (colq >= 144);
             const int cl = colq - 80 * reg + 16 * (reg >> 1);
-            *(lf32x4*)(g.Rg + reg * g.RN * LQ + row * LQ + hh * 80 + cl) = rl.t[u];
-        } else if (it < total) {
+            const unsigned src = (unsigned)((hh * g.RN + row) * (DFF_QKVW / 4) + c4);
+            const unsigned dst = (unsigned)(reg * g.RN * LQ + row * LQ + hh * 80 + cl) >> 2;
+            code = src | dst << 14 | 1u << 28;
+        } else {
             const int ip = it - nq;
             const int row = ip / RL::NP, r2 = ip - row * RL::NP;
             const int hh = r2 / (4 * MT), c4 = r2 - hh * (4 * MT);
-            *(lf32x4*)(g.Pbuf + hh * PT + row * PL + 4 * c4) = rl.t[u];
+            const unsigned src = (unsigned)((hh * g.RN + row) * (PS / 4) + c4);
+            const unsigned dst = (unsigned)(hh * PT + row * PL + 4 * c4) >> 2;
+            code = src | dst << 14;
         }
+        rl.code[u] = code | (it0 < total ? 1u << 29 : 0u);
+    }
+}
+// every lane issues all U loads: a fixed number of loads in flight lets the compiler count vmcnt exactly
+template <int MT, int HGS>
+DEVI void co_reload_issue(CoReload<MT, HGS>& rl, const gfloat* sqkv /* head hg*HGS */, const gfloat* sP) {
+    using RL = CoReload<MT, HGS>;
+#pragma unroll
+    for (int u = 0; u < RL::U; ++u) {
+        const unsigned code = rl.code[u];
+        const gfloat* const base = (code >> 28 & 1u) ? sqkv : sP;
+        rl.t[u] = ld_ntg4(base + 4 * (code & 0x3fffu));
+    }
+    // without this the compiler sinks the loads down to their use in co_reload_commit (no global store in between)
+    asm volatile("" ::: "memory");
+}
+template <int MT, int HGS>
+DEVI void co_reload_commit(const CoReload<MT, HGS>& rl, const CoGeo& g) {
+    using RL = CoReload<MT, HGS>;
+#pragma unroll
+    for (int u = 0; u < RL::U; ++u) {
+        const unsigned code = rl.code[u];
+        lfloat* const base = (code >> 28 & 1u) ? g.Rg : g.Pbuf;
+        if (code >> 29 & 1u) *(lf32x4*)(base + 4 * (code >> 14 & 0x3fffu)) = rl.t[u];
     }
 }
 
@@ -1372,8 +1438,9 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 if (cached) {
                     const int tid = tid_now();
                     CoReload<MT, HGS> rl;
-                    co_reload_issue<MT, HGS>(rl, geo, sqkv_r + (size_t)hg * HGS * RN * DFF_QKVW, sPl, false, tid);
-                    co_reload_commit<MT, HGS>(rl, geo, false, tid);
+                    co_reload_plan<MT, HGS>(rl, geo, false, tid);
+                    co_reload_issue<MT, HGS>(rl, sqkv_r + (size_t)hg * HGS * RN * DFF_QKVW, sPl);
+                    co_reload_commit<MT, HGS>(rl, geo);
                 }
                 else {
                     const int tid = tid_now();
@@ -1507,11 +1574,17 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             }
             store_tall<MT, NTW>(acc_f, tbuf, LH, rows, NT_H, nullptr);
             wg_sync<SPILL>();
+            // The stashed q|k|v|P rows of head group hg + 1 are requested as soon as those of hg have been committed
+            // to LDS, a whole group's worth of phases before they are needed (group 0: before the row stage below):
+            // by the next weight load they have landed, so they delay nothing (vmcnt retires in order).
+            const gfloat* const sqkv = (const gfloat*)(l == 0 ? c.l0 : sb) + c.sl.qkvx;
+            const gfloat* const sPl = (const gfloat*)sb + c.sl.P;
+            CoReload<MT, HGS> rl;
+            co_reload_plan<MT, HGS>(rl, geo, true, tid_now());
+            co_reload_issue<MT, HGS>(rl, sqkv, sPl);
             rowb_ln2_gate1<H>(c, lw, l, tbuf);
             wg_sync<SPILL>();
             pf.tick(14);
-            const gfloat* const sqkv = (const gfloat*)(l == 0 ? c.l0 : sb) + c.sl.qkvx;
-            const gfloat* const sPl = (const gfloat*)sb + c.sl.P;
             f32x4 acc_a[NTW][MT];
             acc_zero<MT, NTW>(acc_a);
             pf.tick(15);
@@ -1520,15 +1593,10 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 // dE/dx_i -= r_i
                 {
                     const int tid = tid_now();
-                    // the stash loads of this head group fly while the G_ext GEMM runs
-                    CoReload<MT, HGS> rl;
-                    co_reload_issue<MT, HGS>(rl, geo, sqkv + (size_t)hg * HGS * RN * DFF_QKVW,
-                                             sPl + (size_t)hg * HGS * RN * c.sl.PS, true, tid);
                     lfloat* const Gl = geo.Rg + 3 * RN * LQ;
                     lfloat* const dxw = geo.dxw;
-                    gemm_wide<MT, NT_H, 1>(abufL, LH, RN, lw.WoxT_p, NT_H, 0, hg * HGS * 5, HGS * 5,
-                        [=](int, float (&)[1]) {},
-                        [=](int nt, int mt, const f32x4& acc, const float (&)[1]) {
+                    gemm_wide_units<MT, NT_H, HGS * 5>(abufL, LH, RN, lw.WoxT_p, NT_H, 0, hg * HGS * 5,
+                        [=](int nt, int mt, const f32x4& acc) {
                             const int lane = tid & 63, quad = lane >> 4, cl = lane & 15;
                             const int hh = nt / 5, tt = nt - 5 * hh;
 #pragma unroll
@@ -1539,8 +1607,12 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                                     if (tt == 4 && cl < 3) dxw[row * 4 + cl] -= acc[r];
                                 }
                             }
-                        });
-                    co_reload_commit<MT, HGS>(rl, geo, true, tid);
+                        },
+                        NoHook());
+                    co_reload_commit<MT, HGS>(rl, geo);
+                    if (hg + 1 < NHG)
+                        co_reload_issue<MT, HGS>(rl, sqkv + (size_t)(hg + 1) * HGS * RN * DFF_QKVW,
+                                                 sPl + (size_t)(hg + 1) * HGS * RN * c.sl.PS);
                     if (GEN) {   // [m1 | m2] rows of this head group (contiguous in the stash and in LDS)
                         const gfloat* const sM = (const gfloat*)sb + c.sl.m12 + (size_t)hg * HGS * RN * 4;
                         for (int i2 = tid; i2 < HGS * RN * 4; i2 += DFF_NTHREADS) geo.m12[i2] = ld_ntg(sM + i2);
