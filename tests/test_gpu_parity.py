@@ -452,3 +452,34 @@ def test_batch_split_over_launches_is_invisible(dff, cfg):
         nat.max_workgroups(2048)
     for a, b in zip(out[2048], out[3]):
         assert np.isfinite(a).all() and np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_langevin_equipartition_at_full_size(dff):
+    """BASELINE config 2 as shipped (256 parallel simulations, 10 000 steps, save interval 250, in-kernel Philox
+    noise): a size-independent property of the BAOA(F)B thermostat (langevin_cgnet.py:447-479).  The O step is
+    v <- vscale v + sqrt(1 - vscale^2) sqrt(1 / (beta m)) xi, so once the velocities have relaxed (1 / friction =
+    1290 steps here) every degree of freedom carries 1 / (2 beta) of kinetic energy whatever the force field is:
+    <KE> = 3 N / (2 beta).  Checks the fused loop, the RNG stream (mean / variance / independence across
+    trajectories) and the unit bookkeeping at the size the benchmark runs."""
+    from dff_amd.langevin import LangevinDiffusion
+    diff, _ = _diffusion(dff, "chignolin", decoder_scale=1e-2, norm=NORM_STD["chignolin"])
+    P, N = 256, 10
+    init = torch.from_numpy(synth.normal((P, N, 3), 11, 4).astype(np.float32)) * NORM_STD["chignolin"]
+    init = init - init.mean(1, keepdim=True)
+    ld = LangevinDiffusion(diff, init, n_timesteps=10000, save_interval=250, t=20, temp_data=340, temp_sim=340, dt=None,
+                           masses=[12.0] * N, friction=1.0, verbose=False, seed=2024)
+    traj = ld.sample()
+    assert traj.shape == (P * 40, N, 3) and torch.isfinite(traj).all()
+    c = twin.langevin_constants(NORM_STD["chignolin"], 20, twin.make_schedule(), 340, 340, [12.0] * N, 1.0, None)
+    ke = np.asarray(ld.kinetic_energies)                      # (n_sims, n_frames)
+    assert ke.shape == (P, 40)
+    expect = 1.5 * N / c["beta"]
+    late = ke[:, 30:]                                         # steps 7750 .. 10000: six relaxation times in
+    assert abs(late.mean() / expect - 1.0) < 0.04, (late.mean(), expect)
+    # per-trajectory KE is chi-square with 3N degrees of freedom: relative variance 2 / (3 N)
+    rel_var = late.var() / late.mean() ** 2
+    assert 0.6 * 2 / (3 * N) < rel_var < 1.5 * 2 / (3 * N), rel_var
+    # early frames are still heating up from v0 = 0: <KE(t)> = KE_eq (1 - exp(-2 friction t))
+    t1 = 250 * c["dt"]
+    assert abs(ke[:, 0].mean() / (expect * (1 - np.exp(-2 * t1))) - 1.0) < 0.12
