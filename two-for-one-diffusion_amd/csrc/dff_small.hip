@@ -110,9 +110,11 @@ DEVI WStream tall_stream(const float* Wp, int KBtot, int kw0) {
 }
 template <int E>
 DEVI void ring_fill(f32x4 (&slot)[E], const WStream& w, int j, int lane) {
+    // uniform 64-bit base (SALU) + zero-extended 32-bit lane offset: the saddr form of global_load, no 64-bit VALU adds
     const gf32x4* p = w.base + (size_t)j * w.estep;
+    const unsigned lo = (unsigned)lane & 63u;   // known bits: lo << 4 cannot wrap
 #pragma unroll
-    for (int e = 0; e < E; ++e) slot[e] = p[(size_t)e * w.pstride + lane];
+    for (int e = 0; e < E; ++e) slot[e] = (p + (size_t)e * w.pstride)[lo];
 }
 template <int E, int DR>
 DEVI void ring_prefetch(Ring<E, DR>& r, const WStream& w, int lane) {
