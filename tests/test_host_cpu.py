@@ -176,3 +176,20 @@ def test_two_rank_gather_gloo(tmp_path):
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("-ok") == 2 and "rank0" in r.stdout and "rank1" in r.stdout, r.stdout
+
+
+def test_bench_finds_the_profiled_traffic_for_the_shipped_kernels():
+    """bench.py's roofline.traffic comes from the committed rocprofv3 PMC summary (profiles/<round>/traffic.json);
+    rocprofv3 prints the full template argument list, the library the short kernel name: both must match."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    t = bench.hbm_traffic_from_profile("dff_small_kernel<64,8>", "chignolin", 256, 250)
+    assert t is not None and 1e9 < t < 1e12
+    assert bench.hbm_traffic_from_profile("dff_fused_kernel<128,3,1,false>", "villin", 256, 250) is not None
+    assert bench.hbm_traffic_from_profile("dff_small_kernel<64,8>", "chignolin", 128, 250) is None   # other workload
+    # algorithmic FLOPs per launch of the headline config (SURVEY section 8d): 22.00 MFLOP x 256 x 250
+    assert abs(bench.MFLOP_PER_CALL["chignolin"] * 1e6 * 256 * 250 - 1.408e12) < 1e6
