@@ -1610,13 +1610,14 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         },
                         NoHook());
                     co_reload_commit<MT, HGS>(rl, geo);
-                    if (hg + 1 < NHG)
-                        co_reload_issue<MT, HGS>(rl, sqkv + (size_t)(hg + 1) * HGS * RN * DFF_QKVW,
-                                                 sPl + (size_t)(hg + 1) * HGS * RN * c.sl.PS);
-                    if (GEN) {   // [m1 | m2] rows of this head group (contiguous in the stash and in LDS)
+                    if (GEN) {   // [m1 | m2] rows of this head group (contiguous in the stash and in LDS); before the
+                                 // next group's rows are requested: a load issued after them would wait for them
                         const gfloat* const sM = (const gfloat*)sb + c.sl.m12 + (size_t)hg * HGS * RN * 4;
                         for (int i2 = tid; i2 < HGS * RN * 4; i2 += DFF_NTHREADS) geo.m12[i2] = ld_ntg(sM + i2);
                     }
+                    if (hg + 1 < NHG)
+                        co_reload_issue<MT, HGS>(rl, sqkv + (size_t)(hg + 1) * HGS * RN * DFF_QKVW,
+                                                 sPl + (size_t)(hg + 1) * HGS * RN * c.sl.PS);
                 }
                 co_fill_x<HGS, GEN>(geo);
                 wg_sync<SPILL>();
