@@ -53,26 +53,55 @@ static std::vector<float> pack_b(int K, int Nout, const std::function<double(int
     return out;
 }
 
+// B operand of v_mfma_f32_16x16x32_bf16 for the split-bf16 GEMMs (dff_kernels.hip gemm_wide_split): per (tile,
+// 32-row k-block, piece h | m | l, lane) eight bf16 = W[32 kb + 8 (lane >> 4) + j][16 nt + (lane & 15)], j = 0..7,
+// two per dword (even j in the low half).  w = h + m + l exactly (truncation split of the fp32 weight).
+static std::vector<uint32_t> pack_b_split(int K, int Nout, const std::function<double(int, int)>& w) {
+    const int KB = K / 32, NT = (Nout + 15) / 16;
+    std::vector<uint32_t> out((size_t)NT * KB * 3 * 64 * 4, 0u);
+    auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+    auto flt = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+    for (int nt = 0; nt < NT; ++nt)
+        for (int kb = 0; kb < KB; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 32 * kb + 8 * (lane >> 4) + j, n = 16 * nt + (lane & 15);
+                    const float v = n < Nout ? (float)w(k, n) : 0.f;
+                    const uint32_t h = bits(v) & 0xffff0000u;
+                    const float r = v - flt(h);
+                    const uint32_t mm = bits(r) & 0xffff0000u;
+                    const float r2 = r - flt(mm);
+                    const uint32_t pc[3] = {h >> 16, mm >> 16, bits(r2) >> 16};
+                    for (int p = 0; p < 3; ++p)
+                        out[((((size_t)nt * KB + kb) * 3 + p) * 64 + lane) * 4 + (j >> 1)] |= pc[p] << (16 * (j & 1));
+                }
+    return out;
+}
+
 // ------------------------------------------------------------------------------------------
 // model handle
 // ------------------------------------------------------------------------------------------
 struct Variant {
     int H, MT, HGS;
-    bool spill, gen;
+    bool spill, gen, spw;
     const void* fn;
     unsigned (*lds_floats)(int N, int G);
     const char* name;
 };
-template <int H, int MT, int HGS, bool SP>
-static unsigned lds_floats_of(int N, int G) { return LdsLayout<H, MT, HGS, SP>(N, G).total; }
+template <int H, int MT, int HGS, bool SP, bool SPW>
+static unsigned lds_floats_of(int N, int G) { return LdsLayout<H, MT, HGS, SP>(N, G, SPW).total; }
 #define VAR(H, MT, HGS, SP)                                                                                     \
-    { H, MT, HGS, SP, false, (const void*)&dff_fused_kernel<H, MT, HGS, SP, false>, &lds_floats_of<H, MT, HGS, SP>,  \
-      "dff_fused_kernel<" #H "," #MT "," #HGS "," #SP ">" },                                                    \
-    { H, MT, HGS, SP, true, (const void*)&dff_fused_kernel<H, MT, HGS, SP, true>, &lds_floats_of<H, MT, HGS, SP>,    \
-      "dff_fused_kernel<" #H "," #MT "," #HGS "," #SP ",gen>" }
+    { H, MT, HGS, SP, false, false, (const void*)&dff_fused_kernel<H, MT, HGS, SP, false, false>,               \
+      &lds_floats_of<H, MT, HGS, SP, false>, "dff_fused_kernel<" #H "," #MT "," #HGS "," #SP ">" },             \
+    { H, MT, HGS, SP, true, false, (const void*)&dff_fused_kernel<H, MT, HGS, SP, true, false>,                 \
+      &lds_floats_of<H, MT, HGS, SP, false>, "dff_fused_kernel<" #H "," #MT "," #HGS "," #SP ",gen>" }
+#define VAR_SPW(H, MT, HGS)                                                                                     \
+    { H, MT, HGS, false, false, true, (const void*)&dff_fused_kernel<H, MT, HGS, false, false, true>,           \
+      &lds_floats_of<H, MT, HGS, false, true>, "dff_fused_kernel<" #H "," #MT "," #HGS ",false,split_bf16>" }
 static const Variant g_variants[] = {
     VAR(64, 1, 4, false),  VAR(64, 2, 2, false),  VAR(96, 1, 4, false),  VAR(96, 2, 2, false),
     VAR(128, 1, 4, false), VAR(128, 2, 2, false), VAR(128, 3, 1, false), VAR(128, 4, 1, true),
+    VAR_SPW(96, 2, 2), VAR_SPW(128, 2, 2), VAR_SPW(128, 3, 1),
 };
 
 struct dff_model {
@@ -102,7 +131,17 @@ struct dff_model {
     bool l0_off = false;                       // debugging: never use the table
     int max_wgs = 2048;                        // workgroups per launch: bounds the stash (grid x stash slot) for big batches
     int last_base = 0;
+    bool split = false;                        // DFF_SPLIT_BF16=1 at model creation: split-bf16 images exist, SPW variants preferred
 };
+
+static int upload_u32(dff_model* m, const std::vector<uint32_t>& h, const unsigned** out) {
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, h.size() * sizeof(uint32_t)));
+    m->allocs.push_back(p);
+    HIPCHK(hipMemcpy(p, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    *out = (const unsigned*)p;
+    return DFF_OK;
+}
 
 static int upload(dff_model* m, const std::vector<float>& h, const float** out) {
     void* p = nullptr;
@@ -185,6 +224,10 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
     dff_model* m = new dff_model();
     m->cfg = *cfg;
     m->device = device;
+    {   // opt-in: K = H weight GEMMs of the generic kernel on the bf16 pipe via the exact three-way split
+        const char* e = getenv("DFF_SPLIT_BF16");
+        m->split = e && e[0] == '1';
+    }
     memset(&m->dev, 0, sizeof m->dev);
     m->dev.N = N; m->dev.H = H; m->dev.L = L; m->dev.T = cfg->timesteps;
 
@@ -316,6 +359,13 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
             return e < 67 ? Woc[(size_t)c * 24 + 3 * h + e - 64] : e == 67 ? Wod[(size_t)c * 8 + h] : 0.0;
         };
         UP(pack_b(H, 8 * 208, [&](int k, int n) { return wqkvx(n, k); }), d.Wqkvx_p);
+        d.Wqkvx_s = d.W1_s = d.W2T_s = nullptr;
+        if (m->split) {
+            int rc_;
+            if ((rc_ = upload_u32(m, pack_b_split(H, 8 * 208, [&](int k, int n) { return wqkvx(n, k); }), &d.Wqkvx_s))) return rc_;
+            if ((rc_ = upload_u32(m, pack_b_split(H, F, [&](int k, int n) { return (double)W1[(size_t)n * H + k]; }), &d.W1_s))) return rc_;
+            if ((rc_ = upload_u32(m, pack_b_split(H, F, [&](int k, int n) { return (double)W2[(size_t)k * F + n]; }), &d.W2T_s))) return rc_;
+        }
         UP(bqkvx, d.bqkvx);
         UP(pack_b(8 * 80, H, [&](int k, int n) { return wox(k, n); }, 5), d.Wox_p);
         UP(pack_b(H, 8 * 80, [&](int k, int n) { return wox(n, k); }), d.WoxT_p);
@@ -561,12 +611,16 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
         return launch_small(m, a, G, stream);
     }
     const Variant* v = nullptr;
-    for (const Variant& c : g_variants)
-        if (c.H == H && c.MT == mt && c.gen == gen) { v = &c; break; }
+    auto pick = [&](int mt_) {
+        const Variant* r = nullptr;
+        for (const Variant& c : g_variants)
+            if (c.H == H && c.MT == mt_ && c.gen == gen && (!c.spw || m->split) && (!r || c.spw)) r = &c;
+        return r;
+    };
+    v = pick(mt);
     if (!v) {  // fall back to one protein per workgroup
         G = 1; mt = mt_min;
-        for (const Variant& c : g_variants)
-            if (c.H == H && c.MT == mt && c.gen == gen) { v = &c; break; }
+        v = pick(mt);
     }
     if (!v) return fail(DFF_EINVAL, "no kernel variant for hidden=%d rows=%d", H, G * N);
     if (want_tab) {

@@ -102,8 +102,9 @@ struct LdsLayout {
     static constexpr int FC = (F % 256 == 0) ? 256 : 128;
     static constexpr int LF = FC + 4;
     static constexpr int NREG = MT < 4 ? 5 : 4;   // a fifth head-group buffer (backward: dQ_ext) where LDS allows
-    unsigned xst, xs, dxs, vst, cm, tn, prof, prow, dxw, m12, abuf, resbuf, Pbuf, dSbuf, Rg, total;
-    __host__ __device__ LdsLayout(int N, int G) {
+    static constexpr int LHS2 = (H + 8) / 2;   // dwords per row of a bf16 piece of the split A operand (SPW variants)
+    unsigned xst, xs, dxs, vst, cm, tn, prof, prow, dxw, m12, abuf, resbuf, Pbuf, dSbuf, Rg, asplit, total;
+    __host__ __device__ LdsLayout(int N, int G, bool spw = false) {
         const unsigned R = (unsigned)(G * N);
         unsigned o = 0;
         xst = o;   o += R * 4;
@@ -125,6 +126,8 @@ struct LdsLayout {
         if (R * LF > rsz) rsz = R * LF;
         if (R * LH > rsz) rsz = R * LH;
         o += rsz + 64;  // slack: clamped A-fragment reads never leave the allocation
+        asplit = o;
+        if (spw) o += 3u * R * LHS2;   // [h | m | l] bf16 pieces of abuf (R x H each, row stride H + 8)
         total = o;
     }
 };
@@ -334,6 +337,116 @@ DEVI void gemm_wide(const lfloat* A, int lda, int rowsA, const float* __restrict
                 }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) epi(nt, mt, NC == 2 ? acc[mt][0] + acc[mt][NC - 1] : acc[mt][0], auxc);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// SPW variants (opt-in, DFF_SPLIT_BF16=1): the K = H weight GEMMs on the bf16 matrix pipe at fp32 accuracy.
+// An fp32 value is the exact sum of three bf16 pieces (truncation split: h = top 16 bits, r = a - h exactly, ...);
+// a.b ~ ah.bh + (am.bh + ah.bm) + (al.bh + ah.bl + am.bm) drops only terms of order 2^-24 (tools_ubench/split_bf16.hip:
+// error vs fp64 <= that of v_mfma_f32_16x16x4_f32).  The weights are split on the host (dff_host.hip pack_b_split),
+// the activations by split_rows once per GEMM input; six v_mfma_f32_16x16x32_bf16 (16 cycles each, and they leave the
+// vector port free: tools_ubench/overlap3.hip) replace eight v_mfma_f32_16x16x4_f32 (32 cycles each).
+// ------------------------------------------------------------------------------------------
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) unsigned lu32;
+typedef __attribute__((address_space(3))) u32x4 lu32x4;
+typedef __attribute__((address_space(1))) u32x4 gu32x4;
+DEVI f32x4 mfma_bf16(const u32x4 a, const u32x4 b, const f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// abuf (R x H fp32, leading dimension H + 4) -> as[piece][row][LHS2] (bf16 pairs): all threads, two columns each
+template <int H>
+DEVI void split_rows(const lfloat* abuf, lu32* as, int R) {
+    constexpr int LH = H + 4, LHS2 = (H + 8) / 2;
+    const int tid_ = tid_now();
+    for (int it = tid_; it < R * (H / 2); it += DFF_NTHREADS) {
+        const int row = it / (H / 2), c2 = it - row * (H / 2);
+        unsigned hh[2], mm[2], ll[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float v = abuf[row * LH + 2 * c2 + q];
+            const unsigned uh = __float_as_uint(v) & 0xffff0000u;
+            const float r = v - __uint_as_float(uh);
+            const unsigned um = __float_as_uint(r) & 0xffff0000u;
+            const float r2 = r - __uint_as_float(um);
+            hh[q] = uh; mm[q] = um; ll[q] = __float_as_uint(r2);
+        }
+        as[(0 * R + row) * LHS2 + c2] = __builtin_amdgcn_perm(hh[1], hh[0], 0x07060302u);
+        as[(1 * R + row) * LHS2 + c2] = __builtin_amdgcn_perm(mm[1], mm[0], 0x07060302u);
+        as[(2 * R + row) * LHS2 + c2] = __builtin_amdgcn_perm(ll[1], ll[0], 0x07060302u);
+    }
+}
+// gemm_wide on the split operands: Wp = pack_b_split image ([tile][k32-block][piece][lane] x 8 bf16), as = split_rows
+// output.  Same tile -> wave assignment, ring and pre / epi contract as gemm_wide.
+template <int MT, int KB32, int NAUX, class Pre, class Epi>
+DEVI void gemm_wide_split(const lu32* as, int R, int rowsA, const unsigned* __restrict__ Wp, int nt0, int ntn, Pre pre, Epi epi) {
+    const int tid_ = tid_now();
+    constexpr int D = 2, LHS2 = (32 * KB32 + 8) / 2;
+    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+    const int kg = lane >> 4, mm = lane & 15;
+    int rowoff[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) rowoff[mt] = min(mt * 16 + mm, rowsA - 1) * LHS2 + 4 * kg;
+    const gu32x4* wp = (const gu32x4*)Wp + lane;
+    const int cnt = wave < ntn ? (ntn - wave + DFF_NWAVES - 1) / DFF_NWAVES : 0;
+    u32x4 b[D][KB32][3];
+    float aux[D][NAUX];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < cnt) {
+#pragma unroll
+            for (int kb = 0; kb < KB32; ++kb)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b[d][kb][p] = wp[(((size_t)(nt0 + wave + DFF_NWAVES * d) * KB32 + kb) * 3 + p) * 64];
+            pre(wave + DFF_NWAVES * d, aux[d]);
+        }
+    for (int i0 = 0; i0 < cnt; i0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int i = i0 + d;
+            if (i < cnt) {
+                const int nt = wave + DFF_NWAVES * i;
+                f32x4 cs[MT], cb[MT];   // small terms / big terms
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) { cs[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; cb[mt] = cs[mt]; }
+#pragma unroll
+                for (int kb = 0; kb < KB32; ++kb) {
+                    u32x4 ah[MT], am[MT], al[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        ah[mt] = *(const lu32x4*)(as + rowoff[mt] + 16 * kb);
+                        am[mt] = *(const lu32x4*)(as + R * LHS2 + rowoff[mt] + 16 * kb);
+                        al[mt] = *(const lu32x4*)(as + 2 * R * LHS2 + rowoff[mt] + 16 * kb);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) cs[mt] = mfma_bf16(al[mt], b[d][kb][0], cs[mt]);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) cb[mt] = mfma_bf16(am[mt], b[d][kb][0], cb[mt]);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) cs[mt] = mfma_bf16(ah[mt], b[d][kb][2], cs[mt]);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) cb[mt] = mfma_bf16(ah[mt], b[d][kb][1], cb[mt]);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) cs[mt] = mfma_bf16(am[mt], b[d][kb][1], cs[mt]);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) cb[mt] = mfma_bf16(ah[mt], b[d][kb][0], cb[mt]);
+                }
+                float auxc[NAUX];
+#pragma unroll
+                for (int q = 0; q < NAUX; ++q) auxc[q] = aux[d][q];
+                if (i + D < cnt) {
+#pragma unroll
+                    for (int kb = 0; kb < KB32; ++kb)
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) b[d][kb][p] = wp[(((size_t)(nt0 + nt + DFF_NWAVES * D) * KB32 + kb) * 3 + p) * 64];
+                    pre(nt + DFF_NWAVES * D, aux[d]);
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) epi(nt, mt, cb[mt] + cs[mt], auxc);
             }
         }
     }
@@ -1295,7 +1408,7 @@ DEVI void wg_sync() {
     __syncthreads();
 }
 
-template <int H, int MT, int HGS, bool SPILL, bool GEN>
+template <int H, int MT, int HGS, bool SPILL, bool GEN, bool SPW>
 __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelDev m, const DffRunArgs a) {
     using LL = LdsLayout<H, MT, HGS, SPILL>;
     constexpr int LH = LL::LH, LQ = LL::LQ, F = LL::F, FC = LL::FC, LF = LL::LF;
@@ -1312,7 +1425,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
     if (c.gcnt <= 0) return;
     c.rows = c.gcnt * c.N;
     c.NP = c.N <= 8 ? 8 : c.N <= 16 ? 16 : c.N <= 32 ? 32 : 64;
-    const LL ll(c.N, c.G);
+    const LL ll(c.N, c.G, SPW);
+    lu32* const asplit = (lu32*)(smem + ll.asplit);
     c.xst = smem + ll.xst; c.xs = smem + ll.xs; c.dxs = smem + ll.dxs; c.vst = smem + ll.vst;
     c.cm = smem + ll.cm; c.tn = smem + ll.tn;
     c.abuf = smem + ll.abuf;
@@ -1430,6 +1544,9 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 row_ln1<H>(c, lw, l);
                 wg_sync<SPILL>();
             }
+            if constexpr (SPW) {
+                if (!cached) { split_rows<H>(abufL, asplit, RN); wg_sync<SPILL>(); }
+            }
             pf.tick(1);
             f32x4 acc_o[NTW][MT];
             acc_zero<MT, NTW>(acc_o);
@@ -1447,9 +1564,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     const gfloat* bq = (const gfloat*)lw.bqkvx + hg * HGS * DFF_QKVW;
                     gfloat* const sq = sqkv + (size_t)hg * HGS * RN * DFF_QKVW;
                     lfloat* const Rl = geo.Rg;
-                    gemm_wide<MT, NT_H, 1>(abufL, LH, RN, lw.Wqkvx_p, NT_H, 0, hg * HGS * 13, HGS * 13,
-                        [=](int nt, float (&aux)[1]) { aux[0] = bq[nt * 16 + (tid & 15)]; },
-                        [=](int nt, int mt, const f32x4& acc, const float (&aux)[1]) {
+                    auto qkv_pre = [=](int nt, float (&aux)[1]) { aux[0] = bq[nt * 16 + (tid & 15)]; };
+                    auto qkv_epi = [=](int nt, int mt, const f32x4& acc, const float (&aux)[1]) {
                             const int lane = tid & 63, quad = lane >> 4, cl = lane & 15;
                             const int hh = nt / 13, tt = nt - 13 * hh;
                             const int reg = (tt >= 5) + (tt >= 9);
@@ -1465,7 +1581,11 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                                     st_ntg(dsts + (size_t)row * DFF_QKVW, v);
                                 }
                             }
-                        });
+                        };
+                    if constexpr (SPW)
+                        gemm_wide_split<MT, H / 32, 1>(asplit, RN, RN, lw.Wqkvx_s, hg * HGS * 13, HGS * 13, qkv_pre, qkv_epi);
+                    else
+                        gemm_wide<MT, NT_H, 1>(abufL, LH, RN, lw.Wqkvx_p, NT_H, 0, hg * HGS * 13, HGS * 13, qkv_pre, qkv_epi);
                 }
                 co_fill_x<HGS, GEN>(geo);
                 wg_sync<SPILL>();
@@ -1489,6 +1609,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             wg_sync<SPILL>();
             row_gate1_ln2<H>(c, lw, l, tbuf);
             wg_sync<SPILL>();
+            if constexpr (SPW) { split_rows<H>(abufL, asplit, RN); wg_sync<SPILL>(); }
             pf.tick(7);
             // FFN: Linear(H,4H) -> GELU(erf) -> Linear(4H,H)   (graph_transformer.py:264-267)
             f32x4 acc_f[NTW][MT];
@@ -1499,9 +1620,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     const gfloat* const b1g = (const gfloat*)lw.b1 + ch * FC;
                     gfloat* const shp = (gfloat*)sb + c.sl.h_pre + ch * FC;
                     lfloat* const hl = geo.Rg;
-                    gemm_wide<MT, NT_H, 1>(abufL, LH, RN, lw.W1_p, NT_H, 0, ch * (FC / 16), FC / 16,
-                        [=](int nt, float (&aux)[1]) { aux[0] = b1g[16 * nt + (tid & 15)]; },
-                        [=](int nt, int mt, const f32x4& acc, const float (&aux)[1]) {
+                    auto w1_pre = [=](int nt, float (&aux)[1]) { aux[0] = b1g[16 * nt + (tid & 15)]; };
+                    auto w1_epi = [=](int nt, int mt, const f32x4& acc, const float (&aux)[1]) {
                             const int lane = tid & 63, quad = lane >> 4, cl = 16 * nt + (lane & 15);
                             const float bv = aux[0];
 #pragma unroll
@@ -1514,7 +1634,11 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                                     hl[row * LF + cl] = gv;
                                 }
                             }
-                        });
+                        };
+                    if constexpr (SPW)
+                        gemm_wide_split<MT, H / 32, 1>(asplit, RN, RN, lw.W1_s, ch * (FC / 16), FC / 16, w1_pre, w1_epi);
+                    else
+                        gemm_wide<MT, NT_H, 1>(abufL, LH, RN, lw.W1_p, NT_H, 0, ch * (FC / 16), FC / 16, w1_pre, w1_epi);
                 }
                 wg_sync<SPILL>();
                 pf.tick(8);
@@ -1537,6 +1661,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             const float* sb = c.stash + (size_t)l * c.sl.layer_stride;
             rowb_gate2<H>(c, lw, l);
             wg_sync<SPILL>();
+            if constexpr (SPW) { split_rows<H>(abufL, asplit, RN); wg_sync<SPILL>(); }
             pf.tick(11);
             // dh = dff W2 ; dh_pre = dh * gelu'(h_pre) ; df = dh_pre W1
             f32x4 acc_f[NTW][MT];
@@ -1546,23 +1671,26 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     const int tid = tid_now();
                     const gfloat* const shp = (const gfloat*)sb + c.sl.h_pre + ch * FC;
                     lfloat* const hl = geo.Rg;
-                    gemm_wide<MT, NT_H, 4 * MT>(abufL, LH, RN, lw.W2T_p, NT_H, 0, ch * (FC / 16), FC / 16,
-                        [=](int nt, float (&aux)[4 * MT]) {
+                    auto w2t_pre = [=](int nt, float (&aux)[4 * MT]) {
                             const int lane = tid & 63, quad = lane >> 4, cl = 16 * nt + (lane & 15);
 #pragma unroll
                             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                                 for (int r = 0; r < 4; ++r)
                                     aux[mt * 4 + r] = ld_ntg(shp + (size_t)min(mt * 16 + quad * 4 + r, rows - 1) * F + cl);
-                        },
-                        [=](int nt, int mt, const f32x4& acc, const float (&aux)[4 * MT]) {
+                        };
+                    auto w2t_epi = [=](int nt, int mt, const f32x4& acc, const float (&aux)[4 * MT]) {
                             const int lane = tid & 63, quad = lane >> 4, cl = 16 * nt + (lane & 15);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const int row = mt * 16 + quad * 4 + r;
                                 if (row < rows) hl[row * LF + cl] = acc[r] * aux[mt * 4 + r];
                             }
-                        });
+                        };
+                    if constexpr (SPW)
+                        gemm_wide_split<MT, H / 32, 4 * MT>(asplit, RN, RN, lw.W2T_s, ch * (FC / 16), FC / 16, w2t_pre, w2t_epi);
+                    else
+                        gemm_wide<MT, NT_H, 4 * MT>(abufL, LH, RN, lw.W2T_p, NT_H, 0, ch * (FC / 16), FC / 16, w2t_pre, w2t_epi);
                 }
                 wg_sync<SPILL>();
                 pf.tick(12);
@@ -1807,8 +1935,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_debug_gemm_kernel(const floa
 
 // explicit instantiations used by the host dispatcher
 #define DFF_INST(H, MT, HGS, SPILL) \
-    template __global__ void dff_fused_kernel<H, MT, HGS, SPILL, false>(const DffModelDev, const DffRunArgs); \
-    template __global__ void dff_fused_kernel<H, MT, HGS, SPILL, true>(const DffModelDev, const DffRunArgs);
+    template __global__ void dff_fused_kernel<H, MT, HGS, SPILL, false, false>(const DffModelDev, const DffRunArgs); \
+    template __global__ void dff_fused_kernel<H, MT, HGS, SPILL, true, false>(const DffModelDev, const DffRunArgs);
 DFF_INST(64, 1, 4, false)
 DFF_INST(64, 2, 2, false)
 DFF_INST(96, 1, 4, false)
@@ -1817,5 +1945,9 @@ DFF_INST(128, 1, 4, false)
 DFF_INST(128, 2, 2, false)
 DFF_INST(128, 3, 1, false)
 DFF_INST(128, 4, 1, true)
+// opt-in split-bf16 weight GEMMs (DFF_SPLIT_BF16=1), shipped input branch
+template __global__ void dff_fused_kernel<96, 2, 2, false, false, true>(const DffModelDev, const DffRunArgs);
+template __global__ void dff_fused_kernel<128, 2, 2, false, false, true>(const DffModelDev, const DffRunArgs);
+template __global__ void dff_fused_kernel<128, 3, 1, false, false, true>(const DffModelDev, const DffRunArgs);
 template __global__ void dff_debug_gemm_kernel<4>(const float*, const float*, int, int, float*);
 template __global__ void dff_debug_gemm_kernel<8>(const float*, const float*, int, int, float*);
