@@ -452,6 +452,98 @@ DEVI void gemm_wide_split(const lu32* as, int R, int rowsA, const unsigned* __re
     }
 }
 
+// The same with a ring of three HALF tiles (k-blocks [0, KB32/2) and [KB32/2, KB32) of a tile are separate entries):
+// 1.5 tiles of lookahead in 18 instead of 24 operand registers per lane, which is what keeps the H = 128 variants
+// out of scratch.  Entries e = 2 i + half; six entries (three tiles) per trip so that slot, half and aux index are static.
+template <int MT, int KB32, int NAUX, class Pre, class Epi>
+DEVI void gemm_wide_split_h(const lu32* as, int R, int rowsA, const unsigned* __restrict__ Wp, int nt0, int ntn, Pre pre, Epi epi) {
+    static_assert(KB32 % 2 == 0, "even number of 32-row k-blocks");
+    const int tid_ = tid_now();
+    constexpr int HB = KB32 / 2, LHS2 = (32 * KB32 + 8) / 2;
+    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+    const int kg = lane >> 4, mm = lane & 15;
+    int rowoff[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) rowoff[mt] = min(mt * 16 + mm, rowsA - 1) * LHS2 + 4 * kg;
+    const gu32x4* wp = (const gu32x4*)Wp + lane;
+    const int cnt = wave < ntn ? (ntn - wave + DFF_NWAVES - 1) / DFF_NWAVES : 0;
+    const int ne = 2 * cnt;
+    u32x4 b[3][HB][3];
+    float aux[3][NAUX];
+    auto fill = [&](u32x4 (&slot)[HB][3], int e) {
+        const size_t tile = (size_t)(nt0 + wave + DFF_NWAVES * (e >> 1));
+#pragma unroll
+        for (int kb = 0; kb < HB; ++kb)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) slot[kb][p] = wp[((tile * KB32 + (e & 1) * HB + kb) * 3 + p) * 64];
+    };
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        if (j < ne) {
+            fill(b[j], j);
+            if ((j & 1) == 0) pre(wave + DFF_NWAVES * (j >> 1), aux[j >> 1]);
+        }
+    f32x4 cs[MT], cb[MT];
+    for (int e0 = 0; e0 < ne; e0 += 6) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int e = e0 + j;
+            if (e < ne) {
+                constexpr int dummy = 0; (void)dummy;
+                const int half = j & 1, slot = j % 3, it = j >> 1;
+                const int nt = wave + DFF_NWAVES * (e >> 1);
+                if (half == 0) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) { cs[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; cb[mt] = cs[mt]; }
+                }
+#pragma unroll
+                for (int kb = 0; kb < HB; ++kb) {
+                    u32x4 ah[MT], am[MT], al[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int o = rowoff[mt] + 16 * (half * HB + kb);
+                        ah[mt] = *(const lu32x4*)(as + o);
+                        am[mt] = *(const lu32x4*)(as + R * LHS2 + o);
+                        al[mt] = *(const lu32x4*)(as + 2 * R * LHS2 + o);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) cs[mt] = mfma_bf16(al[mt], b[slot][kb][0], cs[mt]);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) cb[mt] = mfma_bf16(am[mt], b[slot][kb][0], cb[mt]);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) cs[mt] = mfma_bf16(ah[mt], b[slot][kb][2], cs[mt]);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) cb[mt] = mfma_bf16(ah[mt], b[slot][kb][1], cb[mt]);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) cs[mt] = mfma_bf16(am[mt], b[slot][kb][1], cs[mt]);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) cb[mt] = mfma_bf16(ah[mt], b[slot][kb][0], cb[mt]);
+                }
+                float auxc[NAUX];
+                if (half == 1) {
+#pragma unroll
+                    for (int q = 0; q < NAUX; ++q) auxc[q] = aux[it][q];
+                }
+                if (e + 3 < ne) {
+                    fill(b[slot], e + 3);
+                    // entry e + 3 opens tile (e + 3) >> 1 when it is a first half: its aux slot is ((j + 3) >> 1) % 3
+                    if (((j + 3) & 1) == 0) pre(wave + DFF_NWAVES * ((e + 3) >> 1), aux[((j + 3) >> 1) % 3]);
+                }
+                if (half == 1) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) epi(nt, mt, cb[mt] + cs[mt], auxc);
+                }
+            }
+        }
+    }
+}
+
+template <int MT, int KB32, int NAUX, class Pre, class Epi>
+DEVI void gemm_wide_split_sel(const lu32* as, int R, int rowsA, const unsigned* __restrict__ Wp, int nt0, int ntn, Pre pre, Epi epi) {
+    if constexpr (KB32 % 2 == 0 && KB32 >= 4) gemm_wide_split_h<MT, KB32, NAUX>(as, R, rowsA, Wp, nt0, ntn, pre, epi);
+    else gemm_wide_split<MT, KB32, NAUX>(as, R, rowsA, Wp, nt0, ntn, pre, epi);
+}
+
 // wide GEMM with few output tiles (NTN * MT (tile, row-tile) units <= a few per wave): the UNITS, not the tiles, go
 // round-robin over the waves, so that all four SIMDs carry the same MFMA load; loop-free, all weights loaded up
 // front, hook() as in gemm_wide.  epi(nt_local, mt, acc).
@@ -1583,7 +1675,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                             }
                         };
                     if constexpr (SPW)
-                        gemm_wide_split<MT, H / 32, 1>(asplit, RN, RN, lw.Wqkvx_s, hg * HGS * 13, HGS * 13, qkv_pre, qkv_epi);
+                        gemm_wide_split_sel<MT, H / 32, 1>(asplit, RN, RN, lw.Wqkvx_s, hg * HGS * 13, HGS * 13, qkv_pre, qkv_epi);
                     else
                         gemm_wide<MT, NT_H, 1>(abufL, LH, RN, lw.Wqkvx_p, NT_H, 0, hg * HGS * 13, HGS * 13, qkv_pre, qkv_epi);
                 }
@@ -1636,7 +1728,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                             }
                         };
                     if constexpr (SPW)
-                        gemm_wide_split<MT, H / 32, 1>(asplit, RN, RN, lw.W1_s, ch * (FC / 16), FC / 16, w1_pre, w1_epi);
+                        gemm_wide_split_sel<MT, H / 32, 1>(asplit, RN, RN, lw.W1_s, ch * (FC / 16), FC / 16, w1_pre, w1_epi);
                     else
                         gemm_wide<MT, NT_H, 1>(abufL, LH, RN, lw.W1_p, NT_H, 0, ch * (FC / 16), FC / 16, w1_pre, w1_epi);
                 }
@@ -1688,7 +1780,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                             }
                         };
                     if constexpr (SPW)
-                        gemm_wide_split<MT, H / 32, 4 * MT>(asplit, RN, RN, lw.W2T_s, ch * (FC / 16), FC / 16, w2t_pre, w2t_epi);
+                        gemm_wide_split_sel<MT, H / 32, 4 * MT>(asplit, RN, RN, lw.W2T_s, ch * (FC / 16), FC / 16, w2t_pre, w2t_epi);
                     else
                         gemm_wide<MT, NT_H, 4 * MT>(abufL, LH, RN, lw.W2T_p, NT_H, 0, ch * (FC / 16), FC / 16, w2t_pre, w2t_epi);
                 }
