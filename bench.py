@@ -115,8 +115,11 @@ def north_star_extras(dev, rank, world, P):
     from dff_amd.score import GraphTransformer
     from oracle import synth
     out = {}
-    for cfg in ("chignolin", "villin"):
+    for cfg, split in (("chignolin", False), ("villin", False), ("villin", True)):
         _, N, H, L = synth.SHIPPED_CONFIGS[cfg]
+        # split: the opt-in variants whose K = H weight GEMMs run on the bf16 pipe through an exact three-way split of
+        # every fp32 operand; read when the model is created, off for every other number here
+        os.environ["DFF_SPLIT_BF16"] = "1" if split else "0"
         model = GraphTransformer(N, H, device=dev, n_layers=L, use_intrinsic_coords=True, use_abs_coords=False,
                                  use_distances=False, conservative=True,
                                  state_dict=synth.synth_gnn_params(N, H, L, seed=1234, decoder_scale=1e-2))
@@ -144,9 +147,12 @@ def north_star_extras(dev, rank, world, P):
             dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
             if world > 1:
                 dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-            out[f"{cfg}_{name}"] = world * units / dt.item()
+            out[f"{cfg}_{name}" + ("_split_bf16_opt_in" if split else "")] = world * units / dt.item()
+    os.environ["DFF_SPLIT_BF16"] = "0"
     out["note"] = (f"whole job, batch {P} per GPU; iid = complete 1000-step DDPM chains; md = 1000 Langevin steps, save_interval 250 "
-                   f"(chignolin t=20, villin t=5), host set-up of each call included")
+                   f"(chignolin t=20, villin t=5), host set-up of each call included; *_split_bf16_opt_in: DFF_SPLIT_BF16=1 variants "
+                   f"(weight GEMMs on the bf16 MFMA via an exact 3-way split of every fp32 operand, same parity tolerances), "
+                   f"off for every other number in this line")
     return out
 
 
