@@ -2037,9 +2037,12 @@ DFF_INST(128, 1, 4, false)
 DFF_INST(128, 2, 2, false)
 DFF_INST(128, 3, 1, false)
 DFF_INST(128, 4, 1, true)
-// opt-in split-bf16 weight GEMMs (DFF_SPLIT_BF16=1), shipped input branch
+// opt-in split-bf16 weight GEMMs (DFF_SPLIT_BF16=1)
 template __global__ void dff_fused_kernel<96, 2, 2, false, false, true>(const DffModelDev, const DffRunArgs);
 template __global__ void dff_fused_kernel<128, 2, 2, false, false, true>(const DffModelDev, const DffRunArgs);
 template __global__ void dff_fused_kernel<128, 3, 1, false, false, true>(const DffModelDev, const DffRunArgs);
+template __global__ void dff_fused_kernel<96, 2, 2, false, true, true>(const DffModelDev, const DffRunArgs);
+template __global__ void dff_fused_kernel<128, 2, 2, false, true, true>(const DffModelDev, const DffRunArgs);
+template __global__ void dff_fused_kernel<128, 3, 1, false, true, true>(const DffModelDev, const DffRunArgs);
 template __global__ void dff_debug_gemm_kernel<4>(const float*, const float*, int, int, float*);
 template __global__ void dff_debug_gemm_kernel<8>(const float*, const float*, int, int, float*);
