@@ -538,6 +538,50 @@ DEVI void gemm_wide_split_h(const lu32* as, int R, int rowsA, const unsigned* __
     }
 }
 
+// gemm_wide_units on the split operands (few output tiles: (tile, row-tile) units round-robin over the waves, loop-free)
+template <int MT, int KB32, int NTN, class Epi>
+DEVI void gemm_wide_units_split(const lu32* as, int R, int rowsA, const unsigned* __restrict__ Wp, int nt0, Epi epi) {
+    const int tid_ = tid_now();
+    constexpr int NU = NTN * MT, DU = (NU + DFF_NWAVES - 1) / DFF_NWAVES, LHS2 = (32 * KB32 + 8) / 2;
+    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+    const int kg = lane >> 4, mm = lane & 15;
+    const gu32x4* wp = (const gu32x4*)Wp + lane;
+    u32x4 b[DU][KB32][3];
+#pragma unroll
+    for (int d = 0; d < DU; ++d) {
+        const int u = wave + DFF_NWAVES * d;
+        if (u < NU) {
+            const int nt = u / MT;
+#pragma unroll
+            for (int kb = 0; kb < KB32; ++kb)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b[d][kb][p] = wp[(((size_t)(nt0 + nt) * KB32 + kb) * 3 + p) * 64];
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < DU; ++d) {
+        const int u = wave + DFF_NWAVES * d;
+        if (u < NU) {
+            const int nt = u / MT, mt = u - nt * MT;
+            const int ro = min(mt * 16 + mm, rowsA - 1) * LHS2 + 4 * kg;
+            f32x4 cs = {0.f, 0.f, 0.f, 0.f}, cb = {0.f, 0.f, 0.f, 0.f}, cs2 = cs, cb2 = cs;
+#pragma unroll
+            for (int kb = 0; kb < KB32; ++kb) {
+                const u32x4 ah = *(const lu32x4*)(as + ro + 16 * kb);
+                const u32x4 am = *(const lu32x4*)(as + R * LHS2 + ro + 16 * kb);
+                const u32x4 al = *(const lu32x4*)(as + 2 * R * LHS2 + ro + 16 * kb);
+                cs = mfma_bf16(al, b[d][kb][0], cs);
+                cb = mfma_bf16(am, b[d][kb][0], cb);
+                cs2 = mfma_bf16(ah, b[d][kb][2], cs2);
+                cb2 = mfma_bf16(ah, b[d][kb][1], cb2);
+                cs = mfma_bf16(am, b[d][kb][1], cs);
+                cb = mfma_bf16(ah, b[d][kb][0], cb);
+            }
+            epi(nt, mt, (cb + cb2) + (cs + cs2));
+        }
+    }
+}
+
 template <int MT, int KB32, int NAUX, class Pre, class Epi>
 DEVI void gemm_wide_split_sel(const lu32* as, int R, int rowsA, const unsigned* __restrict__ Wp, int nt0, int ntn, Pre pre, Epi epi) {
     if constexpr (KB32 % 2 == 0 && KB32 >= 4) gemm_wide_split_h<MT, KB32, NAUX>(as, R, rowsA, Wp, nt0, ntn, pre, epi);
@@ -1804,6 +1848,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             co_reload_issue<MT, HGS>(rl, sqkv, sPl);
             rowb_ln2_gate1<H>(c, lw, l, tbuf);
             wg_sync<SPILL>();
+            if constexpr (SPW) { split_rows<H>(abufL, asplit, RN); wg_sync<SPILL>(); }
             pf.tick(14);
             f32x4 acc_a[NTW][MT];
             acc_zero<MT, NTW>(acc_a);
@@ -1815,8 +1860,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     const int tid = tid_now();
                     lfloat* const Gl = geo.Rg + 3 * RN * LQ;
                     lfloat* const dxw = geo.dxw;
-                    gemm_wide_units<MT, NT_H, HGS * 5>(abufL, LH, RN, lw.WoxT_p, NT_H, 0, hg * HGS * 5,
-                        [=](int nt, int mt, const f32x4& acc) {
+                    auto gx_epi = [=](int nt, int mt, const f32x4& acc) {
                             const int lane = tid & 63, quad = lane >> 4, cl = lane & 15;
                             const int hh = nt / 5, tt = nt - 5 * hh;
 #pragma unroll
@@ -1827,8 +1871,11 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                                     if (tt == 4 && cl < 3) dxw[row * 4 + cl] -= acc[r];
                                 }
                             }
-                        },
-                        NoHook());
+                        };
+                    if constexpr (SPW)
+                        gemm_wide_units_split<MT, H / 32, HGS * 5>(asplit, RN, RN, lw.WoxT_s, hg * HGS * 5, gx_epi);
+                    else
+                        gemm_wide_units<MT, NT_H, HGS * 5>(abufL, LH, RN, lw.WoxT_p, NT_H, 0, hg * HGS * 5, gx_epi, NoHook());
                     co_reload_commit<MT, HGS>(rl, geo);
                     if (GEN) {   // [m1 | m2] rows of this head group (contiguous in the stash and in LDS); before the
                                  // next group's rows are requested: a load issued after them would wait for them
