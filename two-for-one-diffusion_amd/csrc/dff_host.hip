@@ -361,13 +361,15 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
             return e < 67 ? Woc[(size_t)c * 24 + 3 * h + e - 64] : e == 67 ? Wod[(size_t)c * 8 + h] : 0.0;
         };
         UP(pack_b(H, 8 * 208, [&](int k, int n) { return wqkvx(n, k); }), d.Wqkvx_p);
-        d.Wqkvx_s = d.W1_s = d.W2T_s = d.WoxT_s = nullptr;
+        d.Wqkvx_s = d.W1_s = d.W2T_s = d.WoxT_s = d.W2_s = d.W1T_s = nullptr;
         if (m->split) {
             int rc_;
             if ((rc_ = upload_u32(m, pack_b_split(H, 8 * 208, [&](int k, int n) { return wqkvx(n, k); }), &d.Wqkvx_s))) return rc_;
             if ((rc_ = upload_u32(m, pack_b_split(H, F, [&](int k, int n) { return (double)W1[(size_t)n * H + k]; }), &d.W1_s))) return rc_;
             if ((rc_ = upload_u32(m, pack_b_split(H, F, [&](int k, int n) { return (double)W2[(size_t)k * F + n]; }), &d.W2T_s))) return rc_;
             if ((rc_ = upload_u32(m, pack_b_split(H, 8 * 80, [&](int k, int n) { return wox(n, k); }), &d.WoxT_s))) return rc_;
+            if ((rc_ = upload_u32(m, pack_b_split(F, H, [&](int k, int n) { return (double)W2[(size_t)n * F + k]; }), &d.W2_s))) return rc_;
+            if ((rc_ = upload_u32(m, pack_b_split(F, H, [&](int k, int n) { return (double)W1[(size_t)k * H + n]; }), &d.W1T_s))) return rc_;
         }
         UP(bqkvx, d.bqkvx);
         UP(pack_b(8 * 80, H, [&](int k, int n) { return wox(k, n); }, 5), d.Wox_p);

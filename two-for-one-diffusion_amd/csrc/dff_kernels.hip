@@ -582,6 +582,89 @@ DEVI void gemm_wide_units_split(const lu32* as, int R, int rowsA, const unsigned
     }
 }
 
+// One element of a split A operand: three 16-bit stores (row-major bf16 pieces [piece][R][LS], LS in bf16 units).
+typedef __attribute__((address_space(3))) unsigned short lu16;
+DEVI void store_split(lu16* as16, int R, int LS, int row, int col, float v) {
+    const unsigned uh = __float_as_uint(v) & 0xffff0000u;
+    const float r = v - __uint_as_float(uh);
+    const unsigned um = __float_as_uint(r) & 0xffff0000u;
+    const float r2 = r - __uint_as_float(um);
+    as16[(0 * R + row) * LS + col] = (unsigned short)(uh >> 16);
+    as16[(1 * R + row) * LS + col] = (unsigned short)(um >> 16);
+    as16[(2 * R + row) * LS + col] = (unsigned short)(__float_as_uint(r2) >> 16);
+}
+// "tall" GEMM (Nout = H) on split operands: acc[i][mt] += A[:, 32 kb ..] W[kb0 + kb], kb < nkb; A pieces as written by
+// store_split with LS = 32 nkb + 8; W = pack_b_split image with KBtot k-blocks per tile.  Wave w owns tiles w + 8 i.
+// One accumulator per output tile, small terms first inside every k-block.
+template <int MT, int NTW>
+DEVI void gemm_tall_split(f32x4 (&acc)[NTW][MT], int nkb, int LS2 /* dwords per piece row */, const lu32* as, int R, int rowsA,
+                          const unsigned* __restrict__ Wp, int KBtot, int kb0, int ntiles) {
+    const int tid_ = tid_now();
+    constexpr int D = 3;
+    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+    const int kg = lane >> 4, mm = lane & 15;
+    int rowoff[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) rowoff[mt] = min(mt * 16 + mm, rowsA - 1) * LS2 + 4 * kg;
+    const gu32x4* wp = (const gu32x4*)Wp + lane;
+    size_t tbase[NTW];
+    bool tok[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int nt = wave + DFF_NWAVES * i;
+        tok[i] = nt < ntiles;
+        tbase[i] = ((size_t)(tok[i] ? nt : 0) * KBtot + kb0) * 3;
+    }
+    if (!tok[0]) return;
+    u32x4 b[D][NTW][3];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < nkb) {
+#pragma unroll
+            for (int i = 0; i < NTW; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b[d][i][p] = wp[(tbase[i] + 3 * d + p) * 64];
+        }
+    for (int k0 = 0; k0 < nkb; k0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int kb = k0 + d;
+            if (kb < nkb) {
+                u32x4 ah[MT], am[MT], al[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int o = rowoff[mt] + 16 * kb;
+                    ah[mt] = *(const lu32x4*)(as + o);
+                    am[mt] = *(const lu32x4*)(as + R * LS2 + o);
+                    al[mt] = *(const lu32x4*)(as + 2 * R * LS2 + o);
+                }
+#pragma unroll
+                for (int i = 0; i < NTW; ++i)
+                    if (tok[i]) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(al[mt], b[d][i][0], acc[i][mt]);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(ah[mt], b[d][i][2], acc[i][mt]);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(am[mt], b[d][i][1], acc[i][mt]);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(am[mt], b[d][i][0], acc[i][mt]);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(ah[mt], b[d][i][1], acc[i][mt]);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(ah[mt], b[d][i][0], acc[i][mt]);
+                    }
+                if (kb + D < nkb) {
+#pragma unroll
+                    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) b[d][i][p] = wp[(tbase[i] + 3 * (kb + D) + p) * 64];
+                }
+            }
+        }
+    }
+}
+
 template <int MT, int KB32, int NAUX, class Pre, class Epi>
 DEVI void gemm_wide_split_sel(const lu32* as, int R, int rowsA, const unsigned* __restrict__ Wp, int nt0, int ntn, Pre pre, Epi epi) {
     if constexpr (KB32 % 2 == 0 && KB32 >= 4) gemm_wide_split_h<MT, KB32, NAUX>(as, R, rowsA, Wp, nt0, ntn, pre, epi);
@@ -1767,7 +1850,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                                     float gv, gp;
                                     gelu_both(acc[r] + bv, gv, gp);
                                     st_ntg(shp + (size_t)row * F + cl, gp);   // the slot "h_pre" holds gelu'(h_pre)
-                                    hl[row * LF + cl] = gv;
+                                    if constexpr (SPW) store_split((lu16*)hl, RN, FC + 8, row, cl, gv);
+                                    else hl[row * LF + cl] = gv;
                                 }
                             }
                         };
@@ -1778,6 +1862,9 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 }
                 wg_sync<SPILL>();
                 pf.tick(8);
+                if constexpr (SPW)
+                    gemm_tall_split<MT, NTW>(acc_f, FC / 32, (FC + 8) / 2, (const lu32*)geo.Rg, RN, RN, lw.W2_s, F / 32, ch * (FC / 32), NT_H);
+                else
                 gemm_tall_kb<MT, NTW, 0>(acc_f, FC / 16,
                     [=](int i, int& aoff, int& wkb) { aoff = 16 * i; wkb = ch * (FC / 16) + i; },
                     geo.Rg, LF, RN, lw.W2_p, F / 16, NT_H);
@@ -1820,7 +1907,10 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const int row = mt * 16 + quad * 4 + r;
-                                if (row < rows) hl[row * LF + cl] = acc[r] * aux[mt * 4 + r];
+                                if (row < rows) {
+                                    if constexpr (SPW) store_split((lu16*)hl, RN, FC + 8, row, cl, acc[r] * aux[mt * 4 + r]);
+                                    else hl[row * LF + cl] = acc[r] * aux[mt * 4 + r];
+                                }
                             }
                         };
                     if constexpr (SPW)
@@ -1830,6 +1920,9 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 }
                 wg_sync<SPILL>();
                 pf.tick(12);
+                if constexpr (SPW)
+                    gemm_tall_split<MT, NTW>(acc_f, FC / 32, (FC + 8) / 2, (const lu32*)geo.Rg, RN, RN, lw.W1T_s, F / 32, ch * (FC / 32), NT_H);
+                else
                 gemm_tall_kb<MT, NTW, 0>(acc_f, FC / 16,
                     [=](int i, int& aoff, int& wkb) { aoff = 16 * i; wkb = ch * (FC / 16) + i; },
                     geo.Rg, LF, RN, lw.W1T_p, F / 16, NT_H);
