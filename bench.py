@@ -246,7 +246,12 @@ def main():
         torch.cuda.synchronize()
         gather_ms = 1e3 * (time.perf_counter() - t1)
     ok = bool(torch.isfinite(frames).all().item()) and bool(torch.isfinite(ld.x).all().item())
-    also = None if args.no_extras else north_star_extras(dev, rank, world, P)
+    also = None
+    if not args.no_extras:
+        try:    # secondary figures must never cost the headline line
+            also = north_star_extras(dev, rank, world, P)
+        except Exception as e:  # noqa: BLE001
+            also = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / K
