@@ -498,26 +498,20 @@ DEVI void gemm_wide_split_h(const lu32* as, int R, int rowsA, const unsigned* __
                 }
 #pragma unroll
                 for (int kb = 0; kb < HB; ++kb) {
-                    u32x4 ah[MT], am[MT], al[MT];
+                    // one row tile's pieces live at a time (3 registers x 4 instead of 9 x 4); its two accumulator chains alternate
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         const int o = rowoff[mt] + 16 * (half * HB + kb);
-                        ah[mt] = *(const lu32x4*)(as + o);
-                        am[mt] = *(const lu32x4*)(as + R * LHS2 + o);
-                        al[mt] = *(const lu32x4*)(as + 2 * R * LHS2 + o);
+                        const u32x4 ah = *(const lu32x4*)(as + o);
+                        const u32x4 am = *(const lu32x4*)(as + R * LHS2 + o);
+                        const u32x4 al = *(const lu32x4*)(as + 2 * R * LHS2 + o);
+                        cs[mt] = mfma_bf16(al, b[slot][kb][0], cs[mt]);
+                        cb[mt] = mfma_bf16(am, b[slot][kb][0], cb[mt]);
+                        cs[mt] = mfma_bf16(ah, b[slot][kb][2], cs[mt]);
+                        cb[mt] = mfma_bf16(ah, b[slot][kb][1], cb[mt]);
+                        cs[mt] = mfma_bf16(am, b[slot][kb][1], cs[mt]);
+                        cb[mt] = mfma_bf16(ah, b[slot][kb][0], cb[mt]);
                     }
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) cs[mt] = mfma_bf16(al[mt], b[slot][kb][0], cs[mt]);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) cb[mt] = mfma_bf16(am[mt], b[slot][kb][0], cb[mt]);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) cs[mt] = mfma_bf16(ah[mt], b[slot][kb][2], cs[mt]);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) cb[mt] = mfma_bf16(ah[mt], b[slot][kb][1], cb[mt]);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) cs[mt] = mfma_bf16(am[mt], b[slot][kb][1], cs[mt]);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) cb[mt] = mfma_bf16(ah[mt], b[slot][kb][0], cb[mt]);
                 }
                 float auxc[NAUX];
                 if (half == 1) {
