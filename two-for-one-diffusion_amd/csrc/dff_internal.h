@@ -34,7 +34,7 @@ struct DffLayerDev {
     // backward (transposed orientation)
     const float *W2T_p;           // K=H, Nout=4H   dh  = dff  W2
     // opt-in (DFF_SPLIT_BF16=1): the K = H images as three bf16 pieces per weight (dff_host.hip pack_b_split)
-    const unsigned *Wqkvx_s, *W1_s, *W2T_s, *WoxT_s, *W2_s, *W1T_s;
+    const unsigned *Wqkvx_s, *W1_s, *W2T_s, *WoxT_s, *W2_s, *W1T_s, *Wox_s;
     const float *W1T_p;           // K=4H, Nout=H   df  = dhp  W1
     // "extended head" images: per head 80 = 64 + 16 extension columns / rows ([u (3) | s | 0...], [xrel (3) | D | 0...])
     const float *Wqkvx_p, *bqkvx; // K=H, Nout=8*208, per head [q 64 | ext 16 | k 64 | v 64]

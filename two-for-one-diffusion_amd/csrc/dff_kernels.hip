@@ -1307,7 +1307,9 @@ DEVI void co_fix_g(const CoGeo& g, int hh, int it, int lane) {   // G_ext ext: [
 // the same wave (its 16 probability rows are all it needs, so no barrier):
 // o_ext = P V_ext -> R0 rows of this tile (Q_ext rows of the tile are dead after its logits);
 // extension tile: xrel_i = sum_j a_ij x_j - x_i
-template <int MT, int HGS, bool GEN>
+// SPW: the 64 regular columns of o_ext are written as bf16 pieces ([piece][RN][64 HGS + 8], into R3 | R4, free in the
+// forward pass) for gemm_tall_split; the extension columns stay fp32 in R0.
+template <int MT, int HGS, bool GEN, bool SPW = false>
 DEVI void co_softmax_pv(const CoGeo& g, gfloat* sP /* P block of head hg*HGS */, gfloat* sM /* m12 block of head hg*HGS (GEN) */) {
     const int tid_ = tid_now(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     constexpr int LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL, PS = 16 * MT;
@@ -1357,7 +1359,10 @@ DEVI void co_softmax_pv(const CoGeo& g, gfloat* sP /* P block of head hg*HGS */,
             if (row < g.rows) {
                 lfloat* d = g.Rg + row * LQ + hh * 80 + col;
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) d[16 * nt] = o[nt][r];
+                for (int nt = 0; nt < 4; ++nt) {
+                    if constexpr (SPW) store_split((lu16*)(g.Rg + 3 * g.RN * LQ), g.RN, 64 * HGS + 8, row, hh * 64 + 16 * nt + col, o[nt][r]);
+                    else d[16 * nt] = o[nt][r];
+                }
                 if (!GEN) d[64] = o[4][r] - g.xs[row * 4 + min(col, 3)];
             }
             if (GEN) {
@@ -1803,11 +1808,18 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 co_fill_x<HGS, GEN>(geo);
                 wg_sync<SPILL>();
                 pf.tick(3);
-                co_softmax_pv<MT, HGS, GEN>(geo, sPl + (size_t)hg * HGS * RN * c.sl.PS,
-                                            (gfloat*)sb + c.sl.m12 + (size_t)hg * HGS * RN * 4);
+                co_softmax_pv<MT, HGS, GEN, SPW>(geo, sPl + (size_t)hg * HGS * RN * c.sl.PS,
+                                                 (gfloat*)sb + c.sl.m12 + (size_t)hg * HGS * RN * 4);
                 wg_sync<SPILL>();
                 pf.tick(4);
                 // attn_out += o_ext [W_o ; W_oc]   (K = 80 per head)
+                if constexpr (SPW) {   // 64 regular rows per head on the split path, the extension block on the fp32 one
+                    gemm_tall_split<MT, NTW>(acc_o, 2 * HGS, (64 * HGS + 8) / 2, (const lu32*)(geo.Rg + 3 * RN * LQ), RN, RN,
+                                             lw.Wox_s, 2 * DFF_HEADS, hg * HGS * 2, NT_H);
+                    gemm_tall_kb<MT, NTW, 5>(acc_o, HGS,
+                        [=](int i, int& aoff, int& wkb) { aoff = i * 80 + 64; wkb = (hg * HGS + i) * 5 + 4; },
+                        geo.Rg, LQ, RN, lw.Wox_p, DFF_HEADS * 5, NT_H);
+                } else
                 gemm_tall_kb<MT, NTW, 5>(acc_o, 5 * HGS,
                     [=](int i, int& aoff, int& wkb) {
                         const int hh = i / 5, kb = i - 5 * hh;
