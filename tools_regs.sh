@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Wno-unused-result "$@" -S --cuda-device-only \
-    two-for-one-diffusion_amd/csrc/dff_host.hip -o /tmp/dff_regs.s 2>/dev/null
+    two-for-one-diffusion_amd/csrc/${DFF_TU:-dff_small}.hip -o /tmp/dff_regs.s 2>/dev/null
 python3 - <<'PY'
 import re
 txt = open('/tmp/dff_regs.s').read()

@@ -11,9 +11,9 @@
 #include <string>
 #include <vector>
 
-// device code: one translation unit (kernel handles, layouts and templates are shared)
-#include "dff_kernels.hip"
-#include "dff_small.hip"
+// the two sampler kernels are their own translation units (dff_kernels.hip, dff_small.hip: they export variant
+// lookups, dff_device.h); the small PWD kernels are compiled here
+#include "dff_device.h"
 #include "dff_pwd.hip"
 
 static thread_local std::string g_err;
@@ -81,31 +81,6 @@ static std::vector<uint32_t> pack_b_split(int K, int Nout, const std::function<d
 // ------------------------------------------------------------------------------------------
 // model handle
 // ------------------------------------------------------------------------------------------
-struct Variant {
-    int H, MT, HGS;
-    bool spill, gen, spw;
-    const void* fn;
-    unsigned (*lds_floats)(int N, int G);
-    const char* name;
-};
-template <int H, int MT, int HGS, bool SP, bool SPW>
-static unsigned lds_floats_of(int N, int G) { return LdsLayout<H, MT, HGS, SP>(N, G, SPW).total; }
-#define VAR(H, MT, HGS, SP)                                                                                     \
-    { H, MT, HGS, SP, false, false, (const void*)&dff_fused_kernel<H, MT, HGS, SP, false, false>,               \
-      &lds_floats_of<H, MT, HGS, SP, false>, "dff_fused_kernel<" #H "," #MT "," #HGS "," #SP ">" },             \
-    { H, MT, HGS, SP, true, false, (const void*)&dff_fused_kernel<H, MT, HGS, SP, true, false>,                 \
-      &lds_floats_of<H, MT, HGS, SP, false>, "dff_fused_kernel<" #H "," #MT "," #HGS "," #SP ",gen>" }
-#define VAR_SPW(H, MT, HGS)                                                                                     \
-    { H, MT, HGS, false, false, true, (const void*)&dff_fused_kernel<H, MT, HGS, false, false, true>,           \
-      &lds_floats_of<H, MT, HGS, false, true>, "dff_fused_kernel<" #H "," #MT "," #HGS ",false,split_bf16>" },  \
-    { H, MT, HGS, false, true, true, (const void*)&dff_fused_kernel<H, MT, HGS, false, true, true>,             \
-      &lds_floats_of<H, MT, HGS, false, true>, "dff_fused_kernel<" #H "," #MT "," #HGS ",false,gen,split_bf16>" }
-static const Variant g_variants[] = {
-    VAR(64, 1, 4, false),  VAR(64, 2, 2, false),  VAR(96, 1, 4, false),  VAR(96, 2, 2, false),
-    VAR(128, 1, 4, false), VAR(128, 2, 2, false), VAR(128, 3, 1, false), VAR(128, 4, 1, true),
-    VAR_SPW(96, 2, 2), VAR_SPW(128, 2, 2), VAR_SPW(128, 3, 1),
-};
-
 struct dff_model {
     dff_config cfg;
     int device;
@@ -459,19 +434,10 @@ static int launch_small(dff_model* m, DffRunArgs& a, int G, hipStream_t stream) 
     // 8 waves (two per SIMD, one head per wave) when the rows fit its 11-row head buffers
     const bool eight = (H == 64 || H == 96) && G * N <= 10 && m->small_waves != 4;
     const bool gen = !(m->cfg.use_intrinsic_coords == 1 && m->cfg.use_distances == 0 && m->cfg.use_abs_coords == 0);
-#define SMALL_PICK(H_, NW_)                                                                                         \
-    do {                                                                                                            \
-        fn = gen ? (const void*)&dff_small_kernel<H_, NW_, true> : (const void*)&dff_small_kernel<H_, NW_, false>;  \
-        lds = SmallLds<H_, NW_>::total;                                                                             \
-        name = gen ? "dff_small_kernel<" #H_ "," #NW_ ",gen>" : "dff_small_kernel<" #H_ "," #NW_ ">";               \
-        nthreads = NW_ * 64;                                                                                        \
-    } while (0)
-    if (eight && H == 64) SMALL_PICK(64, 8);
-    else if (eight)       SMALL_PICK(96, 8);
-    else if (H == 64)     SMALL_PICK(64, 4);
-    else if (H == 96)     SMALL_PICK(96, 4);
-    else                  SMALL_PICK(128, 4);
-#undef SMALL_PICK
+    const int NW = eight ? 8 : 4;
+    if (!dff_small_pick(H, NW, gen, false, &fn, &lds, &name))
+        return fail(DFF_EINVAL, "no <= 16-row kernel for hidden=%d waves=%d in this build", H, NW);
+    nthreads = NW * 64;
     lds *= (unsigned)sizeof(float);
     if (lds > 160 * 1024) return fail(DFF_EINVAL, "LDS budget exceeded (%u bytes)", lds);
     const int grid_all = (a.B + G - 1) / G;
@@ -620,8 +586,12 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
     const Variant* v = nullptr;
     auto pick = [&](int mt_) {
         const Variant* r = nullptr;
-        for (const Variant& c : g_variants)
+        int nv = 0;
+        const Variant* vs = dff_fused_variants(&nv);
+        for (int q = 0; q < nv; ++q) {
+            const Variant& c = vs[q];
             if (c.H == H && c.MT == mt_ && c.gen == gen && (!c.spw || m->split) && (!r || c.spw)) r = &c;
+        }
         return r;
     };
     v = pick(mt);
@@ -707,9 +677,7 @@ extern "C" int dff_debug_gemm(int device, const float* A, const float* W, int M,
     HIPCHK(hipMemcpy(dA, A, (size_t)M * K * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dW, Wp.data(), Wp.size() * 4, hipMemcpyHostToDevice));
     const size_t lds = (size_t)(64 * (K + 4) + 64) * 4;
-    if (K == 64) hipLaunchKernelGGL(dff_debug_gemm_kernel<4>, dim3(1), dim3(DFF_NTHREADS), lds, 0, dA, dW, M, Nout, dO);
-    else hipLaunchKernelGGL(dff_debug_gemm_kernel<8>, dim3(1), dim3(DFF_NTHREADS), lds, 0, dA, dW, M, Nout, dO);
-    HIPCHK(hipGetLastError());
+    HIPCHK((hipError_t)dff_debug_gemm_launch(K, dA, dW, M, Nout, dO, lds));
     HIPCHK(hipMemcpy(out, dO, (size_t)M * Nout * 4, hipMemcpyDeviceToHost));
     (void)hipFree(dA); (void)hipFree(dW); (void)hipFree(dO);
     return DFF_OK;

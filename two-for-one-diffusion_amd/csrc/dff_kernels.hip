@@ -24,223 +24,7 @@
 // term routed through W_oc = W_o W_c.  All dense projections (q|k|v, u, W_o, W_oc, FFN and
 // their transposes for the VJP) run on v_mfma_f32_16x16x4_f32 (exact fp32 == fmaf chain);
 // softmax / LayerNorm / GELU / gates / the N x N contractions run on the VALU out of LDS.
-#include "dff_internal.h"
-#include <type_traits>
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define DEVI __device__ __forceinline__
-
-#define DFF_QKVW 208    // stash row of one head: [q_ext 80 | k 64 | v 64]
-
-// Explicitly address-space-typed pointers: the hot lambdas capture pointers by reference and some
-// closures end up in memory, where a plain `float*` loses its provenance and every access turns
-// into a FLAT op (which waits on BOTH counters and drains the weight ring).  Typed pointers keep
-// ds_* / global_* no matter how they travel.
-typedef __attribute__((address_space(3))) float lfloat;
-typedef __attribute__((address_space(1))) float gfloat;
-typedef f32x4 __attribute__((address_space(3))) lf32x4;
-typedef f32x4 __attribute__((address_space(1))) gf32x4;
-#ifndef DFF_STASH_NT
-#define DFF_STASH_NT 0   // 1: non-temporal stash traffic. Measured: default policy is 3% faster (stash stays in L2/MALL)
-#endif
-#if DFF_STASH_NT
-DEVI void st_ntg(gfloat* p, float v) { __builtin_nontemporal_store(v, p); }
-DEVI float ld_ntg(const gfloat* p) { return __builtin_nontemporal_load(p); }
-DEVI f32x4 ld_ntg4(const gfloat* p) { return __builtin_nontemporal_load((const gf32x4*)p); }
-#else
-DEVI void st_ntg(gfloat* p, float v) { *p = v; }
-DEVI float ld_ntg(const gfloat* p) { return *p; }
-DEVI f32x4 ld_ntg4(const gfloat* p) { return *(const gf32x4*)p; }
-#endif
-
-// ------------------------------------------------------------------------------------------
-// Stash layout (floats, per workgroup).  R = G*N allocated rows, F = 4H.
-// ------------------------------------------------------------------------------------------
-struct StashLayout {
-    unsigned nodes_in, attn_out, ff, h_pre, qkvx, P, m12;  // offsets inside a layer slot
-    unsigned PS;          // leading dimension of a stashed probability row (16 * row tiles)
-    unsigned layer_stride;
-    unsigned dn_spill;   // offset of the (R,H) spill slot for nodes / dn (after all layers)
-    unsigned total;
-};
-
-// qkvx: per head an (R x 208) block, row = [q(64) | u(16) | k(64) | v(64)] (the "extended head" of
-// dff_internal.h); P: per head an (R x PS) block of softmax rows over ALL rows of the workgroup
-// (zeros outside the row's own protein).
-__host__ __device__ inline StashLayout dff_stash_layout(int N, int G, int H, int L) {
-    StashLayout s;
-    const unsigned R = (unsigned)(G * N), F = 4u * H;
-    unsigned o = 0;
-    s.PS = 16u * ((R + 15u) / 16u);
-    s.nodes_in = o; o += R * H;
-    s.attn_out = o; o += R * H;
-    s.ff = o;       o += R * H;
-    s.h_pre = o;    o += R * F;
-    s.qkvx = o;     o += (unsigned)DFF_HEADS * R * DFF_QKVW;
-    s.P = o;        o += (unsigned)DFF_HEADS * R * s.PS;
-    s.m12 = o;      o += (unsigned)DFF_HEADS * R * 4;   // GEN: [sum_j a x_j (3) | sum_j a |x_j|^2] per head and row
-    s.layer_stride = o;
-    s.dn_spill = o * (unsigned)L;
-    s.total = s.dn_spill + R * (H + 4);   // indexed with the LDS leading dimension H + 4
-    s.total = (s.total + 63u) & ~63u;
-    return s;
-}
-
-// ------------------------------------------------------------------------------------------
-// LDS layout (floats).  Computed identically on host (for the launch size) and device.
-// Head-group region Rg: four (R x LQ) buffers Q_ext | K_ext | V_ext | G_ext, a head being 80
-// columns [64 | 16 extension]; Pbuf / dSbuf: per head of the group a (16MT x PL) tile array.
-// ------------------------------------------------------------------------------------------
-template <int H, int MT, int HGS, bool SPILL>
-struct LdsLayout {
-    static constexpr int LH = H + 4;
-    static constexpr int LQ = 80 * HGS + 4;
-    static constexpr int PL = 16 * MT + 4;
-    static constexpr int PT = 16 * MT * PL;   // one head's tile array
-    static constexpr int F = 4 * H;
-    static constexpr int FC = (F % 256 == 0) ? 256 : 128;
-    static constexpr int LF = FC + 4;
-    static constexpr int NREG = MT < 4 ? 5 : 4;   // a fifth head-group buffer (backward: dQ_ext) where LDS allows
-    static constexpr int LHS2 = (H + 8) / 2;   // dwords per row of a bf16 piece of the split A operand (SPW variants)
-    unsigned xst, xs, dxs, vst, cm, tn, prof, prow, dxw, m12, abuf, resbuf, Pbuf, dSbuf, Rg, asplit, total;
-    __host__ __device__ LdsLayout(int N, int G, bool spw = false) {
-        const unsigned R = (unsigned)(G * N);
-        unsigned o = 0;
-        xst = o;   o += R * 4;
-        xs = o;    o += R * 4;
-        dxs = o;   o += R * 4;
-        vst = o;   o += R * 4;
-        cm = o;    o += 16 * 4 * 2;
-        tn = o;    o += 16;
-        prof = o;  o += 2 * DFF_NPROF;
-        prow = o;  o += 64;                    // protein index of each row (-1: pad row)
-        dxw = o;   o += DFF_NWAVES * R * 4;   // per-wave partial dE/dx (summed once per step)
-        m12 = o;   o += HGS * R * 4;          // GEN: reloaded [m1 | m2] of the head group (backward)
-        abuf = o;  o += R * LH;
-        resbuf = o; if (!SPILL) o += R * LH;
-        Pbuf = o;  o += HGS * PT;
-        dSbuf = o; o += HGS * PT;
-        Rg = o;
-        unsigned rsz = (unsigned)NREG * R * LQ;
-        if (R * LF > rsz) rsz = R * LF;
-        if (R * LH > rsz) rsz = R * LH;
-        o += rsz + 64;  // slack: clamped A-fragment reads never leave the allocation
-        asplit = o;
-        if (spw) o += 3u * R * LHS2;   // [h | m | l] bf16 pieces of abuf (R x H each, row stride H + 8)
-        total = o;
-    }
-};
-
-// ------------------------------------------------------------------------------------------
-// small device helpers
-// ------------------------------------------------------------------------------------------
-// all-reduce over an aligned group of 16 lanes (one DPP "row") without touching LDS:
-// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
-template <int CTRL>
-DEVI float dpp_mov(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-// thread index behind an opaque barrier: every stage re-derives its lane / row / address arithmetic from
-// a fresh copy, so LICM cannot hoist hundreds of per-stage invariants to the top of the kernel (where
-// they spill and come back through scratch loads that drain the weight rings).
-DEVI int tid_now() {
-    int t = threadIdx.x;
-    asm volatile("" : "+v"(t));
-    return t;
-}
-DEVI float row16_sum(float v) {
-    v += dpp_mov<0xB1>(v);
-    v += dpp_mov<0x4E>(v);
-    v += dpp_mov<0x141>(v);
-    v += dpp_mov<0x140>(v);
-    return v;
-}
-DEVI float row16_max(float v) {
-    v = fmaxf(v, dpp_mov<0xB1>(v));
-    v = fmaxf(v, dpp_mov<0x4E>(v));
-    v = fmaxf(v, dpp_mov<0x141>(v));
-    v = fmaxf(v, dpp_mov<0x140>(v));
-    return v;
-}
-DEVI float grp16_sum(float v) { return row16_sum(v); }
-DEVI float grp_sum(float v, int np) {
-    for (int o = np >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-DEVI float grp_max(float v, int np) {
-    for (int o = np >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-DEVI float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-DEVI float gelu_grad_f(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) +
-           x * expf(-0.5f * x * x) * 0.39894228040143267794f;
-}
-// GELU(erf) value and derivative in one go: the forward FFN epilogue stashes gelu'(h_pre) so that the
-// backward epilogue is a single multiply (one erf + one exp per element per step instead of two + one)
-// Branch-free erf: |x| <= 0.8: x * P5(x^2);  else 1 - exp(P8(|x|)) with P8 ~ log erfc on [0.8, 4.2]
-// (least-squares fits on Chebyshev nodes; max abs error 1.2e-7 against scipy.special.erf over
-// [-6, 6] in float32 -- the same 1-2 ulp class as the library erff, at about half its instructions).
-#ifndef DFF_FAST_ERF
-#define DFF_FAST_ERF 0   // measured: no faster than the library erff here (the FFN epilogue is not erf-bound)
-#endif
-DEVI float erf_fast(float x) {
-#if DFF_FAST_ERF
-    const float t = fminf(fabsf(x), 4.2f), s = x * x;
-    float a = -6.546706740e-04f;
-    a = fmaf(a, s, 5.086977565e-03f); a = fmaf(a, s, -2.682184972e-02f); a = fmaf(a, s, 1.128313692e-01f);
-    a = fmaf(a, s, -3.761260335e-01f); a = fmaf(a, s, 1.128379164e+00f);
-    a *= x;
-    float b = 1.534366307e-06f;
-    b = fmaf(b, t, -4.404490910e-05f); b = fmaf(b, t, 5.800263089e-04f); b = fmaf(b, t, -4.682034248e-03f);
-    b = fmaf(b, t, 2.620414818e-02f); b = fmaf(b, t, -1.097046865e-01f); b = fmaf(b, t, -6.322175036e-01f);
-    b = fmaf(b, t, -1.130008818e+00f); b = fmaf(b, t, 2.658824129e-04f);
-    b = copysignf(1.0f - __expf(b), x);
-    return t <= 0.8f ? a : b;
-#else
-    return erff(x);
-#endif
-}
-DEVI void gelu_both(float x, float& g, float& gp) {
-    const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
-    g = x * cdf;
-    gp = cdf + x * expf(-0.5f * x * x) * 0.39894228040143267794f;
-}
-
-DEVI float sigmoid_f(float z) { return 1.0f / (1.0f + expf(-z)); }
-DEVI void st_nt(float* p, float v) { __builtin_nontemporal_store(v, p); }
-DEVI float ld_nt(const float* p) { return __builtin_nontemporal_load(p); }
-
-// Philox4x32-10 (Salmon et al. 2011), counter-based: the same (key, counter) always gives the
-// same 4 words, so a trajectory's noise does not depend on how the batch is sharded.
-DEVI void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2,
-                        uint32_t c3, uint32_t (&out)[4]) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        const uint32_t n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-        const uint32_t n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-// standard normal number `c` (0..2) for (item, step, bead): Box-Muller on Philox words.
-DEVI float philox_normal(uint64_t seed, uint64_t item, uint64_t step, uint32_t bead, int c) {
-    uint32_t w[4];
-    philox4x32_10((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)item,
-                  (uint32_t)(item >> 32) ^ (bead << 8), (uint32_t)step, (uint32_t)(step >> 32), w);
-    const float inv = 2.3283064365386963e-10f;  // 2^-32
-    const float u0 = ((float)w[(c >> 1) * 2] + 0.5f) * inv;          // (0,1]
-    const float u1 = ((float)w[(c >> 1) * 2 + 1] + 0.5f) * inv;
-    const float r = sqrtf(-2.0f * logf(u0));
-    const float th = 6.28318530717958647692f * u1;
-    return (c & 1) ? r * sinf(th) : r * cosf(th);
-}
+#include "dff_device.h"
 
 // ------------------------------------------------------------------------------------------
 // MFMA GEMM stages.  A (rows x K) lives in LDS with leading dimension lda (multiple of 4);
@@ -342,22 +126,6 @@ DEVI void gemm_wide(const lfloat* A, int lda, int rowsA, const float* __restrict
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// SPW variants (opt-in, DFF_SPLIT_BF16=1): the K = H weight GEMMs on the bf16 matrix pipe at fp32 accuracy.
-// An fp32 value is the exact sum of three bf16 pieces (truncation split: h = top 16 bits, r = a - h exactly, ...);
-// a.b ~ ah.bh + (am.bh + ah.bm) + (al.bh + ah.bl + am.bm) drops only terms of order 2^-24 (tools_ubench/split_bf16.hip:
-// error vs fp64 <= that of v_mfma_f32_16x16x4_f32).  The weights are split on the host (dff_host.hip pack_b_split),
-// the activations by split_rows once per GEMM input; six v_mfma_f32_16x16x32_bf16 (16 cycles each, and they leave the
-// vector port free: tools_ubench/overlap3.hip) replace eight v_mfma_f32_16x16x4_f32 (32 cycles each).
-// ------------------------------------------------------------------------------------------
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __attribute__((address_space(3))) unsigned lu32;
-typedef __attribute__((address_space(3))) u32x4 lu32x4;
-typedef __attribute__((address_space(1))) u32x4 gu32x4;
-DEVI f32x4 mfma_bf16(const u32x4 a, const u32x4 b, const f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
 // abuf (R x H fp32, leading dimension H + 4) -> as[piece][row][LHS2] (bf16 pairs): all threads, two columns each
 template <int H>
 DEVI void split_rows(const lfloat* abuf, lu32* as, int R) {
@@ -816,37 +584,7 @@ DEVI void store_tall(const f32x4 (&acc)[NTW][MT], float* out, int ld, int rows, 
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// optional per-stage cycle accounting (a.prof != null): thread 0 of block 0 accumulates
-// s_memtime deltas per stage id at stage boundaries; written out at kernel end.
-// ------------------------------------------------------------------------------------------
-struct Prof {
-    unsigned long long* out;
-    unsigned long long last;
-    unsigned long long* acc;   // LDS
-    bool on;
-    DEVI void tick(int id) {
-        if (on) {
-            const unsigned long long t = __builtin_readcyclecounter();
-            acc[id] += t - last;
-            last = t;
-        }
-    }
-};
 
-// ------------------------------------------------------------------------------------------
-// per-workgroup context
-// ------------------------------------------------------------------------------------------
-struct Ctx {
-    int N, G, gcnt, rows, NP, L;
-    int b0;
-    float *xst, *xs, *dxs, *vst, *cm, *tn, *abuf, *resbuf, *Pbuf, *dSbuf, *Rg;
-    float* stash;  // this workgroup's slot
-    const float* l0;   // layer-0 slot the x-independent nodes_in / q|u|k|v are READ from (table entry or own stash)
-    StashLayout sl;
-};
-
-// x-independent layer-0 node features: node_embedding([one_hot(i), t])  (graph_transformer.py:
 // 91-92,100-103) -> resbuf, stashed as nodes_in of layer 0.
 template <int H, bool GEN>
 DEVI void node_embed(const Ctx& c, const DffModelDev& m) {
@@ -1233,13 +971,6 @@ DEVI void co_mm5(f32x4 (&c)[5], const lfloat* T, int mo, const lfloat* B, int ld
     }
 }
 
-// geometry every attention phase needs
-DEVI float quad_sum(float v) {        // all-reduce over the 4 lanes of a DPP quad
-    v += dpp_mov<0xB1>(v);
-    v += dpp_mov<0x4E>(v);
-    return v;
-}
-DEVI float quad_bcast3(float v) { return dpp_mov<0xFF>(v); }   // lane 3 of the quad to all four
 
 // GEN variants (other input branches, oracle/kernel_model_gen.py): the 16-column head extension carries
 //   Q_ext: [u - 2 s x_i (3) | s]    K_ext, V_ext: [x_j (3) | |x_j|^2]    o_ext: [xrel (3) | D]
@@ -1601,18 +1332,6 @@ DEVI void co_reload_commit(const CoReload<MT, HGS>& rl, const CoGeo& g) {
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// centring helpers (utils.py:65-70): per-protein mean over beads
-// ------------------------------------------------------------------------------------------
-DEVI void bead_mean(const Ctx& c, const float* src, float* cm) {
-    const int tid_ = tid_now();
-    if (tid_ < c.gcnt * 4) {
-        const int g = tid_ >> 2, cc = tid_ & 3;
-        float s = 0.f;
-        for (int i = 0; i < c.N; ++i) s += src[(g * c.N + i) * 4 + cc];
-        cm[tid_] = s / (float)c.N;
-    }
-}
 
 // ------------------------------------------------------------------------------------------
 // the kernel
@@ -2171,24 +1890,36 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_debug_gemm_kernel(const floa
         });
 }
 
-// explicit instantiations used by the host dispatcher
-#define DFF_INST(H, MT, HGS, SPILL) \
-    template __global__ void dff_fused_kernel<H, MT, HGS, SPILL, false, false>(const DffModelDev, const DffRunArgs); \
-    template __global__ void dff_fused_kernel<H, MT, HGS, SPILL, true, false>(const DffModelDev, const DffRunArgs);
-DFF_INST(64, 1, 4, false)
-DFF_INST(64, 2, 2, false)
-DFF_INST(96, 1, 4, false)
-DFF_INST(96, 2, 2, false)
-DFF_INST(128, 1, 4, false)
-DFF_INST(128, 2, 2, false)
-DFF_INST(128, 3, 1, false)
-DFF_INST(128, 4, 1, true)
-// opt-in split-bf16 weight GEMMs (DFF_SPLIT_BF16=1)
-template __global__ void dff_fused_kernel<96, 2, 2, false, false, true>(const DffModelDev, const DffRunArgs);
-template __global__ void dff_fused_kernel<128, 2, 2, false, false, true>(const DffModelDev, const DffRunArgs);
-template __global__ void dff_fused_kernel<128, 3, 1, false, false, true>(const DffModelDev, const DffRunArgs);
-template __global__ void dff_fused_kernel<96, 2, 2, false, true, true>(const DffModelDev, const DffRunArgs);
-template __global__ void dff_fused_kernel<128, 2, 2, false, true, true>(const DffModelDev, const DffRunArgs);
-template __global__ void dff_fused_kernel<128, 3, 1, false, true, true>(const DffModelDev, const DffRunArgs);
-template __global__ void dff_debug_gemm_kernel<4>(const float*, const float*, int, int, float*);
-template __global__ void dff_debug_gemm_kernel<8>(const float*, const float*, int, int, float*);
+// ------------------------------------------------------------------------------------------
+// variant table handed to the host dispatcher (dff_host.hip); taking the kernels' addresses instantiates them
+// ------------------------------------------------------------------------------------------
+template <int H, int MT, int HGS, bool SP, bool SPW>
+static unsigned lds_floats_of(int N, int G) { return LdsLayout<H, MT, HGS, SP>(N, G, SPW).total; }
+#define VAR(H, MT, HGS, SP)                                                                                     \
+    { H, MT, HGS, SP, false, false, (const void*)&dff_fused_kernel<H, MT, HGS, SP, false, false>,               \
+      &lds_floats_of<H, MT, HGS, SP, false>, "dff_fused_kernel<" #H "," #MT "," #HGS "," #SP ">" },             \
+    { H, MT, HGS, SP, true, false, (const void*)&dff_fused_kernel<H, MT, HGS, SP, true, false>,                 \
+      &lds_floats_of<H, MT, HGS, SP, false>, "dff_fused_kernel<" #H "," #MT "," #HGS "," #SP ",gen>" }
+#define VAR_SPW(H, MT, HGS)                                                                                     \
+    { H, MT, HGS, false, false, true, (const void*)&dff_fused_kernel<H, MT, HGS, false, false, true>,           \
+      &lds_floats_of<H, MT, HGS, false, true>, "dff_fused_kernel<" #H "," #MT "," #HGS ",false,split_bf16>" },  \
+    { H, MT, HGS, false, true, true, (const void*)&dff_fused_kernel<H, MT, HGS, false, true, true>,             \
+      &lds_floats_of<H, MT, HGS, false, true>, "dff_fused_kernel<" #H "," #MT "," #HGS ",false,gen,split_bf16>" }
+static const Variant g_variants[] = {
+#ifndef DFF_FAST_BUILD
+    VAR(64, 1, 4, false),  VAR(64, 2, 2, false),  VAR(96, 1, 4, false),  VAR(96, 2, 2, false),
+    VAR(128, 1, 4, false), VAR(128, 2, 2, false), VAR(128, 3, 1, false), VAR(128, 4, 1, true),
+    VAR_SPW(96, 2, 2), VAR_SPW(128, 2, 2), VAR_SPW(128, 3, 1),
+#else   // development builds: one variant, so that the <= 16-row kernel can be iterated on quickly
+    VAR(64, 1, 4, false),
+#endif
+};
+const Variant* dff_fused_variants(int* count) {
+    *count = (int)(sizeof(g_variants) / sizeof(g_variants[0]));
+    return g_variants;
+}
+int dff_debug_gemm_launch(int K, const float* dA, const float* dW, int M, int Nout, float* dO, size_t lds) {
+    if (K == 64) hipLaunchKernelGGL(dff_debug_gemm_kernel<4>, dim3(1), dim3(DFF_NTHREADS), lds, 0, dA, dW, M, Nout, dO);
+    else hipLaunchKernelGGL(dff_debug_gemm_kernel<8>, dim3(1), dim3(DFF_NTHREADS), lds, 0, dA, dW, M, Nout, dO);
+    return (int)hipGetLastError();
+}

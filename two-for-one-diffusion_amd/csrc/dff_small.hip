@@ -21,35 +21,7 @@
 //
 // Everything dense runs on v_mfma_f32_16x16x4_f32; VALU work is softmax (in the MFMA C layout),
 // LayerNorm, gates, GELU and the integrator update.
-#pragma once
-#include "dff_internal.h"
-
-#define DFF_XH 80       // extended head width
-#define DFF_XLD 84      // leading dim of the per-wave head buffers
-#define DFF_PLD 20      // leading dim of the per-wave P / dS tiles
-
-struct SmallStash {
-    unsigned nodes_in, attn_out, ff, h_pre, qkv, P, m12;
-    unsigned layer_stride, total;
-};
-__host__ __device__ inline SmallStash dff_small_stash(int N, int G, int H, int L) {
-    SmallStash s;
-    // every array has one extra "dummy" row (index G*N) that absorbs the stores of pad lanes
-    // (rows >= real rows of the 16-row MFMA tile), so epilogues need no exec-masked branches;
-    // P keeps all 16 rows (its pad rows must read back as exact zeros).
-    const unsigned R = (unsigned)(G * N) + 1u, F = 4u * H;
-    unsigned o = 0;
-    s.nodes_in = o; o += R * H;
-    s.attn_out = o; o += R * H;
-    s.ff = o;       o += R * H;
-    s.h_pre = o;    o += R * F;
-    s.qkv = o;      o += DFF_HEADS * R * DFF_QKVW;
-    s.P = o;        o += DFF_HEADS * 16 * 16;
-    s.m12 = o;      o += DFF_HEADS * 16 * 4;   // GEN: [sum_j a x_j (3) | sum_j a |x_j|^2] per head and row
-    s.layer_stride = o;
-    s.total = (o * (unsigned)L + 63u) & ~63u;
-    return s;
-}
+#include "dff_device.h"
 
 // NW = waves per workgroup.  NW = 4: one wave per SIMD, two heads per wave, 16-row head buffers.
 // NW = 8: two waves per SIMD (each hides the other's stalls), one head per wave; to fit 8 wave
@@ -1397,11 +1369,22 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     }
 }
 
-#define DFF_SMALL_INST(H, NW) \
-    template __global__ void dff_small_kernel<H, NW, false>(const DffModelDev, const DffRunArgs); \
-    template __global__ void dff_small_kernel<H, NW, true>(const DffModelDev, const DffRunArgs);
-DFF_SMALL_INST(64, 4)
-DFF_SMALL_INST(96, 4)
-DFF_SMALL_INST(128, 4)
-DFF_SMALL_INST(64, 8)
-DFF_SMALL_INST(96, 8)
+// kernel lookup for the host dispatcher (dff_host.hip); taking the address instantiates the variant
+bool dff_small_pick(int H, int NW, bool gen, bool spw, const void** fn, unsigned* lds_floats, const char** name) {
+#define SMALL_CASE(H_, NW_)                                                                                          \
+    if (H == H_ && NW == NW_ && !spw) {                                                                              \
+        *fn = gen ? (const void*)&dff_small_kernel<H_, NW_, true> : (const void*)&dff_small_kernel<H_, NW_, false>;  \
+        *lds_floats = SmallLds<H_, NW_>::total;                                                                      \
+        *name = gen ? "dff_small_kernel<" #H_ "," #NW_ ",gen>" : "dff_small_kernel<" #H_ "," #NW_ ">";               \
+        return true;                                                                                                 \
+    }
+    SMALL_CASE(64, 8)
+#ifndef DFF_FAST_BUILD
+    SMALL_CASE(64, 4)
+    SMALL_CASE(96, 4)
+    SMALL_CASE(128, 4)
+    SMALL_CASE(96, 8)
+#endif
+#undef SMALL_CASE
+    return false;
+}
