@@ -78,6 +78,44 @@ static std::vector<uint32_t> pack_b_split(int K, int Nout, const std::function<d
     return out;
 }
 
+// Split-bf16 images for the <= 16-row kernel's SPW variants (dff_small.hip, split engine): a sequence of UNITS, each one
+// 16-column output tile nt x 32 A-columns starting at c0, stored [piece h | m | l][lane][8 bf16].  Element j of lane
+// (n = lane & 15, kg = lane >> 4) is W(c0 + 16 (j >> 2) + 4 kg + (j & 3), 16 nt + n): the k order in which that kernel's A
+// fragments hold a 32-column block (two ds_read_b128, at columns 4 kg and 16 + 4 kg).  w = h + m + l exactly.
+static std::vector<uint32_t> pack_units(const std::vector<std::pair<int, int>>& units, int Nout,
+                                        const std::function<double(int, int)>& w) {
+    std::vector<uint32_t> out(units.size() * 3 * 64 * 4, 0u);
+    auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+    auto flt = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+    for (size_t u = 0; u < units.size(); ++u) {
+        const int nt = units[u].first, c0 = units[u].second;
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+                const int c = c0 + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3), n = 16 * nt + (lane & 15);
+                const float v = n < Nout ? (float)w(c, n) : 0.f;
+                const uint32_t h = bits(v) & 0xffff0000u;
+                const float r = v - flt(h);
+                const uint32_t mm = bits(r) & 0xffff0000u;
+                const float r2 = r - flt(mm);
+                const uint32_t pc[3] = {h >> 16, mm >> 16, bits(r2) >> 16};
+                for (int q = 0; q < 3; ++q) out[((u * 3 + q) * 64 + lane) * 4 + (j >> 1)] |= pc[q] << (16 * (j & 1));
+            }
+    }
+    return out;
+}
+static std::vector<std::pair<int, int>> units_wide(int K, int Nout) {   // [tile][k-block]
+    std::vector<std::pair<int, int>> u;
+    for (int nt = 0; nt < (Nout + 15) / 16; ++nt)
+        for (int kb = 0; kb < K / 32; ++kb) u.push_back({nt, 32 * kb});
+    return u;
+}
+static std::vector<std::pair<int, int>> units_tall(int K, int Nout) {   // [k-block][tile]
+    std::vector<std::pair<int, int>> u;
+    for (int kb = 0; kb < K / 32; ++kb)
+        for (int nt = 0; nt < (Nout + 15) / 16; ++nt) u.push_back({nt, 32 * kb});
+    return u;
+}
+
 // ------------------------------------------------------------------------------------------
 // model handle
 // ------------------------------------------------------------------------------------------
@@ -108,7 +146,8 @@ struct dff_model {
     bool l0_off = false;                       // debugging: never use the table
     int max_wgs = 2048;                        // workgroups per launch: bounds the stash (grid x stash slot) for big batches
     int last_base = 0;
-    bool split = false;                        // DFF_SPLIT_BF16=1 at model creation: split-bf16 images exist, SPW variants preferred
+    bool split = false;                        // split-bf16 images exist, SPW variants preferred (DFF_SPLIT_BF16=0 at model creation: never)
+    bool small_split = false;                  // ... and the <= 16-row kernel has an SPW variant for this model
 };
 
 static int upload_u32(dff_model* m, const std::vector<uint32_t>& h, const unsigned** out) {
@@ -201,9 +240,12 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
     dff_model* m = new dff_model();
     m->cfg = *cfg;
     m->device = device;
-    {   // opt-in: K = H weight GEMMs of the generic kernel on the bf16 pipe via the exact three-way split
+    {   // weight GEMMs on the bf16 pipe via the exact three-way split of every fp32 operand, wherever a kernel variant
+        // exists for the shape (default); DFF_SPLIT_BF16=0: every GEMM on v_mfma_f32_16x16x4_f32
         const char* e = getenv("DFF_SPLIT_BF16");
-        m->split = e && e[0] == '1';
+        m->split = !(e && e[0] == '0');
+        const void* fn_; unsigned lds_; const char* nm_;
+        m->small_split = m->split && N <= 10 && dff_small_pick(H, 8, false, true, &fn_, &lds_, &nm_);
     }
     memset(&m->dev, 0, sizeof m->dev);
     m->dev.N = N; m->dev.H = H; m->dev.L = L; m->dev.T = cfg->timesteps;
@@ -348,6 +390,21 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
             // the 64 regular rows of every head of [W_o ; W_oc] (the extension rows stay on the fp32 image)
             if ((rc_ = upload_u32(m, pack_b_split(8 * 64, H, [&](int k, int n) { return wox((k / 64) * 80 + k % 64, n); }), &d.Wox_s))) return rc_;
         }
+        d.Wqkvx_w = d.W1_w = d.W2T_w = d.WoxT_w = d.Wox_t = d.W2_t = d.W1T_t = d.WqkvxT_t = nullptr;
+        if (m->small_split) {
+            int rc_;
+            if ((rc_ = upload_u32(m, pack_units(units_wide(H, 8 * 208), 8 * 208, [&](int k, int n) { return wqkvx(n, k); }), &d.Wqkvx_w))) return rc_;
+            if ((rc_ = upload_u32(m, pack_units(units_wide(H, F), F, [&](int k, int n) { return (double)W1[(size_t)n * H + k]; }), &d.W1_w))) return rc_;
+            if ((rc_ = upload_u32(m, pack_units(units_wide(H, F), F, [&](int k, int n) { return (double)W2[(size_t)k * F + n]; }), &d.W2T_w))) return rc_;
+            if ((rc_ = upload_u32(m, pack_units(units_wide(H, 8 * 80), 8 * 80, [&](int k, int n) { return wox(n, k); }), &d.WoxT_w))) return rc_;
+            // Nout = H: the 64 regular rows of every head of [W_o ; W_oc] / [q | k | v] (extension rows: fp32 k-step off the fp32 images)
+            if ((rc_ = upload_u32(m, pack_units(units_tall(8 * 64, H), H, [&](int c, int n) { return wox((c / 64) * 80 + c % 64, n); }), &d.Wox_t))) return rc_;
+            if ((rc_ = upload_u32(m, pack_units(units_tall(F, H), H, [&](int k, int n) { return (double)W2[(size_t)n * F + k]; }), &d.W2_t))) return rc_;
+            if ((rc_ = upload_u32(m, pack_units(units_tall(F, H), H, [&](int k, int n) { return (double)W1[(size_t)k * H + n]; }), &d.W1T_t))) return rc_;
+            if ((rc_ = upload_u32(m, pack_units(units_tall(8 * 192, H), H, [&](int c, int n) {
+                     const int h = c / 192, cc = c % 192;
+                     return wqkvx(h * 208 + (cc < 64 ? cc : cc + 16), n); }), &d.WqkvxT_t))) return rc_;
+        }
         UP(bqkvx, d.bqkvx);
         UP(pack_b(8 * 80, H, [&](int k, int n) { return wox(k, n); }, 5), d.Wox_p);
         UP(pack_b(H, 8 * 80, [&](int k, int n) { return wox(n, k); }), d.WoxT_p);
@@ -435,7 +492,8 @@ static int launch_small(dff_model* m, DffRunArgs& a, int G, hipStream_t stream) 
     const bool eight = (H == 64 || H == 96) && G * N <= 10 && m->small_waves != 4;
     const bool gen = !(m->cfg.use_intrinsic_coords == 1 && m->cfg.use_distances == 0 && m->cfg.use_abs_coords == 0);
     const int NW = eight ? 8 : 4;
-    if (!dff_small_pick(H, NW, gen, false, &fn, &lds, &name))
+    const bool spw = eight && m->small_split;
+    if (!dff_small_pick(H, NW, gen, spw, &fn, &lds, &name))
         return fail(DFF_EINVAL, "no <= 16-row kernel for hidden=%d waves=%d in this build", H, NW);
     nthreads = NW * 64;
     lds *= (unsigned)sizeof(float);

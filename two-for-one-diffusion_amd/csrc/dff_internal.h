@@ -36,6 +36,9 @@ struct DffLayerDev {
     // opt-in (DFF_SPLIT_BF16=1): the K = H images as three bf16 pieces per weight (dff_host.hip pack_b_split)
     const unsigned *Wqkvx_s, *W1_s, *W2T_s, *WoxT_s, *W2_s, *W1T_s, *Wox_s;
     const float *W1T_p;           // K=4H, Nout=H   df  = dhp  W1
+    // split-bf16 images of all eight weight GEMMs for the <= 16-row kernel (dff_small.hip SPW variants; dff_host.hip
+    // pack_units): *_w K = H, units ordered [tile][k-block]; *_t Nout = H, units ordered [k-block][tile]
+    const unsigned *Wqkvx_w, *W1_w, *W2T_w, *WoxT_w, *Wox_t, *W2_t, *W1T_t, *WqkvxT_t;
     // "extended head" images: per head 80 = 64 + 16 extension columns / rows ([u (3) | s | 0...], [xrel (3) | D | 0...])
     const float *Wqkvx_p, *bqkvx; // K=H, Nout=8*208, per head [q 64 | ext 16 | k 64 | v 64]
     const float *Wox_p;           // K=8*80 per head [o 64 | ext 16], Nout=H

@@ -188,6 +188,145 @@ DEVI void tall_run(Ring<E, DR>& ring, f32x4 (&acc)[E], const FA fa, const WStrea
     if constexpr (REM > 2) tall_step<(PH + 2) % DR, N, E, XKB>(ring, acc, a, fa, w, wn, lane, NREV * DR + 2);
 }
 
+// ---------------------------------------------------------------- split-bf16 engine (SPW variants)
+// The weight GEMMs on the bf16 matrix pipe at fp32 accuracy: an fp32 value is the exact sum of three bf16 pieces
+// (truncation split h | m | l) and  a.b ~ ah.bh + (am.bh + ah.bm) + (al.bh + ah.bl + am.bm)  drops only terms of relative
+// order 2^-24 (tools_ubench/split_bf16.hip: error vs fp64 <= that of v_mfma_f32_16x16x4_f32).  Six
+// v_mfma_f32_16x16x32_bf16 (16 cycles each, and they leave the SIMD's vector port to the sibling wave) replace eight
+// v_mfma_f32_16x16x4_f32 (32 cycles each).  The weights are split on the host (dff_host.hip pack_units); the A operand
+// stays fp32 in LDS, exactly where the fp32 engine reads it, and is split in registers by the wave that consumes it
+// (split8: ~44 VALU per 32-column block, amortised over the 4..13 tiles that use the block).
+// One ring entry = one UNIT = (16-column output tile, 32-row k-block) = three pieces x 16 B per lane; every stream is
+// a linear sequence of units ([tile][k-block] for the K = H GEMMs, [k-block][tile] for the Nout = H ones), the ring holds
+// DR = H/16 units, and the last DR refills of a GEMM fetch the first units of the stream that follows, placed so that
+// the following GEMM starts at ring phase PHN (blocks separated by a barrier always start at phase 0).
+template <int DR>
+struct SRing {
+    u32x4 b[DR][3];
+};
+struct SStream {
+    const gu32x4* base;   // wave-uniform; unit j at base + 192 j, piece p at + 64 p, lane at + lane
+};
+DEVI SStream sstream(const unsigned* Wp, int unit0) { return SStream{(const gu32x4*)Wp + (size_t)unit0 * 192}; }
+DEVI void sfill(u32x4 (&slot)[3], const SStream& w, int j, int lane) {
+    const gu32x4* p = w.base + (size_t)j * 192;
+    const unsigned lo = (unsigned)lane & 63u;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) slot[q] = (p + 64 * q)[lo];
+}
+template <int DR>
+DEVI void sring_prefetch(SRing<DR>& r, const SStream& w, int lane) {
+#pragma unroll
+    for (int j = 0; j < DR; ++j) sfill(r.b[j], w, j, lane);
+}
+// eight fp32 values of a 32-column block (x0: columns 4 kg .. + 3, x1: columns 16 + 4 kg .. + 3 -- what two ds_read_b128
+// of the fp32 engine's A pattern deliver) -> the three bf16 piece operands; element j sits in half j & 1 of dword j >> 1
+DEVI void split8(const f32x4& x0, const f32x4& x1, u32x4& h, u32x4& m, u32x4& l) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float e0 = q < 2 ? x0[2 * q] : x1[2 * q - 4], e1 = q < 2 ? x0[2 * q + 1] : x1[2 * q - 3];
+        const unsigned b0 = __float_as_uint(e0), b1 = __float_as_uint(e1);
+        const float r0 = e0 - __uint_as_float(b0 & 0xffff0000u), r1 = e1 - __uint_as_float(b1 & 0xffff0000u);
+        const unsigned c0 = __float_as_uint(r0), c1 = __float_as_uint(r1);
+        const float s0 = r0 - __uint_as_float(c0 & 0xffff0000u), s1 = r1 - __uint_as_float(c1 & 0xffff0000u);
+        h[q] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+        m[q] = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
+        l[q] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+    }
+}
+template <int KB32>
+DEVI void split_afrag(const f32x4 (&a)[2 * KB32], u32x4 (&ah)[KB32], u32x4 (&am)[KB32], u32x4 (&al)[KB32]) {
+#pragma unroll
+    for (int kb = 0; kb < KB32; ++kb) split8(a[2 * kb], a[2 * kb + 1], ah[kb], am[kb], al[kb]);
+}
+// wide GEMM (K = H = 32 KB32) of one wave on split operands: N output tiles, KB32 units each; two tiles per ring
+// revolution (PAR = tile parity: static slots and aux slot).  aux[par][..]: epilogue operands of the tile with that
+// parity in flight (the caller preloads tiles 0 and 1, pre(t, aux[par]) refills).
+template <int PH, int PHN, int PAR, int N, int KB32, int NAUX, int DR, class Pre, class Epi>
+DEVI void swide_tile(SRing<DR>& ring, float (&aux)[2][NAUX], const u32x4 (&ah)[KB32], const u32x4 (&am)[KB32],
+                     const u32x4 (&al)[KB32], const SStream& w, const SStream& wn, int lane, int t, const Pre& pre, const Epi& epi) {
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f}, cb = {0.f, 0.f, 0.f, 0.f};   // small terms / big terms
+#pragma unroll
+    for (int kb = 0; kb < KB32; ++kb) {
+        const int slot = (PH + PAR * KB32 + kb) % DR;
+        u32x4 (&b)[3] = ring.b[slot];
+        cs = mfma_bf16(al[kb], b[0], cs);
+        cb = mfma_bf16(am[kb], b[0], cb);
+        cs = mfma_bf16(ah[kb], b[2], cs);
+        cb = mfma_bf16(ah[kb], b[1], cb);
+        cs = mfma_bf16(am[kb], b[1], cs);
+        cb = mfma_bf16(ah[kb], b[0], cb);
+        const int u = t * KB32 + kb;
+        if (u + DR < N * KB32) sfill(b, w, u + DR, lane);
+        else sfill(b, wn, (slot - PHN + DR) % DR, lane);
+    }
+    float auxc[NAUX];
+#pragma unroll
+    for (int q = 0; q < NAUX; ++q) auxc[q] = aux[PAR][q];
+    if (t + 2 < N) pre(t + 2, aux[PAR]);
+    epi(t, cb + cs, auxc);
+}
+template <int PH, int PHN, int N, int KB32, int NAUX, int DR, class Pre, class Epi>
+DEVI void swide_run(SRing<DR>& ring, float (&aux)[2][NAUX], const u32x4 (&ah)[KB32], const u32x4 (&am)[KB32],
+                    const u32x4 (&al)[KB32], const SStream& w, const SStream& wn, int lane, const Pre pre, const Epi epi) {
+    static_assert(DR == 2 * KB32, "two tiles per ring revolution");
+    static_assert(N * KB32 >= DR, "a GEMM spans at least one revolution");
+#pragma unroll 1
+    for (int rev = 0; rev < N / 2; ++rev) {
+        swide_tile<PH, PHN, 0, N, KB32, NAUX>(ring, aux, ah, am, al, w, wn, lane, 2 * rev, pre, epi);
+        swide_tile<PH, PHN, 1, N, KB32, NAUX>(ring, aux, ah, am, al, w, wn, lane, 2 * rev + 1, pre, epi);
+    }
+    if constexpr (N % 2 == 1) swide_tile<PH, PHN, 0, N, KB32, NAUX>(ring, aux, ah, am, al, w, wn, lane, N - 1, pre, epi);
+}
+// tall GEMM (Nout = H = 16 E) of one wave on split operands: acc[nt] += A(:, 32-column block kb) . W(unit (kb, nt)),
+// kb < NKB; fa(kb) = this lane's four floats at columns 4 quad of block kb (the second four are 16 floats on).  The next
+// block's A is read from LDS before the MFMAs of this one are issued.  EXT: one fp32 k-step on top for a head's
+// extension columns (of which only 0..3 carry data): A element *ext_a, weights ext_w[nt * ext_ts] (the s = 0 slots of the
+// fp32 image's extension block, dff_host.hip pack_b), requested first and used last.
+template <int PH, int PHN, int NKB, int E, bool EXT, int DR, class FA>
+DEVI void stall_run(SRing<DR>& ring, f32x4 (&acc)[E], const FA fa, const SStream& w, const SStream& wn, int lane,
+                    const lfloat* ext_a = nullptr, const gfloat* ext_w = nullptr, int ext_ts = 0) {
+    static_assert(E == DR, "one k-block per ring revolution");
+    float bx[E];
+    if constexpr (EXT) {
+#pragma unroll
+        for (int nt = 0; nt < E; ++nt) bx[nt] = ext_w[(size_t)nt * ext_ts];
+    }
+    const lfloat* p0 = fa(0);
+    f32x4 x0 = *(const lf32x4*)p0, x1 = *(const lf32x4*)(p0 + 16);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        u32x4 ah, am, al;
+        split8(x0, x1, ah, am, al);
+        if (kb + 1 < NKB) {
+            const lfloat* pn = fa(kb + 1);
+            x0 = *(const lf32x4*)pn; x1 = *(const lf32x4*)(pn + 16);
+        }
+#pragma unroll
+        for (int nt = 0; nt < E; ++nt) acc[nt] = mfma_bf16(al, ring.b[(PH + nt) % DR][0], acc[nt]);
+#pragma unroll
+        for (int nt = 0; nt < E; ++nt) acc[nt] = mfma_bf16(ah, ring.b[(PH + nt) % DR][2], acc[nt]);
+#pragma unroll
+        for (int nt = 0; nt < E; ++nt) acc[nt] = mfma_bf16(am, ring.b[(PH + nt) % DR][1], acc[nt]);
+#pragma unroll
+        for (int nt = 0; nt < E; ++nt) acc[nt] = mfma_bf16(am, ring.b[(PH + nt) % DR][0], acc[nt]);
+#pragma unroll
+        for (int nt = 0; nt < E; ++nt) acc[nt] = mfma_bf16(ah, ring.b[(PH + nt) % DR][1], acc[nt]);
+#pragma unroll
+        for (int nt = 0; nt < E; ++nt) {
+            const int slot = (PH + nt) % DR;
+            acc[nt] = mfma_bf16(ah, ring.b[slot][0], acc[nt]);
+            if (kb + 1 < NKB) sfill(ring.b[slot], w, (kb + 1) * E + nt, lane);
+            else sfill(ring.b[slot], wn, (slot - PHN + DR) % DR, lane);
+        }
+    }
+    if constexpr (EXT) {
+        const float ax = *ext_a;
+#pragma unroll
+        for (int nt = 0; nt < E; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, bx[nt], acc[nt], 0, 0, 0);
+    }
+}
+
 // C layout: acc[r] <-> (row 4*(lane>>4)+r, col lane&15); unconditional (pad rows hold finite junk)
 // rmax: last row of dst (pad lanes beyond it store to that dummy row)
 DEVI void c_store_all(lfloat* dst, int ld, int col0, const f32x4& acc, int lane, int rmax = 15) {
@@ -301,7 +440,7 @@ DEVI void head_commit(const HeadRegs& r, lfloat* Qx, lfloat* Kx, lfloat* Vx, lfl
 }
 
 // ---------------------------------------------------------------- the kernel
-template <int H, int NW, bool GEN>
+template <int H, int NW, bool GEN, bool SPW = false>
 __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m, const DffRunArgs a) {
     using LL = SmallLds<H, NW>;
     constexpr int LH = LL::LH, F = 4 * H, E = H / 16;
@@ -312,6 +451,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     constexpr int RS = RLA * DFF_XLD;        // floats between the Q / K / V / G buffers of a wave
     constexpr int FS = F / NW, NTS = FS / 16, LF = FS + 4;   // FFN hidden slice of a wave
     static_assert(HPW == 1 || HPW == 2, "4 or 8 waves");
+    constexpr int KB32 = H / 32, SDR = 2 * KB32;   // SPW: 32-row k-blocks of a K = H GEMM, split-ring depth in units
+    static_assert(!SPW || (NW == 8 && H % 32 == 0 && FS % 32 == 0 && E == SDR), "split-bf16 variant: one head per wave, whole 32-blocks");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     // the wave index is wave-uniform: say so (readfirstlane), so that every per-wave pointer and
@@ -436,6 +577,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     };
 
     Ring<E, DR> ring;
+    SRing<SDR> sring;   // SPW variants use this one instead (the unused ring is never materialised)
     HeadRegs hr;
     // GELU'(h_pre) slice of the NEXT backward layer, fetched a whole layer ahead (the stash is HBM-resident:
     // its latency is several times the weight ring's run-ahead).  Only when the slice is one ring revolution.
@@ -473,6 +615,18 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     auto s_w1t = [&](const DffLayerDev& lw) { return tall_stream(lw.W1T_p, F / 16, wave * NTS); };
     auto s_woxt = [&](const DffLayerDev& lw, int h) { return wide_stream(lw.WoxT_p, E, h * 5); };
     auto s_qkvt = [&](const DffLayerDev& lw, int h) { return tall_stream(lw.WqkvxT_p, DFF_HEADS * 13, h * 13); };
+    // the same streams of the split images (units, see the split engine above)
+    auto ss_qkv = [&](const DffLayerDev& lw, int h) { return sstream(lw.Wqkvx_w, h * 13 * KB32); };
+    auto ss_wox = [&](const DffLayerDev& lw, int h) { return sstream(lw.Wox_t, h * 2 * E); };
+    auto ss_w1 = [&](const DffLayerDev& lw) { return sstream(lw.W1_w, wave * NTS * KB32); };
+    auto ss_w2 = [&](const DffLayerDev& lw) { return sstream(lw.W2_t, wave * (FS / 32) * E); };
+    auto ss_w2t = [&](const DffLayerDev& lw) { return sstream(lw.W2T_w, wave * NTS * KB32); };
+    auto ss_w1t = [&](const DffLayerDev& lw) { return sstream(lw.W1T_t, wave * (FS / 32) * E); };
+    auto ss_woxt = [&](const DffLayerDev& lw, int h) { return sstream(lw.WoxT_w, h * 5 * KB32); };
+    auto ss_qkvt = [&](const DffLayerDev& lw, int h) { return sstream(lw.WqkvxT_t, h * 6 * E); };
+    // extension-block weights of the tall GEMMs for the fp32 k-step (s = 0 slots of the fp32 images)
+    auto wox_ext = [&](const DffLayerDev& lw, int h, int lane) { return (const gfloat*)lw.Wox_p + ((size_t)(5 * h + 4) * 64 + lane) * 4; };
+    auto qkvt_ext = [&](const DffLayerDev& lw, int h, int lane) { return (const gfloat*)lw.WqkvxT_p + ((size_t)(13 * h + 4) * 64 + lane) * 4; };
     // x extension of K_ext / V_ext: columns 64..79 = [x_j, 0 ...]
     auto write_xext = [&](int lane) {
 #pragma unroll
@@ -543,7 +697,9 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         const bool cached0 = !full0 && (tab || ((a.mode == DFF_MODE_LANGEVIN) && step > 0));
         // first weights of the first block (hidden behind the centring below)
         { const int lane = lane_id();
-        if (cached0) {
+        if constexpr (SPW) {
+            sring_prefetch(sring, cached0 ? ss_wox(m.layer[0], wave) : ss_qkv(m.layer[0], wave), lane);
+        } else if (cached0) {
             const gfloat* sb0 = l0e;
             if constexpr (HPW == 2) head_fetch(hr, sb0 + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
             ring_prefetch<E>(ring, s_wox(m.layer[0], wave), lane);
@@ -620,6 +776,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #pragma unroll
                 for (int nt = 0; nt < E; ++nt) acc_o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 const WStream after = s_w1(lw);   // the FFN block follows
+                const SStream safter = ss_w1(lw);
                 auto head_math = [&](int h) {
                     write_xext(lane);
                     if constexpr (GEN) fix_q(lane);
@@ -660,7 +817,47 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 };
                 const lfloat* const wox_a = Qx + col * DFF_XLD + 4 * quad;
                 auto wox_fa = [=](int kb) { return wox_a + 16 * kb; };
-                if (cached) {
+                auto wox_fa32 = [=](int kb) { return wox_a + 32 * kb; };
+                const lfloat* const wox_xa = Qx + col * DFF_XLD + 64 + quad;   // extension column `quad` of row `col`
+                if constexpr (SPW) {
+                    if (cached) {
+                        head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
+                        head_commit(hr, Qx, Kx, Vx, pb, true, false, lane, RLA);
+                        head_math(wave);
+                        stall_run<0, 0, 2, E, true>(sring, acc_o, wox_fa32, ss_wox(lw, wave), safter, lane, wox_xa, wox_ext(lw, wave, lane), DFF_HEADS * 5 * 256);
+                    } else {
+                        f32x4 afr[E];
+                        load_afrag<E>(afr, abuf, LH, lane);
+                        u32x4 ah[KB32], am[KB32], al[KB32];
+                        split_afrag<KB32>(afr, ah, am, al);
+                        const gfloat* const bqkvx = (const gfloat*)lw.bqkvx;
+                        const int s0 = srow[0], s1 = srow[1], s2 = srow[2], s3 = srow[3];
+                        const int l0 = lro[0], l1 = lro[1], l2 = lro[2], l3 = lro[3];
+                        gfloat* const sqkv = sb + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW + col;
+                        const gfloat* const bh = bqkvx + wave * 13 * 16 + col;
+                        lfloat* const wq = wr + col;
+                        float bq[2][1];
+                        bq[0][0] = bh[0]; bq[1][0] = bh[16];
+                        pf.tick(1);
+                        swide_run<0, 2, 13, KB32, 1>(sring, bq, ah, am, al, ss_qkv(lw, wave), ss_wox(lw, wave), lane,
+                            [=](int t, float (&ax)[1]) { ax[0] = bh[t * 16]; },
+                            [=](int t, const f32x4& acc, const float (&ax)[1]) {
+                                const int reg = (t >= 5) + (t >= 9);
+                                const int cl = 16 * (t - 5 * reg + (reg >> 1));
+                                lfloat* const dl = wq + reg * RS + cl;
+                                gfloat* const ds = sqkv + 16 * t;
+                                const float v0 = acc[0] + ax[0], v1 = acc[1] + ax[0], v2 = acc[2] + ax[0], v3 = acc[3] + ax[0];
+                                dl[l0] = v0; dl[l1] = v1; dl[l2] = v2; dl[l3] = v3;
+                                st_ntg(ds + s0 * DFF_QKVW, v0); st_ntg(ds + s1 * DFF_QKVW, v1);
+                                st_ntg(ds + s2 * DFF_QKVW, v2); st_ntg(ds + s3 * DFF_QKVW, v3);
+                            });
+                        pf.tick(12);
+                        head_math(wave);
+                        pf.tick(13);
+                        stall_run<2, 0, 2, E, true>(sring, acc_o, wox_fa32, ss_wox(lw, wave), safter, lane, wox_xa, wox_ext(lw, wave, lane), DFF_HEADS * 5 * 256);
+                        pf.tick(14);
+                    }
+                } else if (cached) {
                     // layer-0 q_ext / k / v are x-independent and t is fixed: re-read, no GEMM
                     if constexpr (HPW == 2) {
                         head_commit(hr, Qx, Kx, Vx, pb, true, false, lane, RLA);
@@ -774,6 +971,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 DFF_LANE_CONSTS
                 const bool lastl = l == m.L - 1;
                 const WStream after = lastl ? s_w2t(lw) : s_qkv(m.layer[lastl ? l : l + 1], wave);
+                const SStream safter = lastl ? ss_w2t(lw) : ss_qkv(m.layer[lastl ? l : l + 1], wave);
                 f32x4 afr[E];
                 load_afrag<E>(afr, abuf, LH, lane);
                 float b1r[DR][1];
@@ -784,9 +982,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     gfloat* const shp = sb + sl.h_pre + wave * FS + col;
                     lfloat* const hb = hbuf + quad * 4 * LF + col;
                     const int s0 = srow[0] * F, s1 = srow[1] * F, s2 = srow[2] * F, s3 = srow[3] * F;
-                    wide_run<0, NTS, E, 1>(ring, b1r, afr, s_w1(lw), s_w2(lw), lane,
-                        [=](int t, float (&ax)[1]) { ax[0] = b1p[16 * t]; },
-                        [=](int t, const f32x4& acc, const float (&ax)[1]) {
+                    auto w1_pre = [=](int t, float (&ax)[1]) { ax[0] = b1p[16 * t]; };
+                    auto w1_epi = [=](int t, const f32x4& acc, const float (&ax)[1]) {
                             float g0, g1, g2, g3, p0, p1, p2, p3;
                             gelu_both(acc[0] + ax[0], g0, p0); gelu_both(acc[1] + ax[0], g1, p1);
                             gelu_both(acc[2] + ax[0], g2, p2); gelu_both(acc[3] + ax[0], g3, p3);
@@ -794,14 +991,21 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                             st_ntg(shp + s0 + 16 * t, p0); st_ntg(shp + s1 + 16 * t, p1);
                             st_ntg(shp + s2 + 16 * t, p2); st_ntg(shp + s3 + 16 * t, p3);
                             hb[16 * t] = g0; hb[LF + 16 * t] = g1; hb[2 * LF + 16 * t] = g2; hb[3 * LF + 16 * t] = g3;
-                        });
+                        };
+                    if constexpr (SPW) {
+                        u32x4 ah[KB32], am[KB32], al[KB32];
+                        split_afrag<KB32>(afr, ah, am, al);
+                        swide_run<0, 0, NTS, KB32, 1>(sring, b1r, ah, am, al, ss_w1(lw), ss_w2(lw), lane, w1_pre, w1_epi);
+                    } else
+                    wide_run<0, NTS, E, 1>(ring, b1r, afr, s_w1(lw), s_w2(lw), lane, w1_pre, w1_epi);
                 }
                 f32x4 acc_f[E];
 #pragma unroll
                 for (int nt = 0; nt < E; ++nt) acc_f[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 {
                     const lfloat* const ha = hbuf + col * LF + 4 * quad;
-                    tall_run<NTS % DR, NTS, E, -1>(ring, acc_f, [=](int kb) { return ha + 16 * kb; }, s_w2(lw), after, lane);
+                    if constexpr (SPW) stall_run<0, 0, FS / 32, E, false>(sring, acc_f, [=](int kb) { return ha + 32 * kb; }, ss_w2(lw), safter, lane);
+                    else tall_run<NTS % DR, NTS, E, -1>(ring, acc_f, [=](int kb) { return ha + 16 * kb; }, s_w2(lw), after, lane);
                 }
                 static_assert((2 * NTS) % DR == 0, "ring phase");
 #pragma unroll
@@ -932,6 +1136,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             {
                 DFF_LANE_CONSTS
                 const WStream after = s_woxt(lw, wave);
+                const SStream safter = ss_woxt(lw, wave);
                 f32x4 afr[E];
                 load_afrag<E>(afr, abuf, LH, lane);
                 float hp[DR][4];
@@ -953,18 +1158,24 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 }
                 {
                     lfloat* const hb = hbuf + quad * 4 * LF + col;
-                    wide_run<0, NTS, E, 4>(ring, hp, afr, s_w2t(lw), s_w1t(lw), lane, hp_load,
-                        [=](int t, const f32x4& acc, const float (&ax)[4]) {
+                    auto w2t_epi = [=](int t, const f32x4& acc, const float (&ax)[4]) {
                             hb[16 * t] = acc[0] * ax[0]; hb[LF + 16 * t] = acc[1] * ax[1];
                             hb[2 * LF + 16 * t] = acc[2] * ax[2]; hb[3 * LF + 16 * t] = acc[3] * ax[3];
-                        });
+                        };
+                    if constexpr (SPW) {
+                        u32x4 ah[KB32], am[KB32], al[KB32];
+                        split_afrag<KB32>(afr, ah, am, al);
+                        swide_run<0, 0, NTS, KB32, 4>(sring, hp, ah, am, al, ss_w2t(lw), ss_w1t(lw), lane, hp_load, w2t_epi);
+                    } else
+                    wide_run<0, NTS, E, 4>(ring, hp, afr, s_w2t(lw), s_w1t(lw), lane, hp_load, w2t_epi);
                 }
                 f32x4 acc_f[E];
 #pragma unroll
                 for (int nt = 0; nt < E; ++nt) acc_f[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 {
                     const lfloat* const ha = hbuf + col * LF + 4 * quad;
-                    tall_run<NTS % DR, NTS, E, -1>(ring, acc_f, [=](int kb) { return ha + 16 * kb; }, s_w1t(lw), after, lane);
+                    if constexpr (SPW) stall_run<0, 0, FS / 32, E, false>(sring, acc_f, [=](int kb) { return ha + 32 * kb; }, ss_w1t(lw), safter, lane);
+                    else tall_run<NTS % DR, NTS, E, -1>(ring, acc_f, [=](int kb) { return ha + 16 * kb; }, s_w1t(lw), after, lane);
                 }
 #pragma unroll
                 for (int nt = 0; nt < E; ++nt) c_store_all(mypart, LH, 16 * nt, acc_f[nt], lane);
@@ -1031,6 +1242,10 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 const WStream after = l > 0 ? s_w2t(m.layer[l - 1])
                                             : (a.mode == DFF_MODE_LANGEVIN ? s_wox(m.layer[0], wave) : s_qkv(m.layer[0], wave));
                 (void)more;
+                const SStream safter = l > 0 ? ss_w2t(m.layer[l > 0 ? l - 1 : 0])
+                                             : (a.mode == DFF_MODE_LANGEVIN ? ss_wox(m.layer[0], wave) : ss_qkv(m.layer[0], wave));
+                u32x4 dah[KB32], dam[KB32], dal[KB32];   // SPW: dattn as bf16 pieces
+                if constexpr (SPW) split_afrag<KB32>(afr, dah, dam, dal);
                 // G_ext = dattn W_o_ext[h]^T  (5 tiles: [G 64 | r 3 | 0]) -> G region ; dx_i -= r_i
                 auto gext = [&](auto ph, int h, const WStream& wnext) {
                     float none[DR][1] = {};
@@ -1039,6 +1254,21 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     lfloat* const dxp = dxw;
                     const int d0 = dxi[0], d1 = dxi[1], d2 = dxi[2], d3 = dxi[3];
                     wide_run<decltype(ph)::value, 5, E, 1>(ring, none, afr, s_woxt(lw, h), wnext, lane,
+                        [=](int, float (&)[1]) {},
+                        [=](int t, const f32x4& acc, const float (&)[1]) {
+                            gb[l0 + 16 * t] = acc[0]; gb[l1 + 16 * t] = acc[1];
+                            gb[l2 + 16 * t] = acc[2]; gb[l3 + 16 * t] = acc[3];
+                            if (t == 4) { dxp[d0] -= acc[0]; dxp[d1] -= acc[1]; dxp[d2] -= acc[2]; dxp[d3] -= acc[3]; }
+                        });
+                };
+                // the same on the split operands; phn = ring phase of the GEMM that follows (2: this head's QKV_ext^T back-projection)
+                auto sgext = [&](auto phn, int h, const SStream& wnext) {
+                    float none[2][1] = {};
+                    lfloat* const gb = Gx + col;
+                    const int l0 = lro[0], l1 = lro[1], l2 = lro[2], l3 = lro[3];
+                    lfloat* const dxp = dxw;
+                    const int d0 = dxi[0], d1 = dxi[1], d2 = dxi[2], d3 = dxi[3];
+                    swide_run<0, decltype(phn)::value, 5, KB32, 1>(sring, none, dah, dam, dal, ss_woxt(lw, h), wnext, lane,
                         [=](int, float (&)[1]) {},
                         [=](int t, const f32x4& acc, const float (&)[1]) {
                             gb[l0 + 16 * t] = acc[0]; gb[l1 + 16 * t] = acc[1];
@@ -1064,6 +1294,11 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     const lfloat* base = kb < 5 ? gx_ + 16 * kb : kb < 9 ? kx_ + 16 * (kb - 5) : vx_ + 16 * (kb - 9);
                     return base + fa_off;
                 };
+                auto qkvt_fa32 = [=](int kb) {   // 32-column blocks of [dQ | dK | dV] (the extension columns of dQ_ext go separately)
+                    const lfloat* base = kb < 2 ? gx_ + 32 * kb : kb < 4 ? kx_ + 32 * (kb - 2) : vx_ + 32 * (kb - 4);
+                    return base + fa_off;
+                };
+                const lfloat* const qkvt_xa = Gx + col * DFF_XLD + 64 + quad;
                 auto dqkv = [&]() {
                     // dV_ext = P^T G_ext -> V region (ext columns: dx term sum_i a_ij r_i)
                     wv_mm<0, 5, true>(pb, Gx, lane, ks4, [&](int nt, const f32x4& acc) {
@@ -1148,14 +1383,16 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
                         committed();
                         pf.tick(8);
-                        gext(std::integral_constant<int, 0>{}, wave, s_qkvt(lw, wave));
+                        if constexpr (SPW) sgext(std::integral_constant<int, 2>{}, wave, ss_qkvt(lw, wave));
+                        else gext(std::integral_constant<int, 0>{}, wave, s_qkvt(lw, wave));
                         gfix();
                         pf.tick(15);
                         ds_math();
                         pf.tick(16);
                         dqkv();
                         pf.tick(17);
-                        tall_run<5 % DR, 13, E, 4>(ring, acc_a, qkvt_fa, s_qkvt(lw, wave), after, lane);   // 18 entries: phase 0
+                        if constexpr (SPW) stall_run<2, 0, 6, E, true>(sring, acc_a, qkvt_fa32, ss_qkvt(lw, wave), safter, lane, qkvt_xa, qkvt_ext(lw, wave, lane), DFF_HEADS * 13 * 256);
+                        else tall_run<5 % DR, 13, E, 4>(ring, acc_a, qkvt_fa, s_qkvt(lw, wave), after, lane);   // 18 entries: phase 0
                         pf.tick(18);
                     }
 #pragma unroll
@@ -1193,7 +1430,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, true, lane, m12p(wave));
                     head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
                     committed();
-                    gext(std::integral_constant<int, 0>{}, wave, after);
+                    if constexpr (SPW) sgext(std::integral_constant<int, 0>{}, wave, safter);
+                    else gext(std::integral_constant<int, 0>{}, wave, after);
                     gfix();
                     ds_math();
                     dx_only();
@@ -1371,6 +1609,12 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 
 // kernel lookup for the host dispatcher (dff_host.hip); taking the address instantiates the variant
 bool dff_small_pick(int H, int NW, bool gen, bool spw, const void** fn, unsigned* lds_floats, const char** name) {
+    if (H == 64 && NW == 8 && spw) {
+        *fn = gen ? (const void*)&dff_small_kernel<64, 8, true, true> : (const void*)&dff_small_kernel<64, 8, false, true>;
+        *lds_floats = SmallLds<64, 8>::total;
+        *name = gen ? "dff_small_kernel<64,8,gen,split_bf16>" : "dff_small_kernel<64,8,split_bf16>";
+        return true;
+    }
 #define SMALL_CASE(H_, NW_)                                                                                          \
     if (H == H_ && NW == NW_ && !spw) {                                                                              \
         *fn = gen ? (const void*)&dff_small_kernel<H_, NW_, true> : (const void*)&dff_small_kernel<H_, NW_, false>;  \
