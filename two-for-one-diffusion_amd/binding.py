@@ -12,7 +12,7 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdff_amd.so")
+LIB_PATH = os.environ.get("DFF_LIB_PATH") or os.path.join(_HERE, "libdff_amd.so")   # DFF_LIB_PATH: development builds
 DFF_MAX_BEADS = 64
 
 SCHEDULE_NAMES = (
@@ -226,7 +226,7 @@ class Model:
     PROFILE_STAGES = ("centre", "embed+ln1", "gemm_u", "gemm_qkv", "softmax", "pv+xrel", "gemm_wo", "gate1+ln2",
                       "gemm_w1+gelu", "gemm_w2", "gate2", "b_gate2", "b_gemm_w2T", "b_gemm_w1T", "b_ln2+gate1",
                       "b_gemm_woc+u", "b_reload+gemm_woT", "b_ds", "b_dx+dqkv", "b_gemm_qkvT", "b_ln1", "update",
-                      "-", "-")
+                      "x22", "x23")
 
     def profile(self, enable: bool = True):
         _check(self.lib, self.lib.dff_debug_profile(self.handle, int(enable)), "dff_debug_profile")

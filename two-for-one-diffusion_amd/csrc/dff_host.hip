@@ -133,6 +133,7 @@ struct dff_model {
     bool last_small = false;
     unsigned long long* prof = nullptr;
     bool prof_on = false;
+    int prof_wave = 0;
     // last launch
     const char* last_kernel = "";
     int last_grid = 0, last_lds = 0, last_G = 0, last_B = 0;
@@ -505,6 +506,7 @@ static int launch_small(dff_model* m, DffRunArgs& a, int G, hipStream_t stream) 
     if (rc) return rc;
     a.G = G;
     a.prof = m->prof_on ? m->prof : nullptr;
+    a.prof_wave = m->prof_wave < NW ? m->prof_wave : 0;
     a.stash = m->stash;
     a.stash_stride = sl.total;
     HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -817,6 +819,8 @@ extern "C" int dff_debug_profile(dff_model* m, int enable) {
         HIPCHK(hipMemset(m->prof, 0, DFF_NPROF * sizeof(unsigned long long)));
     }
     m->prof_on = enable != 0;
+    m->prof_wave = enable > 1 ? enable - 1 : 0;   // enable = 1 + wave whose view is recorded (<= 16-row kernel)
+    if (enable) HIPCHK(hipMemset(m->prof, 0, DFF_NPROF * sizeof(unsigned long long)));
     return DFF_OK;
 }
 

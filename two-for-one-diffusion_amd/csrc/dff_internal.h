@@ -94,6 +94,7 @@ struct DffRunArgs {
     int* clamp_flag;
     // scratch
     unsigned long long* prof;   // optional: DFF_NPROF per-stage cycle totals of block 0
+    int prof_wave;              // ... as seen by lane 0 of this wave (<= 16-row kernel)
     float* stash;               // per-workgroup stash slots
     unsigned long long stash_stride; // floats per workgroup
     // optional table of precomputed layer-0 inputs (nodes_in, q|u|k|v), one stash-layer-shaped entry per

@@ -345,7 +345,6 @@ DEVI void gemm_wide_units_split(const lu32* as, int R, int rowsA, const unsigned
 }
 
 // One element of a split A operand: three 16-bit stores (row-major bf16 pieces [piece][R][LS], LS in bf16 units).
-typedef __attribute__((address_space(3))) unsigned short lu16;
 DEVI void store_split(lu16* as16, int R, int LS, int row, int col, float v) {
     const unsigned uh = __float_as_uint(v) & 0xffff0000u;
     const float r = v - __uint_as_float(uh);

@@ -37,7 +37,11 @@ struct SmallLds {
     static constexpr unsigned xst = 0, xs = 64, dxs = 128, vst = 192, cm = 256, tn = 384, prof = 400,
                               dxw = 448,                      // [NW][128] per-wave dx partials (+ dummies)
                               abuf = 448 + NW * 128, resbuf = abuf + 16 * LH,
-                              wreg = resbuf + 16 * LH, total = wreg + NW * WREG + 64;
+                              // SPW variants (8 waves): the K = H GEMM input as bf16 pieces, written by the row stages:
+                              // [piece 3][k-block H/32][kg 4][row 16][4 dwords] -- a wave's ds_read_b128 of (row, kg)
+                              // then touches 16 rows x 4 dwords = every bank once, whatever the lane group
+                              asp = resbuf + 16 * LH, asp_size = (NW == 8 && H == 64) ? 3 * (H / 32) * 256 : 0,   // (only H = 64 has SPW variants)
+                              wreg = asp + asp_size, total = wreg + NW * WREG + 64;
 };
 
 // ---------------------------------------------------------------- wave-private MFMA engine
@@ -208,17 +212,17 @@ struct SStream {
     const gu32x4* base;   // wave-uniform; unit j at base + 192 j, piece p at + 64 p, lane at + lane
 };
 DEVI SStream sstream(const unsigned* Wp, int unit0) { return SStream{(const gu32x4*)Wp + (size_t)unit0 * 192}; }
-DEVI void sfill(u32x4 (&slot)[3], const SStream& w, int j, int lane) {
-    const gu32x4* p = w.base + (size_t)j * 192;
+DEVI void sfill(u32x4 (&slot)[3], const gu32x4* p, int lane) {
     const unsigned lo = (unsigned)lane & 63u;
 #pragma unroll
     for (int q = 0; q < 3; ++q) slot[q] = (p + 64 * q)[lo];
 }
-template <int DR>
-DEVI void sring_prefetch(SRing<DR>& r, const SStream& w, int lane) {
-#pragma unroll
-    for (int j = 0; j < DR; ++j) sfill(r.b[j], w, j, lane);
-}
+// The weights a wave needs between two workgroup barriers form ONE sequence of units: N0 units of stream s0 followed by
+// N1 units of s1 (e.g. QKV_ext then [W_o;W_oc]; W1 then W2), and after them the first DR units of the NEXT block (M0
+// units of n0, then units of n1), which the last DR refills of this block request -- so they are in flight during the row
+// stage in between.  Unit i of the block lives in ring slot i % DR; all indices are compile-time (every GEMM below is
+// fully unrolled, which also lets the compiler count the outstanding loads exactly: in a rolled loop the epilogue operands
+// requested two tiles ahead are loop-carried, and the s_waitcnt that joins them drains the whole ring every revolution).
 // eight fp32 values of a 32-column block (x0: columns 4 kg .. + 3, x1: columns 16 + 4 kg .. + 3 -- what two ds_read_b128
 // of the fp32 engine's A pattern deliver) -> the three bf16 piece operands; element j sits in half j & 1 of dword j >> 1
 DEVI void split8(const f32x4& x0, const f32x4& x1, u32x4& h, u32x4& m, u32x4& l) {
@@ -239,54 +243,154 @@ DEVI void split_afrag(const f32x4 (&a)[2 * KB32], u32x4 (&ah)[KB32], u32x4 (&am)
 #pragma unroll
     for (int kb = 0; kb < KB32; ++kb) split8(a[2 * kb], a[2 * kb + 1], ah[kb], am[kb], al[kb]);
 }
-// wide GEMM (K = H = 32 KB32) of one wave on split operands: N output tiles, KB32 units each; two tiles per ring
-// revolution (PAR = tile parity: static slots and aux slot).  aux[par][..]: epilogue operands of the tile with that
-// parity in flight (the caller preloads tiles 0 and 1, pre(t, aux[par]) refills).
-template <int PH, int PHN, int PAR, int N, int KB32, int NAUX, int DR, class Pre, class Epi>
-DEVI void swide_tile(SRing<DR>& ring, float (&aux)[2][NAUX], const u32x4 (&ah)[KB32], const u32x4 (&am)[KB32],
-                     const u32x4 (&al)[KB32], const SStream& w, const SStream& wn, int lane, int t, const Pre& pre, const Epi& epi) {
-    f32x4 cs = {0.f, 0.f, 0.f, 0.f}, cb = {0.f, 0.f, 0.f, 0.f};   // small terms / big terms
-#pragma unroll
-    for (int kb = 0; kb < KB32; ++kb) {
-        const int slot = (PH + PAR * KB32 + kb) % DR;
-        u32x4 (&b)[3] = ring.b[slot];
-        cs = mfma_bf16(al[kb], b[0], cs);
-        cb = mfma_bf16(am[kb], b[0], cb);
-        cs = mfma_bf16(ah[kb], b[2], cs);
-        cb = mfma_bf16(ah[kb], b[1], cb);
-        cs = mfma_bf16(am[kb], b[1], cs);
-        cb = mfma_bf16(ah[kb], b[0], cb);
-        const int u = t * KB32 + kb;
-        if (u + DR < N * KB32) sfill(b, w, u + DR, lane);
-        else sfill(b, wn, (slot - PHN + DR) % DR, lane);
+// A stream is one of two KINDS.  Kind 0: a host-split image (three bf16 pieces per weight, 6 B; dff_host.hip pack_units),
+// units linear.  Kind > 0: the fp32 image of the fp32 engine (4 B per weight; pack_b), whose two 16-row blocks of a unit
+// the consuming wave splits in registers (split8, ~44 VALU per unit): fewer bytes for the GEMMs that are bound by the
+// L2 -> CU weight stream (QKV_ext, its transpose, [W_o;W_oc]), where the SIMDs idle anyway.  Kind 1: K = H image
+// ([tile][16-row block]: unit j at + 128 j); kind KBtot (> 1): Nout = H image with KBtot 16-row blocks per tile, unit
+// (kb, nt) at + nt KBtot 64 + 64 blk(kb), blk(kb) = 2 kb, or 2 kb + 1 from kb = 2 on in the QKV_ext^T image (KBtot =
+// 104), whose heads are [q 0..3 | ext 4 | k 5..8 | v 9..12].
+template <int KIND, int E>
+DEVI const gu32x4* unit_addr(const SStream& w, int j) {
+    if constexpr (KIND == 0) return w.base + (size_t)j * 192;
+    else if constexpr (KIND == 1) return w.base + (size_t)j * 128;
+    else {
+        const int kb = j / E, nt = j - kb * E;
+        return w.base + (size_t)nt * KIND * 64 + (size_t)(2 * kb + (KIND == DFF_HEADS * 13 && kb >= 2 ? 1 : 0)) * 64;
     }
-    float auxc[NAUX];
-#pragma unroll
-    for (int q = 0; q < NAUX; ++q) auxc[q] = aux[PAR][q];
-    if (t + 2 < N) pre(t + 2, aux[PAR]);
-    epi(t, cb + cs, auxc);
 }
-template <int PH, int PHN, int N, int KB32, int NAUX, int DR, class Pre, class Epi>
-DEVI void swide_run(SRing<DR>& ring, float (&aux)[2][NAUX], const u32x4 (&ah)[KB32], const u32x4 (&am)[KB32],
-                    const u32x4 (&al)[KB32], const SStream& w, const SStream& wn, int lane, const Pre pre, const Epi epi) {
-    static_assert(DR == 2 * KB32, "two tiles per ring revolution");
-    static_assert(N * KB32 >= DR, "a GEMM spans at least one revolution");
-#pragma unroll 1
-    for (int rev = 0; rev < N / 2; ++rev) {
-        swide_tile<PH, PHN, 0, N, KB32, NAUX>(ring, aux, ah, am, al, w, wn, lane, 2 * rev, pre, epi);
-        swide_tile<PH, PHN, 1, N, KB32, NAUX>(ring, aux, ah, am, al, w, wn, lane, 2 * rev + 1, pre, epi);
+template <int KIND>
+DEVI void sfill_k(u32x4 (&slot)[3], const gu32x4* p, int lane) {
+    const unsigned lo = (unsigned)lane & 63u;
+    slot[0] = p[lo];
+    slot[1] = (p + 64)[lo];
+    if constexpr (KIND == 0) slot[2] = (p + 128)[lo];
+}
+// the three piece operands of the unit held by a slot
+template <int KIND>
+DEVI void unit_pieces(const u32x4 (&slot)[3], u32x4& bh, u32x4& bm, u32x4& bl) {
+    if constexpr (KIND == 0) { bh = slot[0]; bm = slot[1]; bl = slot[2]; }
+    else split8(__builtin_bit_cast(f32x4, slot[0]), __builtin_bit_cast(f32x4, slot[1]), bh, bm, bl);
+}
+template <int N0_, int N1_, int M0_, int K0_, int K1_, int KN0_, int KN1_, int E_>
+struct SSeq {
+    static constexpr int N0 = N0_, N1 = N1_, M0 = M0_, K0 = K0_, K1 = K1_, KN0 = KN0_, KN1 = KN1_, E = E_;
+    SStream s0, s1, n0, n1;
+    static constexpr int kind(int i) { return i < N0 ? K0 : K1; }   // of unit i of this block
+};
+template <int DR, int I, class Q>
+DEVI void seq_refill(SRing<DR>& ring, const Q& q, int lane) {   // slot of unit I <- unit I + DR (or the next block's)
+    constexpr int slot = I % DR, J = I + DR;
+    if constexpr (J < Q::N0) sfill_k<Q::K0>(ring.b[slot], unit_addr<Q::K0, Q::E>(q.s0, J), lane);
+    else if constexpr (J < Q::N0 + Q::N1) sfill_k<Q::K1>(ring.b[slot], unit_addr<Q::K1, Q::E>(q.s1, J - Q::N0), lane);
+    else if constexpr (slot < Q::M0) sfill_k<Q::KN0>(ring.b[slot], unit_addr<Q::KN0, Q::E>(q.n0, slot), lane);
+    else sfill_k<Q::KN1>(ring.b[slot], unit_addr<Q::KN1, Q::E>(q.n1, slot - Q::M0), lane);
+}
+// first DR units of a block (step start), all from one stream of kind KIND
+template <int DR, int KIND, int E>
+DEVI void sring_prefetch(SRing<DR>& r, const SStream& n0, int lane) {
+#pragma unroll
+    for (int j = 0; j < DR; ++j) sfill_k<KIND>(r.b[j], unit_addr<KIND, E>(n0, j), lane);
+}
+// wide GEMM (K = H = 32 KB32) of one wave on split operands: N output tiles, KB32 units each, the first one unit I0 of
+// the block.  aux[t % 2][..]: epilogue operands of the tiles in flight (the caller preloads tiles 0 and 1,
+// pre(t + 2, aux[t % 2]) requests the next ones right after tile t's were copied out).
+template <int I0, int T, int N, int KB32, int NAUX, int DR, class Q, class Pre, class Epi>
+DEVI void swide_from(SRing<DR>& ring, float (&aux)[2][NAUX], const u32x4 (&ah)[KB32], const u32x4 (&am)[KB32],
+                     const u32x4 (&al)[KB32], const Q& q, int lane, const Pre& pre, const Epi& epi) {
+    if constexpr (T < N) {
+        f32x4 cs = {0.f, 0.f, 0.f, 0.f}, cb = {0.f, 0.f, 0.f, 0.f};   // small terms / big terms
+#pragma unroll
+        for (int kb = 0; kb < KB32; ++kb) {
+            u32x4 bh, bm, bl;
+            unit_pieces<Q::kind(I0 + T * KB32)>(ring.b[(I0 + T * KB32 + kb) % DR], bh, bm, bl);
+            // a slot whose weights were split into temporaries is refilled before its MFMAs are issued
+            if constexpr (Q::kind(I0 + T * KB32) != 0) {
+                if (kb == 0) seq_refill<DR, I0 + T * KB32 + 0>(ring, q, lane);
+                if (kb == 1) seq_refill<DR, I0 + T * KB32 + (KB32 > 1 ? 1 : 0)>(ring, q, lane);
+            }
+            cs = mfma_bf16(al[kb], bh, cs);
+            cb = mfma_bf16(am[kb], bh, cb);
+            cs = mfma_bf16(ah[kb], bl, cs);
+            cb = mfma_bf16(ah[kb], bm, cb);
+            cs = mfma_bf16(am[kb], bm, cs);
+            cb = mfma_bf16(ah[kb], bh, cb);
+        }
+        if constexpr (Q::kind(I0 + T * KB32) == 0) {
+            if constexpr (KB32 >= 1) seq_refill<DR, I0 + T * KB32 + 0>(ring, q, lane);
+            if constexpr (KB32 >= 2) seq_refill<DR, I0 + T * KB32 + 1>(ring, q, lane);
+        }
+        float auxc[NAUX];
+#pragma unroll
+        for (int i = 0; i < NAUX; ++i) auxc[i] = aux[T % 2][i];
+        if constexpr (T + 2 < N) pre(T + 2, aux[T % 2]);
+        epi(T, cb + cs, auxc);
+        swide_from<I0, T + 1, N, KB32, NAUX>(ring, aux, ah, am, al, q, lane, pre, epi);
     }
-    if constexpr (N % 2 == 1) swide_tile<PH, PHN, 0, N, KB32, NAUX>(ring, aux, ah, am, al, w, wn, lane, N - 1, pre, epi);
+}
+template <int I0, int N, int KB32, int NAUX, int DR, class Q, class Pre, class Epi>
+DEVI void swide_run(SRing<DR>& ring, float (&aux)[2][NAUX], const u32x4 (&ah)[KB32], const u32x4 (&am)[KB32],
+                    const u32x4 (&al)[KB32], const Q& q, int lane, const Pre pre, const Epi epi) {
+    static_assert(KB32 <= 2, "refill list");
+    swide_from<I0, 0, N, KB32, NAUX>(ring, aux, ah, am, al, q, lane, pre, epi);
 }
 // tall GEMM (Nout = H = 16 E) of one wave on split operands: acc[nt] += A(:, 32-column block kb) . W(unit (kb, nt)),
-// kb < NKB; fa(kb) = this lane's four floats at columns 4 quad of block kb (the second four are 16 floats on).  The next
-// block's A is read from LDS before the MFMAs of this one are issued.  EXT: one fp32 k-step on top for a head's
-// extension columns (of which only 0..3 carry data): A element *ext_a, weights ext_w[nt * ext_ts] (the s = 0 slots of the
-// fp32 image's extension block, dff_host.hip pack_b), requested first and used last.
-template <int PH, int PHN, int NKB, int E, bool EXT, int DR, class FA>
-DEVI void stall_run(SRing<DR>& ring, f32x4 (&acc)[E], const FA fa, const SStream& w, const SStream& wn, int lane,
+// kb < NKB, unit (kb, nt) = unit I0 + kb E + nt of the block; fa(kb) = this lane's four floats at columns 4 quad of block
+// kb (the second four are 16 floats on).  The next block's A is read from LDS before the MFMAs of this one are issued.
+// EXT: one fp32 k-step on top for a head's extension columns (of which only 0..3 carry data): A element *ext_a, weights
+// ext_w[nt * ext_ts] (the s = 0 slots of the fp32 image's extension block, dff_host.hip pack_b), requested first, used last.
+template <int I0, int KB, int NKB, int E, int DR, class Q, class FA>
+DEVI void stall_from(SRing<DR>& ring, f32x4 (&acc)[E], f32x4& x0, f32x4& x1, const FA& fa, const Q& q, int lane) {
+    if constexpr (KB < NKB) {
+        u32x4 ah, am, al;
+        split8(x0, x1, ah, am, al);
+        if constexpr (KB + 1 < NKB) {
+            const lfloat* pn = fa(KB + 1);
+            x0 = *(const lf32x4*)pn; x1 = *(const lf32x4*)(pn + 16);
+        }
+        if constexpr (Q::kind(I0 + KB * E) == 0) {
+#pragma unroll
+            for (int nt = 0; nt < E; ++nt) acc[nt] = mfma_bf16(al, ring.b[(I0 + KB * E + nt) % DR][0], acc[nt]);
+#pragma unroll
+            for (int nt = 0; nt < E; ++nt) acc[nt] = mfma_bf16(ah, ring.b[(I0 + KB * E + nt) % DR][2], acc[nt]);
+#pragma unroll
+            for (int nt = 0; nt < E; ++nt) acc[nt] = mfma_bf16(am, ring.b[(I0 + KB * E + nt) % DR][1], acc[nt]);
+#pragma unroll
+            for (int nt = 0; nt < E; ++nt) acc[nt] = mfma_bf16(am, ring.b[(I0 + KB * E + nt) % DR][0], acc[nt]);
+#pragma unroll
+            for (int nt = 0; nt < E; ++nt) acc[nt] = mfma_bf16(ah, ring.b[(I0 + KB * E + nt) % DR][1], acc[nt]);
+#pragma unroll
+            for (int nt = 0; nt < E; ++nt) acc[nt] = mfma_bf16(ah, ring.b[(I0 + KB * E + nt) % DR][0], acc[nt]);
+            static_assert(E == 4, "refill list");
+            seq_refill<DR, I0 + KB * E + 0>(ring, q, lane);
+            seq_refill<DR, I0 + KB * E + 1>(ring, q, lane);
+            seq_refill<DR, I0 + KB * E + 2>(ring, q, lane);
+            seq_refill<DR, I0 + KB * E + 3>(ring, q, lane);
+        } else {
+            // fp32 units: split, refill the slot at once, then the unit's six products on two chains
+            auto one = [&](auto nti) {
+                constexpr int nt = decltype(nti)::value;
+                u32x4 bh, bm, bl;
+                unit_pieces<Q::kind(I0 + KB * E)>(ring.b[(I0 + KB * E + nt) % DR], bh, bm, bl);
+                seq_refill<DR, I0 + KB * E + nt>(ring, q, lane);
+                f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+                cs = mfma_bf16(al, bh, cs);
+                acc[nt] = mfma_bf16(am, bh, acc[nt]);
+                cs = mfma_bf16(ah, bl, cs);
+                acc[nt] = mfma_bf16(ah, bm, acc[nt]);
+                cs = mfma_bf16(am, bm, cs);
+                acc[nt] = mfma_bf16(ah, bh, acc[nt]);
+                acc[nt] += cs;
+            };
+            one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{});
+            one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
+        }
+        stall_from<I0, KB + 1, NKB, E>(ring, acc, x0, x1, fa, q, lane);
+    }
+}
+template <int I0, int NKB, int E, bool EXT, int DR, class Q, class FA>
+DEVI void stall_run(SRing<DR>& ring, f32x4 (&acc)[E], const FA fa, const Q& q, int lane,
                     const lfloat* ext_a = nullptr, const gfloat* ext_w = nullptr, int ext_ts = 0) {
-    static_assert(E == DR, "one k-block per ring revolution");
     float bx[E];
     if constexpr (EXT) {
 #pragma unroll
@@ -294,32 +398,7 @@ DEVI void stall_run(SRing<DR>& ring, f32x4 (&acc)[E], const FA fa, const SStream
     }
     const lfloat* p0 = fa(0);
     f32x4 x0 = *(const lf32x4*)p0, x1 = *(const lf32x4*)(p0 + 16);
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-        u32x4 ah, am, al;
-        split8(x0, x1, ah, am, al);
-        if (kb + 1 < NKB) {
-            const lfloat* pn = fa(kb + 1);
-            x0 = *(const lf32x4*)pn; x1 = *(const lf32x4*)(pn + 16);
-        }
-#pragma unroll
-        for (int nt = 0; nt < E; ++nt) acc[nt] = mfma_bf16(al, ring.b[(PH + nt) % DR][0], acc[nt]);
-#pragma unroll
-        for (int nt = 0; nt < E; ++nt) acc[nt] = mfma_bf16(ah, ring.b[(PH + nt) % DR][2], acc[nt]);
-#pragma unroll
-        for (int nt = 0; nt < E; ++nt) acc[nt] = mfma_bf16(am, ring.b[(PH + nt) % DR][1], acc[nt]);
-#pragma unroll
-        for (int nt = 0; nt < E; ++nt) acc[nt] = mfma_bf16(am, ring.b[(PH + nt) % DR][0], acc[nt]);
-#pragma unroll
-        for (int nt = 0; nt < E; ++nt) acc[nt] = mfma_bf16(ah, ring.b[(PH + nt) % DR][1], acc[nt]);
-#pragma unroll
-        for (int nt = 0; nt < E; ++nt) {
-            const int slot = (PH + nt) % DR;
-            acc[nt] = mfma_bf16(ah, ring.b[slot][0], acc[nt]);
-            if (kb + 1 < NKB) sfill(ring.b[slot], w, (kb + 1) * E + nt, lane);
-            else sfill(ring.b[slot], wn, (slot - PHN + DR) % DR, lane);
-        }
-    }
+    stall_from<I0, 0, NKB, E>(ring, acc, x0, x1, fa, q, lane);
     if constexpr (EXT) {
         const float ax = *ext_a;
 #pragma unroll
@@ -451,8 +530,13 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     constexpr int RS = RLA * DFF_XLD;        // floats between the Q / K / V / G buffers of a wave
     constexpr int FS = F / NW, NTS = FS / 16, LF = FS + 4;   // FFN hidden slice of a wave
     static_assert(HPW == 1 || HPW == 2, "4 or 8 waves");
-    constexpr int KB32 = H / 32, SDR = 2 * KB32;   // SPW: 32-row k-blocks of a K = H GEMM, split-ring depth in units
-    static_assert(!SPW || (NW == 8 && H % 32 == 0 && FS % 32 == 0 && E == SDR), "split-bf16 variant: one head per wave, whole 32-blocks");
+    constexpr int KB32 = H / 32, SDR = 4;   // SPW: 32-row k-blocks of a K = H GEMM, split-ring depth in units
+    static_assert(!SPW || (NW == 8 && H == 64 && FS == 32), "split-bf16 variant: one head per wave; the unit counts below are H = 64's");
+    // units per GEMM of a wave (H = 64): QKV_ext 13 tiles x 2, [W_o;W_oc] 2 k-blocks x 4, W1 / W2^T 2 x 2, W2 / W1^T 1 x 4,
+    // [W_o;W_oc]^T 5 x 2, QKV_ext^T 6 x 4
+    constexpr int U_QKV = 13 * KB32, U_WOX = 2 * E, U_W1 = NTS * KB32, U_W2 = (FS / 32) * E, U_GX = 5 * KB32, U_QKVT = 6 * E;
+    constexpr int MW = U_W1 < SDR ? U_W1 : SDR;   // how many of a block's first SDR units come from its first GEMM when that is W1 / W2^T
+    static_assert(!SPW || (U_W1 + U_W2 >= SDR && U_WOX >= SDR && U_GX >= SDR && U_QKV >= SDR), "every block fills the ring");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     // the wave index is wave-uniform: say so (readfirstlane), so that every per-wave pointer and
@@ -468,6 +552,34 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     lfloat* const xst = sm + LL::xst; lfloat* const xs = sm + LL::xs; lfloat* const dxs = sm + LL::dxs;
     lfloat* const vst = sm + LL::vst; lfloat* const cm = sm + LL::cm; lfloat* const tn = sm + LL::tn;
     lfloat* const abuf = sm + LL::abuf; lfloat* const resbuf = sm + LL::resbuf;
+    lu16* const asp16 = (lu16*)(sm + LL::asp);
+    // row-stage store of one element of the K = H GEMM input: fp32 (abuf), or its three bf16 pieces at the position
+    // the consuming waves' A fragments expect (element j of lane (row, kg) of k-block kb: column 32 kb + 16 (j >> 2) + 4 kg + (j & 3))
+    auto a_store = [=](int row, int cl, float v) {
+        if constexpr (SPW) {
+            const unsigned b = __float_as_uint(v);
+            const float r = v - __uint_as_float(b & 0xffff0000u);
+            const unsigned c = __float_as_uint(r);
+            const float s2 = r - __uint_as_float(c & 0xffff0000u);
+            const int kb = cl >> 5, kk = cl & 31, kg = (kk & 15) >> 2, j = ((kk >> 4) << 2) | (kk & 3);
+            lu16* const q = asp16 + ((((kb * 4 + kg) * 16 + row) * 4 + (j >> 1)) * 2 + (j & 1));
+            constexpr int PS = (H / 32) * 256 * 2;   // halfwords per piece
+            q[0] = (unsigned short)(b >> 16); q[PS] = (unsigned short)(c >> 16); q[2 * PS] = (unsigned short)(__float_as_uint(s2) >> 16);
+        } else {
+            abuf[row * LH + cl] = v;
+        }
+    };
+    // ... and a wave's A fragments of it (SPW): pieces of k-block kb for row lane & 15, k-group lane >> 4
+    auto a_load = [=](u32x4 (&ah)[H / 32], u32x4 (&am)[H / 32], u32x4 (&al)[H / 32], int lane) {
+        const lu32* const q = (const lu32*)asp16 + ((lane >> 4) * 16 + (lane & 15)) * 4;
+        constexpr int PS = (H / 32) * 256;
+#pragma unroll
+        for (int kb = 0; kb < H / 32; ++kb) {
+            ah[kb] = *(const lu32x4*)(q + kb * 256);
+            am[kb] = *(const lu32x4*)(q + PS + kb * 256);
+            al[kb] = *(const lu32x4*)(q + 2 * PS + kb * 256);
+        }
+    };
     lfloat* const dxw = sm + LL::dxw + wave * 128;
     lfloat* const wr = sm + LL::wreg + wave * LL::WREG;
     lfloat* const Qx = wr; lfloat* const Kx = wr + RS; lfloat* const Vx = wr + 2 * RS;
@@ -502,7 +614,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     for (int i = tid; i < (int)LL::total; i += NTHR) smem[i] = 0.f;
     __syncthreads();
     Prof pf;
-    pf.on = (a.prof != nullptr) && blockIdx.x == 0 && tid == 0;
+    pf.on = (a.prof != nullptr) && blockIdx.x == 0 && tid == 64 * a.prof_wave;   // one wave's view (wave 0 unless dff_debug_profile asked for another)
     pf.acc = (unsigned long long*)(smem + LL::prof);
     pf.last = __builtin_readcyclecounter();
 
@@ -616,14 +728,15 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     auto s_woxt = [&](const DffLayerDev& lw, int h) { return wide_stream(lw.WoxT_p, E, h * 5); };
     auto s_qkvt = [&](const DffLayerDev& lw, int h) { return tall_stream(lw.WqkvxT_p, DFF_HEADS * 13, h * 13); };
     // the same streams of the split images (units, see the split engine above)
-    auto ss_qkv = [&](const DffLayerDev& lw, int h) { return sstream(lw.Wqkvx_w, h * 13 * KB32); };
-    auto ss_wox = [&](const DffLayerDev& lw, int h) { return sstream(lw.Wox_t, h * 2 * E); };
+    constexpr int KQ = 1, KO = DFF_HEADS * 5, KT = DFF_HEADS * 13;   // stream kinds (unit_addr) of QKV_ext, [W_o;W_oc], QKV_ext^T
+    auto ss_qkv = [&](const DffLayerDev& lw, int h) { return SStream{(const gu32x4*)lw.Wqkvx_p + (size_t)h * 13 * E * 64}; };
+    auto ss_wox = [&](const DffLayerDev& lw, int h) { return SStream{(const gu32x4*)lw.Wox_p + (size_t)h * 5 * 64}; };
     auto ss_w1 = [&](const DffLayerDev& lw) { return sstream(lw.W1_w, wave * NTS * KB32); };
     auto ss_w2 = [&](const DffLayerDev& lw) { return sstream(lw.W2_t, wave * (FS / 32) * E); };
     auto ss_w2t = [&](const DffLayerDev& lw) { return sstream(lw.W2T_w, wave * NTS * KB32); };
     auto ss_w1t = [&](const DffLayerDev& lw) { return sstream(lw.W1T_t, wave * (FS / 32) * E); };
     auto ss_woxt = [&](const DffLayerDev& lw, int h) { return sstream(lw.WoxT_w, h * 5 * KB32); };
-    auto ss_qkvt = [&](const DffLayerDev& lw, int h) { return sstream(lw.WqkvxT_t, h * 6 * E); };
+    auto ss_qkvt = [&](const DffLayerDev& lw, int h) { return SStream{(const gu32x4*)lw.WqkvxT_p + (size_t)h * 13 * 64}; };
     // extension-block weights of the tall GEMMs for the fp32 k-step (s = 0 slots of the fp32 images)
     auto wox_ext = [&](const DffLayerDev& lw, int h, int lane) { return (const gfloat*)lw.Wox_p + ((size_t)(5 * h + 4) * 64 + lane) * 4; };
     auto qkvt_ext = [&](const DffLayerDev& lw, int h, int lane) { return (const gfloat*)lw.WqkvxT_p + ((size_t)(13 * h + 4) * 64 + lane) * 4; };
@@ -698,7 +811,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         // first weights of the first block (hidden behind the centring below)
         { const int lane = lane_id();
         if constexpr (SPW) {
-            sring_prefetch(sring, cached0 ? ss_wox(m.layer[0], wave) : ss_qkv(m.layer[0], wave), lane);
+            if (cached0) sring_prefetch<SDR, KO, E>(sring, ss_wox(m.layer[0], wave), lane);
+            else sring_prefetch<SDR, KQ, E>(sring, ss_qkv(m.layer[0], wave), lane);
         } else if (cached0) {
             const gfloat* sb0 = l0e;
             if constexpr (HPW == 2) head_fetch(hr, sb0 + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
@@ -762,7 +876,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #pragma unroll
                     for (int i = 0; i < HC; ++i) {
                         const int cl = sub + LPR * i;
-                        abuf[rrow * LH + cl] = (x[i] - mean) * rstd * lw.ln1_g[cl] + lw.ln1_b[cl];
+                        a_store(rrow, cl, (x[i] - mean) * rstd * lw.ln1_g[cl] + lw.ln1_b[cl]);
                     }
                 }
                 if (ract) pre_B(lw, sub);
@@ -776,7 +890,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #pragma unroll
                 for (int nt = 0; nt < E; ++nt) acc_o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 const WStream after = s_w1(lw);   // the FFN block follows
-                const SStream safter = ss_w1(lw);
+                const SStream sn0 = ss_w1(lw), sn1 = ss_w2(lw);   // the FFN block's units follow: W1 (U_W1), then W2
                 auto head_math = [&](int h) {
                     write_xext(lane);
                     if constexpr (GEN) fix_q(lane);
@@ -824,12 +938,11 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
                         head_commit(hr, Qx, Kx, Vx, pb, true, false, lane, RLA);
                         head_math(wave);
-                        stall_run<0, 0, 2, E, true>(sring, acc_o, wox_fa32, ss_wox(lw, wave), safter, lane, wox_xa, wox_ext(lw, wave, lane), DFF_HEADS * 5 * 256);
+                        const SSeq<U_WOX, 0, MW, KO, KO, 0, 0, E> sq{ss_wox(lw, wave), ss_wox(lw, wave), sn0, sn1};
+                        stall_run<0, 2, E, true>(sring, acc_o, wox_fa32, sq, lane, wox_xa, wox_ext(lw, wave, lane), DFF_HEADS * 5 * 256);
                     } else {
-                        f32x4 afr[E];
-                        load_afrag<E>(afr, abuf, LH, lane);
                         u32x4 ah[KB32], am[KB32], al[KB32];
-                        split_afrag<KB32>(afr, ah, am, al);
+                        a_load(ah, am, al, lane);
                         const gfloat* const bqkvx = (const gfloat*)lw.bqkvx;
                         const int s0 = srow[0], s1 = srow[1], s2 = srow[2], s3 = srow[3];
                         const int l0 = lro[0], l1 = lro[1], l2 = lro[2], l3 = lro[3];
@@ -839,7 +952,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         float bq[2][1];
                         bq[0][0] = bh[0]; bq[1][0] = bh[16];
                         pf.tick(1);
-                        swide_run<0, 2, 13, KB32, 1>(sring, bq, ah, am, al, ss_qkv(lw, wave), ss_wox(lw, wave), lane,
+                        const SSeq<U_QKV, U_WOX, MW, KQ, KO, 0, 0, E> sq{ss_qkv(lw, wave), ss_wox(lw, wave), sn0, sn1};
+                        swide_run<0, 13, KB32, 1>(sring, bq, ah, am, al, sq, lane,
                             [=](int t, float (&ax)[1]) { ax[0] = bh[t * 16]; },
                             [=](int t, const f32x4& acc, const float (&ax)[1]) {
                                 const int reg = (t >= 5) + (t >= 9);
@@ -854,7 +968,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         pf.tick(12);
                         head_math(wave);
                         pf.tick(13);
-                        stall_run<2, 0, 2, E, true>(sring, acc_o, wox_fa32, ss_wox(lw, wave), safter, lane, wox_xa, wox_ext(lw, wave, lane), DFF_HEADS * 5 * 256);
+                        stall_run<U_QKV, 2, E, true>(sring, acc_o, wox_fa32, sq, lane, wox_xa, wox_ext(lw, wave, lane), DFF_HEADS * 5 * 256);
                         pf.tick(14);
                     }
                 } else if (cached) {
@@ -959,7 +1073,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 float mean, rstd;
                 ln_stats_row(n1, mean, rstd);
 #pragma unroll
-                for (int i = 0; i < HC; ++i) abuf[rrow * LH + sub + LPR * i] = (n1[i] - mean) * rstd * ro[4][i] + ro[5][i];
+                for (int i = 0; i < HC; ++i) a_store(rrow, sub + LPR * i, (n1[i] - mean) * rstd * ro[4][i] + ro[5][i]);
                 // stage C operands: b2, g2 (3), and the next layer's LN1 gamma / beta
                 ro_load(0, lw.b2, sub); ro_load3(1, lw.g2, sub);
                 if (l + 1 < m.L) { ro_load(4, m.layer[l + 1].ln1_g, sub); ro_load(5, m.layer[l + 1].ln1_b, sub); }
@@ -971,9 +1085,12 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 DFF_LANE_CONSTS
                 const bool lastl = l == m.L - 1;
                 const WStream after = lastl ? s_w2t(lw) : s_qkv(m.layer[lastl ? l : l + 1], wave);
-                const SStream safter = lastl ? ss_w2t(lw) : ss_qkv(m.layer[lastl ? l : l + 1], wave);
+                // what follows: the last layer's FFN backward (W2^T, W1^T) or the next layer's QKV_ext (whose units MW.. are "n1")
+                const SStream qn = ss_qkv(m.layer[lastl ? l : l + 1], wave);
+                const SSeq<U_W1, U_W2, MW, 0, 0, 0, 0, E> sqf_last{ss_w1(lw), ss_w2(lw), ss_w2t(lw), ss_w1t(lw)};
+                const SSeq<U_W1, U_W2, SDR, 0, 0, KQ, KQ, E> sqf_next{ss_w1(lw), ss_w2(lw), qn, qn};
                 f32x4 afr[E];
-                load_afrag<E>(afr, abuf, LH, lane);
+                if constexpr (!SPW) load_afrag<E>(afr, abuf, LH, lane);
                 float b1r[DR][1];
                 const gfloat* const b1p = (const gfloat*)lw.b1 + wave * FS + col;
 #pragma unroll
@@ -994,8 +1111,11 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         };
                     if constexpr (SPW) {
                         u32x4 ah[KB32], am[KB32], al[KB32];
-                        split_afrag<KB32>(afr, ah, am, al);
-                        swide_run<0, 0, NTS, KB32, 1>(sring, b1r, ah, am, al, ss_w1(lw), ss_w2(lw), lane, w1_pre, w1_epi);
+                        a_load(ah, am, al, lane);
+                        pf.tick(19);
+                        if (lastl) swide_run<0, NTS, KB32, 1>(sring, b1r, ah, am, al, sqf_last, lane, w1_pre, w1_epi);
+                        else swide_run<0, NTS, KB32, 1>(sring, b1r, ah, am, al, sqf_next, lane, w1_pre, w1_epi);
+                        pf.tick(20);
                     } else
                     wide_run<0, NTS, E, 1>(ring, b1r, afr, s_w1(lw), s_w2(lw), lane, w1_pre, w1_epi);
                 }
@@ -1004,8 +1124,12 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 for (int nt = 0; nt < E; ++nt) acc_f[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 {
                     const lfloat* const ha = hbuf + col * LF + 4 * quad;
-                    if constexpr (SPW) stall_run<0, 0, FS / 32, E, false>(sring, acc_f, [=](int kb) { return ha + 32 * kb; }, ss_w2(lw), safter, lane);
+                    if constexpr (SPW) {
+                        if (lastl) stall_run<U_W1, FS / 32, E, false>(sring, acc_f, [=](int kb) { return ha + 32 * kb; }, sqf_last, lane);
+                        else stall_run<U_W1, FS / 32, E, false>(sring, acc_f, [=](int kb) { return ha + 32 * kb; }, sqf_next, lane);
+                    }
                     else tall_run<NTS % DR, NTS, E, -1>(ring, acc_f, [=](int kb) { return ha + 16 * kb; }, s_w2(lw), after, lane);
+                    pf.tick(21);
                 }
                 static_assert((2 * NTS) % DR == 0, "ring phase");
 #pragma unroll
@@ -1059,7 +1183,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         const int cl = sub + LPR * i;
                         resbuf[rrow * LH + cl] = n2[i];
                         st_ntg(sbn + sl.nodes_in + rrow * H + cl, n2[i]);
-                        abuf[rrow * LH + cl] = (n2[i] - mean) * rstd * ro[4][i] + ro[5][i];
+                        a_store(rrow, cl, (n2[i] - mean) * rstd * ro[4][i] + ro[5][i]);
                     }
                     pre_B(m.layer[l + 1], sub);
                 }
@@ -1124,7 +1248,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
                     const int cl = sub + LPR * i;
-                    abuf[rrow * LH + cl] = dn[i] * g2 + dz * (ro[6][i] + ro[8][i]);
+                    a_store(rrow, cl, dn[i] * g2 + dz * (ro[6][i] + ro[8][i]));
                     resbuf[rrow * LH + cl] = dn[i] * (1.0f - g2) + dz * (ro[7][i] - ro[8][i]);
                 }
                 // stage E operands: attn_out, nodes_in, g1 stay; LN2 gamma -> ro[2]
@@ -1136,9 +1260,10 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             {
                 DFF_LANE_CONSTS
                 const WStream after = s_woxt(lw, wave);
-                const SStream safter = ss_woxt(lw, wave);
+                const SStream gn = ss_woxt(lw, wave);   // this layer's attention backward follows (G_ext GEMM: U_GX >= SDR units)
+                const SSeq<U_W1, U_W2, SDR, 0, 0, 0, 0, E> sqb{ss_w2t(lw), ss_w1t(lw), gn, gn};
                 f32x4 afr[E];
-                load_afrag<E>(afr, abuf, LH, lane);
+                if constexpr (!SPW) load_afrag<E>(afr, abuf, LH, lane);
                 float hp[DR][4];
                 const gfloat* const shp = sb + sl.h_pre + wave * FS + col;
                 const int s0 = srow[0] * F, s1 = srow[1] * F, s2 = srow[2] * F, s3 = srow[3] * F;
@@ -1164,8 +1289,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         };
                     if constexpr (SPW) {
                         u32x4 ah[KB32], am[KB32], al[KB32];
-                        split_afrag<KB32>(afr, ah, am, al);
-                        swide_run<0, 0, NTS, KB32, 4>(sring, hp, ah, am, al, ss_w2t(lw), ss_w1t(lw), lane, hp_load, w2t_epi);
+                        a_load(ah, am, al, lane);
+                        swide_run<0, NTS, KB32, 4>(sring, hp, ah, am, al, sqb, lane, hp_load, w2t_epi);
                     } else
                     wide_run<0, NTS, E, 4>(ring, hp, afr, s_w2t(lw), s_w1t(lw), lane, hp_load, w2t_epi);
                 }
@@ -1174,7 +1299,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 for (int nt = 0; nt < E; ++nt) acc_f[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 {
                     const lfloat* const ha = hbuf + col * LF + 4 * quad;
-                    if constexpr (SPW) stall_run<0, 0, FS / 32, E, false>(sring, acc_f, [=](int kb) { return ha + 32 * kb; }, ss_w1t(lw), safter, lane);
+                    if constexpr (SPW) stall_run<U_W1, FS / 32, E, false>(sring, acc_f, [=](int kb) { return ha + 32 * kb; }, sqb, lane);
                     else tall_run<NTS % DR, NTS, E, -1>(ring, acc_f, [=](int kb) { return ha + 16 * kb; }, s_w1t(lw), after, lane);
                 }
 #pragma unroll
@@ -1194,7 +1319,9 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             if (ract) {
                 float n1[HC], d1[HC], dyg[HC], xh[HC], ps[HC];
                 psum_all(ps, rrow * LH + sub);
+                pf.tick(22);
                 const float g1 = ro_gate(ro[0], ro[1], 3);
+                pf.tick(23);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) n1[i] = ro[0][i] * g1 + ro[1][i] * (1.0f - g1);
                 float mean, rstd;
@@ -1221,7 +1348,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
                     const int cl = sub + LPR * i;
-                    abuf[rrow * LH + cl] = d1[i] * g1 + dz * (ro[3][i] + ro[5][i]);
+                    a_store(rrow, cl, d1[i] * g1 + dz * (ro[3][i] + ro[5][i]));
                     resbuf[rrow * LH + cl] = d1[i] * (1.0f - g1) + dz * (ro[4][i] - ro[5][i]);
                 }
                 // stage F operands: nodes_in stays in ro[1]; LN1 gamma -> ro[2]
@@ -1233,7 +1360,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             {
                 DFF_LANE_CONSTS
                 f32x4 afr[E];
-                load_afrag<E>(afr, abuf, LH, lane);   // dattn
+                if constexpr (!SPW) load_afrag<E>(afr, abuf, LH, lane);   // dattn
                 f32x4 acc_a[E];
 #pragma unroll
                 for (int nt = 0; nt < E; ++nt) acc_a[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1242,10 +1369,12 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 const WStream after = l > 0 ? s_w2t(m.layer[l - 1])
                                             : (a.mode == DFF_MODE_LANGEVIN ? s_wox(m.layer[0], wave) : s_qkv(m.layer[0], wave));
                 (void)more;
-                const SStream safter = l > 0 ? ss_w2t(m.layer[l > 0 ? l - 1 : 0])
-                                             : (a.mode == DFF_MODE_LANGEVIN ? ss_wox(m.layer[0], wave) : ss_qkv(m.layer[0], wave));
+                // what follows: FFN backward of layer l - 1 (W2^T, W1^T); after layer 0 the next step re-stages its own first units
+                const DffLayerDev& lwp = m.layer[l > 0 ? l - 1 : 0];
+                const SSeq<U_GX, U_QKVT, MW, 0, KT, 0, 0, E> sqa{ss_woxt(lw, wave), ss_qkvt(lw, wave), ss_w2t(lwp), ss_w1t(lwp)};
+                const SSeq<U_GX, 0, MW, 0, 0, 0, 0, E> sqa0{ss_woxt(lw, wave), ss_woxt(lw, wave), ss_w2t(lwp), ss_w1t(lwp)};
                 u32x4 dah[KB32], dam[KB32], dal[KB32];   // SPW: dattn as bf16 pieces
-                if constexpr (SPW) split_afrag<KB32>(afr, dah, dam, dal);
+                if constexpr (SPW) a_load(dah, dam, dal, lane);
                 // G_ext = dattn W_o_ext[h]^T  (5 tiles: [G 64 | r 3 | 0]) -> G region ; dx_i -= r_i
                 auto gext = [&](auto ph, int h, const WStream& wnext) {
                     float none[DR][1] = {};
@@ -1262,13 +1391,13 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         });
                 };
                 // the same on the split operands; phn = ring phase of the GEMM that follows (2: this head's QKV_ext^T back-projection)
-                auto sgext = [&](auto phn, int h, const SStream& wnext) {
+                auto sgext = [&](const auto& sq) {
                     float none[2][1] = {};
                     lfloat* const gb = Gx + col;
                     const int l0 = lro[0], l1 = lro[1], l2 = lro[2], l3 = lro[3];
                     lfloat* const dxp = dxw;
                     const int d0 = dxi[0], d1 = dxi[1], d2 = dxi[2], d3 = dxi[3];
-                    swide_run<0, decltype(phn)::value, 5, KB32, 1>(sring, none, dah, dam, dal, ss_woxt(lw, h), wnext, lane,
+                    swide_run<0, 5, KB32, 1>(sring, none, dah, dam, dal, sq, lane,
                         [=](int, float (&)[1]) {},
                         [=](int t, const f32x4& acc, const float (&)[1]) {
                             gb[l0 + 16 * t] = acc[0]; gb[l1 + 16 * t] = acc[1];
@@ -1383,7 +1512,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
                         committed();
                         pf.tick(8);
-                        if constexpr (SPW) sgext(std::integral_constant<int, 2>{}, wave, ss_qkvt(lw, wave));
+                        if constexpr (SPW) sgext(sqa);
                         else gext(std::integral_constant<int, 0>{}, wave, s_qkvt(lw, wave));
                         gfix();
                         pf.tick(15);
@@ -1391,7 +1520,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         pf.tick(16);
                         dqkv();
                         pf.tick(17);
-                        if constexpr (SPW) stall_run<2, 0, 6, E, true>(sring, acc_a, qkvt_fa32, ss_qkvt(lw, wave), safter, lane, qkvt_xa, qkvt_ext(lw, wave, lane), DFF_HEADS * 13 * 256);
+                        if constexpr (SPW) stall_run<U_GX, 6, E, true>(sring, acc_a, qkvt_fa32, sqa, lane, qkvt_xa, qkvt_ext(lw, wave, lane), DFF_HEADS * 13 * 256);
                         else tall_run<5 % DR, 13, E, 4>(ring, acc_a, qkvt_fa, s_qkvt(lw, wave), after, lane);   // 18 entries: phase 0
                         pf.tick(18);
                     }
@@ -1430,7 +1559,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, true, lane, m12p(wave));
                     head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
                     committed();
-                    if constexpr (SPW) sgext(std::integral_constant<int, 0>{}, wave, safter);
+                    if constexpr (SPW) sgext(sqa0);
                     else gext(std::integral_constant<int, 0>{}, wave, after);
                     gfix();
                     ds_math();
