@@ -517,47 +517,44 @@ def test_ddpm_chain_variance_at_full_size(dff):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", ["trp_cage", "bba", "villin"])
+@pytest.mark.parametrize("cfg", ["chignolin", "trp_cage", "bba", "villin"])
 def test_split_bf16_weight_gemms_are_fp32_exact(dff, cfg, golden, monkeypatch):
-    """Opt-in variants (DFF_SPLIT_BF16=1 when the model is created): the K = H weight GEMMs of the generic kernel run
-    on v_mfma_f32_16x16x32_bf16 with every fp32 operand split exactly into three bf16 pieces (six products kept).
-    Held to the SAME tolerances as the fp32-MFMA path, against the reference's float64 forces, plus a fused Langevin
-    run against the fp32-MFMA variant."""
+    """Default variants where they exist (chignolin: all eight weight GEMMs of the <= 16-row kernel; trp-cage, BBA, villin:
+    the K = H ones of the generic kernel): the weight GEMMs run on v_mfma_f32_16x16x32_bf16 with every fp32 operand split
+    exactly into three bf16 pieces (six products kept).  DFF_SPLIT_BF16=0 when the model is created selects the pure
+    v_mfma_f32_16x16x4_f32 variants.  Both are held to the SAME tolerances against the reference's float64 forces, and a
+    fused Langevin run of one is compared with the other."""
     from dff_amd.score import GraphTransformer
     from dff_amd.ddpm import GaussianDiffusion
     from dff_amd.langevin import LangevinDiffusion
     g = golden(f"score_{cfg}.npz")
     _, N, H, L = synth.SHIPPED_CONFIGS[cfg]
-    params = synth.synth_gnn_params(N, H, L, decoder_scale=1.0)
-    suite_runs_split = os.environ.get("DFF_SPLIT_BF16") == "1"   # (the whole suite can also be run with the switch on)
-    monkeypatch.setenv("DFF_SPLIT_BF16", "1")
-    model = GraphTransformer(N, H, device="cuda:0", n_layers=L, use_intrinsic_coords=True, use_abs_coords=False,
-                             use_distances=False, conservative=True, state_dict=params)
-    monkeypatch.setenv("DFF_SPLIT_BF16", "1" if suite_runs_split else "0")
-    f, e = model.native.score(torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["t"]).cuda(), return_energy=True)
-    assert "split_bf16" in model.native.last_launch()[0]
-    f, e = f.cpu().numpy(), e.cpu().numpy()
-    r64, r32 = rel(f, g["forces64"]), rel(g["forces32"], g["forces64"])
-    print(f"{cfg}: rel(hip split,ref64)={r64:.3e} rel(ref32,ref64)={r32:.3e}")
-    assert r64 <= 1e-5 and r64 <= 2.5 * r32
-    assert np.abs(f - g["forces32"]).max() <= 1e-4 * np.abs(g["forces32"]).max()
-    np.testing.assert_allclose(e[..., None], g["energy32"], rtol=0, atol=2e-5)
+
+    def make(split, scale):
+        monkeypatch.setenv("DFF_SPLIT_BF16", "1" if split else "0")
+        return GraphTransformer(N, H, device="cuda:0", n_layers=L, use_intrinsic_coords=True, use_abs_coords=False,
+                                use_distances=False, conservative=True,
+                                state_dict=synth.synth_gnn_params(N, H, L, decoder_scale=scale))
+
+    for split in (True, False):
+        model = make(split, 1.0)
+        f, e = model.native.score(torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["t"]).cuda(), return_energy=True)
+        assert ("split_bf16" in model.native.last_launch()[0]) == split, model.native.last_launch()
+        f, e = f.cpu().numpy(), e.cpu().numpy()
+        r64, r32 = rel(f, g["forces64"]), rel(g["forces32"], g["forces64"])
+        print(f"{cfg}: split={split} rel(hip,ref64)={r64:.3e} rel(ref32,ref64)={r32:.3e}")
+        assert r64 <= 1e-5 and r64 <= 2.5 * r32
+        assert np.abs(f - g["forces32"]).max() <= 1e-4 * np.abs(g["forces32"]).max()
+        np.testing.assert_allclose(e[..., None], g["energy32"], rtol=0, atol=2e-5)
     # 20 fused Langevin steps on supplied noise: split variant vs fp32-MFMA variant
-    base, _ = get_model(dff, cfg, 1e-2)
-    p2 = synth.synth_gnn_params(N, H, L, decoder_scale=1e-2)
-    monkeypatch.setenv("DFF_SPLIT_BF16", "1")
-    m2 = GraphTransformer(N, H, device="cuda:0", n_layers=L, use_intrinsic_coords=True, use_abs_coords=False,
-                          use_distances=False, conservative=True, state_dict=p2)
-    monkeypatch.setenv("DFF_SPLIT_BF16", "1" if suite_runs_split else "0")
     init = torch.from_numpy(synth.normal((6, N, 3), 2, 8).astype(np.float32)) * 3.0
     noises = torch.from_numpy(synth.normal((20, 6, N, 3), 4, 2).astype(np.float32))
     out = []
-    for mdl in (base, m2):
+    for split in (False, True):
+        mdl = make(split, 1e-2)
         diff = GaussianDiffusion(mdl, num_atoms=N, timesteps=1000, norm_factor=3.0)
         ld = LangevinDiffusion(diff, init, n_timesteps=20, save_interval=5, t=20, temp_data=340, temp_sim=340, dt=None,
                                masses=[12.0] * N, friction=1.0, verbose=False)
         out.append(ld.simulate(noises=noises))
-    assert "split_bf16" in m2.native.last_launch()[0]
-    if not suite_runs_split:
-        assert "split_bf16" not in base.native.last_launch()[0]
+        assert ("split_bf16" in mdl.native.last_launch()[0]) == split
     assert rel(out[1], out[0]) <= 2e-5

@@ -728,15 +728,23 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     auto s_woxt = [&](const DffLayerDev& lw, int h) { return wide_stream(lw.WoxT_p, E, h * 5); };
     auto s_qkvt = [&](const DffLayerDev& lw, int h) { return tall_stream(lw.WqkvxT_p, DFF_HEADS * 13, h * 13); };
     // the same streams of the split images (units, see the split engine above)
-    constexpr int KQ = 1, KO = DFF_HEADS * 5, KT = DFF_HEADS * 13;   // stream kinds (unit_addr) of QKV_ext, [W_o;W_oc], QKV_ext^T
-    auto ss_qkv = [&](const DffLayerDev& lw, int h) { return SStream{(const gu32x4*)lw.Wqkvx_p + (size_t)h * 13 * E * 64}; };
-    auto ss_wox = [&](const DffLayerDev& lw, int h) { return SStream{(const gu32x4*)lw.Wox_p + (size_t)h * 5 * 64}; };
+    // stream kinds (unit_addr) of QKV_ext, [W_o;W_oc], QKV_ext^T: 1 = fp32 image split in registers (4 B per weight, +44 VALU per unit),
+    // 0 = host-split image (6 B).  Measured (us / step, chignolin P = 256; Q,O,T): 000 90.1, 100 90.3, 010 90.4, 001 92.0, 011 92.3, 111 94.1:
+    // the extra VALU costs what the smaller stream saves, so all three stay host-split.
+#ifndef DFF_KQ
+#define DFF_KQ 0
+#define DFF_KO 0
+#define DFF_KT 0
+#endif
+    constexpr int KQ = DFF_KQ ? 1 : 0, KO = DFF_KO ? DFF_HEADS * 5 : 0, KT = DFF_KT ? DFF_HEADS * 13 : 0;
+    auto ss_qkv = [&](const DffLayerDev& lw, int h) { return KQ ? SStream{(const gu32x4*)lw.Wqkvx_p + (size_t)h * 13 * E * 64} : sstream(lw.Wqkvx_w, h * 13 * KB32); };
+    auto ss_wox = [&](const DffLayerDev& lw, int h) { return KO ? SStream{(const gu32x4*)lw.Wox_p + (size_t)h * 5 * 64} : sstream(lw.Wox_t, h * 2 * E); };
     auto ss_w1 = [&](const DffLayerDev& lw) { return sstream(lw.W1_w, wave * NTS * KB32); };
     auto ss_w2 = [&](const DffLayerDev& lw) { return sstream(lw.W2_t, wave * (FS / 32) * E); };
     auto ss_w2t = [&](const DffLayerDev& lw) { return sstream(lw.W2T_w, wave * NTS * KB32); };
     auto ss_w1t = [&](const DffLayerDev& lw) { return sstream(lw.W1T_t, wave * (FS / 32) * E); };
     auto ss_woxt = [&](const DffLayerDev& lw, int h) { return sstream(lw.WoxT_w, h * 5 * KB32); };
-    auto ss_qkvt = [&](const DffLayerDev& lw, int h) { return SStream{(const gu32x4*)lw.WqkvxT_p + (size_t)h * 13 * 64}; };
+    auto ss_qkvt = [&](const DffLayerDev& lw, int h) { return KT ? SStream{(const gu32x4*)lw.WqkvxT_p + (size_t)h * 13 * 64} : sstream(lw.WqkvxT_t, h * 6 * E); };
     // extension-block weights of the tall GEMMs for the fp32 k-step (s = 0 slots of the fp32 images)
     auto wox_ext = [&](const DffLayerDev& lw, int h, int lane) { return (const gfloat*)lw.Wox_p + ((size_t)(5 * h + 4) * 64 + lane) * 4; };
     auto qkvt_ext = [&](const DffLayerDev& lw, int h, int lane) { return (const gfloat*)lw.WqkvxT_p + ((size_t)(13 * h + 4) * 64 + lane) * 4; };
