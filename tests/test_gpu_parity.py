@@ -21,7 +21,8 @@ from oracle import synth
 pytestmark = pytest.mark.gpu
 
 CFGS = ["ala2", "chignolin", "trp_cage", "bba", "villin", "protein_g"]
-NORM_STD = {"chignolin": 3.113133430480957, "villin": 6.082900047302246, "ala2": 0.9449278712272644}
+NORM_STD = {"chignolin": 3.113133430480957, "villin": 6.082900047302246, "ala2": 0.9449278712272644,
+            "protein_g": 6.354289531707764, "trp_cage": 5.08211088180542, "bba": 6.294918537139893}
 
 
 @pytest.fixture(scope="module")
@@ -191,7 +192,7 @@ def _diffusion(dff, cfg, decoder_scale=1.0, norm=1.0):
     return GaussianDiffusion(model, num_atoms=model.num_beads, timesteps=1000, norm_factor=norm), params
 
 
-@pytest.mark.parametrize("cfg", ["chignolin", "ala2"])
+@pytest.mark.parametrize("cfg", ["chignolin", "ala2", "trp_cage", "bba", "villin", "protein_g"])
 def test_p_sample_golden(dff, cfg, golden):
     g = golden(f"psample_{cfg}.npz")
     diff, _ = _diffusion(dff, cfg)
@@ -201,12 +202,22 @@ def test_p_sample_golden(dff, cfg, golden):
         np.testing.assert_allclose(y.cpu().numpy(), g[f"y_{t}"], rtol=2e-5, atol=2e-5 * np.abs(g[f"y_{t}"]).max())
 
 
-def test_fused_reverse_loop_golden(dff, golden):
-    """5 fused reverse steps incl. the +-1000 clamp path (ddpm.py:248-251) in ONE launch."""
-    g = golden("ploop_chignolin.npz")
-    diff, _ = _diffusion(dff, "chignolin")
-    y = diff.p_sample_loop_from(torch.from_numpy(g["x5"]), 4, 0, noises=torch.from_numpy(g["noises"]))
-    np.testing.assert_allclose(y.cpu().numpy(), g["x0"], rtol=1e-4, atol=2e-3)
+@pytest.mark.parametrize("cfg", ["chignolin", "protein_g"])
+def test_fused_reverse_loop_golden(dff, cfg, golden):
+    """5 fused reverse steps incl. the +-1000 clamp path (ddpm.py:248-251) in ONE launch (protein G: the SPILL variant of
+    the <= 64-row kernel).  One sample has a coordinate at the clamp, so its entries are O(1000) after centring; every
+    sample is held to 2e-5 x 5 steps relative to ITS OWN largest entry -- the samples that never clamp (entries O(1)) are
+    therefore checked to ~2e-4 absolute, not to the clamped sample's scale."""
+    g = golden(f"ploop_{cfg}.npz")
+    diff, _ = _diffusion(dff, cfg)
+    y = diff.p_sample_loop_from(torch.from_numpy(g["x5"]), 4, 0, noises=torch.from_numpy(g["noises"])).cpu().numpy()
+    clamped = 0
+    for b in range(y.shape[0]):
+        scale = np.abs(g["x0"][b]).max()
+        clamped += scale > 100
+        np.testing.assert_allclose(y[b], g["x0"][b], rtol=0, atol=2e-5 * 5 * scale, err_msg=f"sample {b}")
+    assert clamped == 1
+    y = torch.from_numpy(y)
     with pytest.warns(UserWarning):
         assert diff.check_clamp()
     assert y.mean(1).abs().max().item() < 1e-3
@@ -227,7 +238,10 @@ def test_fused_single_steps_match_p_sample(dff, golden):
 
 @pytest.mark.parametrize("name,cfg", [("langevin_chignolin_0", "chignolin"), ("langevin_chignolin_1", "chignolin"),
                                       ("langevin_chignolin_2", "chignolin"), ("langevin_ala2_3", "ala2"),
-                                      ("langevin_villin_4", "villin"), ("langevin_chignolin_5", "chignolin")])
+                                      ("langevin_villin_4", "villin"), ("langevin_chignolin_5", "chignolin"),
+                                      ("langevin_trp_cage_r20", "trp_cage"), ("langevin_bba_r21", "bba"),
+                                      ("langevin_villin_r22", "villin"), ("langevin_protein_g_r23", "protein_g"),
+                                      ("langevin_protein_g_r24", "protein_g")])
 def test_langevin_golden(dff, name, cfg, golden):
     from dff_amd.langevin import LangevinDiffusion
     g = golden(name + ".npz")
@@ -558,3 +572,59 @@ def test_split_bf16_weight_gemms_are_fp32_exact(dff, cfg, golden, monkeypatch):
         out.append(ld.simulate(noises=noises))
         assert ("split_bf16" in mdl.native.last_launch()[0]) == split
     assert rel(out[1], out[0]) <= 2e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# Full-size parity with a LIVE network at the BASELINE per-GPU batches: the fused loops run K = 8 steps on supplied noise
+# and a handful of trajectories / samples -- the first, the last, and the two either side of a launch boundary (a batch
+# larger than max_workgroups runs as consecutive launches over one bounded stash) -- are compared with the oracle twin run
+# on just those (trajectories are independent, so the twin needs only their rows of x0 and of the noise).
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,P,wgs", [("villin", 256, 100), ("protein_g", 128, 50), ("chignolin", 256, 0)])
+def test_full_size_langevin_subset_vs_oracle(dff, cfg, P, wgs):
+    from dff_amd.langevin import LangevinDiffusion
+    _, N, H, L = synth.SHIPPED_CONFIGS[cfg]
+    K, tlev, temp = 8, 5, {"villin": 360, "protein_g": 350, "chignolin": 340}[cfg]
+    diff, params = _diffusion(dff, cfg, decoder_scale=1e-2, norm=NORM_STD[cfg])
+    x0 = synth.normal((P, N, 3), 31, 3).astype(np.float32)
+    x0 = (x0 - x0.mean(1, keepdims=True)) * NORM_STD[cfg]
+    noises = synth.normal((K, P, N, 3), 32, 4).astype(np.float32)
+    masses = [12.0] * N
+    if wgs:
+        diff.model.native.max_workgroups(wgs)    # P = 256 in launches of 100, 100, 56 workgroups
+    try:
+        ld = LangevinDiffusion(diff, torch.from_numpy(x0), K, save_interval=1, t=tlev, diffusion_steps=1000, temp_data=temp,
+                               temp_sim=temp, dt=None, masses=masses, friction=1.0, kb="consistent", verbose=False)
+        traj = ld.sample(noises=torch.from_numpy(noises)).numpy().reshape(P, K, N, 3)   # simulation-major (langevin.py:205-212)
+    finally:
+        diff.model.native.max_workgroups(2048)
+    idx = sorted({0, 1, P // 2, P - 1} | ({wgs - 1, wgs, 2 * wgs - 1, 2 * wgs} if wgs else set()))
+    c = twin.langevin_constants(NORM_STD[cfg], tlev, twin.make_schedule(), temp, temp, masses, 1.0, None)
+    fr, ke, xl, vl = twin.simulate(twin.to_torch(params), torch.from_numpy(x0[idx]) / NORM_STD[cfg],
+                                   torch.from_numpy(noises[:, idx]), masses, c, L, 1)
+    ref = (fr * NORM_STD[cfg]).numpy()                                # (sims, frames, N, 3)
+    tol = 2e-5 * K
+    np.testing.assert_allclose(traj[idx], ref, rtol=tol, atol=tol * np.abs(ref).max())
+    np.testing.assert_allclose(ld.v.cpu().numpy()[idx], vl.numpy(), rtol=tol, atol=tol * np.abs(vl.numpy()).max())
+    assert np.isfinite(traj).all()
+
+
+@pytest.mark.gpu
+def test_full_size_ddpm_subset_vs_oracle(dff):
+    """BASELINE config 3's batch (4096 chignolin samples per launch call = two launches of 2048 workgroups) with the
+    network live: 8 fused reverse steps t = 7 .. 0 on supplied noise vs the oracle's p_sample_loop on six samples."""
+    cfg, B, K = "chignolin", 4096, 8
+    _, N, H, L = synth.SHIPPED_CONFIGS[cfg]
+    diff, params = _diffusion(dff, cfg)
+    x = synth.normal((B, N, 3), 41, 5).astype(np.float32)
+    x = (x - x.mean(1, keepdims=True)) * 0.6
+    noises = synth.normal((K, B, N, 3), 42, 6).astype(np.float32)
+    y = diff.p_sample_loop_from(torch.from_numpy(x), K - 1, 0, noises=torch.from_numpy(noises)).cpu().numpy()
+    assert diff.model.native.last_launch()[1] == 2048                  # the batch was split at 2048 workgroups
+    idx = [0, 1, 2047, 2048, 3000, 4095]
+    ref = twin.p_sample_loop(twin.to_torch(params), twin.make_schedule(), torch.from_numpy(x[idx]),
+                             torch.from_numpy(noises[:, idx]), K - 1, L).numpy()
+    tol = 2e-5 * K
+    np.testing.assert_allclose(y[idx], ref, rtol=tol, atol=tol * np.abs(ref).max())
+    assert np.isfinite(y).all() and np.abs(y.mean(1)).max() < 1e-4
