@@ -21,6 +21,7 @@ from oracle import synth
 pytestmark = pytest.mark.gpu
 
 CFGS = ["ala2", "chignolin", "trp_cage", "bba", "villin", "protein_g"]
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 NORM_STD = {"chignolin": 3.113133430480957, "villin": 6.082900047302246, "ala2": 0.9449278712272644,
             "protein_g": 6.354289531707764, "trp_cage": 5.08211088180542, "bba": 6.294918537139893}
 
@@ -628,3 +629,76 @@ def test_full_size_ddpm_subset_vs_oracle(dff):
     tol = 2e-5 * K
     np.testing.assert_allclose(y[idx], ref, rtol=tol, atol=tol * np.abs(ref).max())
     assert np.isfinite(y).all() and np.abs(y.mean(1)).max() < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------
+# The N > 1 product path on real kernels (no multi-GPU node needed): two ranks share the one GPU (DFF_DEVICE=0),
+# rendezvous over gloo (DFF_DIST_BACKEND), and run the sample.py-compatible CLI end to end.  Philox counters are the
+# GLOBAL sample / trajectory indices, so the gathered result must equal the one-rank run bit for bit, in
+# simulation-major order (sample.py:180-214, dynamics/langevin.py:205-212).
+# ---------------------------------------------------------------------------------------------
+_TWO_RANK_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, os.environ["DFF_REPO"])
+import dff_amd
+from dff_amd import cli
+out = cli.main(sys.argv[1:])
+if int(os.environ["RANK"]) == 0:
+    torch.save(out, os.environ["DFF_OUT"])
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["iid", "langevin"])
+def test_two_ranks_on_one_gpu_equal_one_rank(dff, tmp_path, mode):
+    import socket
+    import subprocess
+    import sys
+    from dff_amd import cli
+    params, (N, H, L) = _write_model_dir(tmp_path, "chignolin")
+    argv = ["--model_path", str(tmp_path), "--gen_mode", mode, "--seed", "5", "--batch_size_gen", "4"]
+    argv += (["--num_samples_eval", "12"] if mode == "iid" else
+             ["--parallel_sim", "6", "--n_timesteps", "20", "--save_interval", "5", "--masses", "[12.0]*10"])
+    one = cli.main(argv + ["--append_exp_name", "w1"])
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "worker.py"
+    script.write_text(_TWO_RANK_WORKER)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   DFF_DEVICE="0", DFF_DIST_BACKEND="gloo", DFF_REPO=ROOT, DFF_OUT=str(tmp_path / "w2.pt"))
+        procs.append(subprocess.Popen([sys.executable, str(script)] + argv + ["--append_exp_name", "w2"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for pr in procs:
+        out, _ = pr.communicate(timeout=600)
+        assert pr.returncode == 0, out.decode()[-2000:]
+    two = torch.load(tmp_path / "w2.pt")
+    assert two.shape == one.shape == ((12, N, 3) if mode == "iid" else (6 * 4, N, 3))
+    assert torch.equal(two, one), float((two - one).abs().max())
+    saved = torch.load(tmp_path / f"main_eval_output_{mode}_w2" / f"sample-{mode}.pt")
+    assert torch.equal(saved, one)
+
+
+@pytest.mark.gpu
+def test_device_flag_word_persists_and_reports_centre(dff):
+    """One flag word per GaussianDiffusion: a clamp in an EARLIER batch is still reported after later clean batches
+    (the reference warns per step, ddpm.py:248-250), and a chain that ends off-centre -- here: NaNs, which slip through the
+    reference's own entry check just the same -- raises like assert_center_zero (ddpm.py:252); reading clears the word."""
+    diff, _ = _diffusion(dff, "chignolin")
+    N = 10
+    big = torch.zeros(2, N, 3)
+    big[0, 0, 0], big[0, 1, 0] = 4000.0, -4000.0                      # centred, far outside +-1000
+    diff.p_sample_loop_from(big, 999, 999)                             # batch 1: clamps
+    clean = torch.from_numpy(synth.normal((2, N, 3), 5, 5).astype(np.float32))
+    diff.p_sample_loop_from(clean - clean.mean(1, keepdim=True), 3, 0)  # batch 2: does not
+    with pytest.warns(UserWarning, match="Large molecule"):
+        assert diff.check_clamp()
+    assert not diff.check_clamp()                                      # cleared
+    bad = clean - clean.mean(1, keepdim=True)
+    bad[1, 3, 2] = float("nan")
+    diff.p_sample_loop_from(bad, 1, 0)
+    with pytest.raises(AssertionError, match="Center not at zero"):
+        diff.check_clamp()
+    assert not diff.check_clamp()

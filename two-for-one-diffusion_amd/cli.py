@@ -138,7 +138,8 @@ def generate_samples(ddpm, mol, samp_args, args, rank: int, world: int):
         lo = rank * p_local
         ddpm._samples_drawn = lo
         init_mol = sample_from_model(SamplerWrapper(ddpm), p_local, max(1, samp_args.batch_size_gen // world),
-                                     verbose=(rank == 0))
+                                     verbose=(rank == 0), to_cpu=False)      # stays on the device for the integrator
+        ddpm.check_clamp()
         masses = samp_args.masses
         if masses is None:
             masses = specs.default_masses(args.mol)            # sample.py:216-221
@@ -169,7 +170,11 @@ def main(argv=None):
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("DFF_DIST_BACKEND", "nccl")    # RCCL over xGMI; "gloo" when ranks share one GPU (tests)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     args = load_training_args(samp_args.model_path)
     if samp_args.temp_data is None:
         samp_args.temp_data = temp_dict[args.mol.upper()]

@@ -1840,7 +1840,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 const float nzm = (t_int == 0) ? 0.f : 1.f;
                 xn = mean + nzm * expf(0.5f * m.post_logvar[t_int]) * xi;
                 if (xn > 1000.f || xn < -1000.f) {
-                    if (a.clamp_flag) *a.clamp_flag = 1;
+                    if (a.clamp_flag) atomicOr(a.clamp_flag, 1);
                     xn = fminf(fmaxf(xn, -1000.f), 1000.f);
                 }
             }
@@ -1852,6 +1852,13 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             if (act) c.xst[tid] = xn - c.cm[g * 4 + cc];
         }
         wg_sync<SPILL>();
+        // end of a reverse chain: the reference's assert_center_zero(mol) (models/ddpm.py:252, utils.py:73-86) on the device:
+        // bit 1 of the flag word reports a centre of mass >= 1e-3 (bit 0: the +-1000 clamp); the host raises on it
+        if (a.mode == DFF_MODE_DDPM && step == a.n_steps - 1 && a.clamp_flag) {
+            bead_mean(c, c.xst, c.cm);
+            wg_sync<SPILL>();
+            if (tid < c.gcnt * 4 && (tid & 3) < 3 && !(fabsf(c.cm[tid]) < 1e-3f)) atomicOr(a.clamp_flag, 2);
+        }
         pf.tick(21);
     }
     if (pf.on)

@@ -1721,7 +1721,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 const float nzm = (t_int == 0) ? 0.f : 1.f;
                 xn = mean + nzm * expf(0.5f * m.post_logvar[t_int]) * xi;
                 if (xn > 1000.f || xn < -1000.f) {
-                    if (a.clamp_flag) *a.clamp_flag = 1;
+                    if (a.clamp_flag) atomicOr(a.clamp_flag, 1);
                     xn = fminf(fmaxf(xn, -1000.f), 1000.f);
                 }
             }
@@ -1733,6 +1733,12 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             if (act) xst[tid] = xn - cm[g * 4 + cc];
         }
         __syncthreads();
+        // end of a reverse chain: assert_center_zero(mol) (models/ddpm.py:252) on the device -> bit 1 of the flag word
+        if (a.mode == DFF_MODE_DDPM && step == a.n_steps - 1 && a.clamp_flag) {
+            bead_mean(c, (float*)xst, (float*)cm);
+            __syncthreads();
+            if (tid < gcnt * 4 && (tid & 3) < 3 && !(fabsf(cm[tid]) < 1e-3f)) atomicOr(a.clamp_flag, 2);
+        }
         pf.tick(11);
     }
     if (pf.on)

@@ -39,7 +39,8 @@ def assert_center_zero(x, eps=1e-3):
 class GaussianDiffusion:
     def __init__(self, model: GraphTransformer, features=None, num_atoms: Optional[int] = None,
                  timesteps: int = 1000, loss_type="l2", objective="pred_noise", beta_schedule="cosine",
-                 norm_factor: float = 1, loss_weights="ones", seed: int = 0):
+                 p2_loss_weight_gamma: float = 0.0, p2_loss_weight_k: float = 1,   # training-only (ddpm.py:32-33): accepted in
+                 norm_factor: float = 1, loss_weights="ones", seed: int = 0):      # their reference positions, unused here
         if objective != "pred_noise" or beta_schedule != "cosine":
             raise ValueError("only objective='pred_noise', beta_schedule='cosine' (the shipped configs) are supported")
         self.dims = 3
@@ -58,6 +59,10 @@ class GaussianDiffusion:
         self._seed = int(seed)
         self._samples_drawn = 0
         self.last_clamped = False
+        # ONE device flag word for the lifetime of the object, handed to every fused launch and never reset by the
+        # kernels: bit 0 = the +-1000 clamp fired somewhere (ddpm.py:248-250 warns per step), bit 1 = a chain ended with
+        # a centre of mass >= 1e-3 (assert_center_zero, ddpm.py:252).  check_clamp() reads and clears it.
+        self._flag = torch.zeros(1, dtype=torch.int32, device=self.device)
 
     def eval(self):
         return self
@@ -71,6 +76,7 @@ class GaussianDiffusion:
     @torch.no_grad()
     def p_mean_variance(self, x, t):
         """ddpm.py:195-219 with the score network on the HIP path (``dff_score``)."""
+        assert_center_zero(x)                                                   # ddpm.py:199
         model_output = center_zero(self.model(x, self.h, 1.0 * t / self.num_timesteps))
         x_start = (extract(self.sqrt_recip_alphas_cumprod, t, x.shape) * x
                    - extract(self.sqrt_recipm1_alphas_cumprod, t, x.shape) * model_output)
@@ -99,12 +105,13 @@ class GaussianDiffusion:
         """Reverse steps t_start..t_end from a given centred x, each followed by the clamp and
         centring of p_sample_loop (ddpm.py:244-251); normalised units in and out."""
         x = x.detach().to(self.device, torch.float32).contiguous().clone()
-        flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        # the reference's p_mean_variance asserts a centred input at every step (ddpm.py:195-199 via utils.py:73-86); the
+        # fused loop uses x as it comes, so an un-centred start would silently diverge from the reference: refuse it here
+        assert_center_zero(x)
         if noises is not None:
             noises = noises.detach().to(self.device, torch.float32).contiguous()
         self.model.native.ddpm_run(x, t_start, t_end, noise=noises, seed=self._seed,
-                                   sample_offset=self._samples_drawn, clamp_flag=flag)
-        self._flag = flag
+                                   sample_offset=self._samples_drawn, clamp_flag=self._flag)
         return x
 
     @torch.no_grad()
@@ -112,19 +119,22 @@ class GaussianDiffusion:
         """ddpm.py:234-254: x_T = center_zero(randn) then T reverse steps, all on the device."""
         b = shape[0]
         x = torch.empty(shape, device=self.device, dtype=torch.float32)
-        flag = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.model.native.ddpm_run(x, self.num_timesteps - 1, 0, noise=None, seed=self._seed,
-                                   sample_offset=self._samples_drawn, init_prior=True, clamp_flag=flag)
+                                   sample_offset=self._samples_drawn, init_prior=True, clamp_flag=self._flag)
         self._samples_drawn += b
-        self._flag = flag
         return x
 
     def check_clamp(self) -> bool:
-        """Host-side read of the device clamp flag (the reference warns per step, ddpm.py:249)."""
-        f = getattr(self, "_flag", None)
-        self.last_clamped = bool(f.item()) if f is not None else False
+        """ONE host read of the device flag word for everything launched since the last call (the reference syncs three
+        times per step): warns like ddpm.py:249 if the clamp fired in ANY batch, raises like assert_center_zero
+        (ddpm.py:252) if any chain ended off-centre; clears the word."""
+        word = int(self._flag.item())
+        self._flag.zero_()
+        self.last_clamped = bool(word & 1)
         if self.last_clamped:
             warnings.warn("Large molecule encountered in sampling")
+        if word & 2:
+            raise AssertionError("Center not at zero: a reverse chain ended with |centre of mass| >= 0.001")
         return self.last_clamped
 
     @torch.no_grad()

@@ -38,8 +38,9 @@ class SamplerWrapper:
         return self.model.sample(**kwargs)
 
 
-def sample_from_model(sampler, num_saved_samples: int, batch_size: int, verbose: bool = False):
-    """evaluate/evaluators.py:874-888: returns a CPU tensor (num_saved_samples, N, 3)."""
+def sample_from_model(sampler, num_saved_samples: int, batch_size: int, verbose: bool = False, to_cpu: bool = True):
+    """evaluate/evaluators.py:874-888: returns a CPU tensor (num_saved_samples, N, 3).  to_cpu=False keeps the result on the
+    device (the Langevin initial structures are consumed there: no PCIe round trip at config 4's 2048 x 8 simulations)."""
     print(f"Generating {num_saved_samples} samples per GPU. This may take some time.")
     batches = num_to_groups(num_saved_samples, batch_size)
     all_mol_list = []
@@ -47,7 +48,9 @@ def sample_from_model(sampler, num_saved_samples: int, batch_size: int, verbose:
         all_mol_list.append(sampler(batch_size=bs))
         if verbose:
             print(f"Batch {i + 1} from {len(batches)} generated")
-    all_mol = torch.cat(all_mol_list, dim=0).cpu()
+    all_mol = torch.cat(all_mol_list, dim=0)
+    if to_cpu:
+        all_mol = all_mol.cpu()
     print(f"{len(all_mol)} samples generated")
     return all_mol
 
@@ -62,9 +65,10 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def dist_env() -> Tuple[int, int, int]:
-    """(rank, local_rank, world_size) from the torchrun environment (1-process default)."""
-    return (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)),
-            int(os.environ.get("WORLD_SIZE", 1)))
+    """(rank, local_rank, world_size) from the torchrun environment (1-process default).  DFF_DEVICE overrides the
+    device index (several ranks on one GPU: how the multi-rank path is exercised on a one-GPU box)."""
+    local = int(os.environ.get("DFF_DEVICE", os.environ.get("LOCAL_RANK", 0)))
+    return (int(os.environ.get("RANK", 0)), local, int(os.environ.get("WORLD_SIZE", 1)))
 
 
 def gather_variable(local: torch.Tensor, total: int, world: int, group=None) -> torch.Tensor:
