@@ -1,26 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json headline metric on MI355X: Langevin MD-steps/s at batch 256.
 
-Workload (BASELINE.json configs[1], SURVEY.md section 8d "config 2"): chignolin (10 beads, H=64,
-L=3), Langevin, parallel_sim=256 per GPU, noise_level t=20, T_data=T_sim=340 K, m=12, friction
-1, auto dt, save_interval=250; synthetic weights (oracle/synth.py seed 1234, node_decoder x1e-2)
-because the checkpoints are not in the reference mount; x0 ~ N(0,1) centred; in-kernel Philox
-noise.  One "step" = all 256 trajectories of a rank advanced once: score-network forward + VJP
-+ BAOAB update.  The timed region is K steps issued as persistent-kernel launches of
-`--chunk` steps (default 250 = save_interval: one saved frame per launch), state resident in HBM.
+Headline workload (BASELINE.json configs[1], SURVEY.md section 8d "config 2"): chignolin (10 beads, H=64, L=3),
+Langevin, parallel_sim=256 per GPU, noise_level t=20, T_data=T_sim=340 K, m=12, friction 1, auto dt,
+save_interval=250; synthetic weights (synth_weights.py seed 1234, node_decoder x1e-2) because the checkpoints are not in
+the reference mount; x0 ~ N(0,1) centred; in-kernel Philox noise.  One "step" = all 256 trajectories of a rank advanced
+once: score-network forward + VJP + BAOAB update.  Steps are issued as persistent-kernel launches of `--chunk` steps
+(default 250 = save_interval: one saved frame per launch), state resident in HBM.
 
   python bench.py [--gpus N --steps K --warmup W]           (N>1: under torch.distributed.run)
 
-Prints ONE JSON line (rank 0).  `value` is the whole-job aggregate in batch-256 MD-steps/s
-(weak scaling: every rank advances its own 256 trajectories; no data-path collective -- the
-only collective is the final all_gather of frames, timed separately as `gather_ms`).
-`roofline`: fp32 MFMA/VALU peak 157.3 TFLOP/s (MI355X_MICROARCH.md) against the ALGORITHMIC
-FLOPs of SURVEY.md section 8d (22.00 MFLOP per chignolin score call, factorised formulation),
-per-launch durations from HIP events on the launch stream.  `cpu_baseline`: the oracle twin of
-the reference (oracle/reference_twin.py, materialised formulation, torch CPU, all host cores)
-on a bounded number of the same steps.
+The timed region is never shorter than 8 launches: `--steps` / `--warmup` are rounded UP to whole launches and the
+line reports the steps actually run (`steps`, `warmup`) next to the request (`steps_requested`, `warmup_requested`).
+
+Prints ONE JSON line (rank 0).  `value` is the whole-job aggregate in batch-256 MD-steps/s (weak scaling: every rank
+advances its own 256 trajectories; no data-path collective -- the only collective is the final all_gather of frames,
+timed separately as `gather_ms`).  `roofline`: fp32 MFMA/VALU peak 157.3 TFLOP/s (MI355X_MICROARCH.md) against the
+ALGORITHMIC FLOPs of SURVEY.md section 8d (22.00 MFLOP per chignolin score call, factorised formulation), per-launch
+durations from HIP events on the launch stream.  `cpu_baseline`: the oracle twin of the reference
+(oracle/reference_twin.py, materialised formulation, torch CPU) on a bounded number of the same steps.
+`also`: the other figures BASELINE.json's north_star names -- villin (35 beads) Langevin at 256 per GPU, protein G (56
+beads) at 128 per GPU, chignolin / villin i.i.d. samples/s -- each a first-class entry with its own `roofline` object
+(and a `cpu_baseline` for villin), measured after the headline's timed region.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -38,34 +42,66 @@ MFLOP_PER_CALL = {"ala2": 11.27, "chignolin": 22.00, "trp_cage": 102.97, "bba": 
 NORM_STD = {"chignolin": 3.113133430480957, "villin": 6.082900047302246, "protein_g": 6.354289531707764,
             "ala2": 0.9449278712272644, "trp_cage": 5.08211088180542, "bba": 6.294918537139893}
 TEMP = {"chignolin": 340, "villin": 360, "protein_g": 350, "ala2": 300, "trp_cage": 290, "bba": 325}
-PEAK_FP32_TFLOPS = 157.3
+PEAK_FP32_TFLOPS = 157.3            # MI355X_MICROARCH.md: f32 vector = f32 MFMA peak
+PEAK_BF16_DENSE_TFLOPS = 2500.0     # dense bf16 MFMA peak; an exact fp32 product costs six bf16 products
+MIN_LAUNCHES = 8
 
 
 def hbm_traffic_from_profile(kname, cfg, P, chunk):
     """HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes,
-    gfx950 x2 read correction) for this exact kernel + workload: profiles/<round>/traffic.json."""
-    import glob
+    gfx950 x2 read correction) for this exact kernel + workload: profiles/<round>/**/traffic.json (latest round wins)."""
     best = None
+
+    def norm(n):   # rocprofv3 prints the full template argument list, the library the short name
+        n = n.replace(" ", "")
+        for suffix in (",false,false>", ",false>"):
+            if n.endswith(suffix):
+                n = n[:-len(suffix)] + ">"
+        return n.replace(",false,true>", ",split_bf16>")
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "**", "traffic.json"), recursive=True)):
         try:
             t = json.load(open(f))
         except Exception:
             continue
-        # rocprofv3 prints the full template argument list ("<64, 8, false>"), the library the short name ("<64,8>")
-        def norm(n):
-            n = n.replace(" ", "")
-            return n[:-len(",false>")] + ">" if n.endswith(",false>") and n.count(",") in (2, 4) else n
         if norm(t.get("kernel", "")) == norm(kname) and t.get("workload") == f"{cfg} P={P} chunk={chunk}":
             best = t
     return None if best is None else float(best["hbm_bytes_per_launch"])
 
 
-def cpu_baseline(cfg, P, t_level, budget_s=12.0, max_steps=40):
+def kernel_dtype(kname):
+    if "split_bf16" in kname:
+        return ("f32 (weight GEMMs: exact 3-way bf16 split of every fp32 operand, six v_mfma_f32_16x16x32_bf16 products "
+                "per term, fp32 accumulate; attention products and everything else: v_mfma_f32_16x16x4_f32 / fp32 VALU)")
+    return "f32 (v_mfma_f32_16x16x4_f32 and fp32 VALU)"
+
+
+def roofline(cfg, P, steps_per_launch, launch_ms, kname):
+    """bound = fp32 compute: achieved algorithmic TFLOP/s of one launch against 157.3."""
+    avg = float(np.mean(launch_ms))
+    flops = MFLOP_PER_CALL[cfg] * 1e6 * P * steps_per_launch
+    ach = flops / (avg * 1e-3) / 1e12
+    r = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
+         "traffic": hbm_traffic_from_profile(kname, cfg, P, steps_per_launch), "kernel": kname, "avg_launch_ms": avg,
+         "min_launch_ms": float(np.min(launch_ms)), "launches": len(launch_ms), "algorithmic_flops_per_launch": flops,
+         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/)"}
+    if "split_bf16" in kname:
+        r["peak_split_gemms"] = PEAK_BF16_DENSE_TFLOPS / 6.0
+        r["frac_vs_split_peak"] = ach / (PEAK_BF16_DENSE_TFLOPS / 6.0)
+        r["note"] = ("frac is against the fp32 peak (157.3): the arithmetic delivered is fp32-exact.  The weight GEMMs (87% of "
+                     "the MFMA work) run as six bf16 products per fp32 product, whose own roof is the dense bf16 peak / 6 = "
+                     "416.7 TFLOP/s (peak_split_gemms); the attention products stay on the fp32 MFMA (157.3).  Algorithmic "
+                     "HBM bytes are ~600 B per trajectory-step; measured traffic is the activation stash")
+    else:
+        r["note"] = "fp32-compute bound: algorithmic HBM bytes are ~600 B per trajectory-step; measured traffic is the activation stash"
+    return r
+
+
+def cpu_baseline(cfg, P, t_level, budget_s=12.0, max_steps=40, threads=None):
     """Oracle twin timed on the host cores (rank 0, N=1 only).  torch's default of one thread per
     logical core is far from optimal for these small ops, so a 1-step probe picks the best of a
-    few thread counts first; the count used is what `cores` reports."""
+    few thread counts first (or `threads` is taken as given); the count used is what `cores` reports."""
     from oracle import reference_twin as twin
-    from oracle import synth
+    import synth_weights as synth
     _, N, H, L = synth.SHIPPED_CONFIGS[cfg]
     p = twin.to_torch(synth.synth_gnn_params(N, H, L, decoder_scale=1e-2))
     masses = [12.8 if cfg == "ala2" else 12.0] * N
@@ -82,8 +118,10 @@ def cpu_baseline(cfg, P, t_level, budget_s=12.0, max_steps=40):
 
     ncpu = os.cpu_count() or 1
     best_thr, best_t = torch.get_num_threads(), None
+    if threads:
+        torch.set_num_threads(threads)
     x, v = step(x, v)  # warm
-    for thr in sorted({t for t in (8, 16, 32, 64, ncpu // 2) if 1 <= t <= ncpu}):
+    for thr in ([] if threads else sorted({t for t in (8, 16, 32, 64, ncpu // 2) if 1 <= t <= ncpu})):
         torch.set_num_threads(thr)
         x, v = step(x, v)
         t1 = time.perf_counter()
@@ -91,69 +129,100 @@ def cpu_baseline(cfg, P, t_level, budget_s=12.0, max_steps=40):
         dt1 = time.perf_counter() - t1
         if best_t is None or dt1 < best_t:
             best_thr, best_t = thr, dt1
-    torch.set_num_threads(best_thr)
-    for _ in range(2):
+    torch.set_num_threads(threads or best_thr)
+    if not threads:
         x, v = step(x, v)
     n, t0 = 0, time.perf_counter()
-    while n < max_steps and (time.perf_counter() - t0) < budget_s:
+    while n < max_steps and (n < 2 or (time.perf_counter() - t0) < budget_s):
         x, v = step(x, v)
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "MD-steps/s (batch 256)", "cores": torch.get_num_threads(),
+    return {"value": n / dt, "unit": f"MD-steps/s (batch {P})", "cores": torch.get_num_threads(),
             "kind": "port", "ms_per_step": 1e3 * dt / n,
             "sample": f"{n} Langevin steps of the same workload (P={P}, {cfg}) after warm-up and a thread-count probe, "
                       f"oracle/reference_twin.py on {torch.get_num_threads()} threads of {os.cpu_count()} logical cores"}
 
 
-def north_star_extras(dev, rank, world, P):
-    """The other figures BASELINE.json's north_star names, measured AFTER the timed region and reported
-    under `also` (never part of `value`): i.i.d. samples/s (full 1000-step DDPM reverse chains, the layer-0
-    table build included) and Langevin MD-steps/s on chignolin and villin at batch P per GPU."""
-    import torch.distributed as dist
+def make_model(cfg, dev):
+    import synth_weights as synth
     from dff_amd.ddpm import GaussianDiffusion
-    from dff_amd.langevin import LangevinDiffusion
     from dff_amd.score import GraphTransformer
-    from oracle import synth
-    out = {}
-    for cfg, split in (("chignolin", False), ("villin", False), ("villin", True)):
-        _, N, H, L = synth.SHIPPED_CONFIGS[cfg]
-        # split: the opt-in variants whose K = H weight GEMMs run on the bf16 pipe through an exact three-way split of
-        # every fp32 operand (DESIGN.md section 7); read when the model is created, off for every other number here
-        os.environ["DFF_SPLIT_BF16"] = "1" if split else "0"
-        model = GraphTransformer(N, H, device=dev, n_layers=L, use_intrinsic_coords=True, use_abs_coords=False,
-                                 use_distances=False, conservative=True,
-                                 state_dict=synth.synth_gnn_params(N, H, L, seed=1234, decoder_scale=1e-2))
-        diff = GaussianDiffusion(model, num_atoms=N, timesteps=1000, norm_factor=NORM_STD[cfg])
-        diff.seed(77 + rank)
-        x0 = torch.randn(P, N, 3, generator=torch.Generator().manual_seed(2024 + rank))
-        x0 = (x0 - x0.mean(1, keepdim=True)) * NORM_STD[cfg]
+    _, N, H, L = synth.SHIPPED_CONFIGS[cfg]
+    model = GraphTransformer(N, H, device=dev, n_layers=L, use_intrinsic_coords=True, use_abs_coords=False,
+                             use_distances=False, conservative=True,
+                             state_dict=synth.synth_gnn_params(N, H, L, seed=1234, decoder_scale=1e-2))
+    return model, GaussianDiffusion(model, num_atoms=N, timesteps=1000, norm_factor=NORM_STD[cfg]), (N, H, L)
 
-        def iid():
-            return diff.sample(P)
 
-        def md():
-            LangevinDiffusion(diff, x0, 1000, save_interval=250, t=20 if cfg == "chignolin" else 5, temp_data=TEMP[cfg],
-                              temp_sim=TEMP[cfg], dt=None, masses=[12.0] * N, friction=1.0, seed=1234,
-                              verbose=False).simulate(traj_offset=rank * P)
+class Timer:
+    """barrier + synchronize on both sides of the timed launches, HIP events around every launch, max over ranks."""
 
-        for name, fn, units in (("iid_samples_per_s", iid, P), ("md_steps_per_s", md, 1000)):
-            fn()
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            fn()
-            torch.cuda.synchronize()
-            dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-            if world > 1:
-                dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-            out[f"{cfg}_{name}" + ("_split_bf16_opt_in" if split else "")] = world * units / dt.item()
-    os.environ["DFF_SPLIT_BF16"] = "0"
-    out["note"] = (f"whole job, batch {P} per GPU; iid = complete 1000-step DDPM chains; md = 1000 Langevin steps, save_interval 250 "
-                   f"(chignolin t=20, villin t=5), host set-up of each call included; *_split_bf16_opt_in: DFF_SPLIT_BF16=1 variants "
-                   f"(weight GEMMs on the bf16 MFMA via an exact 3-way split of every fp32 operand, same parity tolerances), "
-                   f"off for every other number in this line")
-    return out
+    def __init__(self, dev, world):
+        self.dev, self.world = dev, world
+
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(self, fn, n_warm, n_timed):
+        for i in range(n_warm):
+            fn(i)
+        self.barrier()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_timed)]
+        t0 = time.perf_counter()
+        for j in range(n_timed):
+            ev[j][0].record()
+            fn(n_warm + j)
+            ev[j][1].record()
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        if self.world > 1:
+            import torch.distributed as dist
+            tmax = torch.tensor([elapsed], device=self.dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = tmax.item()
+        return elapsed, [a.elapsed_time(b) for a, b in ev]
+
+
+def langevin_entry(cfg, P, chunk, n_warm, n_timed, dev, rank, world, noise_level=20, group=0):
+    """Langevin MD-steps/s of `cfg` at P trajectories per GPU: n_timed launches of `chunk` fused steps each."""
+    from dff_amd.langevin import LangevinDiffusion
+    model, diff, (N, H, L) = make_model(cfg, dev)
+    if group:
+        model.native.set_group(group)
+    x0 = torch.randn(P, N, 3, generator=torch.Generator().manual_seed(2024 + rank))
+    x0 = (x0 - x0.mean(1, keepdim=True)) * NORM_STD[cfg]
+    masses = [12.8 if cfg == "ala2" else 12.0] * N
+    total = (n_warm + n_timed) * chunk
+    ld = LangevinDiffusion(diff, x0, total, save_interval=chunk, t=noise_level, temp_data=TEMP[cfg],
+                           temp_sim=TEMP[cfg], dt=None, masses=masses, friction=1.0, seed=1234, verbose=False)
+    frames = torch.empty(n_warm + n_timed, P, N, 3, device=dev)
+    ke = torch.empty(n_warm + n_timed, P, device=dev)
+
+    def run_chunk(i):
+        model.native.langevin_run(ld.params, ld.x, ld.v, chunk, chunk, noise=None, seed=1234,
+                                  traj_offset=rank * P, step_offset=i * chunk, frames=frames[i:i + 1], ke=ke[i:i + 1])
+
+    elapsed, launch_ms = Timer(dev, world).run(run_chunk, n_warm, n_timed)
+    K = n_timed * chunk
+    kname, grid, lds = model.native.last_launch()
+    ok = bool(torch.isfinite(frames).all().item()) and bool(torch.isfinite(ld.x).all().item())
+    return {"cfg": cfg, "N": N, "H": H, "L": L, "P": P, "K": K, "elapsed": elapsed, "launch_ms": launch_ms, "kernel": kname,
+            "grid": grid, "lds": lds, "finite": ok, "frames": frames, "chunk": chunk}
+
+
+def iid_entry(cfg, P, n_warm, n_timed, dev, rank, world):
+    """i.i.d. samples/s: complete 1000-step reverse DDPM chains (one fused launch each; the layer-0 table for the 1000
+    noise levels is built by the warm-up call)."""
+    model, diff, (N, H, L) = make_model(cfg, dev)
+    diff.seed(77 + rank)
+    elapsed, launch_ms = Timer(dev, world).run(lambda i: diff.sample(P), n_warm, n_timed)
+    diff.check_clamp()
+    kname, grid, lds = model.native.last_launch()
+    return {"cfg": cfg, "N": N, "H": H, "L": L, "P": P, "elapsed": elapsed, "launch_ms": launch_ms, "kernel": kname,
+            "grid": grid, "lds": lds, "chains": n_timed}
 
 
 def main():
@@ -166,8 +235,8 @@ def main():
     ap.add_argument("--parallel_sim", type=int, default=256, help="trajectories per GPU")
     ap.add_argument("--noise_level", type=int, default=20)
     ap.add_argument("--group", type=int, default=0, help="proteins per workgroup (0 = auto)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--no-extras", action="store_true", help="skip the secondary north-star figures (`also`)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other north-star figures (`also`)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -181,112 +250,78 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
-    import dff_amd
-    from dff_amd.ddpm import GaussianDiffusion
-    from dff_amd.langevin import LangevinDiffusion
-    from dff_amd.score import GraphTransformer
-    from oracle import synth  # synthetic weights only (shared with the parity tests)
+    import dff_amd  # noqa: F401  (loads libdff_amd.so: loud failure if the HIP extension is missing)
 
-    cfg = args.cfg
-    _, N, H, L = synth.SHIPPED_CONFIGS[cfg]
-    P = args.parallel_sim
-    params = synth.synth_gnn_params(N, H, L, seed=1234, decoder_scale=1e-2)
-    model = GraphTransformer(N, H, device=dev, n_layers=L, use_intrinsic_coords=True, use_abs_coords=False,
-                             use_distances=False, conservative=True, state_dict=params)
-    if args.group:
-        model.native.set_group(args.group)
-    diff = GaussianDiffusion(model, num_atoms=N, timesteps=1000, norm_factor=NORM_STD[cfg])
-    g = torch.Generator().manual_seed(2024 + rank)
-    x0 = torch.randn(P, N, 3, generator=g)
-    x0 = (x0 - x0.mean(1, keepdim=True)) * NORM_STD[cfg]
-    chunk = args.chunk
-    K = (args.steps // chunk) * chunk or chunk
-    W = ((args.warmup + chunk - 1) // chunk) * chunk if args.warmup > 0 else 0
-    masses = [12.8 if cfg == "ala2" else 12.0] * N
-    ld = LangevinDiffusion(diff, x0, K + W, save_interval=chunk, t=args.noise_level, temp_data=TEMP[cfg],
-                           temp_sim=TEMP[cfg], dt=None, masses=masses, friction=1.0, seed=1234, verbose=False)
-    n_frames = (K + W) // chunk
-    frames = torch.empty(n_frames, P, N, 3, device=dev)
-    ke = torch.empty(n_frames, P, device=dev)
-
-    def run_chunk(i):
-        model.native.langevin_run(ld.params, ld.x, ld.v, chunk, chunk, noise=None, seed=1234,
-                                  traj_offset=rank * P, step_offset=i * chunk,
-                                  frames=frames[i:i + 1], ke=ke[i:i + 1])
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(W // chunk):
-        run_chunk(i)
-    barrier()
-    nl = K // chunk
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nl)]
-    t0 = time.perf_counter()
-    for j in range(nl):
-        ev[j][0].record()
-        run_chunk(W // chunk + j)
-        ev[j][1].record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    launch_ms = [a.elapsed_time(b) for a, b in ev]
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = tmax.item()
+    cfg, P, chunk = args.cfg, args.parallel_sim, args.chunk
+    n_timed = max(MIN_LAUNCHES, -(-args.steps // chunk))
+    n_warm = max(1, -(-args.warmup // chunk)) if args.warmup > 0 else 0
+    h = langevin_entry(cfg, P, chunk, n_warm, n_timed, dev, rank, world, args.noise_level, args.group)
+    K, W = h["K"], n_warm * chunk
     # the job's only collective: gather the saved frames (xGMI); not part of a "step"
     gather_ms = 0.0
     if world > 1:
+        import torch.distributed as dist
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        out = [torch.empty_like(frames) for _ in range(world)]
-        dist.all_gather(out, frames)
+        out = [torch.empty_like(h["frames"]) for _ in range(world)]
+        dist.all_gather(out, h["frames"])
         torch.cuda.synchronize()
         gather_ms = 1e3 * (time.perf_counter() - t1)
-    ok = bool(torch.isfinite(frames).all().item()) and bool(torch.isfinite(ld.x).all().item())
+
     also = None
     if not args.no_extras:
+        also = {}
         try:    # secondary figures must never cost the headline line
-            also = north_star_extras(dev, rank, world, P)
-        except Exception as e:  # noqa: BLE001
-            also = {"error": f"{type(e).__name__}: {e}"}
+            for name, c2, P2, ch2, nt in (("villin_langevin", "villin", 256, 250, MIN_LAUNCHES),
+                                          ("protein_g_langevin", "protein_g", 128, 250, MIN_LAUNCHES)):
+                e = langevin_entry(c2, P2, ch2, 1, nt, dev, rank, world)
+                also[name] = {
+                    "metric": f"Langevin MD-steps/sec at batch {P2} per GPU ({c2}, {e['N']} beads, H={e['H']}, L={e['L']})",
+                    "value": world * P2 * e["K"] / e["elapsed"] / P2, "unit": f"MD-steps/s (batch-{P2} steps, whole job)",
+                    "ms_per_step": 1e3 * e["elapsed"] / e["K"], "steps": e["K"], "finite": e["finite"],
+                    "trajectory_steps_per_s": world * P2 * e["K"] / e["elapsed"],
+                    "roofline": roofline(c2, P2, ch2, e["launch_ms"], e["kernel"]), "dtype": kernel_dtype(e["kernel"])}
+            for name, c2, P2, nt in (("chignolin_iid", "chignolin", 256, MIN_LAUNCHES), ("villin_iid", "villin", 256, 4)):
+                e = iid_entry(c2, P2, 1, nt, dev, rank, world)
+                also[name] = {
+                    "metric": f"i.i.d. samples/sec at batch {P2} per GPU ({c2}: complete 1000-step reverse DDPM chains)",
+                    "value": world * P2 * nt / e["elapsed"], "unit": "samples/s (whole job)",
+                    "ms_per_reverse_step": 1e3 * e["elapsed"] / (nt * 1000), "chains_timed": nt,
+                    "roofline": roofline(c2, P2, 1000, e["launch_ms"], e["kernel"]), "dtype": kernel_dtype(e["kernel"])}
+        except Exception as ex:  # noqa: BLE001
+            also["error"] = f"{type(ex).__name__}: {ex}"
 
     if rank == 0:
-        ms_per_step = 1e3 * elapsed / K
-        traj_steps = world * P * K / elapsed
+        N, H, L = h["N"], h["H"], h["L"]
+        traj_steps = world * P * K / h["elapsed"]
         value = traj_steps / 256.0
-        kname, grid, lds = model.native.last_launch()
-        avg_launch_ms = float(np.mean(launch_ms))
-        flops_per_launch = MFLOP_PER_CALL[cfg] * 1e6 * P * chunk
-        achieved = flops_per_launch / (avg_launch_ms * 1e-3) / 1e12
         res = {
             "metric": "Langevin MD-steps/sec at batch 256 (chignolin, score fwd+VJP + BAOAB per step)",
             "value": value, "unit": "MD-steps/s (batch-256 steps, whole job)", "n_gpus": world, "steps": K,
-            "warmup": W, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded weights, N(0,1) centred x0, in-kernel Philox noise)",
+            "warmup": W, "ms_per_step": 1e3 * h["elapsed"] / K, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": kernel_dtype(h["kernel"]),
+            "data": "synthetic (seeded weights, N(0,1) centred x0, in-kernel Philox noise)",
+            "steps_requested": args.steps, "warmup_requested": args.warmup,
+            "timing_note": f"steps are issued as persistent launches of {chunk} fused steps; the request is rounded up to whole "
+                           f"launches and the timed region is never shorter than {MIN_LAUNCHES} launches ({n_timed} timed, {n_warm} warm-up)",
             "config": {"workload": f"BASELINE configs[1]: {cfg} ({N} beads, H={H}, L={L}) Langevin, parallel_sim={P}/GPU, "
                                    f"noise_level={args.noise_level}, save_interval={chunk}, 1 persistent launch per {chunk} steps",
                        "parallelism": f"{world} x independent trajectory shards (no data-path collective)",
-                       "kernel": kname, "grid": grid, "lds_bytes": lds},
-            "trajectory_steps_per_s": traj_steps, "finite": ok, "gather_ms": gather_ms,
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": hbm_traffic_from_profile(kname, cfg, P, chunk),
-                         "kernel": kname, "avg_launch_ms": avg_launch_ms, "launches": nl,
-                         "algorithmic_flops_per_launch": flops_per_launch,
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
-                         "note": "fp32-compute bound: algorithmic HBM bytes are only 600 B per trajectory-step "
-                                 "(x, v in/out + noise); measured traffic is dominated by the L2-spilling "
-                                 "activation stash and is ~18% of HBM peak, not the binding roof"},
+                       "kernel": h["kernel"], "grid": h["grid"], "lds_bytes": h["lds"]},
+            "trajectory_steps_per_s": traj_steps, "finite": h["finite"], "gather_ms": gather_ms,
+            "roofline": roofline(cfg, P, chunk, h["launch_ms"], h["kernel"]),
         }
         if also is not None:
             res["also"] = also
         if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(cfg, P, args.noise_level)
             res["speedup_vs_cpu_port"] = value / res["cpu_baseline"]["value"]
+            if also is not None and "villin_langevin" in also:    # ~5 s per step on the host: three steps, same thread count
+                also["villin_langevin"]["cpu_baseline"] = cpu_baseline("villin", 256, 20, budget_s=10.0, max_steps=3,
+                                                                         threads=res["cpu_baseline"]["cores"])
         print(json.dumps(res))
     if world > 1:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

@@ -8,7 +8,7 @@ import dff_amd
 from dff_amd.score import GraphTransformer
 from dff_amd.ddpm import GaussianDiffusion
 from dff_amd.langevin import LangevinDiffusion
-from oracle import synth
+import synth_weights as synth
 MF = {"ala2": 11.27, "chignolin": 22.00, "trp_cage": 102.97, "bba": 107.19, "villin": 190.40, "protein_g": 327.47}
 ap = argparse.ArgumentParser(); ap.add_argument("--cfgs", default="ala2,chignolin,trp_cage,bba,villin,protein_g")
 ap.add_argument("--P", type=int, default=256); ap.add_argument("--steps", type=int, default=100)

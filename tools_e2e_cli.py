@@ -7,7 +7,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import dff_amd
 from dff_amd import cli
-from oracle import synth
+import synth_weights as synth
 
 def write_model_dir(d, cfg):
     mol, N, H, L = synth.SHIPPED_CONFIGS[cfg]

@@ -7,7 +7,7 @@ import dff_amd
 from dff_amd.score import GraphTransformer
 from dff_amd.ddpm import GaussianDiffusion
 from dff_amd.langevin import LangevinDiffusion
-from oracle import synth
+import synth_weights as synth
 ap = argparse.ArgumentParser(); ap.add_argument("--cfg", default="chignolin"); ap.add_argument("--P", type=int, default=256)
 ap.add_argument("--steps", type=int, default=250); ap.add_argument("--group", type=int, default=0)
 ap.add_argument("--waves", default="0", help="comma list: whose view of the stages (<= 16-row kernel; wave 0 otherwise)")

@@ -8,7 +8,7 @@ import dff_amd
 from dff_amd.score import GraphTransformer
 from dff_amd.ddpm import GaussianDiffusion
 from dff_amd.langevin import LangevinDiffusion
-from oracle import synth
+import synth_weights as synth
 for cfg, P in (("villin", 256), ("protein_g", 128), ("trp_cage", 256), ("bba", 256), ("chignolin", 256)):
     _, N, H, L = synth.SHIPPED_CONFIGS[cfg]
     model = GraphTransformer(N, H, device="cuda:0", n_layers=L, use_intrinsic_coords=True, use_abs_coords=False,

@@ -32,6 +32,27 @@ static int fail(int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(DFF_EHIP, "%s failed: %s", #x, hipGetErrorString(e_)); \
     } while (0)
 
+// Every ABI entry runs on the model's device and leaves the caller's current device as it found it (a process that
+// drives several GPUs keeps torch's notion of the current device).
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) { ok = false; return; }
+        if (cur != dev) {
+            if (hipSetDevice(dev) != hipSuccess) { ok = false; return; }
+            prev = cur;
+        }
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define ON_DEVICE(dev)                                                         \
+    DeviceGuard dev_guard_(dev);                                               \
+    if (!dev_guard_.ok) return fail(DFF_EHIP, "cannot select device %d", (int)(dev))
+
 // ------------------------------------------------------------------------------------------
 // packing for the v_mfma_f32_16x16x4_f32 B operand (layout: dff_internal.h)
 // ------------------------------------------------------------------------------------------
@@ -138,12 +159,17 @@ struct dff_model {
     const char* last_kernel = "";
     int last_grid = 0, last_lds = 0, last_G = 0, last_B = 0;
     unsigned long long last_stride = 0;
-    // precomputed layer-0 table (see ensure_l0_table)
-    float* l0_tab = nullptr;
-    size_t l0_floats = 0;
-    int l0_kind = 0, l0_G = 0, l0_waves = -1;   // kind 1: one entry at l0_tnorm (Langevin), 2: one per t (DDPM)
-    float l0_tnorm = 0.f;
-    const void* l0_variant = nullptr;
+    // precomputed layer-0 tables (see ensure_l0_table), keyed independently: [0] one entry at tnorm (Langevin),
+    // [1] one entry per noise level (DDPM) -- `sample.py --gen_mode langevin` uses both, alternately
+    struct L0Table {
+        float* tab = nullptr;
+        size_t floats = 0;
+        bool valid = false;
+        int G = 0, waves = -1;
+        float tnorm = 0.f;
+        const void* variant = nullptr;
+        bool split = false;
+    } l0[2];
     bool l0_off = false;                       // debugging: never use the table
     int max_wgs = 2048;                        // workgroups per launch: bounds the stash (grid x stash slot) for big batches
     int last_base = 0;
@@ -237,8 +263,12 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
     if (cfg->timesteps < 1) return fail(DFF_EINVAL, "timesteps must be >= 1");
     if (n_weights != dff_weight_count(cfg))
         return fail(DFF_EINVAL, "expected %zu weights, got %zu", dff_weight_count(cfg), n_weights);
-    HIPCHK(hipSetDevice(device));
+    ON_DEVICE(device);
     dff_model* m = new dff_model();
+    struct Undo {   // any failure below frees what was uploaded so far
+        dff_model* m;
+        ~Undo() { if (m) dff_model_destroy(m); }
+    } undo{m};
     m->cfg = *cfg;
     m->device = device;
     {   // weight GEMMs on the bf16 pipe via the exact three-way split of every fp32 operand, wherever a kernel variant
@@ -417,17 +447,18 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
     UP(m->sched[10], m->dev.post_c1);
     UP(m->sched[11], m->dev.post_c2);
     UP(m->sched[9], m->dev.post_logvar);
+    undo.m = nullptr;
     *out = m;
     return DFF_OK;
 }
 
 extern "C" void dff_model_destroy(dff_model* m) {
     if (!m) return;
-    (void)hipSetDevice(m->device);
+    DeviceGuard g(m->device);
     for (void* p : m->allocs) (void)hipFree(p);
     if (m->stash) (void)hipFree(m->stash);
     if (m->prof) (void)hipFree(m->prof);
-    if (m->l0_tab) (void)hipFree(m->l0_tab);
+    for (auto& t : m->l0) if (t.tab) (void)hipFree(t.tab);
     delete m;
 }
 
@@ -563,61 +594,61 @@ static int launch_generic(dff_model* m, DffRunArgs& a, int G, const Variant* v, 
 // v == nullptr: rows<=16 kernel, else that variant of the generic kernel.
 static int ensure_l0_table(dff_model* m, int kind, float t_norm, int G, const Variant* v, hipStream_t stream) {
     const int N = m->cfg.n_beads, H = m->cfg.hidden, L = m->cfg.n_layers, T = m->cfg.timesteps;
-    if (m->l0_tab && m->l0_kind == kind && m->l0_G == G && m->l0_waves == m->small_waves && m->l0_variant == (const void*)v &&
-        (kind == 2 || m->l0_tnorm == t_norm))
+    dff_model::L0Table& tb = m->l0[kind - 1];
+    if (tb.valid && tb.G == G && tb.waves == m->small_waves && tb.variant == (const void*)v && tb.split == m->small_split &&
+        (kind == 2 || tb.tnorm == t_norm))
         return DFF_OK;
     const int nent = kind == 2 ? T : 1;
     size_t layer_stride, total;
     if (v) { const StashLayout sl = dff_stash_layout(N, G, H, L); layer_stride = sl.layer_stride; total = sl.total; }
     else   { const SmallStash sl = dff_small_stash(N, G, H, L); layer_stride = sl.layer_stride; total = sl.total; }
     const size_t need = (size_t)nent * layer_stride;
-    if (need > m->l0_floats) {
-        if (m->l0_tab) HIPCHK(hipFree(m->l0_tab));
-        m->l0_tab = nullptr; m->l0_floats = 0;
-        HIPCHK(hipMalloc((void**)&m->l0_tab, need * sizeof(float)));
-        m->l0_floats = need;
+    tb.valid = false;   // invalid until filled
+    if (need > tb.floats) {
+        if (tb.tab) HIPCHK(hipFree(tb.tab));
+        tb.tab = nullptr; tb.floats = 0;
+        HIPCHK(hipMalloc((void**)&tb.tab, need * sizeof(float)));
+        tb.floats = need;
     }
-    m->l0_kind = 0;   // invalid until filled
     int CH = nent < 256 ? nent : 256;         // noise levels (= workgroups) per build launch ...
     if (CH > m->max_wgs) CH = m->max_wgs;     // ... each of which must be ONE kernel launch (its stash is copied out)
     const int Bmax = CH * G;
-    float *xz = nullptr, *tnd = nullptr, *fo = nullptr;
-    HIPCHK(hipMalloc((void**)&xz, (size_t)Bmax * N * 3 * sizeof(float)));
-    HIPCHK(hipMalloc((void**)&fo, (size_t)Bmax * N * 3 * sizeof(float)));
-    HIPCHK(hipMalloc((void**)&tnd, (size_t)Bmax * sizeof(float)));
-    HIPCHK(hipMemsetAsync(xz, 0, (size_t)Bmax * N * 3 * sizeof(float), stream));
-    int rc = DFF_OK;
+    struct Tmp {   // freed on every path
+        float *xz = nullptr, *tnd = nullptr, *fo = nullptr;
+        ~Tmp() { (void)hipFree(xz); (void)hipFree(fo); (void)hipFree(tnd); }
+    } tmp;
+    HIPCHK(hipMalloc((void**)&tmp.xz, (size_t)Bmax * N * 3 * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&tmp.fo, (size_t)Bmax * N * 3 * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&tmp.tnd, (size_t)Bmax * sizeof(float)));
+    HIPCHK(hipMemsetAsync(tmp.xz, 0, (size_t)Bmax * N * 3 * sizeof(float), stream));
     std::vector<float> tn((size_t)Bmax);
-    for (int e0 = 0; e0 < nent && !rc; e0 += CH) {
+    for (int e0 = 0; e0 < nent; e0 += CH) {
         const int ne = nent - e0 < CH ? nent - e0 : CH;
         for (int e = 0; e < ne; ++e)
             for (int g = 0; g < G; ++g)
                 tn[(size_t)e * G + g] = kind == 2 ? (1.0f * (float)(e0 + e)) / (float)T : t_norm;   // as the kernel forms t/T
-        hipError_t er = hipMemcpyAsync(tnd, tn.data(), (size_t)ne * G * sizeof(float), hipMemcpyHostToDevice, stream);
-        if (er == hipSuccess) er = hipStreamSynchronize(stream);   // tn is reused by the next chunk
-        if (er != hipSuccess) { rc = fail(DFF_EHIP, "layer-0 table: %s", hipGetErrorString(er)); break; }
+        HIPCHK(hipMemcpyAsync(tmp.tnd, tn.data(), (size_t)ne * G * sizeof(float), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream));   // tn is reused by the next chunk
         DffRunArgs a;
         memset(&a, 0, sizeof(a));
         a.mode = DFF_MODE_SCORE; a.B = ne * G; a.n_steps = 1; a.save_interval = 1;
-        a.x_in = xz; a.tnorm = tnd; a.force_out = fo;
-        rc = v ? launch_generic(m, a, G, v, stream) : launch_small(m, a, G, stream);
-        if (rc) break;
-        er = hipMemcpy2DAsync(m->l0_tab + (size_t)e0 * layer_stride, layer_stride * sizeof(float), m->stash,
-                              total * sizeof(float), layer_stride * sizeof(float), (size_t)ne,
-                              hipMemcpyDeviceToDevice, stream);
-        if (er == hipSuccess) er = hipStreamSynchronize(stream);
-        if (er != hipSuccess) rc = fail(DFF_EHIP, "layer-0 table copy: %s", hipGetErrorString(er));
+        a.x_in = tmp.xz; a.tnorm = tmp.tnd; a.force_out = tmp.fo;
+        const int rc = v ? launch_generic(m, a, G, v, stream) : launch_small(m, a, G, stream);
+        if (rc) return rc;
+        // only the layer-0 slot of each workgroup's stash is kept
+        HIPCHK(hipMemcpy2DAsync(tb.tab + (size_t)e0 * layer_stride, layer_stride * sizeof(float), m->stash,
+                                total * sizeof(float), layer_stride * sizeof(float), (size_t)ne,
+                                hipMemcpyDeviceToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream));
     }
-    (void)hipFree(xz); (void)hipFree(fo); (void)hipFree(tnd);
-    if (rc) return rc;
-    m->l0_kind = kind; m->l0_G = G; m->l0_waves = m->small_waves; m->l0_tnorm = t_norm; m->l0_variant = (const void*)v;
+    tb.valid = true; tb.G = G; tb.waves = m->small_waves; tb.tnorm = t_norm; tb.variant = (const void*)v; tb.split = m->small_split;
     return DFF_OK;
 }
 
 // choose proteins-per-workgroup and the kernel variant, make sure scratch is large enough, launch
 static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
     const int N = m->cfg.n_beads, H = m->cfg.hidden, L = m->cfg.n_layers;
-    HIPCHK(hipSetDevice(m->device));
+    ON_DEVICE(m->device);
     const int mt_min = (N + 15) / 16;
     // default: one protein per workgroup while that fills the 256 CUs at most ~2x; otherwise
     // pack as many proteins as fit in the row tiles of the smallest variant that holds one.
@@ -639,7 +670,7 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
         if (want_tab) {
             int rc = ensure_l0_table(m, a.mode == DFF_MODE_DDPM ? 2 : 1, a.t_norm, G, nullptr, stream);
             if (rc) return rc;
-            a.l0_tab = m->l0_tab;
+            a.l0_tab = m->l0[a.mode == DFF_MODE_DDPM ? 1 : 0].tab;
         }
         return launch_small(m, a, G, stream);
     }
@@ -663,7 +694,7 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
     if (want_tab) {
         int rc = ensure_l0_table(m, a.mode == DFF_MODE_DDPM ? 2 : 1, a.t_norm, G, v, stream);
         if (rc) return rc;
-        a.l0_tab = m->l0_tab;
+        a.l0_tab = m->l0[a.mode == DFF_MODE_DDPM ? 1 : 0].tab;
     }
     return launch_generic(m, a, G, v, stream);
 }
@@ -728,7 +759,7 @@ extern "C" int dff_ddpm_run(dff_model* m, int batch, float* x, const float* nois
 extern "C" int dff_debug_gemm(int device, const float* A, const float* W, int M, int K, int Nout, float* out) {
     if (!A || !W || !out || M < 1 || M > 64 || Nout % 16 || !(K == 64 || K == 128))
         return fail(DFF_EINVAL, "dff_debug_gemm: M<=64, K in {64,128}, Nout%%16==0");
-    HIPCHK(hipSetDevice(device));
+    ON_DEVICE(device);
     std::vector<float> Wp = pack_b(K, Nout, [&](int k, int n) { return (double)W[(size_t)k * Nout + n]; });
     float *dA, *dW, *dO;
     HIPCHK(hipMalloc((void**)&dA, (size_t)M * K * 4));
@@ -747,7 +778,7 @@ extern "C" int dff_debug_stash(dff_model* m, int b, int layer, int what, float* 
     if (!m || !out || !m->stash || m->last_G <= 0) return fail(DFF_EINVAL, "no stash (run dff_score first)");
     const int N = m->cfg.n_beads, H = m->cfg.hidden, L = m->cfg.n_layers, G = m->last_G;
     if (b < 0 || b >= m->last_B || layer < 0 || layer >= L) return fail(DFF_EINVAL, "bad sample / layer");
-    HIPCHK(hipSetDevice(m->device));
+    ON_DEVICE(m->device);
     HIPCHK(hipDeviceSynchronize());
     if (b < m->last_base) return fail(DFF_EINVAL, "sample %d was not part of the last launch (it started at %d)", b, m->last_base);
     const int wg = (b - m->last_base) / G, g = (b - m->last_base) % G;
@@ -813,7 +844,7 @@ extern "C" int dff_debug_stash(dff_model* m, int b, int layer, int what, float* 
 
 extern "C" int dff_debug_profile(dff_model* m, int enable) {
     if (!m) return fail(DFF_EINVAL, "null model");
-    HIPCHK(hipSetDevice(m->device));
+    ON_DEVICE(m->device);
     if (enable && !m->prof) {
         HIPCHK(hipMalloc((void**)&m->prof, DFF_NPROF * sizeof(unsigned long long)));
         HIPCHK(hipMemset(m->prof, 0, DFF_NPROF * sizeof(unsigned long long)));
@@ -826,7 +857,7 @@ extern "C" int dff_debug_profile(dff_model* m, int enable) {
 
 extern "C" int dff_debug_profile_read(dff_model* m, unsigned long long* out) {
     if (!m || !out || !m->prof) return fail(DFF_EINVAL, "profiling was never enabled");
-    HIPCHK(hipSetDevice(m->device));
+    ON_DEVICE(m->device);
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, m->prof, DFF_NPROF * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return DFF_OK;
@@ -847,7 +878,6 @@ static int pwd_check(int device, const float* x, long long n, int N, int offset,
     if (N < 2 || N > DFF_MAX_BEADS) return fail(DFF_EINVAL, "pwd: n_beads must be 2..%d", DFF_MAX_BEADS);
     npairs = dff_pwd_num_pairs(N, offset);
     if (npairs <= 0) return fail(DFF_EINVAL, "pwd: no bead pairs at offset %d", offset);
-    HIPCHK(hipSetDevice(device));
     return DFF_OK;
 }
 
@@ -864,6 +894,7 @@ extern "C" int dff_pwd_max(int device, const float* x, long long n, int N, int o
     int npairs;
     int rc = pwd_check(device, x, n, N, offset, npairs);
     if (rc) return rc;
+    ON_DEVICE(device);
     if (!max_out) return fail(DFF_EINVAL, "pwd: null output");
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(hipMemsetAsync(max_out, 0, (size_t)npairs * sizeof(float), stream));
@@ -886,6 +917,7 @@ extern "C" int dff_pwd_hist(int device, const float* x, long long n, int N, int 
     int npairs;
     int rc = pwd_check(device, x, n, N, offset, npairs);
     if (rc) return rc;
+    ON_DEVICE(device);
     if (!nbins || !hmax || !hist) return fail(DFF_EINVAL, "pwd: null argument");
     if (max_bins < 1 || ld < max_bins) return fail(DFF_EINVAL, "pwd: need 1 <= max_bins <= ld");
     hipStream_t stream = (hipStream_t)stream_;
