@@ -583,10 +583,20 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     lfloat* const dxw = sm + LL::dxw + wave * 128;
     lfloat* const wr = sm + LL::wreg + wave * LL::WREG;
     lfloat* const Qx = wr; lfloat* const Kx = wr + RS; lfloat* const Vx = wr + 2 * RS;
-    lfloat* const Gx = wr + 3 * RS;
-    lfloat* const pb = wr + 4 * RS; lfloat* const dsb = pb + 16 * DFF_PLD;
-    lfloat* const hbuf = wr;          // FFN hidden slice of this wave (aliases the head buffers)
-    lfloat* const mypart = wr;        // this wave's partial H-wide output (ditto; summed by the row stages)
+    // RELAY (8 waves, H = 64): region order [Q | K | V | P | G | dS], and everything that is not an attention operand --
+    // o_ext = P V_ext, the FFN hidden slice, the wave's partial H-wide outputs -- lives in G | dS.  q_ext, k, v and P of
+    // the LAST layer then survive in LDS from its forward to its backward attention block: no stash reload (and no
+    // exposed HBM round trip) for one layer in three.  Otherwise [Q | K | V | G | P | dS] with those tiles aliasing Q | K.
+    constexpr bool RELAY = NW == 8 && H == 64;
+    constexpr bool KEEP_LAST = RELAY && !GEN;   // (the GEN variants re-derive their x-dependent extension columns on reload)
+    lfloat* const pb = RELAY ? wr + 3 * RS : wr + 4 * RS;
+    lfloat* const Gx = RELAY ? pb + 16 * DFF_PLD : wr + 3 * RS;
+    lfloat* const dsb = RELAY ? Gx + RS : pb + 16 * DFF_PLD;
+    constexpr unsigned MPO = RELAY ? 3 * RS + 16 * DFF_PLD : 0;   // offset of the aliased tiles inside a wave region
+    static_assert(!RELAY || RS + 16 * DFF_PLD >= 16 * (H + 4), "G | dS must hold a 16 x (H + 4) partial-sum tile");
+    lfloat* const Ox = RELAY ? Gx : Qx;   // o_ext
+    lfloat* const hbuf = wr + MPO;        // FFN hidden slice of this wave (aliases head buffers)
+    lfloat* const mypart = wr + MPO;      // this wave's partial H-wide output (ditto; summed by the row stages)
     // sum of the NW waves' partial outputs for this lane's HC columns of a row: ALL NW x HC LDS reads are
     // issued first (one latency), then added in wave order (left to itself the compiler issues one read,
     // waits, adds, issues the next: NW/2 serial LDS latencies inside a stage every other wave waits for)
@@ -596,7 +606,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #pragma unroll
         for (int w = 0; w < NW; ++w)
 #pragma unroll
-            for (int i = 0; i < HC_; ++i) pv[w][i] = sm[LL::wreg + w * LL::WREG + o0 + LPR_ * i];
+            for (int i = 0; i < HC_; ++i) pv[w][i] = sm[LL::wreg + w * LL::WREG + MPO + o0 + LPR_ * i];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < HC_; ++i) {
@@ -933,14 +943,14 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                             } else {
                                 if (nt == 4) v -= (col < 3) ? xs[(quad * 4 + r) * 4 + col] : 0.f;
                             }
-                            Qx[lro[r] + 16 * nt + col] = v;
+                            Ox[lro[r] + 16 * nt + col] = v;
                         }
                     });
                 };
-                const lfloat* const wox_a = Qx + col * DFF_XLD + 4 * quad;
+                const lfloat* const wox_a = Ox + col * DFF_XLD + 4 * quad;
                 auto wox_fa = [=](int kb) { return wox_a + 16 * kb; };
                 auto wox_fa32 = [=](int kb) { return wox_a + 32 * kb; };
-                const lfloat* const wox_xa = Qx + col * DFF_XLD + 64 + quad;   // extension column `quad` of row `col`
+                const lfloat* const wox_xa = Ox + col * DFF_XLD + 64 + quad;   // extension column `quad` of row `col`
                 if constexpr (SPW) {
                     if (cached) {
                         head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
@@ -1516,8 +1526,10 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         tall_run<3, 13, E, 4>(ring, acc_a, qkvt_fa, s_qkvt(lw, h1), after, lane);   // ends at phase 0
                         pf.tick(18);
                     } else {
-                        head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, true, lane, m12p(wave));
-                        head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
+                        if (!(KEEP_LAST && l == m.L - 1)) {   // the last layer's q_ext | k | v | P are still in the head buffers
+                            head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, true, lane, m12p(wave));
+                            head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
+                        }
                         committed();
                         pf.tick(8);
                         if constexpr (SPW) sgext(sqa);
