@@ -41,7 +41,9 @@ struct SmallLds {
                               // [piece 3][k-block H/32][kg 4][row 16][4 dwords] -- a wave's ds_read_b128 of (row, kg)
                               // then touches 16 rows x 4 dwords = every bank once, whatever the lane group
                               asp = resbuf + 16 * LH, asp_size = (NW == 8 && H == 64) ? 3 * (H / 32) * 256 : 0,   // (only H = 64 has SPW variants)
-                              wreg = asp + asp_size, total = wreg + NW * WREG + 64;
+                              // source-offset table of the LDS-DMA head fetch (head_dma): 13 instructions x 64 lanes
+                              dmatab = asp + asp_size, dmatab_size = (NW == 8 && H == 64) ? 13 * 64 : 0,
+                              wreg = dmatab + dmatab_size, total = wreg + NW * WREG + 64;
 };
 
 // ---------------------------------------------------------------- wave-private MFMA engine
@@ -518,6 +520,49 @@ DEVI void head_commit(const HeadRegs& r, lfloat* Qx, lfloat* Kx, lfloat* Vx, lfl
     if (need_p) *(lf32x4*)(pb + (lane >> 2) * DFF_PLD + 4 * (lane & 3)) = r.p;
 }
 
+// q_ext | k | v (| P) of one (layer, head) from the stash (or the layer-0 table) straight into the wave's head buffers by
+// LDS-DMA: global_load_lds_dwordx4 takes a per-lane global address and writes lane i's 16 bytes to LDS at M0 + 16 i, so
+// one instruction fills 1 KiB of the contiguous [Q | K | V | P] regions and the row structure (84-float rows of which 80 /
+// 64 are data, 20-float P rows) is folded into the source addresses.  No registers are held while the data travels, so
+// the request can be issued a whole row stage before the attention block needs it (through registers that prefetch
+// costs 56 VGPRs across the row stage, i.e. spills); the consumer waits with head_dma_wait().  Inline asm because the
+// compiler would order EVERY later LDS read of the wave behind a builtin LDS-DMA (it has no alias information); its own
+// s_waitcnt bookkeeping stays safe: vmcnt retires in order, so the extra loads can only make its waits longer.
+DEVI void lds_dma16(unsigned lds_byte, const gfloat* src) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte), "v"(src) : "memory", "m0");
+}
+DEVI void head_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// table entry of 16-byte slot `sl` of the contiguous [Q | K | V | P] regions: float offset of its source relative to the
+// head's stash rows (q_ext | k | v) or, with bit 31 set, to the head's P tile; 0xffffffff: no such slot
+template <int RLA>
+DEVI unsigned head_dma_entry(int sl, int RA) {
+    constexpr int RQ = RLA * (DFF_XLD / 4);                // 16-byte slots per Q / K / V region
+    constexpr int NP = 16 * DFF_PLD / 4;                   // ... of the P tile
+    if (sl >= 3 * RQ + NP) return 0xffffffffu;
+    const int reg = (sl >= RQ) + (sl >= 2 * RQ) + (sl >= 3 * RQ);
+    const int r = sl - reg * RQ;
+    if (reg < 3) {
+        const int row = r / (DFF_XLD / 4), c4 = r - row * (DFF_XLD / 4);
+        // q_ext: 20 slots of data + 1 pad; k / v: 16 + 4 (extension columns, rewritten by write_xext) + 1 pad
+        const int lim = reg == 0 ? 19 : 15, off = reg == 0 ? 0 : reg == 1 ? 80 : 144;
+        return (unsigned)(min(row, RA) * DFF_QKVW + off + 4 * min(c4, lim));
+    }
+    const int row = r / (DFF_PLD / 4), c4 = r - row * (DFF_PLD / 4);
+    return 0x80000000u | (unsigned)(row * 16 + 4 * min(c4, 3));
+}
+DEVI void head_dma(const lu32* tab, const lfloat* Qx /* wave-uniform; Q | K | V | P contiguous */, const gfloat* sqkv, const gfloat* sp, int lane) {
+    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)Qx);
+    unsigned e[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) e[k] = tab[64 * k + lane];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+        const bool isp = (e[k] >> 31) != 0;
+        const gfloat* src = (isp ? sp : sqkv) + (e[k] & 0x7fffffffu);
+        if (e[k] != 0xffffffffu && (!isp || sp)) lds_dma16(base + 1024u * k, src);
+    }
+}
+
 // ---------------------------------------------------------------- the kernel
 template <int H, int NW, bool GEN, bool SPW = false>
 __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m, const DffRunArgs a) {
@@ -553,6 +598,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     lfloat* const vst = sm + LL::vst; lfloat* const cm = sm + LL::cm; lfloat* const tn = sm + LL::tn;
     lfloat* const abuf = sm + LL::abuf; lfloat* const resbuf = sm + LL::resbuf;
     lu16* const asp16 = (lu16*)(sm + LL::asp);
+    lu32* const dmatab = (lu32*)(sm + LL::dmatab);
     // row-stage store of one element of the K = H GEMM input: fp32 (abuf), or its three bf16 pieces at the position
     // the consuming waves' A fragments expect (element j of lane (row, kg) of k-block kb: column 32 kb + 16 (j >> 2) + 4 kg + (j & 3))
     auto a_store = [=](int row, int cl, float v) {
@@ -589,6 +635,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     // exposed HBM round trip) for one layer in three.  Otherwise [Q | K | V | G | P | dS] with those tiles aliasing Q | K.
     constexpr bool RELAY = NW == 8 && H == 64;
     constexpr bool KEEP_LAST = RELAY && !GEN;   // (the GEN variants re-derive their x-dependent extension columns on reload)
+    constexpr bool HDMA = RELAY && !GEN;        // stash -> head buffers by LDS-DMA, requested a row stage ahead (head_dma)
+    static_assert(!HDMA || DFF_XLD % 4 == 0, "16-byte slots");
     lfloat* const pb = RELAY ? wr + 3 * RS : wr + 4 * RS;
     lfloat* const Gx = RELAY ? pb + 16 * DFF_PLD : wr + 3 * RS;
     lfloat* const dsb = RELAY ? Gx + RS : pb + 16 * DFF_PLD;
@@ -623,6 +671,10 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 
     for (int i = tid; i < (int)LL::total; i += NTHR) smem[i] = 0.f;
     __syncthreads();
+    if constexpr (LL::dmatab_size > 0) {
+        for (int i = tid; i < (int)LL::dmatab_size; i += NTHR) dmatab[i] = head_dma_entry<LL::RLA>(i, G * m.N);
+        __syncthreads();
+    }
     Prof pf;
     pf.on = (a.prof != nullptr) && blockIdx.x == 0 && tid == 64 * a.prof_wave;   // one wave's view (wave 0 unless dff_debug_profile asked for another)
     pf.acc = (unsigned long long*)(smem + LL::prof);
@@ -829,8 +881,12 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         // first weights of the first block (hidden behind the centring below)
         { const int lane = lane_id();
         if constexpr (SPW) {
-            if (cached0) sring_prefetch<SDR, KO, E>(sring, ss_wox(m.layer[0], wave), lane);
-            else sring_prefetch<SDR, KQ, E>(sring, ss_qkv(m.layer[0], wave), lane);
+            if (cached0) {
+                sring_prefetch<SDR, KO, E>(sring, ss_wox(m.layer[0], wave), lane);
+                // layer 0's q_ext | k | v rows of this head (shared table entry): in flight during the centring below
+                // (measured: 86.8 vs 87.3 us / step with a register fetch inside the attention block)
+                if constexpr (HDMA) head_dma(dmatab, Qx, l0e + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, lane);
+            } else sring_prefetch<SDR, KQ, E>(sring, ss_qkv(m.layer[0], wave), lane);
         } else if (cached0) {
             const gfloat* sb0 = l0e;
             if constexpr (HPW == 2) head_fetch(hr, sb0 + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
@@ -908,6 +964,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #pragma unroll
                 for (int nt = 0; nt < E; ++nt) acc_o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 const WStream after = s_w1(lw);   // the FFN block follows
+                // the sampling loops never read the last layer's q_ext | k | v | P back from the stash (KEEP_LAST)
+                const bool st_qkv = !(KEEP_LAST && l == m.L - 1 && l > 0 && a.mode != DFF_MODE_SCORE);
                 const SStream sn0 = ss_w1(lw), sn1 = ss_w2(lw);   // the FFN block's units follow: W1 (U_W1), then W2
                 auto head_math = [&](int h) {
                     write_xext(lane);
@@ -923,7 +981,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         const float den = row16_sum(e);
                         const float p = den > 0.f ? e / den : 0.f;
                         pb[i * DFF_PLD + col] = p;
-                        st_ntg(sb + sl.P + ((size_t)h * 16 + i) * 16 + col, p);
+                        if (st_qkv) st_ntg(sb + sl.P + ((size_t)h * 16 + i) * 16 + col, p);
                     }
                     // O_ext = P V_ext (5 tiles) -> Q region; extension columns become xrel = xbar - x_i
                     wv_mm<0, 5, false>(pb, Vx, lane, ks4, [&](int nt, const f32x4& acc) {
@@ -953,8 +1011,11 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 const lfloat* const wox_xa = Ox + col * DFF_XLD + 64 + quad;   // extension column `quad` of row `col`
                 if constexpr (SPW) {
                     if (cached) {
-                        head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
-                        head_commit(hr, Qx, Kx, Vx, pb, true, false, lane, RLA);
+                        if constexpr (HDMA) head_dma_wait();
+                        else {
+                            head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
+                            head_commit(hr, Qx, Kx, Vx, pb, true, false, lane, RLA);
+                        }
                         head_math(wave);
                         const SSeq<U_WOX, 0, MW, KO, KO, 0, 0, E> sq{ss_wox(lw, wave), ss_wox(lw, wave), sn0, sn1};
                         stall_run<0, 2, E, true>(sring, acc_o, wox_fa32, sq, lane, wox_xa, wox_ext(lw, wave, lane), DFF_HEADS * 5 * 256);
@@ -980,8 +1041,10 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                                 gfloat* const ds = sqkv + 16 * t;
                                 const float v0 = acc[0] + ax[0], v1 = acc[1] + ax[0], v2 = acc[2] + ax[0], v3 = acc[3] + ax[0];
                                 dl[l0] = v0; dl[l1] = v1; dl[l2] = v2; dl[l3] = v3;
-                                st_ntg(ds + s0 * DFF_QKVW, v0); st_ntg(ds + s1 * DFF_QKVW, v1);
-                                st_ntg(ds + s2 * DFF_QKVW, v2); st_ntg(ds + s3 * DFF_QKVW, v3);
+                                if (st_qkv) {
+                                    st_ntg(ds + s0 * DFF_QKVW, v0); st_ntg(ds + s1 * DFF_QKVW, v1);
+                                    st_ntg(ds + s2 * DFF_QKVW, v2); st_ntg(ds + s3 * DFF_QKVW, v3);
+                                }
                             });
                         pf.tick(12);
                         head_math(wave);
@@ -1326,6 +1389,10 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             __syncthreads();
             pf.tick(7);
             // first head of this layer's attention backward: start the stash read (hidden by row stage E)
+            if constexpr (HDMA) {
+                if (!(KEEP_LAST && l == m.L - 1 && l > 0))
+                    head_dma(dmatab, Qx, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, lane_id());
+            }
             if constexpr (HPW == 2) {
                 const int lane = lane_id();
                 head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, l > 0 || full0, lane,
@@ -1526,7 +1593,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         tall_run<3, 13, E, 4>(ring, acc_a, qkvt_fa, s_qkvt(lw, h1), after, lane);   // ends at phase 0
                         pf.tick(18);
                     } else {
-                        if (!(KEEP_LAST && l == m.L - 1)) {   // the last layer's q_ext | k | v | P are still in the head buffers
+                        if constexpr (HDMA) head_dma_wait();   // (requested before row stage E; nothing for the last layer)
+                        else if (!(KEEP_LAST && l == m.L - 1)) {   // the last layer's q_ext | k | v | P are still in the head buffers
                             head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, true, lane, m12p(wave));
                             head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
                         }
@@ -1576,8 +1644,11 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     dx_only();
                     // the next step (if any) re-stages its own first entries at phase 0
                 } else {
-                    head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, true, lane, m12p(wave));
-                    head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
+                    if constexpr (HDMA) head_dma_wait();
+                    else {
+                        head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, true, lane, m12p(wave));
+                        head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
+                    }
                     committed();
                     if constexpr (SPW) sgext(sqa0);
                     else gext(std::integral_constant<int, 0>{}, wave, after);
