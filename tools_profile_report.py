@@ -109,7 +109,11 @@ def main():
     if "SQ_INSTS_MFMA" in C:
         per = C["SQ_INSTS_MFMA"] / (a.chunk * a.P)
         lines.append(f"- MFMA pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GUI cycles) = {mfma_util:.3f}  "
-                     f"(v_mfma_f32_16x16x4_f32: {MFMA_CYCLES} cycles each, {per:.0f} MFMA per trajectory-step)")
+                     f"({per:.0f} MFMA instructions per trajectory-step; v_mfma_f32_16x16x4_f32: {MFMA_CYCLES} cycles each, "
+                     f"v_mfma_f32_16x16x32_bf16 of the split-bf16 variants: 16)")
+        if "SQ_VALU_MFMA_COEXEC_CYCLES" in C and C.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+            lines.append(f"- VALU co-executing with an MFMA: SQ_VALU_MFMA_COEXEC_CYCLES / SQ_VALU_MFMA_BUSY_CYCLES = "
+                         f"{C['SQ_VALU_MFMA_COEXEC_CYCLES'] / C['SQ_VALU_MFMA_BUSY_CYCLES']:.3f}")
     if "SQ_INSTS_VALU" in C and "SQ_INSTS_MFMA" in C:
         lines.append(f"- instruction mix per launch: VALU {C['SQ_INSTS_VALU']:.3e}, MFMA {C['SQ_INSTS_MFMA']:.3e}, "
                      f"LDS {C.get('SQ_INSTS_LDS', 0):.3e}, VMEM rd {C.get('SQ_INSTS_VMEM_RD', 0):.3e} / wr {C.get('SQ_INSTS_VMEM_WR', 0):.3e}, "

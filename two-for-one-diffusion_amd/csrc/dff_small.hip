@@ -1016,9 +1016,12 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                             head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
                             head_commit(hr, Qx, Kx, Vx, pb, true, false, lane, RLA);
                         }
+                        pf.tick(12);
                         head_math(wave);
+                        pf.tick(13);
                         const SSeq<U_WOX, 0, MW, KO, KO, 0, 0, E> sq{ss_wox(lw, wave), ss_wox(lw, wave), sn0, sn1};
                         stall_run<0, 2, E, true>(sring, acc_o, wox_fa32, sq, lane, wox_xa, wox_ext(lw, wave, lane), DFF_HEADS * 5 * 256);
+                        pf.tick(14);
                     } else {
                         u32x4 ah[KB32], am[KB32], al[KB32];
                         a_load(ah, am, al, lane);
