@@ -650,13 +650,16 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
     const int N = m->cfg.n_beads, H = m->cfg.hidden, L = m->cfg.n_layers;
     ON_DEVICE(m->device);
     const int mt_min = (N + 15) / 16;
-    // default: one protein per workgroup while that fills the 256 CUs at most ~2x; otherwise
-    // pack as many proteins as fit in the row tiles of the smallest variant that holds one.
+    // Proteins per workgroup, by measurement (profiles/r02/packing.jsonl).  Packing only ever pays inside the padded rows a
+    // protein occupies anyway: ala2 (5 beads) fits three times into its 16-row tile, and a workgroup takes the same time for
+    // one as for three, so as soon as the batch exceeds one workgroup per CU (256) three per workgroup win (P = 512:
+    // 120 vs 179 us / step).  Spilling into a second row tile never pays: chignolin three to a 32-row tile of the generic
+    // kernel runs at 0.20-0.26 of the fp32 roof against 0.40 for one per workgroup on the <= 16-row kernel, at every batch.
     int G = m->group_override;
     if (G <= 0) {
         G = 1;
         const int cap = (16 * mt_min) / N;  // proteins that fit the padded rows anyway
-        if (a.B >= 512 * cap && cap > 1) G = cap;
+        if (cap > 1 && a.B > 256) G = cap;
     }
     if (G > 16) G = 16;
     int mt = (G * N + 15) / 16;
