@@ -208,7 +208,35 @@ DEVI void gelu_both(float x, float& g, float& gp) {
 #endif
 }
 
-DEVI float sigmoid_f(float z) { return 1.0f / (1.0f + expf(-z)); }
+// Hardware transcendentals (v_exp_f32, v_rcp_f32, v_rsq_f32: ~1 ulp each) for the softmax, the gates and the LayerNorm
+// scale: they sit on serial row-stage paths and in the softmax of every head, where libm's expf / IEEE division / sqrtf
+// cost 10-25 instructions apiece.  The extra error is of the order of one fp32 rounding (forces vs the reference's
+// float64 run stay within the tolerances of tests/test_gpu_parity.py).
+#ifndef DFF_LIBM_ROWMATH
+#define DFF_LIBM_ROWMATH 0   // 1: expf / division / sqrtf as in round 1
+#endif
+DEVI float fast_exp(float x) {   // e^x
+#if DFF_LIBM_ROWMATH
+    return expf(x);
+#else
+    return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+#endif
+}
+DEVI float fast_rcp(float x) {
+#if DFF_LIBM_ROWMATH
+    return 1.0f / x;
+#else
+    return __builtin_amdgcn_rcpf(x);
+#endif
+}
+DEVI float fast_rsqrt(float x) {
+#if DFF_LIBM_ROWMATH
+    return 1.0f / sqrtf(x);
+#else
+    return __builtin_amdgcn_rsqf(x);
+#endif
+}
+DEVI float sigmoid_f(float z) { return fast_rcp(1.0f + fast_exp(-z)); }
 DEVI void st_nt(float* p, float v) { __builtin_nontemporal_store(v, p); }
 DEVI float ld_nt(const float* p) { return __builtin_nontemporal_load(p); }
 

@@ -633,7 +633,7 @@ DEVI void ln_stats(const float (&x)[H / 16], float& mean, float& rstd) {
 #pragma unroll
     for (int i = 0; i < H / 16; ++i) { const float d = x[i] - mean; q += d * d; }
     const float var = grp16_sum(q) * (1.0f / H);
-    rstd = 1.0f / sqrtf(var + 1e-5f);
+    rstd = fast_rsqrt(var + 1e-5f);
 }
 
 // gate = sigmoid(w . [x, res, x-res])   (graph_transformer.py:197-205)
@@ -1067,15 +1067,16 @@ DEVI void co_softmax_pv(const CoGeo& g, gfloat* sP /* P block of head hg*HGS */,
                 float e[MT], den = 0.f;
 #pragma unroll
                 for (int jt = 0; jt < MT; ++jt) {
-                    e[jt] = gj[jt] == gi ? expf(s[jt] - mx) : 0.f;
+                    e[jt] = gj[jt] == gi ? fast_exp(s[jt] - mx) : 0.f;
                     den += e[jt];
                 }
                 den = row16_sum(den);
                 lfloat* pl = g.Pbuf + hh * PT + i * PL + col;
                 gfloat* ps = sP + ((size_t)hh * g.RN + min(i, g.RN - 1)) * PS + col;
+                const float rden = fast_rcp(den);
 #pragma unroll
                 for (int jt = 0; jt < MT; ++jt) {
-                    const float p = gi >= 0 ? e[jt] / den : 0.f;
+                    const float p = gi >= 0 ? e[jt] * rden : 0.f;
                     pl[16 * jt] = p;
                     if (gi >= 0) st_ntg(ps + 16 * jt, p);
                 }

@@ -268,22 +268,37 @@ DEVI void sfill_k(u32x4 (&slot)[3], const gu32x4* p, int lane) {
     slot[1] = (p + 64)[lo];
     if constexpr (KIND == 0) slot[2] = (p + 128)[lo];
 }
+// a unit of a head's EXTENSION output tile ([u | s | 0 ...], [r | g_D | 0 ...]): only output columns 0..3 have weights, i.e.
+// only lanes with (lane & 15) < 4 hold anything but zeros -- they alone load (256 B instead of 1 KiB per piece: these
+// tiles are 1/13 of the QKV_ext stream and 1/5 of the [W_o;W_oc]^T stream)
+DEVI void sfill_ext(u32x4 (&slot)[3], const gu32x4* p, int lane) {
+    const unsigned lo = (unsigned)lane & 63u;
+    const bool has = (lane & 15) < 4;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (has) v = (p + 64 * q)[lo];
+        slot[q] = v;
+    }
+}
 // the three piece operands of the unit held by a slot
 template <int KIND>
 DEVI void unit_pieces(const u32x4 (&slot)[3], u32x4& bh, u32x4& bm, u32x4& bl) {
     if constexpr (KIND == 0) { bh = slot[0]; bm = slot[1]; bl = slot[2]; }
     else split8(__builtin_bit_cast(f32x4, slot[0]), __builtin_bit_cast(f32x4, slot[1]), bh, bm, bl);
 }
-template <int N0_, int N1_, int M0_, int K0_, int K1_, int KN0_, int KN1_, int E_>
+template <int N0_, int N1_, int M0_, int K0_, int K1_, int KN0_, int KN1_, int E_, int XU_ = -1>
 struct SSeq {
     static constexpr int N0 = N0_, N1 = N1_, M0 = M0_, K0 = K0_, K1 = K1_, KN0 = KN0_, KN1 = KN1_, E = E_;
+    static constexpr int XU = XU_;   // units XU, XU + 1 of s0 (kind 0) are an extension output tile (sfill_ext), or -1
     SStream s0, s1, n0, n1;
     static constexpr int kind(int i) { return i < N0 ? K0 : K1; }   // of unit i of this block
 };
 template <int DR, int I, class Q>
 DEVI void seq_refill(SRing<DR>& ring, const Q& q, int lane) {   // slot of unit I <- unit I + DR (or the next block's)
     constexpr int slot = I % DR, J = I + DR;
-    if constexpr (J < Q::N0) sfill_k<Q::K0>(ring.b[slot], unit_addr<Q::K0, Q::E>(q.s0, J), lane);
+    if constexpr (J < Q::N0 && Q::K0 == 0 && Q::XU >= 0 && (J == Q::XU || J == Q::XU + 1)) sfill_ext(ring.b[slot], unit_addr<0, Q::E>(q.s0, J), lane);
+    else if constexpr (J < Q::N0) sfill_k<Q::K0>(ring.b[slot], unit_addr<Q::K0, Q::E>(q.s0, J), lane);
     else if constexpr (J < Q::N0 + Q::N1) sfill_k<Q::K1>(ring.b[slot], unit_addr<Q::K1, Q::E>(q.s1, J - Q::N0), lane);
     else if constexpr (slot < Q::M0) sfill_k<Q::KN0>(ring.b[slot], unit_addr<Q::KN0, Q::E>(q.n0, slot), lane);
     else sfill_k<Q::KN1>(ring.b[slot], unit_addr<Q::KN1, Q::E>(q.n1, slot - Q::M0), lane);
@@ -747,7 +762,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #pragma unroll
         for (int i = 0; i < HC; ++i) { const float d = x[i] - mean; q += d * d; }
         const float var = rsum(q) * (1.0f / H);
-        rstd = 1.0f / sqrtf(var + 1e-5f);
+        rstd = fast_rsqrt(var + 1e-5f);
     };
 
     Ring<E, DR> ring;
@@ -977,9 +992,9 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         const bool ok = (col < rows) && (i < rows) && (i / N == pj);
                         const float s = ok ? S[r] * 0.125f : -INFINITY;
                         const float mx = row16_max(s);
-                        const float e = ok ? expf(s - mx) : 0.f;
+                        const float e = ok ? fast_exp(s - mx) : 0.f;
                         const float den = row16_sum(e);
-                        const float p = den > 0.f ? e / den : 0.f;
+                        const float p = den > 0.f ? e * fast_rcp(den) : 0.f;
                         pb[i * DFF_PLD + col] = p;
                         if (st_qkv) st_ntg(sb + sl.P + ((size_t)h * 16 + i) * 16 + col, p);
                     }
@@ -1034,7 +1049,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         float bq[2][1];
                         bq[0][0] = bh[0]; bq[1][0] = bh[16];
                         pf.tick(1);
-                        const SSeq<U_QKV, U_WOX, MW, KQ, KO, 0, 0, E> sq{ss_qkv(lw, wave), ss_wox(lw, wave), sn0, sn1};
+                        const SSeq<U_QKV, U_WOX, MW, KQ, KO, 0, 0, E, 4 * KB32> sq{ss_qkv(lw, wave), ss_wox(lw, wave), sn0, sn1};   // tile 4 of 13: [u | s]
                         swide_run<0, 13, KB32, 1>(sring, bq, ah, am, al, sq, lane,
                             [=](int t, float (&ax)[1]) { ax[0] = bh[t * 16]; },
                             [=](int t, const f32x4& acc, const float (&ax)[1]) {
@@ -1459,8 +1474,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 (void)more;
                 // what follows: FFN backward of layer l - 1 (W2^T, W1^T); after layer 0 the next step re-stages its own first units
                 const DffLayerDev& lwp = m.layer[l > 0 ? l - 1 : 0];
-                const SSeq<U_GX, U_QKVT, MW, 0, KT, 0, 0, E> sqa{ss_woxt(lw, wave), ss_qkvt(lw, wave), ss_w2t(lwp), ss_w1t(lwp)};
-                const SSeq<U_GX, 0, MW, 0, 0, 0, 0, E> sqa0{ss_woxt(lw, wave), ss_woxt(lw, wave), ss_w2t(lwp), ss_w1t(lwp)};
+                const SSeq<U_GX, U_QKVT, MW, 0, KT, 0, 0, E, 4 * KB32> sqa{ss_woxt(lw, wave), ss_qkvt(lw, wave), ss_w2t(lwp), ss_w1t(lwp)};   // tile 4 of 5: [r | g_D]
+                const SSeq<U_GX, 0, MW, 0, 0, 0, 0, E, 4 * KB32> sqa0{ss_woxt(lw, wave), ss_woxt(lw, wave), ss_w2t(lwp), ss_w1t(lwp)};
                 u32x4 dah[KB32], dam[KB32], dal[KB32];   // SPW: dattn as bf16 pieces
                 if constexpr (SPW) a_load(dah, dam, dal, lane);
                 // G_ext = dattn W_o_ext[h]^T  (5 tiles: [G 64 | r 3 | 0]) -> G region ; dx_i -= r_i
