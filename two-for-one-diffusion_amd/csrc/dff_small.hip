@@ -535,6 +535,26 @@ DEVI void head_commit(const HeadRegs& r, lfloat* Qx, lfloat* Kx, lfloat* Vx, lfl
     if (need_p) *(lf32x4*)(pb + (lane >> 2) * DFF_PLD + 4 * (lane & 3)) = r.p;
 }
 
+// The way out: q_ext | k | v rows of one (layer, head) from the wave's head buffers to the stash as 13 16-byte stores per
+// lane, once the QKV_ext GEMM is done -- instead of 52 scalar stores (with 64-bit address arithmetic each) interleaved
+// with the GEMM's weight loads in its tile epilogues: loads and stores share the in-order vmcnt queue, and a timing-only
+// build without these stores ran 2.2 us / step faster.  Rows beyond the allocated ones go to the dummy stash row.
+DEVI void head_store(const lfloat* Qx, const lfloat* Kx, const lfloat* Vx, gfloat* sqkv, int RA, int lane, int rla) {
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const int it = lane + 64 * u, row = it / 20, c4 = it - row * 20;
+        if (row < rla) *(gf32x4*)(sqkv + min(row, RA) * DFF_QKVW + 4 * c4) = *(const lf32x4*)(Qx + row * DFF_XLD + 4 * c4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int it = lane + 64 * u, row = it >> 4, c4 = it & 15;
+        if (row < rla) {
+            *(gf32x4*)(sqkv + min(row, RA) * DFF_QKVW + 80 + 4 * c4) = *(const lf32x4*)(Kx + row * DFF_XLD + 4 * c4);
+            *(gf32x4*)(sqkv + min(row, RA) * DFF_QKVW + 144 + 4 * c4) = *(const lf32x4*)(Vx + row * DFF_XLD + 4 * c4);
+        }
+    }
+}
+
 // q_ext | k | v (| P) of one (layer, head) from the stash (or the layer-0 table) straight into the wave's head buffers by
 // LDS-DMA: global_load_lds_dwordx4 takes a per-lane global address and writes lane i's 16 bytes to LDS at M0 + 16 i, so
 // one instruction fills 1 KiB of the contiguous [Q | K | V | P] regions and the row structure (84-float rows of which 80 /
@@ -998,8 +1018,9 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         const float den = row16_sum(e);
                         const float p = den > 0.f ? e * fast_rcp(den) : 0.f;
                         pb[i * DFF_PLD + col] = p;
-                        if (st_qkv) st_ntg(sb + sl.P + ((size_t)h * 16 + i) * 16 + col, p);
                     }
+                    // the 16 x 16 tile to the stash as ONE 16-byte store per lane (was four scalar stores)
+                    if (st_qkv) *(gf32x4*)(sb + sl.P + (size_t)h * 256 + 4 * lane) = *(const lf32x4*)(pb + (lane >> 2) * DFF_PLD + 4 * (lane & 3));
                     // O_ext = P V_ext (5 tiles) -> Q region; extension columns become xrel = xbar - x_i
                     wv_mm<0, 5, false>(pb, Vx, lane, ks4, [&](int nt, const f32x4& acc) {
 #pragma unroll
@@ -1043,9 +1064,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         u32x4 ah[KB32], am[KB32], al[KB32];
                         a_load(ah, am, al, lane);
                         const gfloat* const bqkvx = (const gfloat*)lw.bqkvx;
-                        const int s0 = srow[0], s1 = srow[1], s2 = srow[2], s3 = srow[3];
                         const int l0 = lro[0], l1 = lro[1], l2 = lro[2], l3 = lro[3];
-                        gfloat* const sqkv = sb + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW + col;
                         const gfloat* const bh = bqkvx + wave * 13 * 16 + col;
                         lfloat* const wq = wr + col;
                         float bq[2][1];
@@ -1058,14 +1077,10 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                                 const int reg = (t >= 5) + (t >= 9);
                                 const int cl = 16 * (t - 5 * reg + (reg >> 1));
                                 lfloat* const dl = wq + reg * RS + cl;
-                                gfloat* const ds = sqkv + 16 * t;
                                 const float v0 = acc[0] + ax[0], v1 = acc[1] + ax[0], v2 = acc[2] + ax[0], v3 = acc[3] + ax[0];
                                 dl[l0] = v0; dl[l1] = v1; dl[l2] = v2; dl[l3] = v3;
-                                if (st_qkv) {
-                                    st_ntg(ds + s0 * DFF_QKVW, v0); st_ntg(ds + s1 * DFF_QKVW, v1);
-                                    st_ntg(ds + s2 * DFF_QKVW, v2); st_ntg(ds + s3 * DFF_QKVW, v3);
-                                }
                             });
+                        if (st_qkv) head_store(Qx, Kx, Vx, sb + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, RA, lane, RLA);
                         pf.tick(12);
                         head_math(wave);
                         pf.tick(13);
