@@ -1220,10 +1220,12 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                             float g0, g1, g2, g3, p0, p1, p2, p3;
                             gelu_both(acc[0] + ax[0], g0, p0); gelu_both(acc[1] + ax[0], g1, p1);
                             gelu_both(acc[2] + ax[0], g2, p2); gelu_both(acc[3] + ax[0], g3, p3);
-                            // the stash slot "h_pre" holds gelu'(h_pre) in this kernel
-                            st_ntg(shp + s0 + 16 * t, p0); st_ntg(shp + s1 + 16 * t, p1);
-                            st_ntg(shp + s2 + 16 * t, p2); st_ntg(shp + s3 + 16 * t, p3);
+                            // the stash slot "h_pre" holds gelu'(h_pre) in this kernel.  It travels through a second LDS tile
+                            // and leaves as full 128-byte rows after the W2 GEMM (below): stored from here, 64 bytes per row and
+                            // instruction, each store was a partial-line write whose acknowledgement the W2 weights queued
+                            // behind in the in-order vmcnt queue (a timing-only build without the stores: -1.1 us / step)
                             hb[16 * t] = g0; hb[LF + 16 * t] = g1; hb[2 * LF + 16 * t] = g2; hb[3 * LF + 16 * t] = g3;
+                            hb[16 * LF + 16 * t] = p0; hb[17 * LF + 16 * t] = p1; hb[18 * LF + 16 * t] = p2; hb[19 * LF + 16 * t] = p3;
                         };
                     if constexpr (SPW) {
                         u32x4 ah[KB32], am[KB32], al[KB32];
@@ -1246,6 +1248,17 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     }
                     else tall_run<NTS % DR, NTS, E, -1>(ring, acc_f, [=](int kb) { return ha + 16 * kb; }, s_w2(lw), after, lane);
                     pf.tick(21);
+                    // gelu'(h_pre) rows of this wave's hidden slice: LDS tile -> stash, 16 bytes per lane (rows beyond the real
+                    // ones go to the dummy stash row); before the partial sums below reuse the tile
+                    {
+                        const lfloat* const gp = hbuf + 16 * LF;
+                        gfloat* const dst = sb + sl.h_pre + wave * FS;
+#pragma unroll
+                        for (int u = 0; u < (16 * (FS / 4) + 63) / 64; ++u) {
+                            const int e = lane + 64 * u, row = e / (FS / 4), c4 = e - row * (FS / 4);
+                            if (row < 16) *(gf32x4*)(dst + (row < rows ? row : RA) * F + 4 * c4) = *(const lf32x4*)(gp + row * LF + 4 * c4);
+                        }
+                    }
                 }
                 static_assert((2 * NTS) % DR == 0, "ring phase");
 #pragma unroll
