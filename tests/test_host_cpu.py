@@ -191,5 +191,12 @@ def test_bench_finds_the_profiled_traffic_for_the_shipped_kernels():
     assert t is not None and 1e9 < t < 1e12
     assert bench.hbm_traffic_from_profile("dff_fused_kernel<128,3,1,false>", "villin", 256, 250) is not None
     assert bench.hbm_traffic_from_profile("dff_small_kernel<64,8>", "chignolin", 128, 250) is None   # other workload
+    # round 2: the split-bf16 headline kernel (rocprofv3 prints "<64, 8, false, true>") has its own, smaller, traffic figure
+    t2 = bench.hbm_traffic_from_profile("dff_small_kernel<64,8,split_bf16>", "chignolin", 256, 250)
+    assert t2 is not None and t2 < t
+    r = bench.roofline("chignolin", 256, 250, [20.8, 20.9], "dff_small_kernel<64,8,split_bf16>")
+    assert abs(r["frac"] - 1.408e12 / 20.85e-3 / 157.3e12) < 1e-3 and r["peak_split_gemms"] == 2500.0 / 6 and r["traffic"] == t2
+    assert "3-way bf16 split" in bench.kernel_dtype("dff_small_kernel<64,8,split_bf16>")
+    assert "split" not in bench.kernel_dtype("dff_fused_kernel<128,4,1,true>")
     # algorithmic FLOPs per launch of the headline config: 22.00 MFLOP x 256 x 250
     assert abs(bench.MFLOP_PER_CALL["chignolin"] * 1e6 * 256 * 250 - 1.408e12) < 1e6
