@@ -141,6 +141,12 @@ int dff_debug_max_workgroups(dff_model* m, int n);
 /* Debugging: on == 0 makes the sampling loops recompute layer 0 every step instead of reading the
  * precomputed per-noise-level table of layer-0 inputs (results are bit-identical either way). */
 int dff_debug_l0_table(dff_model* m, int on);
+/* Debugging: on == 0 never splits a protein over two workgroups (the PAIR variants of the <= 64-row kernel, chosen
+ * automatically when one workgroup per protein would leave at least half the CUs idle, e.g. protein G at 128 per GPU). */
+int dff_debug_pair(dff_model* m, int on);
+/* *status = 0 if every partial-tile exchange of the PAIR launches so far found its partner (a bounded spin replaces a
+ * hang: non-zero means the results of that launch are invalid).  Synchronises the device. */
+int dff_debug_pair_status(dff_model* m, int* status);
 /* Name of the kernel the last call launched, grid size and dynamic LDS bytes. */
 int dff_last_launch(const dff_model* m, const char** kernel_name, int* grid, int* lds_bytes);
 /* Run one MFMA GEMM stage out(M,Nout) = A(M,K) W(K,Nout) through the same device routine and

@@ -582,8 +582,10 @@ def test_split_bf16_weight_gemms_are_fp32_exact(dff, cfg, golden, monkeypatch):
 # on just those (trajectories are independent, so the twin needs only their rows of x0 and of the noise).
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg,P,wgs", [("villin", 256, 100), ("protein_g", 128, 50), ("chignolin", 256, 0)])
+@pytest.mark.parametrize("cfg,P,wgs", [("villin", 256, 100), ("protein_g", 128, 50), ("protein_g", 128, 0), ("chignolin", 256, 0)])
 def test_full_size_langevin_subset_vs_oracle(dff, cfg, P, wgs):
+    """(protein G at 128 per GPU runs as TWO workgroups per protein -- the PAIR variant, 256 blocks in one launch; the run
+    with a workgroup limit turns that off and exercises the one-workgroup SPILL variant over three launches.)"""
     from dff_amd.langevin import LangevinDiffusion
     _, N, H, L = synth.SHIPPED_CONFIGS[cfg]
     K, tlev, temp = 8, 5, {"villin": 360, "protein_g": 350, "chignolin": 340}[cfg]
@@ -594,12 +596,17 @@ def test_full_size_langevin_subset_vs_oracle(dff, cfg, P, wgs):
     masses = [12.0] * N
     if wgs:
         diff.model.native.max_workgroups(wgs)    # P = 256 in launches of 100, 100, 56 workgroups
+        diff.model.native.pair(False)
     try:
         ld = LangevinDiffusion(diff, torch.from_numpy(x0), K, save_interval=1, t=tlev, diffusion_steps=1000, temp_data=temp,
                                temp_sim=temp, dt=None, masses=masses, friction=1.0, kb="consistent", verbose=False)
         traj = ld.sample(noises=torch.from_numpy(noises)).numpy().reshape(P, K, N, 3)   # simulation-major (langevin.py:205-212)
+        kname = diff.model.native.last_launch()[0]
+        assert ("pair" in kname) == (cfg == "protein_g" and not wgs), kname
+        assert diff.model.native.pair_status() == 0
     finally:
         diff.model.native.max_workgroups(2048)
+        diff.model.native.pair(True)
     idx = sorted({0, 1, P // 2, P - 1} | ({wgs - 1, wgs, 2 * wgs - 1, 2 * wgs} if wgs else set()))
     c = twin.langevin_constants(NORM_STD[cfg], tlev, twin.make_schedule(), temp, temp, masses, 1.0, None)
     fr, ke, xl, vl = twin.simulate(twin.to_torch(params), torch.from_numpy(x0[idx]) / NORM_STD[cfg],
@@ -702,3 +709,36 @@ def test_device_flag_word_persists_and_reports_centre(dff):
     with pytest.raises(AssertionError, match="Center not at zero"):
         diff.check_clamp()
     assert not diff.check_clamp()
+
+
+@pytest.mark.gpu
+def test_pair_variant_equals_one_workgroup_variant(dff, golden):
+    """Two workgroups per protein (PAIR: heads / FFN chunks split, partial tiles exchanged through L2 with agent-scope
+    release / acquire) against the one-workgroup variant of the same kernel: forces vs the reference's float64 run within
+    the usual tolerance for both, each other within 5e-6, every exchange found its partner (status word), repeated launches
+    bit-identical (a lost or stale exchange would show up as run-to-run differences), and a batch that is not a multiple
+    of the 8-protein block groups."""
+    g = golden("score_protein_g.npz")
+    model, _ = get_model(dff, "protein_g")
+    x, t = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["t"]).cuda()
+    out = {}
+    try:
+        for on in (True, False):
+            model.native.pair(on)
+            f = model.native.score(x, t).cpu().numpy()
+            assert ("pair" in model.native.last_launch()[0]) == on
+            assert model.native.pair_status() == 0
+            assert rel(f, g["forces64"]) <= 1e-5
+            out[on] = f
+        assert rel(out[True], out[False]) <= 5e-6
+        model.native.pair(True)
+        xb = torch.from_numpy(synth.normal((13, 56, 3), 6, 6).astype(np.float32)).cuda()      # 13 proteins: 2 block groups
+        tb = torch.full((13,), 0.02).cuda()
+        runs = [model.native.score(xb, tb).cpu().numpy() for _ in range(4)]
+        assert model.native.last_launch()[1] == 32 and model.native.pair_status() == 0
+        for r in runs[1:]:
+            assert np.array_equal(r, runs[0])
+        model.native.pair(False)
+        assert rel(runs[0], model.native.score(xb, tb).cpu().numpy()) <= 5e-6
+    finally:
+        model.native.pair(True)

@@ -67,6 +67,8 @@ SYMBOLS = {
     "dff_pwd_max": (C.c_int, [C.c_int, _P, C.c_longlong, C.c_int, C.c_int, _P, _P]),
     "dff_pwd_hist": (C.c_int, [C.c_int, _P, C.c_longlong, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P]),
     "dff_last_error": (C.c_char_p, []),
+    "dff_debug_pair": (C.c_int, [_P, C.c_int]),
+    "dff_debug_pair_status": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "dff_version": (C.c_char_p, []),
 }
 
@@ -172,6 +174,14 @@ class Model:
 
     def max_workgroups(self, n: int = 2048):
         _check(self.lib, self.lib.dff_debug_max_workgroups(self.handle, int(n)), "dff_debug_max_workgroups")
+
+    def pair(self, on: bool = True):
+        _check(self.lib, self.lib.dff_debug_pair(self.handle, int(on)), "dff_debug_pair")
+
+    def pair_status(self) -> int:
+        st = C.c_int(0)
+        _check(self.lib, self.lib.dff_debug_pair_status(self.handle, C.byref(st)), "dff_debug_pair_status")
+        return st.value
 
     def l0_table(self, on: bool = True):
         _check(self.lib, self.lib.dff_debug_l0_table(self.handle, int(on)), "dff_debug_l0_table")

@@ -377,6 +377,7 @@ struct Variant {
     const void* fn;
     unsigned (*lds_floats)(int N, int G);
     const char* name;
+    bool pair = false;   // two workgroups per protein (dff_fused_kernel<..., PAIR>)
 };
 const Variant* dff_fused_variants(int* count);                                  // dff_kernels.hip
 int dff_debug_gemm_launch(int K, const float* dA, const float* dW, int M, int Nout, float* dO, size_t lds);   // dff_kernels.hip

@@ -175,6 +175,13 @@ struct dff_model {
     int last_base = 0;
     bool split = false;                        // split-bf16 images exist, SPW variants preferred (DFF_SPLIT_BF16=0 at model creation: never)
     bool small_split = false;                  // ... and the <= 16-row kernel has an SPW variant for this model
+    // PAIR variants (two workgroups per protein): partial-tile exchange slots and flags
+    float* xchg = nullptr;
+    size_t xchg_floats = 0;
+    unsigned* xflag = nullptr;
+    size_t xflag_n = 0;
+    bool pair_off = false;                     // debugging: never use a PAIR variant
+    bool last_pair = false;
 };
 
 static int upload_u32(dff_model* m, const std::vector<uint32_t>& h, const unsigned** out) {
@@ -457,6 +464,8 @@ extern "C" void dff_model_destroy(dff_model* m) {
     DeviceGuard g(m->device);
     for (void* p : m->allocs) (void)hipFree(p);
     if (m->stash) (void)hipFree(m->stash);
+    if (m->xchg) (void)hipFree(m->xchg);
+    if (m->xflag) (void)hipFree(m->xflag);
     if (m->prof) (void)hipFree(m->prof);
     for (auto& t : m->l0) if (t.tab) (void)hipFree(t.tab);
     delete m;
@@ -483,6 +492,26 @@ extern "C" int dff_debug_force_generic(dff_model* m, int on) {
 extern "C" int dff_debug_max_workgroups(dff_model* m, int n) {
     if (!m || n < 1) return fail(DFF_EINVAL, "bad workgroup limit");
     m->max_wgs = n;
+    return DFF_OK;
+}
+
+extern "C" int dff_debug_pair(dff_model* m, int on) {
+    if (!m) return fail(DFF_EINVAL, "null model");
+    m->pair_off = on == 0;
+    return DFF_OK;
+}
+
+// 0: every partial-tile exchange of the PAIR launches so far found its partner; non-zero: a bounded spin gave up (results
+// of that launch are invalid).  Synchronises the device.
+extern "C" int dff_debug_pair_status(dff_model* m, int* status) {
+    if (!m || !status) return fail(DFF_EINVAL, "null argument");
+    *status = 0;
+    if (!m->xflag || !m->last_pair) return DFF_OK;
+    ON_DEVICE(m->device);
+    HIPCHK(hipDeviceSynchronize());
+    unsigned w = 0;
+    HIPCHK(hipMemcpy(&w, m->xflag + m->xflag_n - 1, sizeof(unsigned), hipMemcpyDeviceToHost));
+    *status = (int)w;
     return DFF_OK;
 }
 
@@ -561,11 +590,33 @@ static int launch_generic(dff_model* m, DffRunArgs& a, int G, const Variant* v, 
     const int N = m->cfg.n_beads, H = m->cfg.hidden, L = m->cfg.n_layers;
     const unsigned lds = v->lds_floats(N, G) * (unsigned)sizeof(float);
     if (lds > 160 * 1024) return fail(DFF_EINVAL, "LDS budget exceeded (%u bytes) for N=%d G=%d H=%d", lds, N, G, H);
-    const int grid_all = (a.B + G - 1) / G;
-    const int grid_max = grid_all < m->max_wgs ? grid_all : m->max_wgs;
+    // PAIR variants: blocks b and b + 8 share a protein (dff_kernels.hip), 16 blocks per 8 proteins, ONE launch: the caller
+    // has checked that every block gets a CU of its own (both blocks of a pair must be resident at once)
+    const int npairs = v->pair ? 8 * ((a.B + 7) / 8) : 0;
+    const int grid_all = v->pair ? 2 * npairs : (a.B + G - 1) / G;
+    const int grid_max = v->pair ? grid_all : (grid_all < m->max_wgs ? grid_all : m->max_wgs);
     const StashLayout sl = dff_stash_layout(N, G, H, L);
     { int rc = ensure_stash(m, (size_t)grid_max * sl.total); if (rc) return rc; }
+    a.xchg = nullptr; a.xflag = nullptr; a.xpairs = npairs;
+    if (v->pair) {
+        const size_t need = (size_t)npairs * 4 * (size_t)(G * N) * (H + 4), nflag = (size_t)2 * npairs + 1;
+        if (need > m->xchg_floats) {
+            if (m->xchg) HIPCHK(hipFree(m->xchg));
+            m->xchg = nullptr; m->xchg_floats = 0;
+            HIPCHK(hipMalloc((void**)&m->xchg, need * sizeof(float)));
+            m->xchg_floats = need;
+        }
+        if (nflag > m->xflag_n) {
+            if (m->xflag) HIPCHK(hipFree(m->xflag));
+            m->xflag = nullptr; m->xflag_n = 0;
+            HIPCHK(hipMalloc((void**)&m->xflag, nflag * sizeof(unsigned)));
+            m->xflag_n = nflag;
+        }
+        HIPCHK(hipMemsetAsync(m->xflag, 0, nflag * sizeof(unsigned), stream));   // sequence numbers restart at every launch
+        a.xchg = m->xchg; a.xflag = m->xflag;
+    }
     m->last_small = false;
+    m->last_pair = v->pair;
     a.G = G;
     a.prof = m->prof_on ? m->prof : nullptr;
     a.stash = m->stash;
@@ -684,9 +735,16 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
         const Variant* vs = dff_fused_variants(&nv);
         for (int q = 0; q < nv; ++q) {
             const Variant& c = vs[q];
-            if (c.H == H && c.MT == mt_ && c.gen == gen && (!c.spw || m->split) && (!r || c.spw)) r = &c;
+            if (c.H == H && c.MT == mt_ && c.gen == gen && !c.pair && (!c.spw || m->split) && (!r || c.spw)) r = &c;
         }
         return r;
+    };
+    auto pick_pair = [&](int mt_) -> const Variant* {
+        int nv = 0;
+        const Variant* vs = dff_fused_variants(&nv);
+        for (int q = 0; q < nv; ++q)
+            if (vs[q].pair && vs[q].H == H && vs[q].MT == mt_) return &vs[q];
+        return nullptr;
     };
     v = pick(mt);
     if (!v) {  // fall back to one protein per workgroup
@@ -698,6 +756,13 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
         int rc = ensure_l0_table(m, a.mode == DFF_MODE_DDPM ? 2 : 1, a.t_norm, G, v, stream);
         if (rc) return rc;
         a.l0_tab = m->l0[a.mode == DFF_MODE_DDPM ? 1 : 0].tab;
+    }
+    // Two workgroups per protein when one per protein would leave at least half the CUs idle (protein G at 128 per GPU:
+    // 1087 -> ~700 us / step): needs every block resident at once, i.e. at most 256 blocks, and the conservative, shipped
+    // input branch.  (The layer-0 table above is built by the one-workgroup variant: the stash layout is the same.)
+    if (G == 1 && !gen && m->cfg.conservative && !m->pair_off && 2 * 8 * ((a.B + 7) / 8) <= 256) {
+        const Variant* vp = pick_pair(mt);
+        if (vp && !v->spw) v = vp;
     }
     return launch_generic(m, a, G, v, stream);
 }
@@ -779,6 +844,7 @@ extern "C" int dff_debug_gemm(int device, const float* A, const float* W, int M,
 
 extern "C" int dff_debug_stash(dff_model* m, int b, int layer, int what, float* out, size_t n) {
     if (!m || !out || !m->stash || m->last_G <= 0) return fail(DFF_EINVAL, "no stash (run dff_score first)");
+    if (m->last_pair) return fail(DFF_EINVAL, "the last launch split every protein over two workgroups (dff_debug_pair(m, 0) turns that off)");
     const int N = m->cfg.n_beads, H = m->cfg.hidden, L = m->cfg.n_layers, G = m->last_G;
     if (b < 0 || b >= m->last_B || layer < 0 || layer >= L) return fail(DFF_EINVAL, "bad sample / layer");
     ON_DEVICE(m->device);

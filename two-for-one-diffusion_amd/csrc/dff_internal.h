@@ -100,4 +100,9 @@ struct DffRunArgs {
     // optional table of precomputed layer-0 inputs (nodes_in, q|u|k|v), one stash-layer-shaped entry per
     // noise level: entry 0 (Langevin, fixed t) or entry t (DDPM).  Rows-<=16 kernel only.
     const float* l0_tab;
+    // PAIR variants of the <= 64-row kernel (two workgroups per protein): partial-tile exchange slots
+    // [pair][half][parity][rows x (H + 4)] and flags [pair][half] + one error word at [2 * xpairs]
+    float* xchg;
+    unsigned* xflag;
+    int xpairs;
 };

@@ -1345,9 +1345,19 @@ DEVI void wg_sync() {
     __syncthreads();
 }
 
-template <int H, int MT, int HGS, bool SPILL, bool GEN, bool SPW>
+// PAIR: TWO workgroups per protein, for batches that leave half the CUs idle (protein G at 128 per GPU).  Block b and
+// block b + 8 (same XCD under the observed b % 8 placement -- used for speed only) own heads 0..3 / 4..7 and one of the two
+// FFN chunks each; everything row-wise (LayerNorm, gates, the integrator) runs redundantly in both.  The four H-wide GEMM
+// outputs per layer (attention out, FFN out and their backward counterparts) and the final dE/dx are partial sums: each
+// workgroup publishes its partial tile (plain stores -> barrier -> agent-scope release fence -> flag, MI355X_MICROARCH.md
+// "inter-workgroup visibility"), waits for its partner's flag (one lane polls, agent-scope acquire, barrier) and adds the
+// partner's tile -- a + b == b + a, so both workgroups continue with bit-identical values and stay in lockstep without
+// any further communication: 13 exchanges of <= 29 KB per step.  Both blocks of a pair must be resident at once: the host
+// only launches this variant with at most one block per CU.  A bounded spin (xflag error word) replaces a hang.
+template <int H, int MT, int HGS, bool SPILL, bool GEN, bool SPW, bool PAIR = false>
 __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelDev m, const DffRunArgs a) {
     using LL = LdsLayout<H, MT, HGS, SPILL>;
+    static_assert(!PAIR || (!GEN && DFF_HEADS / HGS % 2 == 0 && (4 * H / LL::FC) % 2 == 0), "PAIR splits head groups and FFN chunks in two");
     constexpr int LH = LL::LH, LQ = LL::LQ, F = LL::F, FC = LL::FC, LF = LL::LF;
     constexpr int NT_H = H / 16;                       // output tiles of an H-wide GEMM
     constexpr int NTW = (NT_H + DFF_NWAVES - 1) / DFF_NWAVES;
@@ -1357,9 +1367,12 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
 
     Ctx c;
     c.N = m.N; c.G = a.G; c.L = m.L;
-    c.b0 = a.b_base + blockIdx.x * a.G;
+    // PAIR: blocks b and b + 8 form pair (b & 7) + 8 (b >> 4); hf = which half of the heads / FFN chunks this block owns
+    const int hf = PAIR ? (int)((blockIdx.x >> 3) & 1) : 0;
+    const int unit = PAIR ? (int)((blockIdx.x & 7) + 8 * (blockIdx.x >> 4)) : (int)blockIdx.x;
+    c.b0 = a.b_base + unit * a.G;
     c.gcnt = min(a.G, a.B - c.b0);
-    if (c.gcnt <= 0) return;
+    if (c.gcnt <= 0) return;   // (both blocks of a pair leave together)
     c.rows = c.gcnt * c.N;
     c.NP = c.N <= 8 ? 8 : c.N <= 16 ? 16 : c.N <= 32 ? 32 : 64;
     const LL ll(c.N, c.G, SPW);
@@ -1373,6 +1386,53 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
     c.resbuf = SPILL ? (c.stash + c.sl.dn_spill) : (smem + ll.resbuf);
     float* tbuf = c.Rg;  // GEMM outputs of width H alias the start of the head-group region
     const int tid = threadIdx.x;
+    constexpr int HG0 = 0;
+    const int hg_lo = PAIR ? hf * (NHG / 2) : 0, hg_hi = PAIR ? (hf + 1) * (NHG / 2) : NHG;   // this block's head groups
+    const int ch_lo = PAIR ? hf * (NCH / 2) : 0, ch_hi = PAIR ? (hf + 1) * (NCH / 2) : NCH;   // ... and FFN chunks
+    (void)HG0;
+    // ---- PAIR: partial-tile exchange (see the comment above the kernel) ----
+    unsigned xseq = 0;   // exchanges done so far in this launch (both blocks of a pair count alike)
+    auto pair_exchange = [&](float* tile /* LDS, rows x ncols floats, leading dimension ld */, int ncols, int ld) {
+        if constexpr (PAIR) {
+            const int tid_ = tid_now();
+            const size_t slot_floats = (size_t)(c.G * c.N) * (H + 4);
+            float* const mine = a.xchg + ((size_t)(2 * unit + hf) * 2 + (xseq & 1)) * slot_floats;
+            const float* const theirs = a.xchg + ((size_t)(2 * unit + (1 - hf)) * 2 + (xseq & 1)) * slot_floats;
+            unsigned* const flags = a.xflag + 2 * unit;
+            const int n4 = ncols / 4;   // ncols % 4 == 0, ld % 4 == 0
+            wg_sync<SPILL>();           // the tile is complete
+            for (int it = tid_; it < c.rows * n4; it += DFF_NTHREADS) {
+                const int row = it / n4, c4 = it - row * n4;
+                *(f32x4*)(mine + (size_t)row * ncols + 4 * c4) = *(const f32x4*)(tile + row * ld + 4 * c4);
+            }
+            __syncthreads();
+            if (tid_ == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(flags + hf, xseq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // never hang the GPU: the spin is bounded (~1 s), and once any pair has given up (error word set) nobody spins
+                unsigned* const err = a.xflag + 2 * a.xpairs;
+                unsigned spins = 0;
+                while (__hip_atomic_load(flags + (1 - hf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < xseq + 1) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if ((++spins & 1023u) == 0 &&
+                        (spins > (1u << 21) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                        atomicOr(err, 1u);
+                        break;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            for (int it = tid_; it < c.rows * n4; it += DFF_NTHREADS) {
+                const int row = it / n4, c4 = it - row * n4;
+                float* const t = tile + row * ld + 4 * c4;
+                *(f32x4*)t = *(const f32x4*)t + *(const f32x4*)(theirs + (size_t)row * ncols + 4 * c4);
+            }
+            wg_sync<SPILL>();
+            ++xseq;
+        }
+    };
     const int wave_ = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = c.N, RN = c.G * N, rows = c.rows;
     const lfloat* const abufL = (const lfloat*)smem + ll.abuf;
@@ -1487,7 +1547,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             pf.tick(1);
             f32x4 acc_o[NTW][MT];
             acc_zero<MT, NTW>(acc_o);
-            for (int hg = 0; hg < NHG; ++hg) {
+            for (int hg = hg_lo; hg < hg_hi; ++hg) {
                 // [q|u|k|v] of HGS heads -> R0,R1,R2 (+ stash)
                 if (cached) {
                     const int tid = tid_now();
@@ -1549,7 +1609,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 wg_sync<SPILL>();
                 pf.tick(6);
             }
-            store_tall<MT, NTW>(acc_o, tbuf, LH, rows, NT_H, lw.bo);
+            store_tall<MT, NTW>(acc_o, tbuf, LH, rows, NT_H, hf == 0 ? lw.bo : nullptr);
+            pair_exchange(tbuf, H, LH);
             wg_sync<SPILL>();
             row_gate1_ln2<H>(c, lw, l, tbuf);
             wg_sync<SPILL>();
@@ -1558,7 +1619,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             // FFN: Linear(H,4H) -> GELU(erf) -> Linear(4H,H)   (graph_transformer.py:264-267)
             f32x4 acc_f[NTW][MT];
             acc_zero<MT, NTW>(acc_f);
-            for (int ch = 0; ch < NCH; ++ch) {
+            for (int ch = ch_lo; ch < ch_hi; ++ch) {
                 {
                     const int tid = tid_now();
                     const gfloat* const b1g = (const gfloat*)lw.b1 + ch * FC;
@@ -1596,7 +1657,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 wg_sync<SPILL>();
                 pf.tick(9);
             }
-            store_tall<MT, NTW>(acc_f, tbuf, LH, rows, NT_H, lw.b2);
+            store_tall<MT, NTW>(acc_f, tbuf, LH, rows, NT_H, hf == 0 ? lw.b2 : nullptr);
+            pair_exchange(tbuf, H, LH);
             wg_sync<SPILL>();
             row_gate2<H>(c, m, lw, l, tbuf, l == m.L - 1, a.energy_out);
             wg_sync<SPILL>();
@@ -1614,7 +1676,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             // dh = dff W2 ; dh_pre = dh * gelu'(h_pre) ; df = dh_pre W1
             f32x4 acc_f[NTW][MT];
             acc_zero<MT, NTW>(acc_f);
-            for (int ch = 0; ch < NCH; ++ch) {
+            for (int ch = ch_lo; ch < ch_hi; ++ch) {
                 {
                     const int tid = tid_now();
                     const gfloat* const shp = (const gfloat*)sb + c.sl.h_pre + ch * FC;
@@ -1655,6 +1717,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 pf.tick(13);
             }
             store_tall<MT, NTW>(acc_f, tbuf, LH, rows, NT_H, nullptr);
+            pair_exchange(tbuf, H, LH);
             wg_sync<SPILL>();
             // The stashed q|k|v|P rows of head group hg + 1 are requested as soon as those of hg have been committed
             // to LDS, a whole group's worth of phases before they are needed (group 0: before the row stage below):
@@ -1663,7 +1726,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             const gfloat* const sPl = (const gfloat*)sb + c.sl.P;
             CoReload<MT, HGS> rl;
             co_reload_plan<MT, HGS>(rl, geo, true, tid_now());
-            co_reload_issue<MT, HGS>(rl, sqkv, sPl);
+            co_reload_issue<MT, HGS>(rl, sqkv + (size_t)hg_lo * HGS * RN * DFF_QKVW, sPl + (size_t)hg_lo * HGS * RN * c.sl.PS);
             rowb_ln2_gate1<H>(c, lw, l, tbuf);
             wg_sync<SPILL>();
             if constexpr (SPW) { split_rows<H>(abufL, asplit, RN); wg_sync<SPILL>(); }
@@ -1671,7 +1734,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             f32x4 acc_a[NTW][MT];
             acc_zero<MT, NTW>(acc_a);
             pf.tick(15);
-            for (int hg = 0; hg < NHG; ++hg) {
+            for (int hg = hg_lo; hg < hg_hi; ++hg) {
                 // G_ext = dattn [W_o ; W_oc]^T (dE/do | r = dE/dxrel) for the heads of this group -> R3 ;
                 // dE/dx_i -= r_i
                 {
@@ -1700,7 +1763,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         const gfloat* const sM = (const gfloat*)sb + c.sl.m12 + (size_t)hg * HGS * RN * 4;
                         for (int i2 = tid; i2 < HGS * RN * 4; i2 += DFF_NTHREADS) geo.m12[i2] = ld_ntg(sM + i2);
                     }
-                    if (hg + 1 < NHG)
+                    if (hg + 1 < hg_hi)
                         co_reload_issue<MT, HGS>(rl, sqkv + (size_t)(hg + 1) * HGS * RN * DFF_QKVW,
                                                  sPl + (size_t)(hg + 1) * HGS * RN * c.sl.PS);
                 }
@@ -1744,6 +1807,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             }
             if (l > 0 || full0) {
                 store_tall<MT, NTW>(acc_a, tbuf, LH, rows, NT_H, nullptr);
+                pair_exchange(tbuf, H, LH);
                 wg_sync<SPILL>();
                 rowb_ln1<H>(c, lw, l, tbuf);
                 wg_sync<SPILL>();
@@ -1756,6 +1820,9 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
 #pragma unroll
             for (int w = 0; w < DFF_NWAVES; ++w) sdx += (smem + ll.dxw)[w * RN * 4 + tid];
             c.dxs[tid] = sdx;
+        }
+        if constexpr (PAIR) {   // this block's heads' share of dE/dx + the partner's (rows x 4 floats)
+            if (m.conservative) pair_exchange(c.dxs, 4, 4);
         }
         wg_sync<SPILL>();
         if (full0 && m.conservative) {
@@ -1912,11 +1979,17 @@ static unsigned lds_floats_of(int N, int G) { return LdsLayout<H, MT, HGS, SP>(N
       &lds_floats_of<H, MT, HGS, false, true>, "dff_fused_kernel<" #H "," #MT "," #HGS ",false,split_bf16>" },  \
     { H, MT, HGS, false, true, true, (const void*)&dff_fused_kernel<H, MT, HGS, false, true, true>,             \
       &lds_floats_of<H, MT, HGS, false, true>, "dff_fused_kernel<" #H "," #MT "," #HGS ",false,gen,split_bf16>" }
+template <int H, int MT, int HGS, bool SP>
+static unsigned lds_floats_pair(int N, int G) { return LdsLayout<H, MT, HGS, SP>(N, G, false).total; }
+#define VAR_PAIR(H, MT, HGS, SP)                                                                                  \
+    { H, MT, HGS, SP, false, false, (const void*)&dff_fused_kernel<H, MT, HGS, SP, false, false, true>,           \
+      &lds_floats_pair<H, MT, HGS, SP>, "dff_fused_kernel<" #H "," #MT "," #HGS "," #SP ",pair>", true }
 static const Variant g_variants[] = {
 #ifndef DFF_FAST_BUILD
     VAR(64, 1, 4, false),  VAR(64, 2, 2, false),  VAR(96, 1, 4, false),  VAR(96, 2, 2, false),
     VAR(128, 1, 4, false), VAR(128, 2, 2, false), VAR(128, 3, 1, false), VAR(128, 4, 1, true),
     VAR_SPW(96, 2, 2), VAR_SPW(128, 2, 2), VAR_SPW(128, 3, 1),
+    VAR_PAIR(128, 4, 1, true),
 #else   // development builds: one variant, so that the <= 16-row kernel can be iterated on quickly
     VAR(64, 1, 4, false),
 #endif
