@@ -454,6 +454,7 @@ def test_batch_split_over_launches_is_invisible(dff, cfg):
     kw = dict(n_timesteps=12, save_interval=4, t=20, temp_data=300, temp_sim=300, dt=None, masses=[12.0] * N,
               friction=1.0, verbose=False, seed=5)
     out = {}
+    nat.pair(False)    # (two workgroups per protein is a different variant with its own summation order: tested on its own)
     try:
         for lim in (2048, 3):
             nat.max_workgroups(lim)
@@ -467,6 +468,7 @@ def test_batch_split_over_launches_is_invisible(dff, cfg):
             assert nat.last_launch()[1] == (B if lim == 2048 else B - 3 * ((B - 1) // 3))   # grid of the last launch
     finally:
         nat.max_workgroups(2048)
+        nat.pair(True)
     for a, b in zip(out[2048], out[3]):
         assert np.isfinite(a).all() and np.array_equal(a, b)
 
@@ -712,14 +714,16 @@ def test_device_flag_word_persists_and_reports_centre(dff):
 
 
 @pytest.mark.gpu
-def test_pair_variant_equals_one_workgroup_variant(dff, golden):
+@pytest.mark.parametrize("cfg", ["protein_g", "villin", "trp_cage"])
+def test_pair_variant_equals_one_workgroup_variant(dff, cfg, golden):
     """Two workgroups per protein (PAIR: heads / FFN chunks split, partial tiles exchanged through L2 with agent-scope
     release / acquire) against the one-workgroup variant of the same kernel: forces vs the reference's float64 run within
     the usual tolerance for both, each other within 5e-6, every exchange found its partner (status word), repeated launches
     bit-identical (a lost or stale exchange would show up as run-to-run differences), and a batch that is not a multiple
     of the 8-protein block groups."""
-    g = golden("score_protein_g.npz")
-    model, _ = get_model(dff, "protein_g")
+    g = golden(f"score_{cfg}.npz")
+    model, _ = get_model(dff, cfg)
+    N = synth.SHIPPED_CONFIGS[cfg][1]
     x, t = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["t"]).cuda()
     out = {}
     try:
@@ -732,7 +736,7 @@ def test_pair_variant_equals_one_workgroup_variant(dff, golden):
             out[on] = f
         assert rel(out[True], out[False]) <= 5e-6
         model.native.pair(True)
-        xb = torch.from_numpy(synth.normal((13, 56, 3), 6, 6).astype(np.float32)).cuda()      # 13 proteins: 2 block groups
+        xb = torch.from_numpy(synth.normal((13, N, 3), 6, 6).astype(np.float32)).cuda()      # 13 proteins: 2 block groups
         tb = torch.full((13,), 0.02).cuda()
         runs = [model.native.score(xb, tb).cpu().numpy() for _ in range(4)]
         assert model.native.last_launch()[1] == 32 and model.native.pair_status() == 0

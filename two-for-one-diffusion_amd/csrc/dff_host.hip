@@ -739,11 +739,11 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
         }
         return r;
     };
-    auto pick_pair = [&](int mt_) -> const Variant* {
+    auto pick_pair = [&](int mt_, bool spw_) -> const Variant* {
         int nv = 0;
         const Variant* vs = dff_fused_variants(&nv);
         for (int q = 0; q < nv; ++q)
-            if (vs[q].pair && vs[q].H == H && vs[q].MT == mt_) return &vs[q];
+            if (vs[q].pair && vs[q].H == H && vs[q].MT == mt_ && vs[q].spw == spw_) return &vs[q];
         return nullptr;
     };
     v = pick(mt);
@@ -760,9 +760,9 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
     // Two workgroups per protein when one per protein would leave at least half the CUs idle (protein G at 128 per GPU:
     // 1087 -> ~700 us / step): needs every block resident at once, i.e. at most 256 blocks, and the conservative, shipped
     // input branch.  (The layer-0 table above is built by the one-workgroup variant: the stash layout is the same.)
-    if (G == 1 && !gen && m->cfg.conservative && !m->pair_off && 2 * 8 * ((a.B + 7) / 8) <= 256) {
-        const Variant* vp = pick_pair(mt);
-        if (vp && !v->spw) v = vp;
+    if (G == 1 && !gen && m->cfg.conservative && !m->pair_off && 2 * 8 * ((a.B + 7) / 8) <= (m->max_wgs < 256 ? m->max_wgs : 256)) {
+        const Variant* vp = pick_pair(mt, v->spw);
+        if (vp) v = vp;
     }
     return launch_generic(m, a, G, v, stream);
 }

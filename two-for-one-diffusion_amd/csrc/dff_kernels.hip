@@ -1979,17 +1979,18 @@ static unsigned lds_floats_of(int N, int G) { return LdsLayout<H, MT, HGS, SP>(N
       &lds_floats_of<H, MT, HGS, false, true>, "dff_fused_kernel<" #H "," #MT "," #HGS ",false,split_bf16>" },  \
     { H, MT, HGS, false, true, true, (const void*)&dff_fused_kernel<H, MT, HGS, false, true, true>,             \
       &lds_floats_of<H, MT, HGS, false, true>, "dff_fused_kernel<" #H "," #MT "," #HGS ",false,gen,split_bf16>" }
-template <int H, int MT, int HGS, bool SP>
-static unsigned lds_floats_pair(int N, int G) { return LdsLayout<H, MT, HGS, SP>(N, G, false).total; }
 #define VAR_PAIR(H, MT, HGS, SP)                                                                                  \
     { H, MT, HGS, SP, false, false, (const void*)&dff_fused_kernel<H, MT, HGS, SP, false, false, true>,           \
-      &lds_floats_pair<H, MT, HGS, SP>, "dff_fused_kernel<" #H "," #MT "," #HGS "," #SP ",pair>", true }
+      &lds_floats_of<H, MT, HGS, SP, false>, "dff_fused_kernel<" #H "," #MT "," #HGS "," #SP ",pair>", true }
+#define VAR_PAIR_SPW(H, MT, HGS)                                                                                  \
+    { H, MT, HGS, false, false, true, (const void*)&dff_fused_kernel<H, MT, HGS, false, false, true, true>,       \
+      &lds_floats_of<H, MT, HGS, false, true>, "dff_fused_kernel<" #H "," #MT "," #HGS ",false,split_bf16,pair>", true }
 static const Variant g_variants[] = {
 #ifndef DFF_FAST_BUILD
     VAR(64, 1, 4, false),  VAR(64, 2, 2, false),  VAR(96, 1, 4, false),  VAR(96, 2, 2, false),
     VAR(128, 1, 4, false), VAR(128, 2, 2, false), VAR(128, 3, 1, false), VAR(128, 4, 1, true),
     VAR_SPW(96, 2, 2), VAR_SPW(128, 2, 2), VAR_SPW(128, 3, 1),
-    VAR_PAIR(128, 4, 1, true),
+    VAR_PAIR(128, 4, 1, true), VAR_PAIR_SPW(128, 3, 1), VAR_PAIR_SPW(128, 2, 2),
 #else   // development builds: one variant, so that the <= 16-row kernel can be iterated on quickly
     VAR(64, 1, 4, false),
 #endif
