@@ -714,7 +714,7 @@ def test_device_flag_word_persists_and_reports_centre(dff):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", ["protein_g", "villin", "trp_cage"])
+@pytest.mark.parametrize("cfg", ["protein_g", "villin", "trp_cage", "bba"])
 def test_pair_variant_equals_one_workgroup_variant(dff, cfg, golden):
     """Two workgroups per protein (PAIR: heads / FFN chunks split, partial tiles exchanged through L2 with agent-scope
     release / acquire) against the one-workgroup variant of the same kernel: forces vs the reference's float64 run within

@@ -1357,7 +1357,7 @@ DEVI void wg_sync() {
 template <int H, int MT, int HGS, bool SPILL, bool GEN, bool SPW, bool PAIR = false>
 __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelDev m, const DffRunArgs a) {
     using LL = LdsLayout<H, MT, HGS, SPILL>;
-    static_assert(!PAIR || (!GEN && DFF_HEADS / HGS % 2 == 0 && (4 * H / LL::FC) % 2 == 0), "PAIR splits head groups and FFN chunks in two");
+    static_assert(!PAIR || (!GEN && DFF_HEADS / HGS % 2 == 0 && 4 * H / LL::FC >= 2), "PAIR splits head groups and FFN chunks in two");
     constexpr int LH = LL::LH, LQ = LL::LQ, F = LL::F, FC = LL::FC, LF = LL::LF;
     constexpr int NT_H = H / 16;                       // output tiles of an H-wide GEMM
     constexpr int NTW = (NT_H + DFF_NWAVES - 1) / DFF_NWAVES;
@@ -1388,7 +1388,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
     const int tid = threadIdx.x;
     constexpr int HG0 = 0;
     const int hg_lo = PAIR ? hf * (NHG / 2) : 0, hg_hi = PAIR ? (hf + 1) * (NHG / 2) : NHG;   // this block's head groups
-    const int ch_lo = PAIR ? hf * (NCH / 2) : 0, ch_hi = PAIR ? (hf + 1) * (NCH / 2) : NCH;   // ... and FFN chunks
+    const int ch_lo = PAIR ? hf * ((NCH + 1) / 2) : 0, ch_hi = PAIR && hf == 0 ? (NCH + 1) / 2 : NCH;   // ... and FFN chunks (H = 96: 2 + 1)
     (void)HG0;
     // ---- PAIR: partial-tile exchange (see the comment above the kernel) ----
     unsigned xseq = 0;   // exchanges done so far in this launch (both blocks of a pair count alike)
@@ -1990,7 +1990,7 @@ static const Variant g_variants[] = {
     VAR(64, 1, 4, false),  VAR(64, 2, 2, false),  VAR(96, 1, 4, false),  VAR(96, 2, 2, false),
     VAR(128, 1, 4, false), VAR(128, 2, 2, false), VAR(128, 3, 1, false), VAR(128, 4, 1, true),
     VAR_SPW(96, 2, 2), VAR_SPW(128, 2, 2), VAR_SPW(128, 3, 1),
-    VAR_PAIR(128, 4, 1, true), VAR_PAIR_SPW(128, 3, 1), VAR_PAIR_SPW(128, 2, 2),
+    VAR_PAIR(128, 4, 1, true), VAR_PAIR_SPW(128, 3, 1), VAR_PAIR_SPW(128, 2, 2), VAR_PAIR_SPW(96, 2, 2),
 #else   // development builds: one variant, so that the <= 16-row kernel can be iterated on quickly
     VAR(64, 1, 4, false),
 #endif
