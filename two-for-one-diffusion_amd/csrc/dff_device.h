@@ -25,11 +25,18 @@ typedef f32x4 __attribute__((address_space(1))) gf32x4;
 DEVI void st_ntg(gfloat* p, float v) { __builtin_nontemporal_store(v, p); }
 DEVI float ld_ntg(const gfloat* p) { return __builtin_nontemporal_load(p); }
 DEVI f32x4 ld_ntg4(const gfloat* p) { return __builtin_nontemporal_load((const gf32x4*)p); }
+DEVI void st_ntg4(gfloat* p, const f32x4 v) { __builtin_nontemporal_store(v, (gf32x4*)p); }
 #else
 DEVI void st_ntg(gfloat* p, float v) { *p = v; }
 DEVI float ld_ntg(const gfloat* p) { return *p; }
 DEVI f32x4 ld_ntg4(const gfloat* p) { return *(const gf32x4*)p; }
+DEVI void st_ntg4(gfloat* p, const f32x4 v) { *(gf32x4*)p = v; }
 #endif
+// four consecutive floats (16-byte aligned) into a scalar aux array of an epilogue
+DEVI void ld4_aux(float* aux, const gfloat* p) {
+    const f32x4 v = *(const gf32x4*)p;
+    aux[0] = v[0]; aux[1] = v[1]; aux[2] = v[2]; aux[3] = v[3];
+}
 
 // ------------------------------------------------------------------------------------------
 // Stash layout (floats, per workgroup).  R = G*N allocated rows, F = 4H.
@@ -284,6 +291,8 @@ typedef __attribute__((address_space(3))) unsigned lu32;
 typedef __attribute__((address_space(3))) u32x4 lu32x4;
 typedef __attribute__((address_space(3))) unsigned short lu16;
 typedef __attribute__((address_space(1))) u32x4 gu32x4;
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) u32x2 lu32x2;
 DEVI f32x4 mfma_bf16(const u32x4 a, const u32x4 b, const f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }

@@ -28,8 +28,10 @@
 
 // ------------------------------------------------------------------------------------------
 // MFMA GEMM stages.  A (rows x K) lives in LDS with leading dimension lda (multiple of 4);
-// B is the packed weight image in global memory (see dff_internal.h); C layout of
-// v_mfma_f32_16x16x4_f32: lane l holds column (l & 15), rows 4*(l >> 4) + r, r = 0..3.
+// B is the packed weight image in global memory (see dff_internal.h).  The products are issued TRANSPOSED (the weight
+// fragment as the MFMA's first operand, the activation fragment as its second), so that of an output tile lane l holds
+// ROW (l & 15) and the four consecutive COLUMNS 4*(l >> 4) + r, r = 0..3: every epilogue then moves 16 bytes per lane
+// (one LDS write, one stash store) instead of four scattered dwords.
 // ------------------------------------------------------------------------------------------
 DEVI void mfma4(f32x4& acc, const f32x4 a, const f32x4 b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc, 0, 0, 0);
@@ -108,7 +110,7 @@ DEVI void gemm_wide(const lfloat* A, int lda, int rowsA, const float* __restrict
                     for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
-                            acc[mt][kb % NC] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s4], b[d][kb][s4], acc[mt][kb % NC], 0, 0, 0);
+                            acc[mt][kb % NC] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[d][kb][s4], a[mt][s4], acc[mt][kb % NC], 0, 0, 0);
                 }
                 float auxc[NAUX];
 #pragma unroll
@@ -191,17 +193,17 @@ DEVI void gemm_wide_split(const lu32* as, int R, int rowsA, const unsigned* __re
                         al[mt] = *(const lu32x4*)(as + 2 * R * LHS2 + rowoff[mt] + 16 * kb);
                     }
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) cs[mt] = mfma_bf16(al[mt], b[d][kb][0], cs[mt]);
+                    for (int mt = 0; mt < MT; ++mt) cs[mt] = mfma_bf16(b[d][kb][0], al[mt], cs[mt]);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) cb[mt] = mfma_bf16(am[mt], b[d][kb][0], cb[mt]);
+                    for (int mt = 0; mt < MT; ++mt) cb[mt] = mfma_bf16(b[d][kb][0], am[mt], cb[mt]);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) cs[mt] = mfma_bf16(ah[mt], b[d][kb][2], cs[mt]);
+                    for (int mt = 0; mt < MT; ++mt) cs[mt] = mfma_bf16(b[d][kb][2], ah[mt], cs[mt]);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) cb[mt] = mfma_bf16(ah[mt], b[d][kb][1], cb[mt]);
+                    for (int mt = 0; mt < MT; ++mt) cb[mt] = mfma_bf16(b[d][kb][1], ah[mt], cb[mt]);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) cs[mt] = mfma_bf16(am[mt], b[d][kb][1], cs[mt]);
+                    for (int mt = 0; mt < MT; ++mt) cs[mt] = mfma_bf16(b[d][kb][1], am[mt], cs[mt]);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) cb[mt] = mfma_bf16(ah[mt], b[d][kb][0], cb[mt]);
+                    for (int mt = 0; mt < MT; ++mt) cb[mt] = mfma_bf16(b[d][kb][0], ah[mt], cb[mt]);
                 }
                 float auxc[NAUX];
 #pragma unroll
@@ -273,12 +275,12 @@ DEVI void gemm_wide_split_h(const lu32* as, int R, int rowsA, const unsigned* __
                         const u32x4 ah = *(const lu32x4*)(as + o);
                         const u32x4 am = *(const lu32x4*)(as + R * LHS2 + o);
                         const u32x4 al = *(const lu32x4*)(as + 2 * R * LHS2 + o);
-                        cs[mt] = mfma_bf16(al, b[slot][kb][0], cs[mt]);
-                        cb[mt] = mfma_bf16(am, b[slot][kb][0], cb[mt]);
-                        cs[mt] = mfma_bf16(ah, b[slot][kb][2], cs[mt]);
-                        cb[mt] = mfma_bf16(ah, b[slot][kb][1], cb[mt]);
-                        cs[mt] = mfma_bf16(am, b[slot][kb][1], cs[mt]);
-                        cb[mt] = mfma_bf16(ah, b[slot][kb][0], cb[mt]);
+                        cs[mt] = mfma_bf16(b[slot][kb][0], al, cs[mt]);
+                        cb[mt] = mfma_bf16(b[slot][kb][0], am, cb[mt]);
+                        cs[mt] = mfma_bf16(b[slot][kb][2], ah, cs[mt]);
+                        cb[mt] = mfma_bf16(b[slot][kb][1], ah, cb[mt]);
+                        cs[mt] = mfma_bf16(b[slot][kb][1], am, cs[mt]);
+                        cb[mt] = mfma_bf16(b[slot][kb][0], ah, cb[mt]);
                     }
                 }
                 float auxc[NAUX];
@@ -332,12 +334,12 @@ DEVI void gemm_wide_units_split(const lu32* as, int R, int rowsA, const unsigned
                 const u32x4 ah = *(const lu32x4*)(as + ro + 16 * kb);
                 const u32x4 am = *(const lu32x4*)(as + R * LHS2 + ro + 16 * kb);
                 const u32x4 al = *(const lu32x4*)(as + 2 * R * LHS2 + ro + 16 * kb);
-                cs = mfma_bf16(al, b[d][kb][0], cs);
-                cb = mfma_bf16(am, b[d][kb][0], cb);
-                cs2 = mfma_bf16(ah, b[d][kb][2], cs2);
-                cb2 = mfma_bf16(ah, b[d][kb][1], cb2);
-                cs = mfma_bf16(am, b[d][kb][1], cs);
-                cb = mfma_bf16(ah, b[d][kb][0], cb);
+                cs = mfma_bf16(b[d][kb][0], al, cs);
+                cb = mfma_bf16(b[d][kb][0], am, cb);
+                cs2 = mfma_bf16(b[d][kb][2], ah, cs2);
+                cb2 = mfma_bf16(b[d][kb][1], ah, cb2);
+                cs = mfma_bf16(b[d][kb][1], am, cs);
+                cb = mfma_bf16(b[d][kb][0], ah, cb);
             }
             epi(nt, mt, (cb + cb2) + (cs + cs2));
         }
@@ -353,6 +355,22 @@ DEVI void store_split(lu16* as16, int R, int LS, int row, int col, float v) {
     as16[(0 * R + row) * LS + col] = (unsigned short)(uh >> 16);
     as16[(1 * R + row) * LS + col] = (unsigned short)(um >> 16);
     as16[(2 * R + row) * LS + col] = (unsigned short)(__float_as_uint(r2) >> 16);
+}
+// Four consecutive columns (col % 4 == 0) of one row: one 8-byte store per piece (LS2 = dwords per piece row, even).
+DEVI void store_split4(lu32* as, int R, int LS2, int row, int col, const f32x4 v) {
+    unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned uh = __float_as_uint(v[q]) & 0xffff0000u;
+        const float r = v[q] - __uint_as_float(uh);
+        const unsigned um = __float_as_uint(r) & 0xffff0000u;
+        const float r2 = r - __uint_as_float(um);
+        hh[q] = uh; mm[q] = um; ll[q] = __float_as_uint(r2);
+    }
+    const int o = row * LS2 + (col >> 1);
+    *(lu32x2*)(as + 0 * R * LS2 + o) = (u32x2){__builtin_amdgcn_perm(hh[1], hh[0], 0x07060302u), __builtin_amdgcn_perm(hh[3], hh[2], 0x07060302u)};
+    *(lu32x2*)(as + 1 * R * LS2 + o) = (u32x2){__builtin_amdgcn_perm(mm[1], mm[0], 0x07060302u), __builtin_amdgcn_perm(mm[3], mm[2], 0x07060302u)};
+    *(lu32x2*)(as + 2 * R * LS2 + o) = (u32x2){__builtin_amdgcn_perm(ll[1], ll[0], 0x07060302u), __builtin_amdgcn_perm(ll[3], ll[2], 0x07060302u)};
 }
 // "tall" GEMM (Nout = H) on split operands: acc[i][mt] += A[:, 32 kb ..] W[kb0 + kb], kb < nkb; A pieces as written by
 // store_split with LS = 32 nkb + 8; W = pack_b_split image with KBtot k-blocks per tile.  Wave w owns tiles w + 8 i.
@@ -403,17 +421,17 @@ DEVI void gemm_tall_split(f32x4 (&acc)[NTW][MT], int nkb, int LS2 /* dwords per 
                 for (int i = 0; i < NTW; ++i)
                     if (tok[i]) {
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(al[mt], b[d][i][0], acc[i][mt]);
+                        for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][0], al[mt], acc[i][mt]);
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(ah[mt], b[d][i][2], acc[i][mt]);
+                        for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][2], ah[mt], acc[i][mt]);
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(am[mt], b[d][i][1], acc[i][mt]);
+                        for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][1], am[mt], acc[i][mt]);
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(am[mt], b[d][i][0], acc[i][mt]);
+                        for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][0], am[mt], acc[i][mt]);
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(ah[mt], b[d][i][1], acc[i][mt]);
+                        for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][1], ah[mt], acc[i][mt]);
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(ah[mt], b[d][i][0], acc[i][mt]);
+                        for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][0], ah[mt], acc[i][mt]);
                     }
                 if (kb + D < nkb) {
 #pragma unroll
@@ -466,8 +484,8 @@ DEVI void gemm_wide_units(const lfloat* A, int lda, int rowsA, const float* __re
                 const f32x4 a0 = *(const lf32x4*)(ap + 16 * kb), a1 = *(const lf32x4*)(ap + 16 * kb + 16);
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s4], b[d][kb][s4], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s4], b[d][kb + 1][s4], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[d][kb][s4], a0[s4], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b[d][kb + 1][s4], a1[s4], acc1, 0, 0, 0);
                 }
             }
             epi(nt, mt, acc0 + acc1);
@@ -525,7 +543,7 @@ DEVI void gemm_tall_kb(f32x4 (&acc)[NTW][MT], int nkb, KF kf, const lfloat* A, i
                         if (tok[i]) {
 #pragma unroll
                             for (int mt = 0; mt < MT; ++mt)
-                                acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[mt], b[d][i][0], acc[i][mt], 0, 0, 0);
+                                acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[d][i][0], ax[mt], acc[i][mt], 0, 0, 0);
                         }
                 } else {
                     f32x4 a[MT];
@@ -538,7 +556,7 @@ DEVI void gemm_tall_kb(f32x4 (&acc)[NTW][MT], int nkb, KF kf, const lfloat* A, i
                             if (tok[i]) {
 #pragma unroll
                                 for (int mt = 0; mt < MT; ++mt)
-                                    acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s4], b[d][i][s4], acc[i][mt], 0, 0, 0);
+                                    acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[d][i][s4], a[mt][s4], acc[i][mt], 0, 0, 0);
                             }
                 }
                 if (ib + D < nkb) {
@@ -567,19 +585,17 @@ DEVI void store_tall(const f32x4 (&acc)[NTW][MT], float* out, int ld, int rows, 
                      const float* __restrict__ bias) {
     const int tid_ = tid_now();
     const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
-    const int quad = lane >> 4, col = lane & 15;
+    const int quad = lane >> 4, rl = lane & 15;
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
         const int nt = wave + DFF_NWAVES * i;
         if (nt >= ntiles) continue;
-        const float bv = bias ? bias[16 * nt + col] : 0.f;
+        const f32x4 bv = bias ? *(const f32x4*)(bias + 16 * nt + 4 * quad) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = mt * 16 + quad * 4 + r;
-                if (row < rows) out[row * ld + 16 * nt + col] = acc[i][mt][r] + bv;
-            }
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row = mt * 16 + rl;
+            if (row < rows) *(f32x4*)(out + row * ld + 16 * nt + 4 * quad) = acc[i][mt] + bv;
+        }
     }
 }
 
@@ -1561,28 +1577,21 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     const gfloat* bq = (const gfloat*)lw.bqkvx + hg * HGS * DFF_QKVW;
                     gfloat* const sq = sqkv + (size_t)hg * HGS * RN * DFF_QKVW;
                     lfloat* const Rl = geo.Rg;
-                    auto qkv_pre = [=](int nt, float (&aux)[1]) { aux[0] = bq[nt * 16 + (tid & 15)]; };
-                    auto qkv_epi = [=](int nt, int mt, const f32x4& acc, const float (&aux)[1]) {
-                            const int lane = tid & 63, quad = lane >> 4, cl = lane & 15;
+                    auto qkv_pre = [=](int nt, float (&aux)[4]) { ld4_aux(aux, bq + nt * 16 + 4 * ((tid & 63) >> 4)); };
+                    auto qkv_epi = [=](int nt, int mt, const f32x4& acc, const float (&aux)[4]) {
+                            const int lane = tid & 63, c4 = 4 * (lane >> 4), row = mt * 16 + (lane & 15);
                             const int hh = nt / 13, tt = nt - 13 * hh;
                             const int reg = (tt >= 5) + (tt >= 9);
-                            const float bv = aux[0];
-                            lfloat* dstl = Rl + reg * RN * LQ + hh * 80 + 16 * (tt - 5 * reg + (reg >> 1)) + cl;
-                            gfloat* dsts = sq + (size_t)hh * RN * DFF_QKVW + 16 * tt + cl;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int row = mt * 16 + quad * 4 + r;
-                                if (row < rows) {
-                                    const float v = acc[r] + bv;
-                                    dstl[row * LQ] = v;
-                                    st_ntg(dsts + (size_t)row * DFF_QKVW, v);
-                                }
+                            if (row < rows) {
+                                const f32x4 v = acc + (f32x4){aux[0], aux[1], aux[2], aux[3]};
+                                *(lf32x4*)(Rl + reg * RN * LQ + row * LQ + hh * 80 + 16 * (tt - 5 * reg + (reg >> 1)) + c4) = v;
+                                st_ntg4(sq + (size_t)hh * RN * DFF_QKVW + (size_t)row * DFF_QKVW + 16 * tt + c4, v);
                             }
                         };
                     if constexpr (SPW)
-                        gemm_wide_split_sel<MT, H / 32, 1>(asplit, RN, RN, lw.Wqkvx_s, hg * HGS * 13, HGS * 13, qkv_pre, qkv_epi);
+                        gemm_wide_split_sel<MT, H / 32, 4>(asplit, RN, RN, lw.Wqkvx_s, hg * HGS * 13, HGS * 13, qkv_pre, qkv_epi);
                     else
-                        gemm_wide<MT, NT_H, 1>(abufL, LH, RN, lw.Wqkvx_p, NT_H, 0, hg * HGS * 13, HGS * 13, qkv_pre, qkv_epi);
+                        gemm_wide<MT, NT_H, 4>(abufL, LH, RN, lw.Wqkvx_p, NT_H, 0, hg * HGS * 13, HGS * 13, qkv_pre, qkv_epi);
                 }
                 co_fill_x<HGS, GEN>(geo);
                 wg_sync<SPILL>();
@@ -1625,26 +1634,22 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     const gfloat* const b1g = (const gfloat*)lw.b1 + ch * FC;
                     gfloat* const shp = (gfloat*)sb + c.sl.h_pre + ch * FC;
                     lfloat* const hl = geo.Rg;
-                    auto w1_pre = [=](int nt, float (&aux)[1]) { aux[0] = b1g[16 * nt + (tid & 15)]; };
-                    auto w1_epi = [=](int nt, int mt, const f32x4& acc, const float (&aux)[1]) {
-                            const int lane = tid & 63, quad = lane >> 4, cl = 16 * nt + (lane & 15);
-                            const float bv = aux[0];
+                    auto w1_pre = [=](int nt, float (&aux)[4]) { ld4_aux(aux, b1g + 16 * nt + 4 * ((tid & 63) >> 4)); };
+                    auto w1_epi = [=](int nt, int mt, const f32x4& acc, const float (&aux)[4]) {
+                            const int lane = tid & 63, cl = 16 * nt + 4 * (lane >> 4), row = mt * 16 + (lane & 15);
+                            if (row < rows) {
+                                f32x4 gv, gp;
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int row = mt * 16 + quad * 4 + r;
-                                if (row < rows) {
-                                    float gv, gp;
-                                    gelu_both(acc[r] + bv, gv, gp);
-                                    st_ntg(shp + (size_t)row * F + cl, gp);   // the slot "h_pre" holds gelu'(h_pre)
-                                    if constexpr (SPW) store_split((lu16*)hl, RN, FC + 8, row, cl, gv);
-                                    else hl[row * LF + cl] = gv;
-                                }
+                                for (int r = 0; r < 4; ++r) { float v_, p_; gelu_both(acc[r] + aux[r], v_, p_); gv[r] = v_; gp[r] = p_; }
+                                st_ntg4(shp + (size_t)row * F + cl, gp);   // the slot "h_pre" holds gelu'(h_pre)
+                                if constexpr (SPW) store_split4((lu32*)hl, RN, (FC + 8) / 2, row, cl, gv);
+                                else *(lf32x4*)(hl + row * LF + cl) = gv;
                             }
                         };
                     if constexpr (SPW)
-                        gemm_wide_split_sel<MT, H / 32, 1>(asplit, RN, RN, lw.W1_s, ch * (FC / 16), FC / 16, w1_pre, w1_epi);
+                        gemm_wide_split_sel<MT, H / 32, 4>(asplit, RN, RN, lw.W1_s, ch * (FC / 16), FC / 16, w1_pre, w1_epi);
                     else
-                        gemm_wide<MT, NT_H, 1>(abufL, LH, RN, lw.W1_p, NT_H, 0, ch * (FC / 16), FC / 16, w1_pre, w1_epi);
+                        gemm_wide<MT, NT_H, 4>(abufL, LH, RN, lw.W1_p, NT_H, 0, ch * (FC / 16), FC / 16, w1_pre, w1_epi);
                 }
                 wg_sync<SPILL>();
                 pf.tick(8);
@@ -1682,22 +1687,17 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     const gfloat* const shp = (const gfloat*)sb + c.sl.h_pre + ch * FC;
                     lfloat* const hl = geo.Rg;
                     auto w2t_pre = [=](int nt, float (&aux)[4 * MT]) {
-                            const int lane = tid & 63, quad = lane >> 4, cl = 16 * nt + (lane & 15);
+                            const int lane = tid & 63, cl = 16 * nt + 4 * (lane >> 4);
 #pragma unroll
                             for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                                for (int r = 0; r < 4; ++r)
-                                    aux[mt * 4 + r] = ld_ntg(shp + (size_t)min(mt * 16 + quad * 4 + r, rows - 1) * F + cl);
+                                ld4_aux(aux + 4 * mt, shp + (size_t)min(mt * 16 + (lane & 15), rows - 1) * F + cl);
                         };
                     auto w2t_epi = [=](int nt, int mt, const f32x4& acc, const float (&aux)[4 * MT]) {
-                            const int lane = tid & 63, quad = lane >> 4, cl = 16 * nt + (lane & 15);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int row = mt * 16 + quad * 4 + r;
-                                if (row < rows) {
-                                    if constexpr (SPW) store_split((lu16*)hl, RN, FC + 8, row, cl, acc[r] * aux[mt * 4 + r]);
-                                    else hl[row * LF + cl] = acc[r] * aux[mt * 4 + r];
-                                }
+                            const int lane = tid & 63, cl = 16 * nt + 4 * (lane >> 4), row = mt * 16 + (lane & 15);
+                            if (row < rows) {
+                                const f32x4 v = acc * (f32x4){aux[mt * 4], aux[mt * 4 + 1], aux[mt * 4 + 2], aux[mt * 4 + 3]};
+                                if constexpr (SPW) store_split4((lu32*)hl, RN, (FC + 8) / 2, row, cl, v);
+                                else *(lf32x4*)(hl + row * LF + cl) = v;
                             }
                         };
                     if constexpr (SPW)
@@ -1742,14 +1742,14 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     lfloat* const Gl = geo.Rg + 3 * RN * LQ;
                     lfloat* const dxw = geo.dxw;
                     auto gx_epi = [=](int nt, int mt, const f32x4& acc) {
-                            const int lane = tid & 63, quad = lane >> 4, cl = lane & 15;
+                            const int lane = tid & 63, quad = lane >> 4, row = mt * 16 + (lane & 15);
                             const int hh = nt / 5, tt = nt - 5 * hh;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int row = mt * 16 + quad * 4 + r;
-                                if (row < rows) {
-                                    Gl[row * LQ + hh * 80 + 16 * tt + cl] = acc[r];
-                                    if (tt == 4 && cl < 3) dxw[row * 4 + cl] -= acc[r];
+                            if (row < rows) {
+                                *(lf32x4*)(Gl + row * LQ + hh * 80 + 16 * tt + 4 * quad) = acc;
+                                if (tt == 4 && quad == 0) {   // r = dE/dxrel: columns 64..66 of the head
+                                    dxw[row * 4 + 0] -= acc[0];
+                                    dxw[row * 4 + 1] -= acc[1];
+                                    dxw[row * 4 + 2] -= acc[2];
                                 }
                             }
                         };
@@ -1955,12 +1955,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_debug_gemm_kernel(const floa
     gemm_wide<4, KB, 1>((const lfloat*)smem, LD, M, Wp, KB, 0, 0, Nout / 16,
         [=](int, float (&)[1]) {},
         [=](int nt, int mt, const f32x4& acc, const float (&)[1]) {
-            const int lane = threadIdx.x & 63, quad = lane >> 4, col = 16 * nt + (lane & 15);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = mt * 16 + quad * 4 + r;
-                if (row < M) out[row * Nout + col] = acc[r];
-            }
+            const int lane = threadIdx.x & 63, col = 16 * nt + 4 * (lane >> 4), row = mt * 16 + (lane & 15);
+            if (row < M) *(f32x4*)(out + row * Nout + col) = acc;
         });
 }
 
@@ -1991,6 +1987,8 @@ static const Variant g_variants[] = {
     VAR(128, 1, 4, false), VAR(128, 2, 2, false), VAR(128, 3, 1, false), VAR(128, 4, 1, true),
     VAR_SPW(96, 2, 2), VAR_SPW(128, 2, 2), VAR_SPW(128, 3, 1),
     VAR_PAIR(128, 4, 1, true), VAR_PAIR_SPW(128, 3, 1), VAR_PAIR_SPW(128, 2, 2), VAR_PAIR_SPW(96, 2, 2),
+#elif defined(DFF_ONLY_VILLIN)   // development builds: the villin variant alone
+    VAR_SPW(128, 3, 1),
 #else   // development builds: one variant, so that the <= 16-row kernel can be iterated on quickly
     VAR(64, 1, 4, false),
 #endif
