@@ -46,6 +46,8 @@ struct StashLayout {
     unsigned PS;          // leading dimension of a stashed probability row (16 * row tiles)
     unsigned layer_stride;
     unsigned dn_spill;   // offset of the (R,H) spill slot for nodes / dn (after all layers)
+    unsigned junk;       // 256 floats nobody reads: where the stash stores of pad rows / surplus tiles land, so that every
+                         // epilogue issues the same number of stores (the compiler can then count the loads in flight)
     unsigned total;
 };
 
@@ -66,8 +68,8 @@ __host__ __device__ inline StashLayout dff_stash_layout(int N, int G, int H, int
     s.m12 = o;      o += (unsigned)DFF_HEADS * R * 4;   // GEN: [sum_j a x_j (3) | sum_j a |x_j|^2] per head and row
     s.layer_stride = o;
     s.dn_spill = o * (unsigned)L;
-    s.total = s.dn_spill + R * (H + 4);   // indexed with the LDS leading dimension H + 4
-    s.total = (s.total + 63u) & ~63u;
+    s.junk = (s.dn_spill + R * (H + 4) + 3u) & ~3u;   // dn_spill is indexed with the LDS leading dimension H + 4
+    s.total = (s.junk + 256u + 63u) & ~63u;
     return s;
 }
 

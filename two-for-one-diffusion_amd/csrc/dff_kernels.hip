@@ -122,7 +122,7 @@ DEVI void gemm_wide(const lfloat* A, int lda, int rowsA, const float* __restrict
                     pre(nt + DFF_NWAVES * D, aux[d]);
                 }
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) epi(nt, mt, NC == 2 ? acc[mt][0] + acc[mt][NC - 1] : acc[mt][0], auxc);
+                for (int mt = 0; mt < MT; ++mt) epi(nt, mt, NC == 2 ? acc[mt][0] + acc[mt][NC - 1] : acc[mt][0], auxc, true);
             }
         }
     }
@@ -216,7 +216,7 @@ DEVI void gemm_wide_split(const lu32* as, int R, int rowsA, const unsigned* __re
                     pre(nt + DFF_NWAVES * D, aux[d]);
                 }
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) epi(nt, mt, cb[mt] + cs[mt], auxc);
+                for (int mt = 0; mt < MT; ++mt) epi(nt, mt, cb[mt] + cs[mt], auxc, true);
             }
         }
     }
@@ -295,9 +295,88 @@ DEVI void gemm_wide_split_h(const lu32* as, int R, int rowsA, const unsigned* __
                 }
                 if (half == 1) {
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) epi(nt, mt, cb[mt] + cs[mt], auxc);
+                    for (int mt = 0; mt < MT; ++mt) epi(nt, mt, cb[mt] + cs[mt], auxc, true);
                 }
             }
+        }
+    }
+}
+
+// The same, loop-free: NTN is a compile-time tile count, every wave runs ceil(NTN / 8) tiles (a wave without a tile
+// of its own in the last round repeats tile NTN - 1 with valid = false: it would idle at the barrier anyway), and
+// pre / epi issue the SAME global loads and stores for every tile (epilogues redirect what must not be stored to the
+// stash's junk slot).  With no control flow around VMEM the compiler counts the operations in flight exactly;
+// in the looped version every `if` around a store made it wait for one more YOUNGER load, i.e. the ring drained
+// (s_waitcnt vmcnt(0) in front of every MFMA block).  epi(nt, mt, acc, aux, valid).
+template <int MT, int KB32, int NTN, int NAUX, class Pre, class Epi>
+DEVI void gemm_wide_split_st(const lu32* as, int R, int rowsA, const unsigned* __restrict__ Wp, int nt0, Pre pre, Epi epi) {
+    constexpr bool HALVES = KB32 % 2 == 0 && KB32 >= 4;
+    constexpr int NHALF = HALVES ? 2 : 1, HB = KB32 / NHALF, LHS2 = (32 * KB32 + 8) / 2;
+    constexpr int CNT = (NTN + DFF_NWAVES - 1) / DFF_NWAVES, NE = CNT * NHALF;
+    constexpr int DR = NE < (HALVES ? 3 : 2) ? NE : (HALVES ? 3 : 2);
+    constexpr int NA = 3;
+    const int tid_ = tid_now();
+    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+    const int kg = lane >> 4, mm = lane & 15;
+    int rowoff[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) rowoff[mt] = min(mt * 16 + mm, rowsA - 1) * LHS2 + 4 * kg;
+    const gu32x4* wp = (const gu32x4*)Wp + lane;
+    u32x4 b[DR][HB][3];
+    float aux[NA][NAUX];
+    auto tile_of = [&](int i) { return min(wave + DFF_NWAVES * i, NTN - 1); };
+    auto fill = [&](u32x4 (&slot)[HB][3], int e) {
+        const size_t tile = (size_t)(nt0 + tile_of(e / NHALF));
+#pragma unroll
+        for (int kb = 0; kb < HB; ++kb)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) slot[kb][p] = wp[((tile * KB32 + (e % NHALF) * HB + kb) * 3 + p) * 64];
+    };
+#pragma unroll
+    for (int j = 0; j < DR; ++j) {
+        fill(b[j], j);
+        if (j % NHALF == 0) pre(tile_of(j / NHALF), aux[(j / NHALF) % NA]);
+    }
+    // the loads above are issued HERE: left alone, the scheduler sinks each next to its first use (one L2 latency
+    // per k-block instead of one per GEMM)
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 cs[MT], cb[MT];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int i = e / NHALF, half = e % NHALF, slot = e % DR;
+        if (half == 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) { cs[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; cb[mt] = cs[mt]; }
+        }
+        // a surplus tile (last round only) skips its products: a wave-uniform branch with no VMEM inside, so the
+        // counts stay exact, and the wave gets out of the way of its SIMD partner
+        if (NTN % DFF_NWAVES == 0 || i < CNT - 1 || wave + DFF_NWAVES * i < NTN) {
+#pragma unroll
+            for (int kb = 0; kb < HB; ++kb) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int o = rowoff[mt] + 16 * (half * HB + kb);
+                    const u32x4 ah = *(const lu32x4*)(as + o);
+                    const u32x4 am = *(const lu32x4*)(as + R * LHS2 + o);
+                    const u32x4 al = *(const lu32x4*)(as + 2 * R * LHS2 + o);
+                    cs[mt] = mfma_bf16(b[slot][kb][0], al, cs[mt]);
+                    cb[mt] = mfma_bf16(b[slot][kb][0], am, cb[mt]);
+                    cs[mt] = mfma_bf16(b[slot][kb][2], ah, cs[mt]);
+                    cb[mt] = mfma_bf16(b[slot][kb][1], ah, cb[mt]);
+                    cs[mt] = mfma_bf16(b[slot][kb][1], am, cs[mt]);
+                    cb[mt] = mfma_bf16(b[slot][kb][0], ah, cb[mt]);
+                }
+            }
+        }
+        if (e + DR < NE) {
+            fill(b[slot], e + DR);
+            if ((e + DR) % NHALF == 0) pre(tile_of((e + DR) / NHALF), aux[((e + DR) / NHALF) % NA]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (half == NHALF - 1) {
+            const bool valid = wave + DFF_NWAVES * i < NTN;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) epi(tile_of(i), mt, cb[mt] + cs[mt], aux[i % NA], valid);
         }
     }
 }
@@ -440,6 +519,72 @@ DEVI void gemm_tall_split(f32x4 (&acc)[NTW][MT], int nkb, int LS2 /* dwords per 
                         for (int p = 0; p < 3; ++p) b[d][i][p] = wp[(tbase[i] + 3 * (kb + D) + p) * 64];
                 }
             }
+        }
+    }
+}
+
+// The same with a compile-time k-block count: loop-free, so that the ring (D k-blocks ahead) is waited for exactly.
+template <int MT, int NTW, int NKB>
+DEVI void gemm_tall_split_st(f32x4 (&acc)[NTW][MT], int LS2 /* dwords per piece row */, const lu32* as, int R, int rowsA,
+                             const unsigned* __restrict__ Wp, int KBtot, int kb0, int ntiles) {
+    const int tid_ = tid_now();
+    constexpr int D = NKB < 4 ? NKB : 4;
+    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+    const int kg = lane >> 4, mm = lane & 15;
+    int rowoff[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) rowoff[mt] = min(mt * 16 + mm, rowsA - 1) * LS2 + 4 * kg;
+    const gu32x4* wp = (const gu32x4*)Wp + lane;
+    size_t tbase[NTW];
+    bool tok[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int nt = wave + DFF_NWAVES * i;
+        tok[i] = nt < ntiles;
+        tbase[i] = ((size_t)(tok[i] ? nt : 0) * KBtot + kb0) * 3;
+    }
+    if (!tok[0]) return;
+    u32x4 b[D][NTW][3];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) b[d][i][p] = wp[(tbase[i] + 3 * d + p) * 64];
+    __builtin_amdgcn_sched_barrier(0);   // issue the ring's loads here (see gemm_wide_split_st)
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        const int d = kb % D;
+        u32x4 ah[MT], am[MT], al[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int o = rowoff[mt] + 16 * kb;
+            ah[mt] = *(const lu32x4*)(as + o);
+            am[mt] = *(const lu32x4*)(as + R * LS2 + o);
+            al[mt] = *(const lu32x4*)(as + 2 * R * LS2 + o);
+        }
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+            if (i == 0 || tok[i]) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][0], al[mt], acc[i][mt]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][2], ah[mt], acc[i][mt]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][1], am[mt], acc[i][mt]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][0], am[mt], acc[i][mt]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][1], ah[mt], acc[i][mt]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][0], ah[mt], acc[i][mt]);
+            }
+        if (kb + D < NKB) {
+#pragma unroll
+            for (int i = 0; i < NTW; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b[d][i][p] = wp[(tbase[i] + 3 * (kb + D) + p) * 64];
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -1578,18 +1723,18 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     gfloat* const sq = sqkv + (size_t)hg * HGS * RN * DFF_QKVW;
                     lfloat* const Rl = geo.Rg;
                     auto qkv_pre = [=](int nt, float (&aux)[4]) { ld4_aux(aux, bq + nt * 16 + 4 * ((tid & 63) >> 4)); };
-                    auto qkv_epi = [=](int nt, int mt, const f32x4& acc, const float (&aux)[4]) {
+                    gfloat* const junk = (gfloat*)c.stash + c.sl.junk + 4 * (tid & 63);
+                    auto qkv_epi = [=](int nt, int mt, const f32x4& acc, const float (&aux)[4], bool valid) {
                             const int lane = tid & 63, c4 = 4 * (lane >> 4), row = mt * 16 + (lane & 15);
                             const int hh = nt / 13, tt = nt - 13 * hh;
                             const int reg = (tt >= 5) + (tt >= 9);
-                            if (row < rows) {
-                                const f32x4 v = acc + (f32x4){aux[0], aux[1], aux[2], aux[3]};
-                                *(lf32x4*)(Rl + reg * RN * LQ + row * LQ + hh * 80 + 16 * (tt - 5 * reg + (reg >> 1)) + c4) = v;
-                                st_ntg4(sq + (size_t)hh * RN * DFF_QKVW + (size_t)row * DFF_QKVW + 16 * tt + c4, v);
-                            }
+                            const bool ok = valid && row < rows;
+                            const f32x4 v = acc + (f32x4){aux[0], aux[1], aux[2], aux[3]};
+                            if (ok) *(lf32x4*)(Rl + reg * RN * LQ + row * LQ + hh * 80 + 16 * (tt - 5 * reg + (reg >> 1)) + c4) = v;
+                            st_ntg4(ok ? sq + (size_t)hh * RN * DFF_QKVW + (size_t)row * DFF_QKVW + 16 * tt + c4 : junk, v);
                         };
                     if constexpr (SPW)
-                        gemm_wide_split_sel<MT, H / 32, 4>(asplit, RN, RN, lw.Wqkvx_s, hg * HGS * 13, HGS * 13, qkv_pre, qkv_epi);
+                        gemm_wide_split_st<MT, H / 32, HGS * 13, 4>(asplit, RN, RN, lw.Wqkvx_s, hg * HGS * 13, qkv_pre, qkv_epi);
                     else
                         gemm_wide<MT, NT_H, 4>(abufL, LH, RN, lw.Wqkvx_p, NT_H, 0, hg * HGS * 13, HGS * 13, qkv_pre, qkv_epi);
                 }
@@ -1602,7 +1747,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 pf.tick(4);
                 // attn_out += o_ext [W_o ; W_oc]   (K = 80 per head)
                 if constexpr (SPW) {   // 64 regular rows per head on the split path, the extension block on the fp32 one
-                    gemm_tall_split<MT, NTW>(acc_o, 2 * HGS, (64 * HGS + 8) / 2, (const lu32*)(geo.Rg + 3 * RN * LQ), RN, RN,
+                    gemm_tall_split_st<MT, NTW, 2 * HGS>(acc_o, (64 * HGS + 8) / 2, (const lu32*)(geo.Rg + 3 * RN * LQ), RN, RN,
                                              lw.Wox_s, 2 * DFF_HEADS, hg * HGS * 2, NT_H);
                     gemm_tall_kb<MT, NTW, 5>(acc_o, HGS,
                         [=](int i, int& aoff, int& wkb) { aoff = i * 80 + 64; wkb = (hg * HGS + i) * 5 + 4; },
@@ -1635,26 +1780,28 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     gfloat* const shp = (gfloat*)sb + c.sl.h_pre + ch * FC;
                     lfloat* const hl = geo.Rg;
                     auto w1_pre = [=](int nt, float (&aux)[4]) { ld4_aux(aux, b1g + 16 * nt + 4 * ((tid & 63) >> 4)); };
-                    auto w1_epi = [=](int nt, int mt, const f32x4& acc, const float (&aux)[4]) {
+                    gfloat* const junk = (gfloat*)c.stash + c.sl.junk + 4 * (tid & 63);
+                    auto w1_epi = [=](int nt, int mt, const f32x4& acc, const float (&aux)[4], bool valid) {
                             const int lane = tid & 63, cl = 16 * nt + 4 * (lane >> 4), row = mt * 16 + (lane & 15);
-                            if (row < rows) {
-                                f32x4 gv, gp;
+                            const bool ok = valid && row < rows;
+                            f32x4 gv, gp;
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) { float v_, p_; gelu_both(acc[r] + aux[r], v_, p_); gv[r] = v_; gp[r] = p_; }
-                                st_ntg4(shp + (size_t)row * F + cl, gp);   // the slot "h_pre" holds gelu'(h_pre)
+                            for (int r = 0; r < 4; ++r) { float v_, p_; gelu_both(acc[r] + aux[r], v_, p_); gv[r] = v_; gp[r] = p_; }
+                            st_ntg4(ok ? shp + (size_t)row * F + cl : junk, gp);   // the slot "h_pre" holds gelu'(h_pre)
+                            if (ok) {
                                 if constexpr (SPW) store_split4((lu32*)hl, RN, (FC + 8) / 2, row, cl, gv);
                                 else *(lf32x4*)(hl + row * LF + cl) = gv;
                             }
                         };
                     if constexpr (SPW)
-                        gemm_wide_split_sel<MT, H / 32, 4>(asplit, RN, RN, lw.W1_s, ch * (FC / 16), FC / 16, w1_pre, w1_epi);
+                        gemm_wide_split_st<MT, H / 32, FC / 16, 4>(asplit, RN, RN, lw.W1_s, ch * (FC / 16), w1_pre, w1_epi);
                     else
                         gemm_wide<MT, NT_H, 4>(abufL, LH, RN, lw.W1_p, NT_H, 0, ch * (FC / 16), FC / 16, w1_pre, w1_epi);
                 }
                 wg_sync<SPILL>();
                 pf.tick(8);
                 if constexpr (SPW)
-                    gemm_tall_split<MT, NTW>(acc_f, FC / 32, (FC + 8) / 2, (const lu32*)geo.Rg, RN, RN, lw.W2_s, F / 32, ch * (FC / 32), NT_H);
+                    gemm_tall_split_st<MT, NTW, FC / 32>(acc_f, (FC + 8) / 2, (const lu32*)geo.Rg, RN, RN, lw.W2_s, F / 32, ch * (FC / 32), NT_H);
                 else
                 gemm_tall_kb<MT, NTW, 0>(acc_f, FC / 16,
                     [=](int i, int& aoff, int& wkb) { aoff = 16 * i; wkb = ch * (FC / 16) + i; },
@@ -1692,23 +1839,23 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                             for (int mt = 0; mt < MT; ++mt)
                                 ld4_aux(aux + 4 * mt, shp + (size_t)min(mt * 16 + (lane & 15), rows - 1) * F + cl);
                         };
-                    auto w2t_epi = [=](int nt, int mt, const f32x4& acc, const float (&aux)[4 * MT]) {
+                    auto w2t_epi = [=](int nt, int mt, const f32x4& acc, const float (&aux)[4 * MT], bool valid) {
                             const int lane = tid & 63, cl = 16 * nt + 4 * (lane >> 4), row = mt * 16 + (lane & 15);
-                            if (row < rows) {
+                            if (valid && row < rows) {
                                 const f32x4 v = acc * (f32x4){aux[mt * 4], aux[mt * 4 + 1], aux[mt * 4 + 2], aux[mt * 4 + 3]};
                                 if constexpr (SPW) store_split4((lu32*)hl, RN, (FC + 8) / 2, row, cl, v);
                                 else *(lf32x4*)(hl + row * LF + cl) = v;
                             }
                         };
                     if constexpr (SPW)
-                        gemm_wide_split_sel<MT, H / 32, 4 * MT>(asplit, RN, RN, lw.W2T_s, ch * (FC / 16), FC / 16, w2t_pre, w2t_epi);
+                        gemm_wide_split_st<MT, H / 32, FC / 16, 4 * MT>(asplit, RN, RN, lw.W2T_s, ch * (FC / 16), w2t_pre, w2t_epi);
                     else
                         gemm_wide<MT, NT_H, 4 * MT>(abufL, LH, RN, lw.W2T_p, NT_H, 0, ch * (FC / 16), FC / 16, w2t_pre, w2t_epi);
                 }
                 wg_sync<SPILL>();
                 pf.tick(12);
                 if constexpr (SPW)
-                    gemm_tall_split<MT, NTW>(acc_f, FC / 32, (FC + 8) / 2, (const lu32*)geo.Rg, RN, RN, lw.W1T_s, F / 32, ch * (FC / 32), NT_H);
+                    gemm_tall_split_st<MT, NTW, FC / 32>(acc_f, (FC + 8) / 2, (const lu32*)geo.Rg, RN, RN, lw.W1T_s, F / 32, ch * (FC / 32), NT_H);
                 else
                 gemm_tall_kb<MT, NTW, 0>(acc_f, FC / 16,
                     [=](int i, int& aoff, int& wkb) { aoff = 16 * i; wkb = ch * (FC / 16) + i; },
@@ -1954,7 +2101,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_debug_gemm_kernel(const floa
     __syncthreads();
     gemm_wide<4, KB, 1>((const lfloat*)smem, LD, M, Wp, KB, 0, 0, Nout / 16,
         [=](int, float (&)[1]) {},
-        [=](int nt, int mt, const f32x4& acc, const float (&)[1]) {
+        [=](int nt, int mt, const f32x4& acc, const float (&)[1], bool) {
             const int lane = threadIdx.x & 63, col = 16 * nt + 4 * (lane >> 4), row = mt * 16 + (lane & 15);
             if (row < M) *(f32x4*)(out + row * Nout + col) = acc;
         });
@@ -1987,8 +2134,8 @@ static const Variant g_variants[] = {
     VAR(128, 1, 4, false), VAR(128, 2, 2, false), VAR(128, 3, 1, false), VAR(128, 4, 1, true),
     VAR_SPW(96, 2, 2), VAR_SPW(128, 2, 2), VAR_SPW(128, 3, 1),
     VAR_PAIR(128, 4, 1, true), VAR_PAIR_SPW(128, 3, 1), VAR_PAIR_SPW(128, 2, 2), VAR_PAIR_SPW(96, 2, 2),
-#elif defined(DFF_ONLY_VILLIN)   // development builds: the villin variant alone
-    VAR_SPW(128, 3, 1),
+#elif defined(DFF_ONLY)   // development builds: one named variant, e.g. -DDFF_ONLY="VAR_SPW(128,3,1)"
+    DFF_ONLY,
 #else   // development builds: one variant, so that the <= 16-row kernel can be iterated on quickly
     VAR(64, 1, 4, false),
 #endif
