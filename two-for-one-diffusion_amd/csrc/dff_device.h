@@ -299,6 +299,21 @@ DEVI f32x4 mfma_bf16(const u32x4 a, const u32x4 b, const f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// eight consecutive fp32 (x0 = k 0..3, x1 = k 4..7) -> the three bf16-pair operands of v_mfma_f32_16x16x32_bf16 (~44 VALU)
+DEVI void split8(const f32x4& x0, const f32x4& x1, u32x4& h, u32x4& m, u32x4& l) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float e0 = q < 2 ? x0[2 * q] : x1[2 * q - 4], e1 = q < 2 ? x0[2 * q + 1] : x1[2 * q - 3];
+        const unsigned b0 = __float_as_uint(e0), b1 = __float_as_uint(e1);
+        const float r0 = e0 - __uint_as_float(b0 & 0xffff0000u), r1 = e1 - __uint_as_float(b1 & 0xffff0000u);
+        const unsigned c0 = __float_as_uint(r0), c1 = __float_as_uint(r1);
+        const float s0 = r0 - __uint_as_float(c0 & 0xffff0000u), s1 = r1 - __uint_as_float(c1 & 0xffff0000u);
+        h[q] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+        m[q] = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
+        l[q] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // optional per-stage cycle accounting (a.prof != null): thread 0 of block 0 accumulates
 // s_memtime deltas per stage id at stage boundaries; written out at kernel end.

@@ -416,7 +416,7 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
             return e < 67 ? Woc[(size_t)c * 24 + 3 * h + e - 64] : e == 67 ? Wod[(size_t)c * 8 + h] : 0.0;
         };
         UP(pack_b(H, 8 * 208, [&](int k, int n) { return wqkvx(n, k); }), d.Wqkvx_p);
-        d.Wqkvx_s = d.W1_s = d.W2T_s = d.WoxT_s = d.W2_s = d.W1T_s = d.Wox_s = nullptr;
+        d.Wqkvx_s = d.W1_s = d.W2T_s = d.WoxT_s = d.W2_s = d.W1T_s = d.Wox_s = d.WqkvxT_s = nullptr;
         if (m->split) {
             int rc_;
             if ((rc_ = upload_u32(m, pack_b_split(H, 8 * 208, [&](int k, int n) { return wqkvx(n, k); }), &d.Wqkvx_s))) return rc_;
@@ -427,6 +427,10 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
             if ((rc_ = upload_u32(m, pack_b_split(F, H, [&](int k, int n) { return (double)W1[(size_t)k * H + n]; }), &d.W1T_s))) return rc_;
             // the 64 regular rows of every head of [W_o ; W_oc] (the extension rows stay on the fp32 image)
             if ((rc_ = upload_u32(m, pack_b_split(8 * 64, H, [&](int k, int n) { return wox((k / 64) * 80 + k % 64, n); }), &d.Wox_s))) return rc_;
+            // ... and the 192 regular rows [q | k | v] of every head of QKV_ext^T
+            if ((rc_ = upload_u32(m, pack_b_split(8 * 192, H, [&](int c, int n) {
+                     const int h = c / 192, cc = c % 192;
+                     return wqkvx(h * 208 + (cc < 64 ? cc : cc + 16), n); }), &d.WqkvxT_s))) return rc_;
         }
         d.Wqkvx_w = d.W1_w = d.W2T_w = d.WoxT_w = d.Wox_t = d.W2_t = d.W1T_t = d.WqkvxT_t = nullptr;
         if (m->small_split) {

@@ -34,7 +34,7 @@ struct DffLayerDev {
     // backward (transposed orientation)
     const float *W2T_p;           // K=H, Nout=4H   dh  = dff  W2
     // opt-in (DFF_SPLIT_BF16=1): the K = H images as three bf16 pieces per weight (dff_host.hip pack_b_split)
-    const unsigned *Wqkvx_s, *W1_s, *W2T_s, *WoxT_s, *W2_s, *W1T_s, *Wox_s;
+    const unsigned *Wqkvx_s, *W1_s, *W2T_s, *WoxT_s, *W2_s, *W1T_s, *Wox_s, *WqkvxT_s;
     const float *W1T_p;           // K=4H, Nout=H   df  = dhp  W1
     // split-bf16 images of all eight weight GEMMs for the <= 16-row kernel (dff_small.hip SPW variants; dff_host.hip
     // pack_units): *_w K = H, units ordered [tile][k-block]; *_t Nout = H, units ordered [k-block][tile]

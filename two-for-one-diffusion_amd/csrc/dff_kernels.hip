@@ -589,6 +589,77 @@ DEVI void gemm_tall_split_st(f32x4 (&acc)[NTW][MT], int LS2 /* dwords per piece 
     }
 }
 
+// d(LN1 out) += [dq | dk | dv] [W_q | W_k | W_v] of HGS heads on the split engine.  The operand rows live in LDS as fp32
+// (dQ_ext in head buffer regQ, dK in 1, dV in 2: there is no room for their bf16 pieces), so every wave splits the
+// fragments it reads in registers (split8): ~130 VALU next to 18 bf16 MFMAs per 32-column block, against the
+// 24 fp32 MFMAs (32 cycles each, vector port blocked) of the fp32 engine.  Ws = pack_b_split image of the 192 regular
+// rows per head; the extension rows (du) stay on the fp32 image (gemm_tall_kb, one k-step per head).
+template <int MT, int NTW, int HGS>
+DEVI void gemm_tall_qkvT_split(f32x4 (&acc)[NTW][MT], const lfloat* Rg, int regQ, int RN, const unsigned* __restrict__ Ws,
+                               int head0, int ntiles) {
+    constexpr int LQ = 80 * HGS + 4, NKB = 6 * HGS, D = 4, KBtot = 6 * DFF_HEADS;
+    const int tid_ = tid_now();
+    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+    const int kg = lane >> 4, mm = lane & 15;
+    int rowoff[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) rowoff[mt] = min(mt * 16 + mm, RN - 1) * LQ + 8 * kg;
+    const gu32x4* wp = (const gu32x4*)Ws + lane;
+    size_t tbase[NTW];
+    bool tok[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int nt = wave + DFF_NWAVES * i;
+        tok[i] = nt < ntiles;
+        tbase[i] = ((size_t)(tok[i] ? nt : 0) * KBtot + 6 * head0) * 3;
+    }
+    if (!tok[0]) return;
+    u32x4 b[D][NTW][3];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) b[d][i][p] = wp[(tbase[i] + 3 * d + p) * 64];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        const int d = kb % D;
+        const int hh = kb / 6, part = (kb % 6) / 2, half = kb % 2;
+        const int aoff = (part == 0 ? regQ : part) * RN * LQ + hh * 80 + 32 * half;
+        u32x4 ah[MT], am[MT], al[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const lfloat* ap = Rg + aoff + rowoff[mt];
+            const f32x4 x0 = *(const lf32x4*)ap, x1 = *(const lf32x4*)(ap + 4);
+            split8(x0, x1, ah[mt], am[mt], al[mt]);
+        }
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+            if (i == 0 || tok[i]) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][0], al[mt], acc[i][mt]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][2], ah[mt], acc[i][mt]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][1], am[mt], acc[i][mt]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][0], am[mt], acc[i][mt]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][1], ah[mt], acc[i][mt]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][0], ah[mt], acc[i][mt]);
+            }
+        if (kb + D < NKB) {
+#pragma unroll
+            for (int i = 0; i < NTW; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b[d][i][p] = wp[(tbase[i] + 3 * (kb + D) + p) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 template <int MT, int KB32, int NAUX, class Pre, class Epi>
 DEVI void gemm_wide_split_sel(const lu32* as, int R, int rowsA, const unsigned* __restrict__ Wp, int nt0, int ntn, Pre pre, Epi epi) {
     if constexpr (KB32 % 2 == 0 && KB32 >= 4) gemm_wide_split_h<MT, KB32, NAUX>(as, R, rowsA, Wp, nt0, ntn, pre, epi);
@@ -1934,6 +2005,15 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     wg_sync<SPILL>();
                     pf.tick(18);
                     // d(LN1 out) += [dq|du] W_qu + dk W_k + dv W_v   (K order per head [q64|u16|k64|v64])
+                    if constexpr (SPW) {
+                        gemm_tall_qkvT_split<MT, NTW, HGS>(acc_a, geo.Rg, FIVE ? 4 : 3, RN, lw.WqkvxT_s, hg * HGS, NT_H);
+                        gemm_tall_kb<MT, NTW, 13>(acc_a, HGS,
+                            [=](int i, int& aoff, int& wkb) {
+                                aoff = (FIVE ? 4 : 3) * RN * LQ + i * 80 + 64;
+                                wkb = (hg * HGS + i) * 13 + 4;
+                            },
+                            geo.Rg, LQ, RN, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
+                    } else
                     gemm_tall_kb<MT, NTW, 13>(acc_a, 13 * HGS,
                         [=](int i, int& aoff, int& wkb) {
                             const int hh = i / 13, tt = i - 13 * hh;

@@ -227,19 +227,6 @@ DEVI void sfill(u32x4 (&slot)[3], const gu32x4* p, int lane) {
 // requested two tiles ahead are loop-carried, and the s_waitcnt that joins them drains the whole ring every revolution).
 // eight fp32 values of a 32-column block (x0: columns 4 kg .. + 3, x1: columns 16 + 4 kg .. + 3 -- what two ds_read_b128
 // of the fp32 engine's A pattern deliver) -> the three bf16 piece operands; element j sits in half j & 1 of dword j >> 1
-DEVI void split8(const f32x4& x0, const f32x4& x1, u32x4& h, u32x4& m, u32x4& l) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float e0 = q < 2 ? x0[2 * q] : x1[2 * q - 4], e1 = q < 2 ? x0[2 * q + 1] : x1[2 * q - 3];
-        const unsigned b0 = __float_as_uint(e0), b1 = __float_as_uint(e1);
-        const float r0 = e0 - __uint_as_float(b0 & 0xffff0000u), r1 = e1 - __uint_as_float(b1 & 0xffff0000u);
-        const unsigned c0 = __float_as_uint(r0), c1 = __float_as_uint(r1);
-        const float s0 = r0 - __uint_as_float(c0 & 0xffff0000u), s1 = r1 - __uint_as_float(c1 & 0xffff0000u);
-        h[q] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
-        m[q] = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
-        l[q] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
-    }
-}
 template <int KB32>
 DEVI void split_afrag(const f32x4 (&a)[2 * KB32], u32x4 (&ah)[KB32], u32x4 (&am)[KB32], u32x4 (&al)[KB32]) {
 #pragma unroll
