@@ -122,7 +122,7 @@ DEVI void gemm_wide(const lfloat* A, int lda, int rowsA, const float* __restrict
                     pre(nt + DFF_NWAVES * D, aux[d]);
                 }
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) epi(nt, mt, NC == 2 ? acc[mt][0] + acc[mt][NC - 1] : acc[mt][0], auxc, true);
+                for (int mt = 0; mt < MT; ++mt) epi(nt, mt, NC == 2 ? acc[mt][0] + acc[mt][NC - 1] : acc[mt][0], auxc, true, 0);
             }
         }
     }
@@ -216,7 +216,7 @@ DEVI void gemm_wide_split(const lu32* as, int R, int rowsA, const unsigned* __re
                     pre(nt + DFF_NWAVES * D, aux[d]);
                 }
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) epi(nt, mt, cb[mt] + cs[mt], auxc, true);
+                for (int mt = 0; mt < MT; ++mt) epi(nt, mt, cb[mt] + cs[mt], auxc, true, 0);
             }
         }
     }
@@ -295,7 +295,7 @@ DEVI void gemm_wide_split_h(const lu32* as, int R, int rowsA, const unsigned* __
                 }
                 if (half == 1) {
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) epi(nt, mt, cb[mt] + cs[mt], auxc, true);
+                    for (int mt = 0; mt < MT; ++mt) epi(nt, mt, cb[mt] + cs[mt], auxc, true, 0);
                 }
             }
         }
@@ -308,15 +308,17 @@ DEVI void gemm_wide_split_h(const lu32* as, int R, int rowsA, const unsigned* __
 // stash's junk slot).  With no control flow around VMEM the compiler counts the operations in flight exactly;
 // in the looped version every `if` around a store made it wait for one more YOUNGER load, i.e. the ring drained
 // (s_waitcnt vmcnt(0) in front of every MFMA block).  epi(nt, mt, acc, aux, valid).
-template <int MT, int KB32, int NTN, int NAUX, class Pre, class Epi>
+// Waves W0 .. W0 + NWV - 1 share the tiles (the others must not call); epi also gets the round index i (compile time
+// after unrolling: an epilogue may park the tile in registers, see the head loop of the forward pass).
+template <int MT, int KB32, int NTN, int NAUX, int W0 = 0, int NWV = DFF_NWAVES, int DRMAX = 3, class Pre, class Epi>
 DEVI void gemm_wide_split_st(const lu32* as, int R, int rowsA, const unsigned* __restrict__ Wp, int nt0, Pre pre, Epi epi) {
     constexpr bool HALVES = KB32 % 2 == 0 && KB32 >= 4;
     constexpr int NHALF = HALVES ? 2 : 1, HB = KB32 / NHALF, LHS2 = (32 * KB32 + 8) / 2;
-    constexpr int CNT = (NTN + DFF_NWAVES - 1) / DFF_NWAVES, NE = CNT * NHALF;
-    constexpr int DR = NE < (HALVES ? 3 : 2) ? NE : (HALVES ? 3 : 2);
+    constexpr int CNT = (NTN + NWV - 1) / NWV, NE = CNT * NHALF;
+    constexpr int DR0 = HALVES ? (DRMAX < 3 ? DRMAX : 3) : 2, DR = NE < DR0 ? NE : DR0;
     constexpr int NA = 3;
     const int tid_ = tid_now();
-    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6) - W0;
     const int kg = lane >> 4, mm = lane & 15;
     int rowoff[MT];
 #pragma unroll
@@ -324,7 +326,7 @@ DEVI void gemm_wide_split_st(const lu32* as, int R, int rowsA, const unsigned* _
     const gu32x4* wp = (const gu32x4*)Wp + lane;
     u32x4 b[DR][HB][3];
     float aux[NA][NAUX];
-    auto tile_of = [&](int i) { return min(wave + DFF_NWAVES * i, NTN - 1); };
+    auto tile_of = [&](int i) { return min(wave + NWV * i, NTN - 1); };
     auto fill = [&](u32x4 (&slot)[HB][3], int e) {
         const size_t tile = (size_t)(nt0 + tile_of(e / NHALF));
 #pragma unroll
@@ -350,7 +352,7 @@ DEVI void gemm_wide_split_st(const lu32* as, int R, int rowsA, const unsigned* _
         }
         // a surplus tile (last round only) skips its products: a wave-uniform branch with no VMEM inside, so the
         // counts stay exact, and the wave gets out of the way of its SIMD partner
-        if (NTN % DFF_NWAVES == 0 || i < CNT - 1 || wave + DFF_NWAVES * i < NTN) {
+        if (NTN % NWV == 0 || i < CNT - 1 || wave + NWV * i < NTN) {
 #pragma unroll
             for (int kb = 0; kb < HB; ++kb) {
 #pragma unroll
@@ -374,9 +376,9 @@ DEVI void gemm_wide_split_st(const lu32* as, int R, int rowsA, const unsigned* _
             __builtin_amdgcn_sched_barrier(0);
         }
         if (half == NHALF - 1) {
-            const bool valid = wave + DFF_NWAVES * i < NTN;
+            const bool valid = wave + NWV * i < NTN;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) epi(tile_of(i), mt, cb[mt] + cs[mt], aux[i % NA], valid);
+            for (int mt = 0; mt < MT; ++mt) epi(tile_of(i), mt, cb[mt] + cs[mt], aux[i % NA], valid, i);
         }
     }
 }
@@ -1272,7 +1274,8 @@ DEVI void co_fix_g(const CoGeo& g, int hh, int it, int lane) {   // G_ext ext: [
 // SPW: the 64 regular columns of o_ext are written as bf16 pieces ([piece][RN][64 HGS + 8], into R3 | R4, free in the
 // forward pass) for gemm_tall_split; the extension columns stay fp32 in R0.
 template <int MT, int HGS, bool GEN, bool SPW = false>
-DEVI void co_softmax_pv(const CoGeo& g, gfloat* sP /* P block of head hg*HGS */, gfloat* sM /* m12 block of head hg*HGS (GEN) */) {
+DEVI void co_softmax_pv(const CoGeo& g, gfloat* sP /* P block of head hg*HGS */, gfloat* sM /* m12 block of head hg*HGS (GEN) */,
+                        lfloat* oxt = nullptr /* != null: the extension columns of o_ext go here (rows x 16 HGS) instead of R0 */) {
     const int tid_ = tid_now(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     constexpr int LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL, PS = 16 * MT;
     const int quad = lane >> 4, col = lane & 15;
@@ -1326,7 +1329,11 @@ DEVI void co_softmax_pv(const CoGeo& g, gfloat* sP /* P block of head hg*HGS */,
                     if constexpr (SPW) store_split((lu16*)(g.Rg + 3 * g.RN * LQ), g.RN, 64 * HGS + 8, row, hh * 64 + 16 * nt + col, o[nt][r]);
                     else d[16 * nt] = o[nt][r];
                 }
-                if (!GEN) d[64] = o[4][r] - g.xs[row * 4 + min(col, 3)];
+                if (!GEN) {
+                    const float xr = o[4][r] - g.xs[row * 4 + min(col, 3)];
+                    if (oxt) oxt[row * (16 * HGS) + hh * 16 + col] = xr;
+                    else d[64] = xr;
+                }
             }
             if (GEN) {
                 // extension tile [m1 (3) | m2]: xrel = m1 - x_i ; D = |x_i|^2 - 2 x_i.m1 + m2  (columns 0..3 = one DPP quad)
@@ -1779,7 +1786,84 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             pf.tick(1);
             f32x4 acc_o[NTW][MT];
             acc_zero<MT, NTW>(acc_o);
-            for (int hg = hg_lo; hg < hg_hi; ++hg) {
+            // The split variants run the head loop as a two-stage pipeline: the logits / softmax / PV of a head group keep
+            // only HGS * MT waves busy (a wave owns a row tile), so the other waves compute QKV_ext of the NEXT group
+            // meanwhile and park its tiles in registers; they write them (LDS + stash) next to the W_o GEMM of the
+            // current group, once the barrier has retired its q | k | v.  o_ext's extension columns live in dSbuf
+            // (idle in the forward pass) so that R0 is free by then.
+            constexpr bool PIPE = SPW && !GEN && HGS == 1 && MT < DFF_NWAVES;   // HGS = 2: the parked tiles (7 x MT) do not fit the register file
+            lfloat* const oxt = PIPE ? geo.dSbuf : nullptr;
+            auto wo_gemm = [&](int hg) {
+                gemm_tall_split_st<MT, NTW, 2 * HGS>(acc_o, (64 * HGS + 8) / 2, (const lu32*)(geo.Rg + 3 * RN * LQ), RN, RN,
+                                                     lw.Wox_s, 2 * DFF_HEADS, hg * HGS * 2, NT_H);
+                if (oxt)
+                    gemm_tall_kb<MT, NTW, 5>(acc_o, HGS,
+                        [=](int i, int& aoff, int& wkb) { aoff = i * 16; wkb = (hg * HGS + i) * 5 + 4; },
+                        oxt, 16 * HGS, RN, lw.Wox_p, DFF_HEADS * 5, NT_H);
+                else
+                    gemm_tall_kb<MT, NTW, 5>(acc_o, HGS,
+                        [=](int i, int& aoff, int& wkb) { aoff = i * 80 + 64; wkb = (hg * HGS + i) * 5 + 4; },
+                        geo.Rg, LQ, RN, lw.Wox_p, DFF_HEADS * 5, NT_H);
+            };
+            if constexpr (PIPE) if (!cached) {
+                constexpr int NI = HGS * MT, NWH = DFF_NWAVES - NI, NTQ = HGS * 13, CNTH = (NTQ + NWH - 1) / NWH;
+                const int tid = tid_now();
+                lfloat* const Rl = geo.Rg;
+                gfloat* const junk = (gfloat*)c.stash + c.sl.junk + 4 * (tid & 63);
+                auto mk_pre = [=](int hg) {
+                    const gfloat* bq = (const gfloat*)lw.bqkvx + hg * HGS * DFF_QKVW;
+                    return [=](int nt, float (&aux)[4]) { ld4_aux(aux, bq + nt * 16 + 4 * ((tid & 63) >> 4)); };
+                };
+                auto mk_epi = [=](int hg) {
+                    gfloat* const sq = sqkv + (size_t)hg * HGS * RN * DFF_QKVW;
+                    return [=](int nt, int mt, const f32x4& acc, const float (&aux)[4], bool valid, int) {
+                        const int lane = tid & 63, c4 = 4 * (lane >> 4), row = mt * 16 + (lane & 15);
+                        const int hh = nt / 13, tt = nt - 13 * hh;
+                        const int reg = (tt >= 5) + (tt >= 9);
+                        const bool ok = valid && row < rows;
+                        const f32x4 v = acc + (f32x4){aux[0], aux[1], aux[2], aux[3]};
+                        if (ok) *(lf32x4*)(Rl + reg * RN * LQ + row * LQ + hh * 80 + 16 * (tt - 5 * reg + (reg >> 1)) + c4) = v;
+                        st_ntg4(ok ? sq + (size_t)hh * RN * DFF_QKVW + (size_t)row * DFF_QKVW + 16 * tt + c4 : junk, v);
+                    };
+                };
+                gemm_wide_split_st<MT, H / 32, NTQ, 4>(asplit, RN, RN, lw.Wqkvx_s, hg_lo * NTQ, mk_pre(hg_lo), mk_epi(hg_lo));
+                co_fill_x<HGS, GEN>(geo);   // once per layer: the forward pass never overwrites the K_ext / V_ext extension columns
+                wg_sync<SPILL>();
+                pf.tick(3);
+                for (int hg = hg_lo; hg < hg_hi; ++hg) {
+                    const bool more = hg + 1 < hg_hi;
+                    f32x4 held[CNTH][MT];   // per iteration: nothing to keep alive on the softmax waves' path
+                    if (wave_ < NI) {
+                        co_softmax_pv<MT, HGS, GEN, SPW>(geo, sPl + (size_t)hg * HGS * RN * c.sl.PS,
+                                                         (gfloat*)sb + c.sl.m12 + (size_t)hg * HGS * RN * 4, oxt);
+                    } else if (more) {
+                        gemm_wide_split_st<MT, H / 32, NTQ, 1, NI, NWH, 2>(asplit, RN, RN, lw.Wqkvx_s, (hg + 1) * NTQ,
+                            [](int, float (&)[1]) {},
+                            [&](int, int mt, const f32x4& acc, const float (&)[1], bool, int i) { held[i][mt] = acc; });
+                    }
+                    wg_sync<SPILL>();
+                    pf.tick(4);
+                    float bias4[CNTH][4];
+                    if (more && wave_ >= NI) {   // the parked tiles' biases: requested before W_o's weights, used after its products
+                        auto pre = mk_pre(hg + 1);
+#pragma unroll
+                        for (int i = 0; i < CNTH; ++i) pre(min(wave_ - NI + NWH * i, NTQ - 1), bias4[i]);
+                    }
+                    wo_gemm(hg);
+                    if (more && wave_ >= NI) {
+                        auto epi = mk_epi(hg + 1);
+#pragma unroll
+                        for (int i = 0; i < CNTH; ++i) {
+                            const int wv = wave_ - NI + NWH * i;
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt) epi(min(wv, NTQ - 1), mt, held[i][mt], bias4[i], wv < NTQ, i);
+                        }
+                    }
+                    wg_sync<SPILL>();
+                    pf.tick(6);
+                }
+            }
+            for (int hg = hg_lo; hg < ((PIPE && !cached) ? hg_lo : hg_hi); ++hg) {
                 // [q|u|k|v] of HGS heads -> R0,R1,R2 (+ stash)
                 if (cached) {
                     const int tid = tid_now();
@@ -1795,7 +1879,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     lfloat* const Rl = geo.Rg;
                     auto qkv_pre = [=](int nt, float (&aux)[4]) { ld4_aux(aux, bq + nt * 16 + 4 * ((tid & 63) >> 4)); };
                     gfloat* const junk = (gfloat*)c.stash + c.sl.junk + 4 * (tid & 63);
-                    auto qkv_epi = [=](int nt, int mt, const f32x4& acc, const float (&aux)[4], bool valid) {
+                    auto qkv_epi = [=](int nt, int mt, const f32x4& acc, const float (&aux)[4], bool valid, int) {
                             const int lane = tid & 63, c4 = 4 * (lane >> 4), row = mt * 16 + (lane & 15);
                             const int hh = nt / 13, tt = nt - 13 * hh;
                             const int reg = (tt >= 5) + (tt >= 9);
@@ -1813,16 +1897,12 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 wg_sync<SPILL>();
                 pf.tick(3);
                 co_softmax_pv<MT, HGS, GEN, SPW>(geo, sPl + (size_t)hg * HGS * RN * c.sl.PS,
-                                                 (gfloat*)sb + c.sl.m12 + (size_t)hg * HGS * RN * 4);
+                                                 (gfloat*)sb + c.sl.m12 + (size_t)hg * HGS * RN * 4, oxt);
                 wg_sync<SPILL>();
                 pf.tick(4);
                 // attn_out += o_ext [W_o ; W_oc]   (K = 80 per head)
                 if constexpr (SPW) {   // 64 regular rows per head on the split path, the extension block on the fp32 one
-                    gemm_tall_split_st<MT, NTW, 2 * HGS>(acc_o, (64 * HGS + 8) / 2, (const lu32*)(geo.Rg + 3 * RN * LQ), RN, RN,
-                                             lw.Wox_s, 2 * DFF_HEADS, hg * HGS * 2, NT_H);
-                    gemm_tall_kb<MT, NTW, 5>(acc_o, HGS,
-                        [=](int i, int& aoff, int& wkb) { aoff = i * 80 + 64; wkb = (hg * HGS + i) * 5 + 4; },
-                        geo.Rg, LQ, RN, lw.Wox_p, DFF_HEADS * 5, NT_H);
+                    wo_gemm(hg);
                 } else
                 gemm_tall_kb<MT, NTW, 5>(acc_o, 5 * HGS,
                     [=](int i, int& aoff, int& wkb) {
@@ -1852,7 +1932,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     lfloat* const hl = geo.Rg;
                     auto w1_pre = [=](int nt, float (&aux)[4]) { ld4_aux(aux, b1g + 16 * nt + 4 * ((tid & 63) >> 4)); };
                     gfloat* const junk = (gfloat*)c.stash + c.sl.junk + 4 * (tid & 63);
-                    auto w1_epi = [=](int nt, int mt, const f32x4& acc, const float (&aux)[4], bool valid) {
+                    auto w1_epi = [=](int nt, int mt, const f32x4& acc, const float (&aux)[4], bool valid, int) {
                             const int lane = tid & 63, cl = 16 * nt + 4 * (lane >> 4), row = mt * 16 + (lane & 15);
                             const bool ok = valid && row < rows;
                             f32x4 gv, gp;
@@ -1910,7 +1990,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                             for (int mt = 0; mt < MT; ++mt)
                                 ld4_aux(aux + 4 * mt, shp + (size_t)min(mt * 16 + (lane & 15), rows - 1) * F + cl);
                         };
-                    auto w2t_epi = [=](int nt, int mt, const f32x4& acc, const float (&aux)[4 * MT], bool valid) {
+                    auto w2t_epi = [=](int nt, int mt, const f32x4& acc, const float (&aux)[4 * MT], bool valid, int) {
                             const int lane = tid & 63, cl = 16 * nt + 4 * (lane >> 4), row = mt * 16 + (lane & 15);
                             if (valid && row < rows) {
                                 const f32x4 v = acc * (f32x4){aux[mt * 4], aux[mt * 4 + 1], aux[mt * 4 + 2], aux[mt * 4 + 3]};
@@ -2181,7 +2261,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_debug_gemm_kernel(const floa
     __syncthreads();
     gemm_wide<4, KB, 1>((const lfloat*)smem, LD, M, Wp, KB, 0, 0, Nout / 16,
         [=](int, float (&)[1]) {},
-        [=](int nt, int mt, const f32x4& acc, const float (&)[1], bool) {
+        [=](int nt, int mt, const f32x4& acc, const float (&)[1], bool, int) {
             const int lane = threadIdx.x & 63, col = 16 * nt + 4 * (lane >> 4), row = mt * 16 + (lane & 15);
             if (row < M) *(f32x4*)(out + row * Nout + col) = acc;
         });
