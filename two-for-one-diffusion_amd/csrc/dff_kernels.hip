@@ -1640,14 +1640,22 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             unsigned* const flags = a.xflag + 2 * unit;
             const int n4 = ncols / 4;   // ncols % 4 == 0, ld % 4 == 0
             wg_sync<SPILL>();           // the tile is complete
+            // The tile travels as agent-scope relaxed atomics (8 bytes each): such a store is written through to the
+            // device's coherence point and such a load bypasses the non-coherent caches, so publishing needs no
+            // release / acquire FENCE -- at agent scope those write back / invalidate the XCD's whole L2, which is full of
+            // dirty stash lines (measured: ~10 us per exchange, 17 % of the protein G step).  Order is kept at the ISA
+            // level: every thread waits for its own stores (s_waitcnt vmcnt(0)) before the barrier that precedes the flag
+            // store, and the tile is read only after the barrier that follows the flag poll.
             for (int it = tid_; it < c.rows * n4; it += DFF_NTHREADS) {
                 const int row = it / n4, c4 = it - row * n4;
-                *(f32x4*)(mine + (size_t)row * ncols + 4 * c4) = *(const f32x4*)(tile + row * ld + 4 * c4);
+                const f32x4 v = *(const f32x4*)(tile + row * ld + 4 * c4);
+                unsigned long long* dst = (unsigned long long*)(mine + (size_t)row * ncols + 4 * c4);
+                __hip_atomic_store(dst, ((unsigned long long)__float_as_uint(v[1]) << 32) | __float_as_uint(v[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + 1, ((unsigned long long)__float_as_uint(v[3]) << 32) | __float_as_uint(v[2]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid_ == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __hip_atomic_store(flags + hf, xseq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // never hang the GPU: the spin is bounded (~1 s), and once any pair has given up (error word set) nobody spins
                 unsigned* const err = a.xflag + 2 * a.xpairs;
@@ -1660,13 +1668,16 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         break;
                     }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
             __syncthreads();
             for (int it = tid_; it < c.rows * n4; it += DFF_NTHREADS) {
                 const int row = it / n4, c4 = it - row * n4;
                 float* const t = tile + row * ld + 4 * c4;
-                *(f32x4*)t = *(const f32x4*)t + *(const f32x4*)(theirs + (size_t)row * ncols + 4 * c4);
+                unsigned long long* src = (unsigned long long*)(theirs + (size_t)row * ncols + 4 * c4);
+                const unsigned long long p0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long p1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *(f32x4*)t = *(const f32x4*)t + (f32x4){__uint_as_float((unsigned)p0), __uint_as_float((unsigned)(p0 >> 32)),
+                                                        __uint_as_float((unsigned)p1), __uint_as_float((unsigned)(p1 >> 32))};
             }
             wg_sync<SPILL>();
             ++xseq;
