@@ -1640,7 +1640,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             unsigned* const flags = a.xflag + 2 * unit;
             const int n4 = ncols / 4;   // ncols % 4 == 0, ld % 4 == 0
             wg_sync<SPILL>();           // the tile is complete
-            // The tile travels as agent-scope relaxed atomics (8 bytes each): such a store is written through to the
+            // The tile travels as agent-scope (sc1) 16-byte stores and loads: such a store is written through to the
             // device's coherence point and such a load bypasses the non-coherent caches, so publishing needs no
             // release / acquire FENCE -- at agent scope those write back / invalidate the XCD's whole L2, which is full of
             // dirty stash lines (measured: ~10 us per exchange, 17 % of the protein G step).  Order is kept at the ISA
@@ -1649,9 +1649,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             for (int it = tid_; it < c.rows * n4; it += DFF_NTHREADS) {
                 const int row = it / n4, c4 = it - row * n4;
                 const f32x4 v = *(const f32x4*)(tile + row * ld + 4 * c4);
-                unsigned long long* dst = (unsigned long long*)(mine + (size_t)row * ncols + 4 * c4);
-                __hip_atomic_store(dst, ((unsigned long long)__float_as_uint(v[1]) << 32) | __float_as_uint(v[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(dst + 1, ((unsigned long long)__float_as_uint(v[3]) << 32) | __float_as_uint(v[2]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(mine + (size_t)row * ncols + 4 * c4), "v"(v) : "memory");
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -1670,14 +1668,26 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 }
             }
             __syncthreads();
-            for (int it = tid_; it < c.rows * n4; it += DFF_NTHREADS) {
-                const int row = it / n4, c4 = it - row * n4;
-                float* const t = tile + row * ld + 4 * c4;
-                unsigned long long* src = (unsigned long long*)(theirs + (size_t)row * ncols + 4 * c4);
-                const unsigned long long p0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long p1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                *(f32x4*)t = *(const f32x4*)t + (f32x4){__uint_as_float((unsigned)p0), __uint_as_float((unsigned)(p0 >> 32)),
-                                                        __uint_as_float((unsigned)p1), __uint_as_float((unsigned)(p1 >> 32))};
+            {   // all of this thread's loads in flight at once (at most 4: rows <= 64, ncols <= 128), one wait, then the adds
+                f32x4 pv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int it = tid_ + k * DFF_NTHREADS;
+                    const int row = it / n4, c4 = it - row * n4;
+                    pv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (it < c.rows * n4)
+                        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(pv[k]) : "v"(theirs + (size_t)row * ncols + 4 * c4) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3])::"memory");
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int it = tid_ + k * DFF_NTHREADS;
+                    const int row = it / n4, c4 = it - row * n4;
+                    if (it < c.rows * n4) {
+                        float* const t = tile + row * ld + 4 * c4;
+                        *(f32x4*)t = *(const f32x4*)t + pv[k];
+                    }
+                }
             }
             wg_sync<SPILL>();
             ++xseq;
