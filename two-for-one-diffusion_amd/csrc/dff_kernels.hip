@@ -128,6 +128,68 @@ DEVI void gemm_wide(const lfloat* A, int lda, int rowsA, const float* __restrict
     }
 }
 
+// gemm_wide, loop-free (see gemm_wide_split_st below for why): NTN tiles over the 8 waves, ceil(NTN / 8) rounds, ring of
+// half tiles (KB / 2 k-blocks), a surplus tile in the last round repeats tile NTN - 1 with valid = false, and pre / epi
+// issue the same VMEM operations for every tile.
+template <int MT, int KB, int NTN, int NAUX, class Pre, class Epi>
+DEVI void gemm_wide_st(const lfloat* A, int lda, int rowsA, const float* __restrict__ Wp, int nt0, Pre pre, Epi epi) {
+    static_assert(KB % 2 == 0, "even number of k-blocks");
+    constexpr int HB = KB / 2, CNT = (NTN + DFF_NWAVES - 1) / DFF_NWAVES, NE = 2 * CNT, DR = NE < 3 ? NE : 3, NA = 3;
+    const int tid_ = tid_now();
+    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+    const int kk = lane >> 4, mm = lane & 15;
+    int rowoff[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) rowoff[mt] = min(mt * 16 + mm, rowsA - 1) * lda + 4 * kk;
+    const gf32x4* wp = (const gf32x4*)Wp + lane;
+    f32x4 b[DR][HB];
+    float aux[NA][NAUX];
+    auto tile_of = [&](int i) { return min(wave + DFF_NWAVES * i, NTN - 1); };
+    auto fill = [&](f32x4 (&slot)[HB], int e) {
+        const size_t tile = (size_t)(nt0 + tile_of(e / 2));
+#pragma unroll
+        for (int kb = 0; kb < HB; ++kb) slot[kb] = wp[(tile * KB + (e % 2) * HB + kb) * 64];
+    };
+#pragma unroll
+    for (int j = 0; j < DR; ++j) {
+        fill(b[j], j);
+        if (j % 2 == 0) pre(tile_of(j / 2), aux[(j / 2) % NA]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[MT];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int i = e / 2, half = e % 2, slot = e % DR;
+        if (half == 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (NTN % DFF_NWAVES == 0 || i < CNT - 1 || wave + DFF_NWAVES * i < NTN) {
+#pragma unroll
+            for (int kb = 0; kb < HB; ++kb) {
+                f32x4 a[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a[mt] = *(const lf32x4*)(A + rowoff[mt] + 16 * (half * HB + kb));
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[slot][kb][s4], a[mt][s4], acc[mt], 0, 0, 0);
+            }
+        }
+        if (e + DR < NE) {
+            fill(b[slot], e + DR);
+            if ((e + DR) % 2 == 0) pre(tile_of((e + DR) / 2), aux[((e + DR) / 2) % NA]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (half == 1) {
+            const bool valid = wave + DFF_NWAVES * i < NTN;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) epi(tile_of(i), mt, acc[mt], aux[i % NA], valid, i);
+        }
+    }
+}
+
 // abuf (R x H fp32, leading dimension H + 4) -> as[piece][row][LHS2] (bf16 pairs): all threads, two columns each
 template <int H>
 DEVI void split_rows(const lfloat* abuf, lu32* as, int R) {
@@ -785,6 +847,77 @@ DEVI void gemm_tall_kb(f32x4 (&acc)[NTW][MT], int nkb, KF kf, const lfloat* A, i
                     for (int i = 0; i < NTW; ++i) b[d][i] = wp[(tbase[i] + wkb) * 64];
                 }
             }
+        }
+    }
+}
+
+// gemm_tall_kb with a compile-time block count: loop-free (exact waits for the ring of D k-blocks)
+template <int MT, int NTW, int XPER, int NKB, class KF>
+DEVI void gemm_tall_kb_st(f32x4 (&acc)[NTW][MT], KF kf, const lfloat* A, int lda, int rowsA,
+                          const float* __restrict__ Wp, int KBtot, int ntiles) {
+    const int tid_ = tid_now();
+    constexpr int D = NKB < 4 ? NKB : 4;
+    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+    const int kk = lane >> 4, mm = lane & 15;
+    int rowoff[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) rowoff[mt] = min(mt * 16 + mm, rowsA - 1) * lda + 4 * kk;
+    const gf32x4* wp = (const gf32x4*)Wp + lane;
+    size_t tbase[NTW];
+    bool tok[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int nt = wave + DFF_NWAVES * i;
+        tok[i] = nt < ntiles;
+        tbase[i] = (size_t)(tok[i] ? nt : 0) * KBtot;
+    }
+    if (!tok[0]) return;
+    f32x4 b[D][NTW];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        int aoff_, wkb;
+        kf(d, aoff_, wkb);
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) b[d][i] = wp[(tbase[i] + wkb) * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ib = 0; ib < NKB; ++ib) {
+        const int d = ib % D;
+        int aoff, wkb;
+        kf(ib, aoff, wkb);
+        const bool ext = XPER > 0 && wkb % (XPER > 0 ? XPER : 1) == 4;
+        if (ext) {
+            float ax[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) ax[mt] = A[aoff + rowoff[mt] - 3 * kk];
+#pragma unroll
+            for (int i = 0; i < NTW; ++i)
+                if (i == 0 || tok[i]) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[d][i][0], ax[mt], acc[i][mt], 0, 0, 0);
+                }
+        } else {
+            f32x4 a[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = *(const lf32x4*)(A + aoff + rowoff[mt]);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int i = 0; i < NTW; ++i)
+                    if (i == 0 || tok[i]) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[d][i][s4], a[mt][s4], acc[i][mt], 0, 0, 0);
+                    }
+        }
+        if (ib + D < NKB) {
+            int aoff2, wkb2;
+            kf(ib + D, aoff2, wkb2);
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) b[d][i] = wp[(tbase[i] + wkb2) * 64];
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -1912,7 +2045,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     if constexpr (SPW)
                         gemm_wide_split_st<MT, H / 32, HGS * 13, 4>(asplit, RN, RN, lw.Wqkvx_s, hg * HGS * 13, qkv_pre, qkv_epi);
                     else
-                        gemm_wide<MT, NT_H, 4>(abufL, LH, RN, lw.Wqkvx_p, NT_H, 0, hg * HGS * 13, HGS * 13, qkv_pre, qkv_epi);
+                        gemm_wide_st<MT, NT_H, HGS * 13, 4>(abufL, LH, RN, lw.Wqkvx_p, hg * HGS * 13, qkv_pre, qkv_epi);
                 }
                 co_fill_x<HGS, GEN>(geo);
                 wg_sync<SPILL>();
@@ -1925,7 +2058,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 if constexpr (SPW) {   // 64 regular rows per head on the split path, the extension block on the fp32 one
                     wo_gemm(hg);
                 } else
-                gemm_tall_kb<MT, NTW, 5>(acc_o, 5 * HGS,
+                gemm_tall_kb_st<MT, NTW, 5, 5 * HGS>(acc_o,
                     [=](int i, int& aoff, int& wkb) {
                         const int hh = i / 5, kb = i - 5 * hh;
                         aoff = hh * 80 + 16 * kb;
@@ -1968,14 +2101,14 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     if constexpr (SPW)
                         gemm_wide_split_st<MT, H / 32, FC / 16, 4>(asplit, RN, RN, lw.W1_s, ch * (FC / 16), w1_pre, w1_epi);
                     else
-                        gemm_wide<MT, NT_H, 4>(abufL, LH, RN, lw.W1_p, NT_H, 0, ch * (FC / 16), FC / 16, w1_pre, w1_epi);
+                        gemm_wide_st<MT, NT_H, FC / 16, 4>(abufL, LH, RN, lw.W1_p, ch * (FC / 16), w1_pre, w1_epi);
                 }
                 wg_sync<SPILL>();
                 pf.tick(8);
                 if constexpr (SPW)
                     gemm_tall_split_st<MT, NTW, FC / 32>(acc_f, (FC + 8) / 2, (const lu32*)geo.Rg, RN, RN, lw.W2_s, F / 32, ch * (FC / 32), NT_H);
                 else
-                gemm_tall_kb<MT, NTW, 0>(acc_f, FC / 16,
+                gemm_tall_kb_st<MT, NTW, 0, FC / 16>(acc_f,
                     [=](int i, int& aoff, int& wkb) { aoff = 16 * i; wkb = ch * (FC / 16) + i; },
                     geo.Rg, LF, RN, lw.W2_p, F / 16, NT_H);
                 wg_sync<SPILL>();
@@ -2022,14 +2155,14 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     if constexpr (SPW)
                         gemm_wide_split_st<MT, H / 32, FC / 16, 4 * MT>(asplit, RN, RN, lw.W2T_s, ch * (FC / 16), w2t_pre, w2t_epi);
                     else
-                        gemm_wide<MT, NT_H, 4 * MT>(abufL, LH, RN, lw.W2T_p, NT_H, 0, ch * (FC / 16), FC / 16, w2t_pre, w2t_epi);
+                        gemm_wide_st<MT, NT_H, FC / 16, 4 * MT>(abufL, LH, RN, lw.W2T_p, ch * (FC / 16), w2t_pre, w2t_epi);
                 }
                 wg_sync<SPILL>();
                 pf.tick(12);
                 if constexpr (SPW)
                     gemm_tall_split_st<MT, NTW, FC / 32>(acc_f, (FC + 8) / 2, (const lu32*)geo.Rg, RN, RN, lw.W1T_s, F / 32, ch * (FC / 32), NT_H);
                 else
-                gemm_tall_kb<MT, NTW, 0>(acc_f, FC / 16,
+                gemm_tall_kb_st<MT, NTW, 0, FC / 16>(acc_f,
                     [=](int i, int& aoff, int& wkb) { aoff = 16 * i; wkb = ch * (FC / 16) + i; },
                     geo.Rg, LF, RN, lw.W1T_p, F / 16, NT_H);
                 wg_sync<SPILL>();
@@ -2115,7 +2248,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                             },
                             geo.Rg, LQ, RN, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
                     } else
-                    gemm_tall_kb<MT, NTW, 13>(acc_a, 13 * HGS,
+                    gemm_tall_kb_st<MT, NTW, 13, 13 * HGS>(acc_a,
                         [=](int i, int& aoff, int& wkb) {
                             const int hh = i / 13, tt = i - 13 * hh;
                             const int part = (tt >= 5) + (tt >= 9);
