@@ -52,12 +52,18 @@ def hbm_traffic_from_profile(kname, cfg, P, chunk):
     gfx950 x2 read correction) for this exact kernel + workload: profiles/<round>/**/traffic.json (latest round wins)."""
     best = None
 
-    def norm(n):   # rocprofv3 prints the full template argument list, the library the short name
-        n = n.replace(" ", "")
-        for suffix in (",false,false>", ",false>"):
-            if n.endswith(suffix):
-                n = n[:-len(suffix)] + ">"
-        return n.replace(",false,true>", ",split_bf16>")
+    def norm(n):   # rocprofv3 prints the full template argument list, the library its own short name
+        n = n.replace(" ", "").replace("void", "")
+        if "<" not in n:
+            return n
+        base, args = n.split("<", 1)
+        args = args.rstrip(">").split(",")
+        if all(x in ("true", "false") or x.isdigit() for x in args):   # rocprofv3 form
+            flags = (("gen", "split_bf16") if base == "dff_small_kernel" else ("gen", "split_bf16", "pair"))
+            nfix = 2 if base == "dff_small_kernel" else 4               # <H, NW, ...> / <H, MT, HGS, SPILL, ...>
+            tail = [f for f, v in zip(flags, args[nfix:]) if v == "true"]
+            args = args[:nfix] + tail
+        return base + "<" + ",".join(args) + ">"
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "**", "traffic.json"), recursive=True)):
         try:
             t = json.load(open(f))
