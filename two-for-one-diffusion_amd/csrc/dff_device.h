@@ -9,6 +9,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define DEVI __device__ __forceinline__
 
 #define DFF_QKVW 208    // stash row of one head: [q_ext 80 | k 64 | v 64]
+// Row padding (bf16 elements) of every split A operand in LDS.  A row stride of 8 dwords mod 64 makes the ds_read_b128
+// fragment reads conflict-free: the 16 lanes of a read group are rows {0-3, 12-15} of one 8-element k-group and rows
+// {4-11} of the next, i.e. bank slots (2 row + kg) mod 16 = all even | all odd.  (8 elements = 4 dwords mod 64 put row 11
+// of k-group 1 on row 12 of k-group 0: 41 % conflict cycles in profiles/r02/villin.)
+#define DFF_SPAD 16
 
 // Explicitly address-space-typed pointers: the hot lambdas capture pointers by reference and some
 // closures end up in memory, where a plain `float*` loses its provenance and every access turns
@@ -88,7 +93,7 @@ struct LdsLayout {
     static constexpr int FC = (F % 256 == 0) ? 256 : 128;
     static constexpr int LF = FC + 4;
     static constexpr int NREG = MT < 4 ? 5 : 4;   // a fifth head-group buffer (backward: dQ_ext) where LDS allows
-    static constexpr int LHS2 = (H + 8) / 2;   // dwords per row of a bf16 piece of the split A operand (SPW variants)
+    static constexpr int LHS2 = (H + DFF_SPAD) / 2;   // dwords per row of a bf16 piece of the split A operand (SPW variants)
     unsigned xst, xs, dxs, vst, cm, tn, prof, prow, dxw, m12, abuf, resbuf, Pbuf, dSbuf, Rg, asplit, total;
     __host__ __device__ LdsLayout(int N, int G, bool spw = false) {
         const unsigned R = (unsigned)(G * N);

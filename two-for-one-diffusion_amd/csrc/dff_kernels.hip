@@ -193,7 +193,7 @@ DEVI void gemm_wide_st(const lfloat* A, int lda, int rowsA, const float* __restr
 // abuf (R x H fp32, leading dimension H + 4) -> as[piece][row][LHS2] (bf16 pairs): all threads, two columns each
 template <int H>
 DEVI void split_rows(const lfloat* abuf, lu32* as, int R) {
-    constexpr int LH = H + 4, LHS2 = (H + 8) / 2;
+    constexpr int LH = H + 4, LHS2 = (H + DFF_SPAD) / 2;
     const int tid_ = tid_now();
     for (int it = tid_; it < R * (H / 2); it += DFF_NTHREADS) {
         const int row = it / (H / 2), c2 = it - row * (H / 2);
@@ -217,7 +217,7 @@ DEVI void split_rows(const lfloat* abuf, lu32* as, int R) {
 template <int MT, int KB32, int NAUX, class Pre, class Epi>
 DEVI void gemm_wide_split(const lu32* as, int R, int rowsA, const unsigned* __restrict__ Wp, int nt0, int ntn, Pre pre, Epi epi) {
     const int tid_ = tid_now();
-    constexpr int D = 2, LHS2 = (32 * KB32 + 8) / 2;
+    constexpr int D = 2, LHS2 = (32 * KB32 + DFF_SPAD) / 2;
     const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     const int kg = lane >> 4, mm = lane & 15;
     int rowoff[MT];
@@ -291,7 +291,7 @@ template <int MT, int KB32, int NAUX, class Pre, class Epi>
 DEVI void gemm_wide_split_h(const lu32* as, int R, int rowsA, const unsigned* __restrict__ Wp, int nt0, int ntn, Pre pre, Epi epi) {
     static_assert(KB32 % 2 == 0, "even number of 32-row k-blocks");
     const int tid_ = tid_now();
-    constexpr int HB = KB32 / 2, LHS2 = (32 * KB32 + 8) / 2;
+    constexpr int HB = KB32 / 2, LHS2 = (32 * KB32 + DFF_SPAD) / 2;
     const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     const int kg = lane >> 4, mm = lane & 15;
     int rowoff[MT];
@@ -375,7 +375,7 @@ DEVI void gemm_wide_split_h(const lu32* as, int R, int rowsA, const unsigned* __
 template <int MT, int KB32, int NTN, int NAUX, int W0 = 0, int NWV = DFF_NWAVES, int DRMAX = 3, class Pre, class Epi>
 DEVI void gemm_wide_split_st(const lu32* as, int R, int rowsA, const unsigned* __restrict__ Wp, int nt0, Pre pre, Epi epi) {
     constexpr bool HALVES = KB32 % 2 == 0 && KB32 >= 4;
-    constexpr int NHALF = HALVES ? 2 : 1, HB = KB32 / NHALF, LHS2 = (32 * KB32 + 8) / 2;
+    constexpr int NHALF = HALVES ? 2 : 1, HB = KB32 / NHALF, LHS2 = (32 * KB32 + DFF_SPAD) / 2;
     constexpr int CNT = (NTN + NWV - 1) / NWV, NE = CNT * NHALF;
     constexpr int DR0 = HALVES ? (DRMAX < 3 ? DRMAX : 3) : 2, DR = NE < DR0 ? NE : DR0;
     constexpr int NA = 3;
@@ -449,7 +449,7 @@ DEVI void gemm_wide_split_st(const lu32* as, int R, int rowsA, const unsigned* _
 template <int MT, int KB32, int NTN, class Epi>
 DEVI void gemm_wide_units_split(const lu32* as, int R, int rowsA, const unsigned* __restrict__ Wp, int nt0, Epi epi) {
     const int tid_ = tid_now();
-    constexpr int NU = NTN * MT, DU = (NU + DFF_NWAVES - 1) / DFF_NWAVES, LHS2 = (32 * KB32 + 8) / 2;
+    constexpr int NU = NTN * MT, DU = (NU + DFF_NWAVES - 1) / DFF_NWAVES, LHS2 = (32 * KB32 + DFF_SPAD) / 2;
     const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     const int kg = lane >> 4, mm = lane & 15;
     const gu32x4* wp = (const gu32x4*)Wp + lane;
@@ -1459,7 +1459,7 @@ DEVI void co_softmax_pv(const CoGeo& g, gfloat* sP /* P block of head hg*HGS */,
                 lfloat* d = g.Rg + row * LQ + hh * 80 + col;
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
-                    if constexpr (SPW) store_split((lu16*)(g.Rg + 3 * g.RN * LQ), g.RN, 64 * HGS + 8, row, hh * 64 + 16 * nt + col, o[nt][r]);
+                    if constexpr (SPW) store_split((lu16*)(g.Rg + 3 * g.RN * LQ), g.RN, 64 * HGS + DFF_SPAD, row, hh * 64 + 16 * nt + col, o[nt][r]);
                     else d[16 * nt] = o[nt][r];
                 }
                 if (!GEN) {
@@ -1948,7 +1948,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             constexpr bool PIPE = SPW && !GEN && HGS == 1 && MT < DFF_NWAVES;   // HGS = 2: the parked tiles (7 x MT) do not fit the register file
             lfloat* const oxt = PIPE ? geo.dSbuf : nullptr;
             auto wo_gemm = [&](int hg) {
-                gemm_tall_split_st<MT, NTW, 2 * HGS>(acc_o, (64 * HGS + 8) / 2, (const lu32*)(geo.Rg + 3 * RN * LQ), RN, RN,
+                gemm_tall_split_st<MT, NTW, 2 * HGS>(acc_o, (64 * HGS + DFF_SPAD) / 2, (const lu32*)(geo.Rg + 3 * RN * LQ), RN, RN,
                                                      lw.Wox_s, 2 * DFF_HEADS, hg * HGS * 2, NT_H);
                 if (oxt)
                     gemm_tall_kb<MT, NTW, 5>(acc_o, HGS,
@@ -2094,7 +2094,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                             for (int r = 0; r < 4; ++r) { float v_, p_; gelu_both(acc[r] + aux[r], v_, p_); gv[r] = v_; gp[r] = p_; }
                             st_ntg4(ok ? shp + (size_t)row * F + cl : junk, gp);   // the slot "h_pre" holds gelu'(h_pre)
                             if (ok) {
-                                if constexpr (SPW) store_split4((lu32*)hl, RN, (FC + 8) / 2, row, cl, gv);
+                                if constexpr (SPW) store_split4((lu32*)hl, RN, (FC + DFF_SPAD) / 2, row, cl, gv);
                                 else *(lf32x4*)(hl + row * LF + cl) = gv;
                             }
                         };
@@ -2106,7 +2106,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 wg_sync<SPILL>();
                 pf.tick(8);
                 if constexpr (SPW)
-                    gemm_tall_split_st<MT, NTW, FC / 32>(acc_f, (FC + 8) / 2, (const lu32*)geo.Rg, RN, RN, lw.W2_s, F / 32, ch * (FC / 32), NT_H);
+                    gemm_tall_split_st<MT, NTW, FC / 32>(acc_f, (FC + DFF_SPAD) / 2, (const lu32*)geo.Rg, RN, RN, lw.W2_s, F / 32, ch * (FC / 32), NT_H);
                 else
                 gemm_tall_kb_st<MT, NTW, 0, FC / 16>(acc_f,
                     [=](int i, int& aoff, int& wkb) { aoff = 16 * i; wkb = ch * (FC / 16) + i; },
@@ -2148,7 +2148,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                             const int lane = tid & 63, cl = 16 * nt + 4 * (lane >> 4), row = mt * 16 + (lane & 15);
                             if (valid && row < rows) {
                                 const f32x4 v = acc * (f32x4){aux[mt * 4], aux[mt * 4 + 1], aux[mt * 4 + 2], aux[mt * 4 + 3]};
-                                if constexpr (SPW) store_split4((lu32*)hl, RN, (FC + 8) / 2, row, cl, v);
+                                if constexpr (SPW) store_split4((lu32*)hl, RN, (FC + DFF_SPAD) / 2, row, cl, v);
                                 else *(lf32x4*)(hl + row * LF + cl) = v;
                             }
                         };
@@ -2160,7 +2160,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 wg_sync<SPILL>();
                 pf.tick(12);
                 if constexpr (SPW)
-                    gemm_tall_split_st<MT, NTW, FC / 32>(acc_f, (FC + 8) / 2, (const lu32*)geo.Rg, RN, RN, lw.W1T_s, F / 32, ch * (FC / 32), NT_H);
+                    gemm_tall_split_st<MT, NTW, FC / 32>(acc_f, (FC + DFF_SPAD) / 2, (const lu32*)geo.Rg, RN, RN, lw.W1T_s, F / 32, ch * (FC / 32), NT_H);
                 else
                 gemm_tall_kb_st<MT, NTW, 0, FC / 16>(acc_f,
                     [=](int i, int& aoff, int& wkb) { aoff = 16 * i; wkb = ch * (FC / 16) + i; },
