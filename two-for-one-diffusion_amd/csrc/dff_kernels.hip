@@ -489,6 +489,50 @@ DEVI void gemm_wide_units_split(const lu32* as, int R, int rowsA, const unsigned
     }
 }
 
+// The (tile, row-tile) units of ONE head's G_ext GEMM (5 column tiles x MT row tiles) on waves W0 .. W0 + NWV - 1 only,
+// results parked in registers (backward head pipeline: the other waves are busy with dS meanwhile).  Unit u = w + NWV d.
+template <int MT, int KB32, int W0, int NWV>
+DEVI void gx_units_hold(const lu32* as, int R, int rowsA, const unsigned* __restrict__ Wp, int nt0,
+                        f32x4 (&held)[(5 * MT + NWV - 1) / NWV]) {
+    constexpr int NU = 5 * MT, DU = (NU + NWV - 1) / NWV, LHS2 = (32 * KB32 + DFF_SPAD) / 2;
+    const int tid_ = tid_now();
+    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6) - W0;
+    const int kg = lane >> 4, mm = lane & 15;
+    const gu32x4* wp = (const gu32x4*)Wp + lane;
+    u32x4 b[2][KB32][3];
+    auto fill = [&](u32x4 (&slot)[KB32][3], int d) {
+        const int nt = min(wave + NWV * d, NU - 1) / MT;
+#pragma unroll
+        for (int kb = 0; kb < KB32; ++kb)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) slot[kb][p] = wp[(((size_t)(nt0 + nt) * KB32 + kb) * 3 + p) * 64];
+    };
+    fill(b[0], 0);
+    if (DU > 1) fill(b[1], 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int d = 0; d < DU; ++d) {
+        const int u = min(wave + NWV * d, NU - 1);
+        const int mt = u - (u / MT) * MT;
+        const int ro = min(mt * 16 + mm, rowsA - 1) * LHS2 + 4 * kg;
+        f32x4 cs = {0.f, 0.f, 0.f, 0.f}, cb = {0.f, 0.f, 0.f, 0.f}, cs2 = cs, cb2 = cs;
+#pragma unroll
+        for (int kb = 0; kb < KB32; ++kb) {
+            const u32x4 ah = *(const lu32x4*)(as + ro + 16 * kb);
+            const u32x4 am = *(const lu32x4*)(as + R * LHS2 + ro + 16 * kb);
+            const u32x4 al = *(const lu32x4*)(as + 2 * R * LHS2 + ro + 16 * kb);
+            cs = mfma_bf16(b[d % 2][kb][0], al, cs);
+            cb = mfma_bf16(b[d % 2][kb][0], am, cb);
+            cs2 = mfma_bf16(b[d % 2][kb][2], ah, cs2);
+            cb2 = mfma_bf16(b[d % 2][kb][1], ah, cb2);
+            cs = mfma_bf16(b[d % 2][kb][1], am, cs);
+            cb = mfma_bf16(b[d % 2][kb][0], ah, cb);
+        }
+        if (d + 2 < DU) { fill(b[d % 2], d + 2); __builtin_amdgcn_sched_barrier(0); }
+        held[d] = (cb + cb2) + (cs + cs2);
+    }
+}
+
 // One element of a split A operand: three 16-bit stores (row-major bf16 pieces [piece][R][LS], LS in bf16 units).
 DEVI void store_split(lu16* as16, int R, int LS, int row, int col, float v) {
     const unsigned uh = __float_as_uint(v) & 0xffff0000u;
@@ -2297,7 +2341,76 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             f32x4 acc_a[NTW][MT];
             acc_zero<MT, NTW>(acc_a);
             pf.tick(15);
-            for (int hg = hg_lo; hg < hg_hi; ++hg) {
+            // Backward head pipeline of the variants that have one in the forward pass (SPW, !GEN, HGS = 1): dS / dQ keep only
+            // MT waves busy, so the others compute G_ext of the NEXT head meanwhile (5 MT units, parked in registers) and
+            // write it once dV / dK and the back-projection of the current head are done with R3.
+            constexpr bool PIPEB = SPW && !GEN && HGS == 1 && MT < 4 && (5 * MT) % (DFF_NWAVES - MT) == 0;
+            if constexpr (PIPEB) {
+                constexpr int NI = MT, NWH = DFF_NWAVES - NI, DU = 5 * MT / NWH;
+                const int tid = tid_now();
+                lfloat* const Gl = geo.Rg + 3 * RN * LQ;
+                lfloat* const dxw = geo.dxw;
+                auto gx_epi = [=](int nt, int mt, const f32x4& acc) {
+                        const int lane = tid & 63, quad = lane >> 4, row = mt * 16 + (lane & 15);
+                        if (row < rows) {
+                            *(lf32x4*)(Gl + row * LQ + 16 * nt + 4 * quad) = acc;
+                            if (nt == 4 && quad == 0) {   // r = dE/dxrel: columns 64..66 of the head
+                                dxw[row * 4 + 0] -= acc[0];
+                                dxw[row * 4 + 1] -= acc[1];
+                                dxw[row * 4 + 2] -= acc[2];
+                            }
+                        }
+                    };
+                auto commit_issue = [&](int hg) {   // rows of head hg -> LDS, request those of hg + 1
+                    co_reload_commit<MT, HGS>(rl, geo);
+                    if (hg + 1 < hg_hi)
+                        co_reload_issue<MT, HGS>(rl, sqkv + (size_t)(hg + 1) * RN * DFF_QKVW, sPl + (size_t)(hg + 1) * RN * c.sl.PS);
+                    co_fill_x<HGS, GEN>(geo);
+                };
+                gemm_wide_units_split<MT, H / 32, 5>(asplit, RN, RN, lw.WoxT_s, hg_lo * 5, gx_epi);
+                commit_issue(hg_lo);
+                wg_sync<SPILL>();
+                pf.tick(16);
+                const bool deep = l > 0 || full0;
+                for (int hg = hg_lo; hg < hg_hi; ++hg) {
+                    const bool more = hg + 1 < hg_hi;
+                    f32x4 gheld[DU];
+                    if (wave_ < NI) {
+                        if (deep) co_ds<MT, HGS, true, GEN>(geo);
+                        else co_ds<MT, HGS, false, GEN>(geo);
+                    } else if (more) {
+                        gx_units_hold<MT, H / 32, NI, NWH>(asplit, RN, RN, lw.WoxT_s, (hg + 1) * 5, gheld);
+                    }
+                    wg_sync<SPILL>();
+                    pf.tick(17);
+                    if (deep) {
+                        co_dv_dk<MT, HGS, false, GEN>(geo);
+                        wg_sync<SPILL>();
+                        pf.tick(18);
+                        gemm_tall_qkvT_split<MT, NTW, HGS>(acc_a, geo.Rg, 4, RN, lw.WqkvxT_s, hg, NT_H);
+                        gemm_tall_kb<MT, NTW, 13>(acc_a, HGS,
+                            [=](int i, int& aoff, int& wkb) { aoff = 4 * RN * LQ + i * 80 + 64; wkb = (hg + i) * 13 + 4; },
+                            geo.Rg, LQ, RN, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
+                    } else {
+                        co_dv_dk<MT, HGS, true, GEN>(geo);
+                    }
+                    wg_sync<SPILL>();
+                    pf.tick(19);
+                    if (more) {
+                        if (wave_ >= NI) {
+#pragma unroll
+                            for (int d = 0; d < DU; ++d) {
+                                const int u = wave_ - NI + NWH * d;
+                                gx_epi(u / MT, u - (u / MT) * MT, gheld[d]);
+                            }
+                        }
+                        commit_issue(hg + 1);
+                        wg_sync<SPILL>();
+                        pf.tick(16);
+                    }
+                }
+            }
+            for (int hg = hg_lo; hg < (PIPEB ? hg_lo : hg_hi); ++hg) {
                 // G_ext = dattn [W_o ; W_oc]^T (dE/do | r = dE/dxrel) for the heads of this group -> R3 ;
                 // dE/dx_i -= r_i
                 {
