@@ -489,12 +489,12 @@ DEVI void gemm_wide_units_split(const lu32* as, int R, int rowsA, const unsigned
     }
 }
 
-// The (tile, row-tile) units of ONE head's G_ext GEMM (5 column tiles x MT row tiles) on waves W0 .. W0 + NWV - 1 only,
+// The (tile, row-tile) units of a head group's G_ext GEMM (NT = 5 HGS column tiles x MT row tiles) on waves W0 .. W0 + NWV - 1 only,
 // results parked in registers (backward head pipeline: the other waves are busy with dS meanwhile).  Unit u = w + NWV d.
-template <int MT, int KB32, int W0, int NWV>
+template <int MT, int KB32, int NT, int W0, int NWV>
 DEVI void gx_units_hold(const lu32* as, int R, int rowsA, const unsigned* __restrict__ Wp, int nt0,
-                        f32x4 (&held)[(5 * MT + NWV - 1) / NWV]) {
-    constexpr int NU = 5 * MT, DU = (NU + NWV - 1) / NWV, LHS2 = (32 * KB32 + DFF_SPAD) / 2;
+                        f32x4 (&held)[(NT * MT + NWV - 1) / NWV]) {
+    constexpr int NU = NT * MT, DU = (NU + NWV - 1) / NWV, LHS2 = (32 * KB32 + DFF_SPAD) / 2;
     const int tid_ = tid_now();
     const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6) - W0;
     const int kg = lane >> 4, mm = lane & 15;
@@ -2344,17 +2344,21 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             // Backward head pipeline of the variants that have one in the forward pass (SPW, !GEN, HGS = 1): dS / dQ keep only
             // MT waves busy, so the others compute G_ext of the NEXT head meanwhile (5 MT units, parked in registers) and
             // write it once dV / dK and the back-projection of the current head are done with R3.
-            constexpr bool PIPEB = SPW && !GEN && HGS == 1 && MT < 4 && (5 * MT) % (DFF_NWAVES - MT) == 0;
+            // Measured per shape: (128,3,1) villin 631 -> 586 us, (96,2,2) BBA 338 -> 329; (128,2,2) trp-cage 363 -> 391 (the 20 parked
+            // units + two K = 128 weight tiles in flight spill: 248 B of scratch), so that shape keeps the serial loop.
+            constexpr bool PIPEB = SPW && !GEN && MT < 4 && HGS * MT < DFF_NWAVES && (5 * HGS * MT) % (DFF_NWAVES - HGS * MT) == 0 &&
+                                   !(H == 128 && HGS == 2);
             if constexpr (PIPEB) {
-                constexpr int NI = MT, NWH = DFF_NWAVES - NI, DU = 5 * MT / NWH;
+                constexpr int NI = HGS * MT, NWH = DFF_NWAVES - NI, NTG = 5 * HGS, DU = NTG * MT / NWH;
                 const int tid = tid_now();
                 lfloat* const Gl = geo.Rg + 3 * RN * LQ;
                 lfloat* const dxw = geo.dxw;
                 auto gx_epi = [=](int nt, int mt, const f32x4& acc) {
                         const int lane = tid & 63, quad = lane >> 4, row = mt * 16 + (lane & 15);
+                        const int hh = nt / 5, tt = nt - 5 * hh;
                         if (row < rows) {
-                            *(lf32x4*)(Gl + row * LQ + 16 * nt + 4 * quad) = acc;
-                            if (nt == 4 && quad == 0) {   // r = dE/dxrel: columns 64..66 of the head
+                            *(lf32x4*)(Gl + row * LQ + hh * 80 + 16 * tt + 4 * quad) = acc;
+                            if (tt == 4 && quad == 0) {   // r = dE/dxrel: columns 64..66 of the head
                                 dxw[row * 4 + 0] -= acc[0];
                                 dxw[row * 4 + 1] -= acc[1];
                                 dxw[row * 4 + 2] -= acc[2];
@@ -2364,10 +2368,11 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 auto commit_issue = [&](int hg) {   // rows of head hg -> LDS, request those of hg + 1
                     co_reload_commit<MT, HGS>(rl, geo);
                     if (hg + 1 < hg_hi)
-                        co_reload_issue<MT, HGS>(rl, sqkv + (size_t)(hg + 1) * RN * DFF_QKVW, sPl + (size_t)(hg + 1) * RN * c.sl.PS);
+                        co_reload_issue<MT, HGS>(rl, sqkv + (size_t)(hg + 1) * HGS * RN * DFF_QKVW,
+                                                 sPl + (size_t)(hg + 1) * HGS * RN * c.sl.PS);
                     co_fill_x<HGS, GEN>(geo);
                 };
-                gemm_wide_units_split<MT, H / 32, 5>(asplit, RN, RN, lw.WoxT_s, hg_lo * 5, gx_epi);
+                gemm_wide_units_split<MT, H / 32, NTG>(asplit, RN, RN, lw.WoxT_s, hg_lo * NTG, gx_epi);
                 commit_issue(hg_lo);
                 wg_sync<SPILL>();
                 pf.tick(16);
@@ -2379,7 +2384,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         if (deep) co_ds<MT, HGS, true, GEN>(geo);
                         else co_ds<MT, HGS, false, GEN>(geo);
                     } else if (more) {
-                        gx_units_hold<MT, H / 32, NI, NWH>(asplit, RN, RN, lw.WoxT_s, (hg + 1) * 5, gheld);
+                        gx_units_hold<MT, H / 32, NTG, NI, NWH>(asplit, RN, RN, lw.WoxT_s, (hg + 1) * NTG, gheld);
                     }
                     wg_sync<SPILL>();
                     pf.tick(17);
@@ -2387,9 +2392,9 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         co_dv_dk<MT, HGS, false, GEN>(geo);
                         wg_sync<SPILL>();
                         pf.tick(18);
-                        gemm_tall_qkvT_split<MT, NTW, HGS>(acc_a, geo.Rg, 4, RN, lw.WqkvxT_s, hg, NT_H);
+                        gemm_tall_qkvT_split<MT, NTW, HGS>(acc_a, geo.Rg, 4, RN, lw.WqkvxT_s, hg * HGS, NT_H);
                         gemm_tall_kb<MT, NTW, 13>(acc_a, HGS,
-                            [=](int i, int& aoff, int& wkb) { aoff = 4 * RN * LQ + i * 80 + 64; wkb = (hg + i) * 13 + 4; },
+                            [=](int i, int& aoff, int& wkb) { aoff = 4 * RN * LQ + i * 80 + 64; wkb = (hg * HGS + i) * 13 + 4; },
                             geo.Rg, LQ, RN, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
                     } else {
                         co_dv_dk<MT, HGS, true, GEN>(geo);
