@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Race screen at the BASELINE sizes: every shipped architecture, 200 Langevin steps at batch 256 (protein G 128),
-four times from the same state and seed -- the saved frames must be bit-identical (the kernels have no atomics and
-no inter-workgroup communication, so any difference is a missing barrier or an LDS / stash overrun)."""
+four times from the same state and seed -- the saved frames must be bit-identical (the kernels have no atomics; the
+PAIR variants exchange partial sums between two workgroups in a fixed order: any difference is a missing barrier, an
+LDS / stash overrun or a hand-off that let a stale tile through)."""
 import sys, os, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import dff_amd
@@ -9,7 +10,8 @@ from dff_amd.score import GraphTransformer
 from dff_amd.ddpm import GaussianDiffusion
 from dff_amd.langevin import LangevinDiffusion
 import synth_weights as synth
-for cfg, P in (("villin", 256), ("protein_g", 128), ("trp_cage", 256), ("bba", 256), ("chignolin", 256)):
+for cfg, P in (("villin", 256), ("protein_g", 128), ("trp_cage", 256), ("bba", 256), ("chignolin", 256),
+               ("villin", 128), ("trp_cage", 128), ("bba", 128), ("protein_g", 60)):   # 128 / 60: the two-workgroups-per-protein variants
     _, N, H, L = synth.SHIPPED_CONFIGS[cfg]
     model = GraphTransformer(N, H, device="cuda:0", n_layers=L, use_intrinsic_coords=True, use_abs_coords=False,
                              use_distances=False, conservative=True, state_dict=synth.synth_gnn_params(N, H, L, decoder_scale=1e-2))
@@ -21,5 +23,5 @@ for cfg, P in (("villin", 256), ("protein_g", 128), ("trp_cage", 256), ("bba", 2
                                masses=[12.0] * N, friction=1.0, verbose=False, seed=3)
         outs.append(torch.from_numpy(ld.simulate()).clone())
     same = all(torch.equal(outs[0], o) for o in outs[1:])
-    print(cfg, "4 repeats bit-identical:", same, "finite:", bool(torch.isfinite(outs[0]).all()), flush=True)
+    print(cfg, P, model.native.last_launch()[0], "pair status", model.native.pair_status(), "4 repeats bit-identical:", same, "finite:", bool(torch.isfinite(outs[0]).all()), flush=True)
     assert same
