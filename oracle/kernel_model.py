@@ -69,6 +69,33 @@ def fold_weights(p: Dict[str, np.ndarray], n_layers: int) -> dict:
     return out
 
 
+def fold_kv(fw: dict) -> dict:
+    """H == head dimension only: the same network with k = v = LayerNorm output (what dff_host.hip does when
+    hidden == 64): q'_h = W_k,h^T (W_q,h n + b_q,h) (the j-constant part of the logits drops out of the softmax),
+    W_o,h' = W_o,h W_v,h, b_o' += W_o b_v.  W_u / W_oc stay those of the ORIGINAL q and W_o.  forward() / backward()
+    on the result give the same energies and forces; the stashed q, k, v are q', n, n."""
+    out = dict(fw)
+    out["layers"] = []
+    for lw in fw["layers"]:
+        H = lw["Wq"].shape[1]
+        if H != DH:
+            out["layers"].append(lw)
+            continue
+        n = dict(lw)
+        Wq, bq, Wo = np.zeros_like(lw["Wq"]), np.zeros_like(lw["bq"]), np.zeros_like(lw["Wo"])
+        eye = np.zeros_like(lw["Wk"])
+        for h in range(HEADS):
+            s = slice(h * DH, (h + 1) * DH)
+            Wq[s] = lw["Wk"][s].T @ lw["Wq"][s]
+            bq[s] = lw["Wk"][s].T @ lw["bq"][s]
+            Wo[:, s] = lw["Wo"][:, s] @ lw["Wv"][s]
+            eye[s] = np.eye(DH)
+        n.update(Wq=Wq, bq=bq, Wk=eye, bk=np.zeros_like(lw["bk"]), Wv=eye.copy(), bv=np.zeros_like(lw["bv"]),
+                 Wo=Wo, bo=lw["bo"] + lw["Wo"] @ lw["bv"])
+        out["layers"].append(n)
+    return out
+
+
 # ----------------------------------------------------------------------------- pieces
 def layer_norm(x, g, b, eps=1e-5):
     mu = x.mean(-1, keepdims=True)

@@ -94,6 +94,8 @@ def test_stash_intermediates_vs_kernel_model(dff, golden):
     model.native.score(torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["t"]).cuda())
     torch.cuda.synchronize()
     fw = km.fold_weights(params, L)
+    if H == km.DH and os.environ.get("DFF_FOLD_KV", "1") != "0":   # hidden == head dimension: the library folds W_k / W_v away
+        fw = km.fold_kv(fw)
     xc = g["x"].astype(np.float64)
     xc -= xc.mean(1, keepdims=True)
     _, st = km.forward(fw, xc, g["t"])

@@ -175,6 +175,7 @@ struct dff_model {
     int last_base = 0;
     bool split = false;                        // split-bf16 images exist, SPW variants preferred (DFF_SPLIT_BF16=0 at model creation: never)
     bool small_split = false;                  // ... and the <= 16-row kernel has an SPW variant for this model
+    bool fold_kv = false;                      // H == 64: k = v = LayerNorm output (W_k folded into W_q, W_v into W_o); DFF_FOLD_KV=0: never
     // PAIR variants (two workgroups per protein): partial-tile exchange slots and flags
     float* xchg = nullptr;
     size_t xchg_floats = 0;
@@ -282,6 +283,8 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
         // exists for the shape (default); DFF_SPLIT_BF16=0: every GEMM on v_mfma_f32_16x16x4_f32
         const char* e = getenv("DFF_SPLIT_BF16");
         m->split = !(e && e[0] == '0');
+        const char* ef = getenv("DFF_FOLD_KV");
+        m->fold_kv = H == DFF_DH && !(ef && ef[0] == '0');
         const void* fn_; unsigned lds_; const char* nm_;
         m->small_split = m->split && N <= 10 && dff_small_pick(H, 8, false, true, &fn_, &lds_, &nm_);
     }
@@ -380,6 +383,40 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
             for (int r = 0; r < I; ++r) s += (double)Wo[(size_t)c * I + r] * bc[r];
             bof[c] = s;
         }
+        // ---- H == head dimension: fold W_k into W_q and W_v into W_o (float64) ----
+        // logits: q.k_j = (W_k,h^T q_i).n_j + [constant in j], so with q'_ih = W_k,h^T (W_q,h n_i + b_q,h) the keys are the
+        // LayerNorm rows n_j themselves; values: W_o,h sum_j a_ij (W_v,h n_j + b_v,h) = (W_o,h W_v,h) sum_j a_ij n_j + W_o,h b_v,h.
+        // The kernels keep their [q | u | k | v] layout: the k and v blocks of the images become identities (exactly
+        // representable, so k = v = n bit for bit) and the <= 16-row kernel skips them altogether.  u, s, W_oc, W_od above
+        // are built from the ORIGINAL q and W_o: the edge terms are untouched.
+        std::vector<double> Mq, cq, Wof;
+        if (m->fold_kv) {
+            Mq.assign((size_t)I * H, 0.0); cq.assign(I, 0.0); Wof.assign((size_t)H * I, 0.0);
+            for (int h = 0; h < DFF_HEADS; ++h)
+                for (int e = 0; e < DFF_DH; ++e) {
+                    for (int c = 0; c < H; ++c) {
+                        double sq = 0;
+                        for (int dd = 0; dd < DFF_DH; ++dd)
+                            sq += (double)Wkv[(size_t)(h * 64 + dd) * H + e] * Wq[(size_t)(h * 64 + dd) * H + c];
+                        Mq[(size_t)(h * 64 + e) * H + c] = sq;
+                    }
+                    double sc = 0;
+                    for (int dd = 0; dd < DFF_DH; ++dd) sc += (double)Wkv[(size_t)(h * 64 + dd) * H + e] * bq[h * 64 + dd];
+                    cq[h * 64 + e] = sc;
+                    for (int c = 0; c < H; ++c) {
+                        double so = 0;
+                        for (int dd = 0; dd < DFF_DH; ++dd)
+                            so += (double)Wo[(size_t)c * I + h * 64 + dd] * Wkv[(size_t)(I + h * 64 + dd) * H + e];
+                        Wof[(size_t)c * I + h * 64 + e] = so;
+                    }
+                }
+            for (int c = 0; c < H; ++c) {
+                double sbv = 0;
+                for (int r = 0; r < I; ++r) sbv += (double)Wo[(size_t)c * I + r] * bkv[I + r];
+                bof[c] += sbv;
+            }
+        }
+        const bool fold = m->fold_kv;
         std::vector<float> bo32(H);
         for (int c = 0; c < H; ++c) bo32[c] = (float)bof[c];
 
@@ -398,21 +435,22 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
         // extended-head images: column e of head h: [0,64) q, [64,67) u, [67,80) 0, [80,144) k, [144,208) v
         auto wqkvx = [&](int col, int c) -> double {
             const int h = col / 208, e = col % 208;
-            if (e < 64) return Wq[(size_t)(h * 64 + e) * H + c];
+            if (e < 64) return fold ? Mq[(size_t)(h * 64 + e) * H + c] : (double)Wq[(size_t)(h * 64 + e) * H + c];
             if (e < 80) return e < 67 ? Wu[(size_t)(3 * h + e - 64) * H + c] : e == 67 ? Wsd[(size_t)h * H + c] : 0.0;
+            if (fold) return (e < 144 ? e - 80 : e - 144) == c ? 1.0 : 0.0;
             if (e < 144) return Wkv[(size_t)(h * 64 + e - 80) * H + c];
             return Wkv[(size_t)(I + h * 64 + e - 144) * H + c];
         };
         std::vector<float> bqkvx(8 * 208, 0.f);
         for (int col = 0; col < 8 * 208; ++col) {
             const int h = col / 208, e = col % 208;
-            bqkvx[col] = e < 64 ? bq[h * 64 + e] : e < 67 ? (float)bu[3 * h + e - 64] : e == 67 ? (float)bsd[h] : e < 80 ? 0.f
-                         : e < 144 ? bkv[h * 64 + e - 80] : bkv[I + h * 64 + e - 144];
+            bqkvx[col] = e < 64 ? (fold ? (float)cq[h * 64 + e] : bq[h * 64 + e]) : e < 67 ? (float)bu[3 * h + e - 64] : e == 67 ? (float)bsd[h]
+                         : e < 80 ? 0.f : fold ? 0.f : e < 144 ? bkv[h * 64 + e - 80] : bkv[I + h * 64 + e - 144];
         }
         // output projection with the xrel rows: row e of head h: [0,64) W_o[:, h*64+e], [64,67) W_oc[:, 3h+e-64]
         auto wox = [&](int krow, int c) -> double {
             const int h = krow / 80, e = krow % 80;
-            if (e < 64) return Wo[(size_t)c * I + h * 64 + e];
+            if (e < 64) return fold ? Wof[(size_t)c * I + h * 64 + e] : (double)Wo[(size_t)c * I + h * 64 + e];
             return e < 67 ? Woc[(size_t)c * 24 + 3 * h + e - 64] : e == 67 ? Wod[(size_t)c * 8 + h] : 0.0;
         };
         UP(pack_b(H, 8 * 208, [&](int k, int n) { return wqkvx(n, k); }), d.Wqkvx_p);
