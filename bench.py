@@ -59,7 +59,7 @@ def hbm_traffic_from_profile(kname, cfg, P, chunk):
         base, args = n.split("<", 1)
         args = args.rstrip(">").split(",")
         if all(x in ("true", "false") or x.isdigit() for x in args):   # rocprofv3 form
-            flags = (("gen", "split_bf16") if base == "dff_small_kernel" else ("gen", "split_bf16", "pair"))
+            flags = (("gen", "split_bf16", "fold_kv") if base == "dff_small_kernel" else ("gen", "split_bf16", "pair"))
             nfix = 2 if base == "dff_small_kernel" else 4               # <H, NW, ...> / <H, MT, HGS, SPILL, ...>
             tail = [f for f, v in zip(flags, args[nfix:]) if v == "true"]
             args = args[:nfix] + tail

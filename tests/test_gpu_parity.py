@@ -108,6 +108,8 @@ def test_stash_intermediates_vs_kernel_model(dff, golden):
                        q=s["q"][b].transpose(1, 0, 2).reshape(N, 512), k=s["k"][b].transpose(1, 0, 2).reshape(N, 512),
                        v=s["v"][b].transpose(1, 0, 2).reshape(N, 512), P=s["P"][b])
             for name, ref in exp.items():
+                if name in ("k", "v") and "fold_kv" in model.native.last_launch()[0]:
+                    continue   # keys and values ARE the LayerNorm rows there: never projected, never stashed
                 got = model.native.debug_stash(b, l, name)
                 err = np.abs(got - ref).max() / max(1.0, np.abs(ref).max())
                 worst[name] = max(worst.get(name, 0.0), err)

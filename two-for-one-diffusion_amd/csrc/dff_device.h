@@ -413,4 +413,4 @@ struct Variant {
 const Variant* dff_fused_variants(int* count);                                  // dff_kernels.hip
 int dff_debug_gemm_launch(int K, const float* dA, const float* dW, int M, int Nout, float* dO, size_t lds);   // dff_kernels.hip
 // the <= 16-row kernel for (H, NW waves, input-branch variant, split-bf16 weight GEMMs); false if not built
-bool dff_small_pick(int H, int NW, bool gen, bool spw, const void** fn, unsigned* lds_floats, const char** name);   // dff_small.hip
+bool dff_small_pick(int H, int NW, bool gen, bool spw, const void** fn, unsigned* lds_floats, const char** name, bool fold = false);   // dff_small.hip

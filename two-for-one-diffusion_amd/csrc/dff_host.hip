@@ -473,6 +473,12 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
         d.Wqkvx_w = d.W1_w = d.W2T_w = d.WoxT_w = d.Wox_t = d.W2_t = d.W1T_t = d.WqkvxT_t = nullptr;
         if (m->small_split) {
             int rc_;
+            // fold_kv on the shipped input branch: the <= 16-row kernel's FOLD variant streams [q' | u] (5 tiles per head) and
+            // back-projects dQ only (2 k-blocks per head); k = v = LayerNorm output never goes through a GEMM there
+            const bool sfold = m->fold_kv && intr && !dist && !ab;
+            if (sfold) {
+                if ((rc_ = upload_u32(m, pack_units(units_wide(H, 8 * 80), 8 * 80, [&](int k, int n) { return wqkvx((n / 80) * 208 + n % 80, k); }), &d.Wqkvx_w))) return rc_;
+            } else
             if ((rc_ = upload_u32(m, pack_units(units_wide(H, 8 * 208), 8 * 208, [&](int k, int n) { return wqkvx(n, k); }), &d.Wqkvx_w))) return rc_;
             if ((rc_ = upload_u32(m, pack_units(units_wide(H, F), F, [&](int k, int n) { return (double)W1[(size_t)n * H + k]; }), &d.W1_w))) return rc_;
             if ((rc_ = upload_u32(m, pack_units(units_wide(H, F), F, [&](int k, int n) { return (double)W2[(size_t)k * F + n]; }), &d.W2T_w))) return rc_;
@@ -481,6 +487,9 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
             if ((rc_ = upload_u32(m, pack_units(units_tall(8 * 64, H), H, [&](int c, int n) { return wox((c / 64) * 80 + c % 64, n); }), &d.Wox_t))) return rc_;
             if ((rc_ = upload_u32(m, pack_units(units_tall(F, H), H, [&](int k, int n) { return (double)W2[(size_t)n * F + k]; }), &d.W2_t))) return rc_;
             if ((rc_ = upload_u32(m, pack_units(units_tall(F, H), H, [&](int k, int n) { return (double)W1[(size_t)k * H + n]; }), &d.W1T_t))) return rc_;
+            if (sfold) {
+                if ((rc_ = upload_u32(m, pack_units(units_tall(8 * 64, H), H, [&](int c, int n) { return wqkvx((c / 64) * 208 + c % 64, n); }), &d.WqkvxT_t))) return rc_;
+            } else
             if ((rc_ = upload_u32(m, pack_units(units_tall(8 * 192, H), H, [&](int c, int n) {
                      const int h = c / 192, cc = c % 192;
                      return wqkvx(h * 208 + (cc < 64 ? cc : cc + 16), n); }), &d.WqkvxT_t))) return rc_;
@@ -596,7 +605,7 @@ static int launch_small(dff_model* m, DffRunArgs& a, int G, hipStream_t stream) 
     const bool gen = !(m->cfg.use_intrinsic_coords == 1 && m->cfg.use_distances == 0 && m->cfg.use_abs_coords == 0);
     const int NW = eight ? 8 : 4;
     const bool spw = eight && m->small_split;
-    if (!dff_small_pick(H, NW, gen, spw, &fn, &lds, &name))
+    if (!dff_small_pick(H, NW, gen, spw, &fn, &lds, &name, m->fold_kv))
         return fail(DFF_EINVAL, "no <= 16-row kernel for hidden=%d waves=%d in this build", H, NW);
     nthreads = NW * 64;
     lds *= (unsigned)sizeof(float);

@@ -526,12 +526,14 @@ DEVI void head_commit(const HeadRegs& r, lfloat* Qx, lfloat* Kx, lfloat* Vx, lfl
 // lane, once the QKV_ext GEMM is done -- instead of 52 scalar stores (with 64-bit address arithmetic each) interleaved
 // with the GEMM's weight loads in its tile epilogues: loads and stores share the in-order vmcnt queue, and a timing-only
 // build without these stores ran 2.2 us / step faster.  Rows beyond the allocated ones go to the dummy stash row.
+template <bool QONLY = false>
 DEVI void head_store(const lfloat* Qx, const lfloat* Kx, const lfloat* Vx, gfloat* sqkv, int RA, int lane, int rla) {
 #pragma unroll
     for (int u = 0; u < 5; ++u) {
         const int it = lane + 64 * u, row = it / 20, c4 = it - row * 20;
         if (row < rla) *(gf32x4*)(sqkv + min(row, RA) * DFF_QKVW + 4 * c4) = *(const lf32x4*)(Qx + row * DFF_XLD + 4 * c4);
     }
+    if (QONLY) return;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int it = lane + 64 * u, row = it >> 4, c4 = it & 15;
@@ -558,13 +560,14 @@ DEVI void lds_dma16(unsigned lds_byte, const gfloat* src) {
 DEVI void head_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // table entry of 16-byte slot `sl` of the contiguous [Q | K | V | P] regions: float offset of its source relative to the
 // head's stash rows (q_ext | k | v) or, with bit 31 set, to the head's P tile; 0xffffffff: no such slot
-template <int RLA>
+template <int RLA, bool QONLY = false>
 DEVI unsigned head_dma_entry(int sl, int RA) {
     constexpr int RQ = RLA * (DFF_XLD / 4);                // 16-byte slots per Q / K / V region
     constexpr int NP = 16 * DFF_PLD / 4;                   // ... of the P tile
     if (sl >= 3 * RQ + NP) return 0xffffffffu;
     const int reg = (sl >= RQ) + (sl >= 2 * RQ) + (sl >= 3 * RQ);
     const int r = sl - reg * RQ;
+    if (QONLY && (reg == 1 || reg == 2)) return 0xffffffffu;   // FOLD: the K / V regions are not loaded
     if (reg < 3) {
         const int row = r / (DFF_XLD / 4), c4 = r - row * (DFF_XLD / 4);
         // q_ext: 20 slots of data + 1 pad; k / v: 16 + 4 (extension columns, rewritten by write_xext) + 1 pad
@@ -588,8 +591,13 @@ DEVI void head_dma(const lu32* tab, const lfloat* Qx /* wave-uniform; Q | K | V 
 }
 
 // ---------------------------------------------------------------- the kernel
-template <int H, int NW, bool GEN, bool SPW = false>
+// FOLD (hidden == head dimension, dff_host.hip folds W_k into W_q and W_v into W_o): keys and values ARE the LayerNorm rows,
+// so the QKV_ext GEMM has 5 tiles per head instead of 13 (q' | u), K_ext = V_ext is ONE shared fp32 copy of the LayerNorm
+// output (+ x), written by the row stages next to its bf16 pieces, dK and dV go straight into the wave's partial of
+// d(LayerNorm output) (identity back-projection) and the QKV_ext^T GEMM keeps only its dQ blocks; only q' is stashed.
+template <int H, int NW, bool GEN, bool SPW = false, bool FOLD = false>
 __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m, const DffRunArgs a) {
+    static_assert(!FOLD || (SPW && !GEN && H == DFF_DH), "FOLD: the split, shipped-branch, hidden == 64 variant");
     using LL = SmallLds<H, NW>;
     constexpr int LH = LL::LH, F = 4 * H, E = H / 16;
     constexpr int NTHR = NW * 64;            // threads
@@ -603,7 +611,9 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     static_assert(!SPW || (NW == 8 && H == 64 && FS == 32), "split-bf16 variant: one head per wave; the unit counts below are H = 64's");
     // units per GEMM of a wave (H = 64): QKV_ext 13 tiles x 2, [W_o;W_oc] 2 k-blocks x 4, W1 / W2^T 2 x 2, W2 / W1^T 1 x 4,
     // [W_o;W_oc]^T 5 x 2, QKV_ext^T 6 x 4
-    constexpr int U_QKV = 13 * KB32, U_WOX = 2 * E, U_W1 = NTS * KB32, U_W2 = (FS / 32) * E, U_GX = 5 * KB32, U_QKVT = 6 * E;
+    constexpr int NQT = FOLD ? 5 : 13;        // output tiles per head of the QKV_ext GEMM ([q' | u] or [q | u | k | v])
+    constexpr int NKT = FOLD ? 2 : 6;         // 32-row k-blocks per head of its transpose (dQ or dQ | dK | dV)
+    constexpr int U_QKV = NQT * KB32, U_WOX = 2 * E, U_W1 = NTS * KB32, U_W2 = (FS / 32) * E, U_GX = 5 * KB32, U_QKVT = NKT * E;
     constexpr int MW = U_W1 < SDR ? U_W1 : SDR;   // how many of a block's first SDR units come from its first GEMM when that is W1 / W2^T
     static_assert(!SPW || (U_W1 + U_W2 >= SDR && U_WOX >= SDR && U_GX >= SDR && U_QKV >= SDR), "every block fills the ring");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -652,7 +662,10 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     };
     lfloat* const dxw = sm + LL::dxw + wave * 128;
     lfloat* const wr = sm + LL::wreg + wave * LL::WREG;
-    lfloat* const Qx = wr; lfloat* const Kx = wr + RS; lfloat* const Vx = wr + 2 * RS;
+    // FOLD: K_ext = V_ext = the shared LayerNorm rows, kept in wave 0's (otherwise unused) K region
+    lfloat* const Nx = sm + LL::wreg + RS;
+    lfloat* const Qx = wr; lfloat* const Kx = FOLD ? Nx : wr + RS; lfloat* const Vx = FOLD ? Nx : wr + 2 * RS;
+    auto n_store = [=](int row, int cl, float v) { if constexpr (FOLD) Nx[row * DFF_XLD + cl] = v; };
     // RELAY (8 waves, H = 64): region order [Q | K | V | P | G | dS], and everything that is not an attention operand --
     // o_ext = P V_ext, the FFN hidden slice, the wave's partial H-wide outputs -- lives in G | dS.  q_ext, k, v and P of
     // the LAST layer then survive in LDS from its forward to its backward attention block: no stash reload (and no
@@ -696,7 +709,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     for (int i = tid; i < (int)LL::total; i += NTHR) smem[i] = 0.f;
     __syncthreads();
     if constexpr (LL::dmatab_size > 0) {
-        for (int i = tid; i < (int)LL::dmatab_size; i += NTHR) dmatab[i] = head_dma_entry<LL::RLA>(i, G * m.N);
+        for (int i = tid; i < (int)LL::dmatab_size; i += NTHR) dmatab[i] = head_dma_entry<LL::RLA, FOLD>(i, G * m.N);
         __syncthreads();
     }
     Prof pf;
@@ -823,14 +836,14 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #define DFF_KT 0
 #endif
     constexpr int KQ = DFF_KQ ? 1 : 0, KO = DFF_KO ? DFF_HEADS * 5 : 0, KT = DFF_KT ? DFF_HEADS * 13 : 0;
-    auto ss_qkv = [&](const DffLayerDev& lw, int h) { return KQ ? SStream{(const gu32x4*)lw.Wqkvx_p + (size_t)h * 13 * E * 64} : sstream(lw.Wqkvx_w, h * 13 * KB32); };
+    auto ss_qkv = [&](const DffLayerDev& lw, int h) { return KQ ? SStream{(const gu32x4*)lw.Wqkvx_p + (size_t)h * 13 * E * 64} : sstream(lw.Wqkvx_w, h * U_QKV); };
     auto ss_wox = [&](const DffLayerDev& lw, int h) { return KO ? SStream{(const gu32x4*)lw.Wox_p + (size_t)h * 5 * 64} : sstream(lw.Wox_t, h * 2 * E); };
     auto ss_w1 = [&](const DffLayerDev& lw) { return sstream(lw.W1_w, wave * NTS * KB32); };
     auto ss_w2 = [&](const DffLayerDev& lw) { return sstream(lw.W2_t, wave * (FS / 32) * E); };
     auto ss_w2t = [&](const DffLayerDev& lw) { return sstream(lw.W2T_w, wave * NTS * KB32); };
     auto ss_w1t = [&](const DffLayerDev& lw) { return sstream(lw.W1T_t, wave * (FS / 32) * E); };
     auto ss_woxt = [&](const DffLayerDev& lw, int h) { return sstream(lw.WoxT_w, h * 5 * KB32); };
-    auto ss_qkvt = [&](const DffLayerDev& lw, int h) { return KT ? SStream{(const gu32x4*)lw.WqkvxT_p + (size_t)h * 13 * 64} : sstream(lw.WqkvxT_t, h * 6 * E); };
+    auto ss_qkvt = [&](const DffLayerDev& lw, int h) { return KT ? SStream{(const gu32x4*)lw.WqkvxT_p + (size_t)h * 13 * 64} : sstream(lw.WqkvxT_t, h * U_QKVT); };
     // extension-block weights of the tall GEMMs for the fp32 k-step (s = 0 slots of the fp32 images)
     auto wox_ext = [&](const DffLayerDev& lw, int h, int lane) { return (const gfloat*)lw.Wox_p + ((size_t)(5 * h + 4) * 64 + lane) * 4; };
     auto qkvt_ext = [&](const DffLayerDev& lw, int h, int lane) { return (const gfloat*)lw.WqkvxT_p + ((size_t)(13 * h + 4) * 64 + lane) * 4; };
@@ -959,8 +972,21 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 DFF_ROW_CONSTS
                 if (cached) {
                     if (ract) {
+                        float x[HC];
 #pragma unroll
-                        for (int i = 0; i < HC; ++i) resbuf[rrow * LH + sub + LPR * i] = ld_ntg(sbq + sl.nodes_in + rrow * H + sub + LPR * i);
+                        for (int i = 0; i < HC; ++i) {
+                            x[i] = ld_ntg(sbq + sl.nodes_in + rrow * H + sub + LPR * i);
+                            resbuf[rrow * LH + sub + LPR * i] = x[i];
+                        }
+                        if constexpr (FOLD) {   // the attention block needs layer 0's LayerNorm rows even when its q' comes from the table
+                            float mean, rstd;
+                            ln_stats_row(x, mean, rstd);
+#pragma unroll
+                            for (int i = 0; i < HC; ++i) {
+                                const int cl = sub + LPR * i;
+                                n_store(rrow, cl, (x[i] - mean) * rstd * lw.ln1_g[cl] + lw.ln1_b[cl]);
+                            }
+                        }
                     }
                 } else if (ract) {
                     float x[HC];
@@ -974,7 +1000,9 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #pragma unroll
                     for (int i = 0; i < HC; ++i) {
                         const int cl = sub + LPR * i;
-                        a_store(rrow, cl, (x[i] - mean) * rstd * lw.ln1_g[cl] + lw.ln1_b[cl]);
+                        const float nv = (x[i] - mean) * rstd * lw.ln1_g[cl] + lw.ln1_b[cl];
+                        a_store(rrow, cl, nv);
+                        n_store(rrow, cl, nv);
                     }
                 }
                 if (ract) pre_B(lw, sub);
@@ -1058,7 +1086,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         bq[0][0] = bh[0]; bq[1][0] = bh[16];
                         pf.tick(1);
                         const SSeq<U_QKV, U_WOX, MW, KQ, KO, 0, 0, E, 4 * KB32> sq{ss_qkv(lw, wave), ss_wox(lw, wave), sn0, sn1};   // tile 4 of 13: [u | s]
-                        swide_run<0, 13, KB32, 1>(sring, bq, ah, am, al, sq, lane,
+                        swide_run<0, NQT, KB32, 1>(sring, bq, ah, am, al, sq, lane,
                             [=](int t, float (&ax)[1]) { ax[0] = bh[t * 16]; },
                             [=](int t, const f32x4& acc, const float (&ax)[1]) {
                                 const int reg = (t >= 5) + (t >= 9);
@@ -1067,7 +1095,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                                 const float v0 = acc[0] + ax[0], v1 = acc[1] + ax[0], v2 = acc[2] + ax[0], v3 = acc[3] + ax[0];
                                 dl[l0] = v0; dl[l1] = v1; dl[l2] = v2; dl[l3] = v3;
                             });
-                        if (st_qkv) head_store(Qx, Kx, Vx, sb + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, RA, lane, RLA);
+                        if (st_qkv) head_store<FOLD>(Qx, Kx, Vx, sb + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, RA, lane, RLA);
                         pf.tick(12);
                         head_math(wave);
                         pf.tick(13);
@@ -1299,7 +1327,9 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         const int cl = sub + LPR * i;
                         resbuf[rrow * LH + cl] = n2[i];
                         st_ntg(sbn + sl.nodes_in + rrow * H + cl, n2[i]);
-                        a_store(rrow, cl, (n2[i] - mean) * rstd * ro[4][i] + ro[5][i]);
+                        const float nv = (n2[i] - mean) * rstd * ro[4][i] + ro[5][i];
+                        a_store(rrow, cl, nv);
+                        n_store(rrow, cl, nv);
                     }
                     pre_B(m.layer[l + 1], sub);
                 }
@@ -1471,6 +1501,15 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     a_store(rrow, cl, d1[i] * g1 + dz * (ro[3][i] + ro[5][i]));
                     resbuf[rrow * LH + cl] = d1[i] * (1.0f - g1) + dz * (ro[4][i] - ro[5][i]);
                 }
+                if constexpr (FOLD) {   // this layer's LayerNorm rows (the keys / values of its attention block), as the forward pass made them
+                    float mean1, rstd1;
+                    ln_stats_row(ro[1], mean1, rstd1);
+#pragma unroll
+                    for (int i = 0; i < HC; ++i) {
+                        const int cl = sub + LPR * i;
+                        n_store(rrow, cl, (ro[1][i] - mean1) * rstd1 * lw.ln1_g[cl] + lw.ln1_b[cl]);
+                    }
+                }
                 // stage F operands: nodes_in stays in ro[1]; LN1 gamma -> ro[2]
                 if (l > 0 || full0) ro_load(2, lw.ln1_g, sub);
             } }
@@ -1551,9 +1590,10 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 auto dqkv = [&]() {
                     // dV_ext = P^T G_ext -> V region (ext columns: dx term sum_i a_ij r_i)
                     wv_mm<0, 5, true>(pb, Gx, lane, ks4, [&](int nt, const f32x4& acc) {
+                        if constexpr (FOLD) { if (nt < 4) acc_a[nt < 4 ? nt : 0] += acc; }   // v = n: dV IS a term of d(LayerNorm output)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            Vx[lro[r] + 16 * nt + col] = acc[r];
+                            if constexpr (!FOLD) Vx[lro[r] + 16 * nt + col] = acc[r];
                             if (nt == 4) dxw[dxi[r]] += GEN ? dx_ext(quad * 4 + r, col, acc[r]) : acc[r];
                         }
                     });
@@ -1570,9 +1610,10 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     });
                     // dK_ext = dS^T Q_ext -> K region (ext columns: dx term sum_i dS_ij u_i)
                     wv_mm<0, 5, true>(dsb, Qx, lane, ks4, [&](int nt, const f32x4& acc) {
+                        if constexpr (FOLD) { if (nt < 4) acc_a[nt < 4 ? nt : 0] += acc; }   // k = n: so is dK
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            Kx[lro[r] + 16 * nt + col] = acc[r];
+                            if constexpr (!FOLD) Kx[lro[r] + 16 * nt + col] = acc[r];
                             if (nt == 4) dxw[dxi[r]] += GEN ? dx_ext(quad * 4 + r, col, acc[r]) : acc[r];
                         }
                     });
@@ -1643,7 +1684,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         pf.tick(16);
                         dqkv();
                         pf.tick(17);
-                        if constexpr (SPW) stall_run<U_GX, 6, E, true>(sring, acc_a, qkvt_fa32, sqa, lane, qkvt_xa, qkvt_ext(lw, wave, lane), DFF_HEADS * 13 * 256);
+                        if constexpr (SPW) stall_run<U_GX, NKT, E, true>(sring, acc_a, qkvt_fa32, sqa, lane, qkvt_xa, qkvt_ext(lw, wave, lane), DFF_HEADS * 13 * 256);
                         else tall_run<5 % DR, 13, E, 4>(ring, acc_a, qkvt_fa, s_qkvt(lw, wave), after, lane);   // 18 entries: phase 0
                         pf.tick(18);
                     }
@@ -1869,7 +1910,13 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 }
 
 // kernel lookup for the host dispatcher (dff_host.hip); taking the address instantiates the variant
-bool dff_small_pick(int H, int NW, bool gen, bool spw, const void** fn, unsigned* lds_floats, const char** name) {
+bool dff_small_pick(int H, int NW, bool gen, bool spw, const void** fn, unsigned* lds_floats, const char** name, bool fold) {
+    if (H == 64 && NW == 8 && spw && fold && !gen) {
+        *fn = (const void*)&dff_small_kernel<64, 8, false, true, true>;
+        *lds_floats = SmallLds<64, 8>::total;
+        *name = "dff_small_kernel<64,8,split_bf16,fold_kv>";
+        return true;
+    }
     if (H == 64 && NW == 8 && spw) {
         *fn = gen ? (const void*)&dff_small_kernel<64, 8, true, true> : (const void*)&dff_small_kernel<64, 8, false, true>;
         *lds_floats = SmallLds<64, 8>::total;
