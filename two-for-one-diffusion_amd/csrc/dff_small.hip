@@ -861,7 +861,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             }
             if (row < RLA) {
                 Kx[row * DFF_XLD + 64 + cc] = xv;
-                Vx[row * DFF_XLD + 64 + cc] = xv;
+                if constexpr (!FOLD) Vx[row * DFF_XLD + 64 + cc] = xv;   // (FOLD: the same buffer)
             }
         }
     };
