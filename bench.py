@@ -97,6 +97,11 @@ def roofline(cfg, P, steps_per_launch, launch_ms, kname):
                      "the MFMA work) run as six bf16 products per fp32 product, whose own roof is the dense bf16 peak / 6 = "
                      "416.7 TFLOP/s (peak_split_gemms); the attention products stay on the fp32 MFMA (157.3).  Algorithmic "
                      "HBM bytes are ~600 B per trajectory-step; measured traffic is the activation stash")
+        if "fold_kv" in kname:
+            r["note"] += (".  algorithmic_flops_per_launch is SURVEY 8d's official count for the factorised formulation; this "
+                          "kernel issues ~26 % fewer MFMA instructions than that formulation needs, because with hidden == "
+                          "head dimension the key / value projections are folded into the query / output projections "
+                          "(exact algebra, DESIGN.md section 2)")
     else:
         r["note"] = "fp32-compute bound: algorithmic HBM bytes are ~600 B per trajectory-step; measured traffic is the activation stash"
     return r
