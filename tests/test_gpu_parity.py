@@ -581,6 +581,52 @@ def test_split_bf16_weight_gemms_are_fp32_exact(dff, cfg, golden, monkeypatch):
     assert rel(out[1], out[0]) <= 2e-5
 
 
+@pytest.mark.gpu
+def test_kv_fold_matches_the_unfolded_network(dff, golden, monkeypatch):
+    """hidden == head dimension (chignolin): by default the library folds W_k into W_q and W_v into W_o (keys = values =
+    LayerNorm rows; the <= 16-row FOLD kernel never projects or stashes them).  DFF_FOLD_KV=0 at model creation keeps the
+    checkpoint's own four projections.  Both against the reference's float64 forces at the same tolerances, on the <= 16-row
+    kernels (8 and 4 waves) and on the generic kernel (which runs the identity blocks), plus a fused Langevin run of one
+    against the other."""
+    from dff_amd.score import GraphTransformer
+    from dff_amd.ddpm import GaussianDiffusion
+    from dff_amd.langevin import LangevinDiffusion
+    g = golden("score_chignolin.npz")
+    _, N, H, L = synth.SHIPPED_CONFIGS["chignolin"]
+
+    def make(fold, scale):
+        monkeypatch.setenv("DFF_FOLD_KV", "1" if fold else "0")
+        return GraphTransformer(N, H, device="cuda:0", n_layers=L, use_intrinsic_coords=True, use_abs_coords=False,
+                                use_distances=False, conservative=True,
+                                state_dict=synth.synth_gnn_params(N, H, L, decoder_scale=scale))
+
+    r32 = rel(g["forces32"], g["forces64"])
+    for fold in (True, False):
+        model = make(fold, 1.0)
+        for path in ("small8", "small4", "generic"):
+            model.native.force_generic(path == "generic")
+            model.native.small_waves(4 if path == "small4" else 0)
+            f, e = model.native.score(torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["t"]).cuda(), return_energy=True)
+            name = model.native.last_launch()[0]
+            assert ("fold_kv" in name) == (fold and path == "small8"), (fold, path, name)
+            r64 = rel(f.cpu().numpy(), g["forces64"])
+            print(f"fold={fold} {path}: {name} rel(hip,ref64)={r64:.3e} rel(ref32,ref64)={r32:.3e}")
+            assert r64 <= 1e-5 and r64 <= 2.5 * r32
+            np.testing.assert_allclose(e.cpu().numpy()[..., None], g["energy32"], rtol=0, atol=2e-5)
+        model.native.force_generic(False)
+        model.native.small_waves(0)
+    init = torch.from_numpy(synth.normal((6, N, 3), 2, 8).astype(np.float32)) * 3.0
+    noises = torch.from_numpy(synth.normal((20, 6, N, 3), 4, 2).astype(np.float32))
+    out = []
+    for fold in (False, True):
+        mdl = make(fold, 1e-2)
+        diff = GaussianDiffusion(mdl, num_atoms=N, timesteps=1000, norm_factor=3.0)
+        ld = LangevinDiffusion(diff, init, n_timesteps=20, save_interval=5, t=20, temp_data=340, temp_sim=340, dt=None,
+                               masses=[12.0] * N, friction=1.0, verbose=False)
+        out.append(ld.simulate(noises=noises))
+    assert rel(out[1], out[0]) <= 2e-5
+
+
 # ---------------------------------------------------------------------------------------------
 # Full-size parity with a LIVE network at the BASELINE per-GPU batches: the fused loops run K = 8 steps on supplied noise
 # and a handful of trajectories / samples -- the first, the last, and the two either side of a launch boundary (a batch
