@@ -673,6 +673,25 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     constexpr bool RELAY = NW == 8 && H == 64;
     constexpr bool KEEP_LAST = RELAY && !GEN;   // (the GEN variants re-derive their x-dependent extension columns on reload)
     constexpr bool HDMA = RELAY && !GEN;        // stash -> head buffers by LDS-DMA, requested a row stage ahead (head_dma)
+    // FOLD frees every wave's K / V region (but wave 0's K region: the shared LayerNorm rows), so the layer BEFORE the last
+    // one keeps its q' and P in LDS too: copied there after its forward attention, copied back before its backward one --
+    // with the layer-0 table and KEEP_LAST no q' / P of a 3-layer model ever goes through the stash in the sampling loops.
+    constexpr bool KEEP2 = FOLD && KEEP_LAST;
+    lfloat* const Qsave = wr + 2 * RS;                                                        // own V region
+    lfloat* const Psave = wave == 0 ? sm + LL::wreg + LL::WREG + RS + 16 * DFF_PLD : wr + RS;   // own K region (wave 0: second slot of wave 1's)
+    static_assert(!KEEP2 || RS >= 2 * 16 * DFF_PLD, "two P tiles in a K region");
+    auto keep2_copy = [=](const lfloat* qs, lfloat* qd, const lfloat* ps, lfloat* pd, int lane) {
+#pragma unroll
+        for (int u = 0; u < (RS / 4 + 63) / 64; ++u) {
+            const int it = lane + 64 * u;
+            if (it < RS / 4) *(lf32x4*)(qd + 4 * it) = *(const lf32x4*)(qs + 4 * it);
+        }
+#pragma unroll
+        for (int u = 0; u < (16 * DFF_PLD / 4 + 63) / 64; ++u) {
+            const int it = lane + 64 * u;
+            if (it < 16 * DFF_PLD / 4) *(lf32x4*)(pd + 4 * it) = *(const lf32x4*)(ps + 4 * it);
+        }
+    };
     static_assert(!HDMA || DFF_XLD % 4 == 0, "16-byte slots");
     lfloat* const pb = RELAY ? wr + 3 * RS : wr + 4 * RS;
     lfloat* const Gx = RELAY ? pb + 16 * DFF_PLD : wr + 3 * RS;
@@ -1017,7 +1036,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 for (int nt = 0; nt < E; ++nt) acc_o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 const WStream after = s_w1(lw);   // the FFN block follows
                 // the sampling loops never read the last layer's q_ext | k | v | P back from the stash (KEEP_LAST)
-                const bool st_qkv = !(KEEP_LAST && l == m.L - 1 && l > 0 && a.mode != DFF_MODE_SCORE);
+                const bool keep2 = KEEP2 && l == m.L - 2 && l > 0 && a.mode != DFF_MODE_SCORE;
+                const bool st_qkv = !(KEEP_LAST && l == m.L - 1 && l > 0 && a.mode != DFF_MODE_SCORE) && !keep2;
                 const SStream sn0 = ss_w1(lw), sn1 = ss_w2(lw);   // the FFN block's units follow: W1 (U_W1), then W2
                 auto head_math = [&](int h) {
                     write_xext(lane);
@@ -1098,6 +1118,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         if (st_qkv) head_store<FOLD>(Qx, Kx, Vx, sb + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, RA, lane, RLA);
                         pf.tick(12);
                         head_math(wave);
+                        if constexpr (KEEP2) { if (keep2) keep2_copy(Qx, Qsave, pb, Psave, lane); }
                         pf.tick(13);
                         stall_run<U_QKV, 2, E, true>(sring, acc_o, wox_fa32, sq, lane, wox_xa, wox_ext(lw, wave, lane), DFF_HEADS * 5 * 256);
                         pf.tick(14);
@@ -1455,7 +1476,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             pf.tick(7);
             // first head of this layer's attention backward: start the stash read (hidden by row stage E)
             if constexpr (HDMA) {
-                if (!(KEEP_LAST && l == m.L - 1 && l > 0))
+                if (!(KEEP_LAST && l == m.L - 1 && l > 0) && !(KEEP2 && l == m.L - 2 && l > 0 && a.mode != DFF_MODE_SCORE))
                     head_dma(dmatab, Qx, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, lane_id());
             }
             if constexpr (HPW == 2) {
@@ -1669,7 +1690,10 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         tall_run<3, 13, E, 4>(ring, acc_a, qkvt_fa, s_qkvt(lw, h1), after, lane);   // ends at phase 0
                         pf.tick(18);
                     } else {
-                        if constexpr (HDMA) head_dma_wait();   // (requested before row stage E; nothing for the last layer)
+                        if constexpr (HDMA) {
+                            head_dma_wait();   // (requested before row stage E; nothing for the last layer)
+                            if constexpr (KEEP2) { if (l == m.L - 2 && l > 0 && a.mode != DFF_MODE_SCORE) keep2_copy(Qsave, Qx, Psave, pb, lane); }
+                        }
                         else if (!(KEEP_LAST && l == m.L - 1)) {   // the last layer's q_ext | k | v | P are still in the head buffers
                             head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, true, lane, m12p(wave));
                             head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
