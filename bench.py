@@ -154,6 +154,34 @@ def cpu_baseline(cfg, P, t_level, budget_s=12.0, max_steps=40, threads=None):
                       f"oracle/reference_twin.py on {torch.get_num_threads()} threads of {os.cpu_count()} logical cores"}
 
 
+def cpu_baseline_iid(cfg, P, budget_s=8.0, max_steps=20, threads=8):
+    """The i.i.d. metric's CPU leg: reverse DDPM steps (models/ddpm.py:221-232: score network + posterior update) of the
+    oracle twin at batch P on the host cores.  A sample is a complete 1000-step chain, so samples/s = P / (1000 x seconds
+    per reverse step); the steps timed are a bounded sample from the top of the chain (every step costs the same: one
+    score call of the same shape)."""
+    from oracle import reference_twin as twin
+    import synth_weights as synth
+    _, N, H, L = synth.SHIPPED_CONFIGS[cfg]
+    p = twin.to_torch(synth.synth_gnn_params(N, H, L, decoder_scale=1e-2))
+    sched = twin.make_schedule()
+    g = torch.Generator().manual_seed(2025)
+    x = twin.center_zero(torch.randn(P, N, 3, generator=g))
+    torch.set_num_threads(threads)
+    t = 999
+    x = twin.center_zero(twin.p_sample(p, sched, x, t, torch.randn(P, N, 3, generator=g), L))   # warm
+    n, t0 = 0, time.perf_counter()
+    while n < max_steps and (n < 2 or (time.perf_counter() - t0) < budget_s):
+        t -= 1
+        x = twin.center_zero(torch.clamp(twin.p_sample(p, sched, x, t, torch.randn(P, N, 3, generator=g), L), -1000, 1000))
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": P / (1000.0 * dt), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "ms_per_reverse_step": 1e3 * dt,
+            "sample": f"{n} reverse DDPM steps (t = 998 .. {t}) of the same workload (batch {P}, {cfg}) after one warm-up step, "
+                      f"oracle/reference_twin.py p_sample on {torch.get_num_threads()} threads of {os.cpu_count()} logical cores; "
+                      f"a sample = 1000 such steps"}
+
+
 def make_model(cfg, dev):
     import synth_weights as synth
     from dff_amd.ddpm import GaussianDiffusion
@@ -162,7 +190,7 @@ def make_model(cfg, dev):
     model = GraphTransformer(N, H, device=dev, n_layers=L, use_intrinsic_coords=True, use_abs_coords=False,
                              use_distances=False, conservative=True,
                              state_dict=synth.synth_gnn_params(N, H, L, seed=1234, decoder_scale=1e-2))
-    return model, GaussianDiffusion(model, num_atoms=N, timesteps=1000, norm_factor=NORM_STD[cfg]), (N, H, L)
+    return model, GaussianDiffusion(model, num_atoms=N, timesteps=1000, norm_factor=NORM_STD[cfg], defer_checks=True), (N, H, L)
 
 
 class Timer:
@@ -191,7 +219,7 @@ class Timer:
         elapsed = time.perf_counter() - t0
         if self.world > 1:
             import torch.distributed as dist
-            tmax = torch.tensor([elapsed], device=self.dev, dtype=torch.float64)
+            tmax = torch.tensor([elapsed], device=self.dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = tmax.item()
         return elapsed, [a.elapsed_time(b) for a, b in ev]
@@ -246,24 +274,46 @@ def main():
     ap.add_argument("--parallel_sim", type=int, default=256, help="trajectories per GPU")
     ap.add_argument("--noise_level", type=int, default=20)
     ap.add_argument("--group", type=int, default=0, help="proteins per workgroup (0 = auto)")
+    ap.add_argument("--mode", default="langevin", choices=["langevin", "iid"],
+                    help="iid: time complete 1000-step reverse DDPM chains of --cfg at --parallel_sim per GPU instead (profiling runs)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
     ap.add_argument("--no-extras", action="store_true", help="skip the other north-star figures (`also`)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", 0))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
+    import dff_amd  # noqa: F401  (loads libdff_amd.so: loud failure if the HIP extension is missing)
+    from dff_amd.sampling import dist_backend, dist_env
+
+    # RANK / LOCAL_RANK / WORLD_SIZE from torchrun; the test knobs of dist_env() (several ranks on ONE GPU over gloo, under
+    # DFF_TEST_KNOBS=1) let the one-GPU box execute this N > 1 path: tests/test_gpu_parity.py::test_bench_two_ranks_on_one_gpu
+    rank, local_rank, world = dist_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
-
-    import dff_amd  # noqa: F401  (loads libdff_amd.so: loud failure if the HIP extension is missing)
+        backend = dist_backend()
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     cfg, P, chunk = args.cfg, args.parallel_sim, args.chunk
+    if args.mode == "iid":   # the i.i.d. workload on its own (what tools_rocprof.sh profiles for `also.*_iid.roofline.traffic`)
+        nt = max(4, -(-args.steps // 1000))
+        e = iid_entry(cfg, P, 1, nt, dev, rank, world)
+        if rank == 0:
+            print(json.dumps({"metric": f"i.i.d. samples/sec at batch {P} per GPU ({cfg}: complete 1000-step reverse DDPM chains)",
+                              "value": world * P * nt / e["elapsed"], "unit": "samples/s (whole job)", "n_gpus": world,
+                              "steps": nt * 1000, "warmup": 1000, "ms_per_step": 1e3 * e["elapsed"] / (nt * 1000),
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": kernel_dtype(e["kernel"]),
+                              "data": "synthetic (seeded weights, in-kernel Philox noise)",
+                              "config": {"workload": f"{cfg} iid, batch {P}/GPU, 1000 reverse steps per launch", "kernel": e["kernel"]},
+                              "roofline": roofline(cfg, P, 1000, e["launch_ms"], e["kernel"])}))
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
     n_timed = max(MIN_LAUNCHES, -(-args.steps // chunk))
     n_warm = max(1, -(-args.warmup // chunk)) if args.warmup > 0 else 0
     h = langevin_entry(cfg, P, chunk, n_warm, n_timed, dev, rank, world, args.noise_level, args.group)
@@ -274,8 +324,9 @@ def main():
         import torch.distributed as dist
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        out = [torch.empty_like(h["frames"]) for _ in range(world)]
-        dist.all_gather(out, h["frames"])
+        fr = h["frames"] if dist.get_backend() == "nccl" else h["frames"].cpu()
+        out = [torch.empty_like(fr) for _ in range(world)]
+        dist.all_gather(out, fr)
         torch.cuda.synchronize()
         gather_ms = 1e3 * (time.perf_counter() - t1)
 
@@ -292,7 +343,9 @@ def main():
                     "ms_per_step": 1e3 * e["elapsed"] / e["K"], "steps": e["K"], "finite": e["finite"],
                     "trajectory_steps_per_s": world * P2 * e["K"] / e["elapsed"],
                     "roofline": roofline(c2, P2, ch2, e["launch_ms"], e["kernel"]), "dtype": kernel_dtype(e["kernel"])}
-            for name, c2, P2, nt in (("chignolin_iid", "chignolin", 256, MIN_LAUNCHES), ("villin_iid", "villin", 256, 4)):
+            # chignolin_iid_512: BASELINE configs[2] in its own per-GPU shape (batch 4096 over 8 GPUs, sample.py:185-189)
+            for name, c2, P2, nt in (("chignolin_iid", "chignolin", 256, MIN_LAUNCHES), ("chignolin_iid_512", "chignolin", 512, 4),
+                                     ("villin_iid", "villin", 256, 4)):
                 e = iid_entry(c2, P2, 1, nt, dev, rank, world)
                 also[name] = {
                     "metric": f"i.i.d. samples/sec at batch {P2} per GPU ({c2}: complete 1000-step reverse DDPM chains)",
@@ -330,6 +383,15 @@ def main():
             if also is not None and "villin_langevin" in also:    # ~5 s per step on the host: three steps, same thread count
                 also["villin_langevin"]["cpu_baseline"] = cpu_baseline("villin", 256, 20, budget_s=10.0, max_steps=3,
                                                                          threads=res["cpu_baseline"]["cores"])
+            if also is not None:    # the i.i.d. metric's CPU legs (north_star: "alongside the CPU-reference number")
+                for name, c2, bud, mx in (("chignolin_iid", "chignolin", 8.0, 20), ("villin_iid", "villin", 8.0, 2)):
+                    if name in also:
+                        also[name]["cpu_baseline"] = cpu_baseline_iid(c2, 256, budget_s=bud, max_steps=mx,
+                                                                      threads=res["cpu_baseline"]["cores"])
+                        also[name]["speedup_vs_cpu_port"] = also[name]["value"] / also[name]["cpu_baseline"]["value"]
+                if "chignolin_iid_512" in also and "chignolin_iid" in also and "cpu_baseline" in also["chignolin_iid"]:
+                    also["chignolin_iid_512"]["cpu_baseline"] = dict(also["chignolin_iid"]["cpu_baseline"],
+                                                                     note="measured at batch 256 (the CPU port's samples/s does not grow with the batch)")
         print(json.dumps(res))
     if world > 1:
         import torch.distributed as dist

@@ -126,6 +126,17 @@ int dff_ddpm_run(dff_model* m, int batch, float* x_dev, const float* noise_dev, 
                  uint64_t sample_offset, int t_start, int t_end, int init_prior,
                  int* clamp_flag_dev, void* stream);
 
+/* Sticky status word of everything this model has launched so far (synchronises the device).  0 = fine.  Bit 0: a launch
+ * of a two-workgroups-per-protein kernel variant (chosen automatically for batches that would leave half the CUs idle, see
+ * dff_debug_pair) gave up waiting for a partner workgroup -- possible only when the GPU is shared with another process or
+ * partitioned below the CU count the driver reports; the results of that launch are invalid.  The samplers call this at
+ * their host synchronisation points (end of LangevinDiffusion.simulate, GaussianDiffusion.check_clamp, the CLI) and raise;
+ * the next such launch on the same model also refuses with DFF_EHIP.  The reference has no counterpart (one process, one
+ * kernel per op).  NOTE: which variant runs depends on the per-call batch (<= n_CUs / 2 proteins), and the two variants sum
+ * in different orders: trajectories are bit-reproducible for a fixed per-rank batch, not across batch splits that cross
+ * that threshold. */
+int dff_model_status(dff_model* m, unsigned* status);
+
 /* ---- introspection / debugging (used by tests and bench.py, not by samplers) ---- */
 
 /* Proteins handled per workgroup for this model (0 = choose automatically from batch). */
@@ -144,8 +155,7 @@ int dff_debug_l0_table(dff_model* m, int on);
 /* Debugging: on == 0 never splits a protein over two workgroups (the PAIR variants of the <= 64-row kernel, chosen
  * automatically when one workgroup per protein would leave at least half the CUs idle, e.g. protein G at 128 per GPU). */
 int dff_debug_pair(dff_model* m, int on);
-/* *status = 0 if every partial-tile exchange of the PAIR launches so far found its partner (a bounded spin replaces a
- * hang: non-zero means the results of that launch are invalid).  Synchronises the device. */
+/* dff_model_status for tests: *status = the sticky word, which is then CLEARED.  Synchronises the device. */
 int dff_debug_pair_status(dff_model* m, int* status);
 /* Name of the kernel the last call launched, grid size and dynamic LDS bytes. */
 int dff_last_launch(const dff_model* m, const char** kernel_name, int* grid, int* lds_bytes);

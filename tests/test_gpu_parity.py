@@ -4,9 +4,11 @@ golden vectors recorded from the reference.  Run with ``-m gpu`` on an MI355X.
 Tolerances (fp32 path): the reference's own float32 run differs from its
 float64 run by ~1.1-1.7e-6 relative (printed by tests/golden/make_golden.py).  The HIP path uses
 a different (factorised) formulation and MFMA k-order, so it is held to
-    ||F_hip - F_ref64|| / ||F_ref64||  <=  1e-5        (measured: see DESIGN.md)
+    ||F_hip - F_ref64|| / ||F_ref64||  <=  GUARD x ||F_ref32 - F_ref64|| / ||F_ref64||     (GUARD = 2.5: "no worse than
+                                           the reference's own float32 run, up to a small factor"; and <= 1e-5 absolutely)
     max|F_hip - F_ref32|               <=  1e-4 * max|F_ref32|
-and single integrator / reverse steps on identical noise to 2e-5 relative.
+single integrator / reverse steps on identical noise to 2e-5 relative (measured ~1e-7), and K-step fused trajectories to
+STEP_TOL x K = 5e-6 K relative (round 3: tightened from 2e-5 K; a 5x regression of the measured error no longer passes).
 """
 import os
 
@@ -49,9 +51,21 @@ def get_model(dff, cfg, decoder_scale=1.0):
     return _models[key]
 
 
+GUARD = 2.5        # rel(hip, ref64) <= GUARD * rel(ref32, ref64)
+STEP_TOL = 5e-6    # per fused step, relative to the trajectory's largest entry
+
+
 def rel(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+def twin_refs(params, x, t, L):
+    """The oracle's float32 and float64 forces for (x, t) (numpy in, numpy out): the twin is bit-identical to the
+    reference in float32 (tests/test_oracle_golden.py) and the same code in float64."""
+    r32 = twin.score(twin.to_torch(params), torch.from_numpy(x), torch.from_numpy(t), L).numpy()
+    r64 = twin.score(twin.to_torch(params, torch.float64), torch.from_numpy(x).double(), torch.from_numpy(t).double(), L).numpy()
+    return r32, r64
 
 
 def test_mfma_gemm_stage(dff):
@@ -78,7 +92,7 @@ def test_score_vs_reference_golden(dff, cfg, golden):
     r64 = rel(f, g["forces64"])
     r32 = rel(g["forces32"], g["forces64"])
     print(f"{cfg}: rel(hip,ref64)={r64:.3e} rel(ref32,ref64)={r32:.3e} kernel={model.native.last_launch()}")
-    assert r64 <= 1e-5
+    assert r64 <= 1e-5 and r64 <= GUARD * r32
     assert np.abs(f - g["forces32"]).max() <= 1e-4 * np.abs(g["forces32"]).max()
     np.testing.assert_allclose(e[..., None], g["energy32"], rtol=0, atol=2e-5)
     assert np.abs(f.sum(1)).max() < 2e-6  # mean-free forces
@@ -132,14 +146,14 @@ def test_grouping_and_ragged_batches(dff, cfg, G):
     B = 7
     x = synth.normal((B, N, 3), 11, 3).astype(np.float32)
     t = np.linspace(0.001, 0.9, B).astype(np.float32)
-    ref = twin.score(twin.to_torch(params), torch.from_numpy(x), torch.from_numpy(t), L).numpy()
+    ref32, ref64 = twin_refs(params, x, t, L)
     model.native.set_group(G)
     try:
         f = model.native.score(torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()).cpu().numpy()
-        print(cfg, G, model.native.last_launch(), rel(f, ref))
+        print(cfg, G, model.native.last_launch(), rel(f, ref64), rel(ref32, ref64))
     finally:
         model.native.set_group(0)
-    assert rel(f, ref) <= 1e-5
+    assert rel(f, ref64) <= min(1e-5, GUARD * rel(ref32, ref64))
 
 
 @pytest.mark.parametrize("cfg", ["ala2", "chignolin"])
@@ -211,20 +225,20 @@ def test_p_sample_golden(dff, cfg, golden):
 def test_fused_reverse_loop_golden(dff, cfg, golden):
     """5 fused reverse steps incl. the +-1000 clamp path (ddpm.py:248-251) in ONE launch (protein G: the SPILL variant of
     the <= 64-row kernel).  One sample has a coordinate at the clamp, so its entries are O(1000) after centring; every
-    sample is held to 2e-5 x 5 steps relative to ITS OWN largest entry -- the samples that never clamp (entries O(1)) are
-    therefore checked to ~2e-4 absolute, not to the clamped sample's scale."""
+    sample is held to STEP_TOL x 5 steps relative to ITS OWN largest entry -- the samples that never clamp (entries O(1)) are
+    therefore checked to ~2.5e-5 absolute, not to the clamped sample's scale."""
     g = golden(f"ploop_{cfg}.npz")
     diff, _ = _diffusion(dff, cfg)
-    y = diff.p_sample_loop_from(torch.from_numpy(g["x5"]), 4, 0, noises=torch.from_numpy(g["noises"])).cpu().numpy()
+    with pytest.warns(UserWarning, match="Large molecule"):   # the chain's own end-of-loop check (ddpm.py:249), no extra call needed
+        y = diff.p_sample_loop_from(torch.from_numpy(g["x5"]), 4, 0, noises=torch.from_numpy(g["noises"])).cpu().numpy()
+    assert diff.last_clamped and not diff.check_clamp()       # ... which also cleared the word
     clamped = 0
     for b in range(y.shape[0]):
         scale = np.abs(g["x0"][b]).max()
         clamped += scale > 100
-        np.testing.assert_allclose(y[b], g["x0"][b], rtol=0, atol=2e-5 * 5 * scale, err_msg=f"sample {b}")
+        np.testing.assert_allclose(y[b], g["x0"][b], rtol=0, atol=STEP_TOL * 5 * scale, err_msg=f"sample {b}")
     assert clamped == 1
     y = torch.from_numpy(y)
-    with pytest.warns(UserWarning):
-        assert diff.check_clamp()
     assert y.mean(1).abs().max().item() < 1e-3
 
 
@@ -246,7 +260,8 @@ def test_fused_single_steps_match_p_sample(dff, golden):
                                       ("langevin_villin_4", "villin"), ("langevin_chignolin_5", "chignolin"),
                                       ("langevin_trp_cage_r20", "trp_cage"), ("langevin_bba_r21", "bba"),
                                       ("langevin_villin_r22", "villin"), ("langevin_protein_g_r23", "protein_g"),
-                                      ("langevin_protein_g_r24", "protein_g")])
+                                      ("langevin_protein_g_r24", "protein_g"),
+                                      ("langevin_chignolin_kcal_r30", "chignolin"), ("langevin_villin_kcal_r31", "villin")])
 def test_langevin_golden(dff, name, cfg, golden):
     from dff_amd.langevin import LangevinDiffusion
     g = golden(name + ".npz")
@@ -254,13 +269,16 @@ def test_langevin_golden(dff, name, cfg, golden):
     diff, _ = _diffusion(dff, cfg, decoder_scale=1e-2, norm=norm)
     friction = None if g["friction"] < 0 else float(g["friction"])
     K, save = int(g["K"]), int(g["save"])
+    kb = str(g["kb"]) if "kb" in g.files else "consistent"       # round-3 vectors: kb="kcal" (dynamics/langevin.py:141-144)
     ld = LangevinDiffusion(diff, torch.from_numpy(g["init"]), K, save_interval=save, t=int(g["t_level"]),
                            diffusion_steps=1000, temp_data=float(g["temp"]), temp_sim=float(g["temp"]),
-                           dt=float(g["dt"]), masses=[float(m) for m in g["masses"]], friction=friction,
-                           kb="consistent", verbose=False)
+                           dt=None if kb == "kcal" else float(g["dt"]),     # (kcal: the derived dt of :161-167 is under test too)
+                           masses=[float(m) for m in g["masses"]], friction=friction, kb=kb, verbose=False)
+    if kb == "kcal":
+        assert abs(ld.dt / float(g["dt"]) - 1.0) < 1e-6
     traj = ld.sample(noises=torch.from_numpy(g["noises"]))
     assert traj.shape == g["traj"].shape and traj.dtype == torch.float32 and traj.device.type == "cpu"
-    tol = 2e-5 * K
+    tol = STEP_TOL * K
     np.testing.assert_allclose(traj.numpy(), g["traj"], rtol=tol, atol=tol * np.abs(g["traj"]).max())
     np.testing.assert_allclose(ld.x.cpu().numpy(), g["x_last"], rtol=tol, atol=tol * np.abs(g["x_last"]).max())
     if friction is not None:
@@ -664,7 +682,7 @@ def test_full_size_langevin_subset_vs_oracle(dff, cfg, P, wgs):
     fr, ke, xl, vl = twin.simulate(twin.to_torch(params), torch.from_numpy(x0[idx]) / NORM_STD[cfg],
                                    torch.from_numpy(noises[:, idx]), masses, c, L, 1)
     ref = (fr * NORM_STD[cfg]).numpy()                                # (sims, frames, N, 3)
-    tol = 2e-5 * K
+    tol = STEP_TOL * K
     np.testing.assert_allclose(traj[idx], ref, rtol=tol, atol=tol * np.abs(ref).max())
     np.testing.assert_allclose(ld.v.cpu().numpy()[idx], vl.numpy(), rtol=tol, atol=tol * np.abs(vl.numpy()).max())
     assert np.isfinite(traj).all()
@@ -685,7 +703,7 @@ def test_full_size_ddpm_subset_vs_oracle(dff):
     idx = [0, 1, 2047, 2048, 3000, 4095]
     ref = twin.p_sample_loop(twin.to_torch(params), twin.make_schedule(), torch.from_numpy(x[idx]),
                              torch.from_numpy(noises[:, idx]), K - 1, L).numpy()
-    tol = 2e-5 * K
+    tol = STEP_TOL * K
     np.testing.assert_allclose(y[idx], ref, rtol=tol, atol=tol * np.abs(ref).max())
     assert np.isfinite(y).all() and np.abs(y.mean(1)).max() < 1e-4
 
@@ -727,7 +745,7 @@ def test_two_ranks_on_one_gpu_equal_one_rank(dff, tmp_path, mode):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   DFF_DEVICE="0", DFF_DIST_BACKEND="gloo", DFF_REPO=ROOT, DFF_OUT=str(tmp_path / "w2.pt"))
+                   DFF_TEST_KNOBS="1", DFF_DEVICE="0", DFF_DIST_BACKEND="gloo", DFF_REPO=ROOT, DFF_OUT=str(tmp_path / "w2.pt"))
         procs.append(subprocess.Popen([sys.executable, str(script)] + argv + ["--append_exp_name", "w2"], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for pr in procs:
@@ -741,11 +759,48 @@ def test_two_ranks_on_one_gpu_equal_one_rank(dff, tmp_path, mode):
 
 
 @pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu(dff):
+    """bench.py's N > 1 path (process group, barriers, max-over-ranks timing, the frame all_gather, rank-0 JSON line)
+    executed for real: two ranks share the one GPU (test knobs of sampling.dist_env, gloo rendezvous).  The ranks are
+    time-sliced, so the whole-job value is about the one-rank value (twice the work in twice the time), not 2x."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    args = ["--steps", "500", "--warmup", "250", "--no-cpu", "--no-extras"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args, capture_output=True, text=True,
+                         timeout=600, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert one.returncode == 0, one.stdout[-1500:] + one.stderr[-1500:]
+    r1 = json.loads(one.stdout.strip().splitlines()[-1])
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   DFF_TEST_KNOBS="1", DFF_DEVICE="0", DFF_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [pr.communicate(timeout=900) for pr in procs]
+    for pr, (o, e) in zip(procs, outs):
+        assert pr.returncode == 0, o[-1500:] + e[-1500:]
+    assert outs[1][0].strip() == ""                                    # only rank 0 prints
+    r2 = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert r2["n_gpus"] == 2 and r2["steps"] == r1["steps"] == 2000 and r2["scaling"] == "weak" and r2["finite"]
+    assert r2["metric"] == r1["metric"] and r2["config"]["kernel"] == r1["config"]["kernel"]
+    assert r2["gather_ms"] > 0.0 and r1["gather_ms"] == 0.0
+    ratio = r2["value"] / r1["value"]
+    print(f"bench 2 ranks on 1 GPU: value {r2['value']:.1f} vs 1 rank {r1['value']:.1f} (ratio {ratio:.2f})")
+    assert 0.45 < ratio < 1.35, ratio
+
+
+@pytest.mark.gpu
 def test_device_flag_word_persists_and_reports_centre(dff):
     """One flag word per GaussianDiffusion: a clamp in an EARLIER batch is still reported after later clean batches
     (the reference warns per step, ddpm.py:248-250), and a chain that ends off-centre -- here: NaNs, which slip through the
     reference's own entry check just the same -- raises like assert_center_zero (ddpm.py:252); reading clears the word."""
     diff, _ = _diffusion(dff, "chignolin")
+    diff.defer_checks = True          # as the CLI / bench.py run it: many batches, ONE check at the end
     N = 10
     big = torch.zeros(2, N, 3)
     big[0, 0, 0], big[0, 1, 0] = 4000.0, -4000.0                      # centred, far outside +-1000
@@ -761,6 +816,12 @@ def test_device_flag_word_persists_and_reports_centre(dff):
     with pytest.raises(AssertionError, match="Center not at zero"):
         diff.check_clamp()
     assert not diff.check_clamp()
+    # default (defer_checks=False): every chain entry point checks at its own end, like ddpm.py:249-252
+    diff.defer_checks = False
+    with pytest.warns(UserWarning, match="Large molecule"):
+        diff.p_sample_loop_from(big, 999, 999)
+    with pytest.raises(AssertionError, match="Center not at zero"):
+        diff.p_sample_loop_from(bad, 1, 0)
 
 
 @pytest.mark.gpu
@@ -782,7 +843,9 @@ def test_pair_variant_equals_one_workgroup_variant(dff, cfg, golden):
             f = model.native.score(x, t).cpu().numpy()
             assert ("pair" in model.native.last_launch()[0]) == on
             assert model.native.pair_status() == 0
-            assert rel(f, g["forces64"]) <= 1e-5
+            r64, r32 = rel(f, g["forces64"]), rel(g["forces32"], g["forces64"])
+            print(f"{cfg}: pair={on} rel(hip,ref64)={r64:.3e} rel(ref32,ref64)={r32:.3e}")
+            assert r64 <= 1e-5 and r64 <= GUARD * r32
             out[on] = f
         assert rel(out[True], out[False]) <= 5e-6
         model.native.pair(True)

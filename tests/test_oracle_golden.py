@@ -112,15 +112,19 @@ def test_p_sample_loop_with_clamp(golden):
 
 @pytest.mark.parametrize("name,cfg", [("langevin_chignolin_0", "chignolin"), ("langevin_chignolin_1", "chignolin"),
                                       ("langevin_chignolin_2", "chignolin"), ("langevin_ala2_3", "ala2"),
-                                      ("langevin_villin_4", "villin"), ("langevin_chignolin_5", "chignolin")])
+                                      ("langevin_villin_4", "villin"), ("langevin_chignolin_5", "chignolin"),
+                                      ("langevin_chignolin_kcal_r30", "chignolin"), ("langevin_villin_kcal_r31", "villin")])
 def test_langevin(name, cfg, golden):
     g = golden(name + ".npz")
     _, N, H, L = synth.SHIPPED_CONFIGS[cfg]
     p = twin.to_torch(synth.synth_gnn_params(N, H, L, decoder_scale=1e-2))
     friction = None if g["friction"] < 0 else float(g["friction"])
     norm = float(g["norm"])
+    kb = str(g["kb"]) if "kb" in g.files else "consistent"       # round-3 vectors: kb="kcal" (dynamics/langevin.py:141-144)
     c = twin.langevin_constants(norm, int(g["t_level"]), twin.make_schedule(), float(g["temp"]), float(g["temp"]),
-                                list(g["masses"]), friction, float(g["dt"]))
+                                list(g["masses"]), friction, None if kb == "kcal" else float(g["dt"]), kb=kb)
+    if kb == "kcal":
+        assert abs(c["dt"] / float(g["dt"]) - 1.0) < 1e-6
     fr, ke, xl, vl = twin.simulate(p, torch.from_numpy(g["init"]) / norm, torch.from_numpy(g["noises"]),
                                    list(g["masses"]), c, L, int(g["save"]))
     np.testing.assert_allclose((fr.reshape(-1, N, 3) * norm).numpy(), g["traj"], rtol=1e-6, atol=1e-6)

@@ -11,6 +11,12 @@ rm -rf $OUT; mkdir -p $OUT
 BENCH="python $ROOT/bench.py --steps 1000 --warmup 250 --no-cpu --no-extras $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 i=0
+if [ "${DFF_PMC_SETS:-all}" = "traffic" ]; then   # HBM bytes only: FETCH_SIZE and WRITE_SIZE, each in its own pass
+  for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+    i=$((i+1))
+    rocprofv3 --pmc $set --output-format csv -d $OUT/pmc$i -o pmc -- $BENCH > $OUT/pmc$i.log 2>&1
+  done
+else
 for set in "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU" \
@@ -20,6 +26,7 @@ for set in "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE" \
   i=$((i+1))
   rocprofv3 --pmc $set --output-format csv -d $OUT/pmc$i -o pmc -- $BENCH > $OUT/pmc$i.log 2>&1
 done
+fi
 python - <<PY
 import csv, glob, os, collections, json
 out = "$OUT"

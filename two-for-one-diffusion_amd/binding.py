@@ -69,6 +69,7 @@ SYMBOLS = {
     "dff_last_error": (C.c_char_p, []),
     "dff_debug_pair": (C.c_int, [_P, C.c_int]),
     "dff_debug_pair_status": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "dff_model_status": (C.c_int, [_P, C.POINTER(C.c_uint)]),
     "dff_version": (C.c_char_p, []),
 }
 
@@ -182,6 +183,21 @@ class Model:
         st = C.c_int(0)
         _check(self.lib, self.lib.dff_debug_pair_status(self.handle, C.byref(st)), "dff_debug_pair_status")
         return st.value
+
+    def status(self) -> int:
+        """Sticky status word of every launch so far (dff_model_status; synchronises the device)."""
+        st = C.c_uint(0)
+        _check(self.lib, self.lib.dff_model_status(self.handle, C.byref(st)), "dff_model_status")
+        return st.value
+
+    def check(self):
+        """Raise if any launch so far reported a failure the kernels cannot return synchronously (bit 0: a
+        two-workgroups-per-protein launch lost its partner workgroup).  Called at the samplers' host sync points."""
+        w = self.status()
+        if w:
+            raise RuntimeError(f"libdff_amd: device-side failure word {w:#x}: a two-workgroups-per-protein kernel launch timed "
+                               f"out waiting for its partner workgroup (GPU shared or partitioned?); results are invalid. "
+                               f"Model.pair(False) selects the one-workgroup kernels.")
 
     def l0_table(self, on: bool = True):
         _check(self.lib, self.lib.dff_debug_l0_table(self.handle, int(on)), "dff_debug_l0_table")

@@ -23,7 +23,7 @@ from pathlib import Path
 import torch
 
 from . import specs, weights
-from .sampling import SamplerWrapper, dist_env, gather_variable, sample_from_model, shard_range
+from .sampling import SamplerWrapper, dist_backend, dist_env, gather_variable, sample_from_model, shard_range
 
 
 def parse_masses(text: str):
@@ -115,7 +115,8 @@ def build_diffusion(args, model_path: str, checkpoint: str, device, seed: int = 
                                 conservative=args.conservative, state_dict=params, timesteps=args.diffusion_steps)
     ddpm = GaussianDiffusion(model=model_nn, features=torch.eye(mol.n_beads), num_atoms=mol.n_beads,
                              timesteps=args.diffusion_steps, norm_factor=norm_factor,
-                             loss_weights=getattr(args, "loss_weights", "ones"), seed=seed)
+                             loss_weights=getattr(args, "loss_weights", "ones"), seed=seed,
+                             defer_checks=True)   # generate_samples checks once after all its batches (one host sync)
     return ddpm, mol
 
 
@@ -170,7 +171,7 @@ def main(argv=None):
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        backend = os.environ.get("DFF_DIST_BACKEND", "nccl")    # RCCL over xGMI; "gloo" when ranks share one GPU (tests)
+        backend = dist_backend()    # "nccl" = RCCL over xGMI; a test knob selects "gloo" when ranks share one GPU
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:

@@ -183,6 +183,8 @@ struct dff_model {
     size_t xflag_n = 0;
     bool pair_off = false;                     // debugging: never use a PAIR variant
     bool last_pair = false;
+    bool pair_used = false;                    // a PAIR launch has run since the sticky error word was last read
+    int n_cus = 0;                             // hipDeviceAttributeMultiprocessorCount of `device`
 };
 
 static int upload_u32(dff_model* m, const std::vector<uint32_t>& h, const unsigned** out) {
@@ -279,6 +281,7 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
     } undo{m};
     m->cfg = *cfg;
     m->device = device;
+    HIPCHK(hipDeviceGetAttribute(&m->n_cus, hipDeviceAttributeMultiprocessorCount, device));
     {   // weight GEMMs on the bf16 pipe via the exact three-way split of every fp32 operand, wherever a kernel variant
         // exists for the shape (default); DFF_SPLIT_BF16=0: every GEMM on v_mfma_f32_16x16x4_f32
         const char* e = getenv("DFF_SPLIT_BF16");
@@ -552,18 +555,33 @@ extern "C" int dff_debug_pair(dff_model* m, int on) {
     return DFF_OK;
 }
 
-// 0: every partial-tile exchange of the PAIR launches so far found its partner; non-zero: a bounded spin gave up (results
-// of that launch are invalid).  Synchronises the device.
-extern "C" int dff_debug_pair_status(dff_model* m, int* status) {
-    if (!m || !status) return fail(DFF_EINVAL, "null argument");
-    *status = 0;
-    if (!m->xflag || !m->last_pair) return DFF_OK;
+// Sticky status of the model's launches so far: bit 0 = a PAIR launch (two workgroups per protein) gave up waiting for a
+// partner workgroup (bounded spin instead of a hang; the results of that launch are invalid).  The word lives at
+// xflag[0], is only ever OR-ed by the kernels and is never cleared by a launch, so an error in ANY launch of a chunked
+// run is still there when the caller looks.  Synchronises the device.
+static int read_status(dff_model* m, unsigned* word, bool clear) {
+    *word = 0;
+    if (!m->xflag) return DFF_OK;
     ON_DEVICE(m->device);
     HIPCHK(hipDeviceSynchronize());
-    unsigned w = 0;
-    HIPCHK(hipMemcpy(&w, m->xflag + m->xflag_n - 1, sizeof(unsigned), hipMemcpyDeviceToHost));
-    *status = (int)w;
+    HIPCHK(hipMemcpy(word, m->xflag, sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (clear && *word) HIPCHK(hipMemset(m->xflag, 0, sizeof(unsigned)));
+    m->pair_used = false;
     return DFF_OK;
+}
+
+extern "C" int dff_model_status(dff_model* m, unsigned* status) {
+    if (!m || !status) return fail(DFF_EINVAL, "null argument");
+    return read_status(m, status, false);
+}
+
+// debugging form: reads AND clears
+extern "C" int dff_debug_pair_status(dff_model* m, int* status) {
+    if (!m || !status) return fail(DFF_EINVAL, "null argument");
+    unsigned w = 0;
+    const int rc = read_status(m, &w, true);
+    *status = (int)w;
+    return rc;
 }
 
 extern "C" int dff_debug_l0_table(dff_model* m, int on) {
@@ -657,14 +675,23 @@ static int launch_generic(dff_model* m, DffRunArgs& a, int G, const Variant* v, 
             HIPCHK(hipMalloc((void**)&m->xchg, need * sizeof(float)));
             m->xchg_floats = need;
         }
-        if (nflag > m->xflag_n) {
-            if (m->xflag) HIPCHK(hipFree(m->xflag));
+        if (nflag > m->xflag_n) {   // word 0 (sticky error word) survives the re-allocation
+            unsigned keep = 0;
+            if (m->xflag) {
+                HIPCHK(hipStreamSynchronize(stream));
+                HIPCHK(hipMemcpy(&keep, m->xflag, sizeof(unsigned), hipMemcpyDeviceToHost));
+                HIPCHK(hipFree(m->xflag));
+            }
             m->xflag = nullptr; m->xflag_n = 0;
-            HIPCHK(hipMalloc((void**)&m->xflag, nflag * sizeof(unsigned)));
-            m->xflag_n = nflag;
+            const size_t cap = nflag < 513 ? 513 : nflag;
+            HIPCHK(hipMalloc((void**)&m->xflag, cap * sizeof(unsigned)));
+            HIPCHK(hipMemcpy(m->xflag, &keep, sizeof(unsigned), hipMemcpyHostToDevice));
+            m->xflag_n = cap;
         }
-        HIPCHK(hipMemsetAsync(m->xflag, 0, nflag * sizeof(unsigned), stream));   // sequence numbers restart at every launch
+        // sequence numbers restart at every launch; the error word at [0] is NOT touched
+        HIPCHK(hipMemsetAsync(m->xflag + 1, 0, (nflag - 1) * sizeof(unsigned), stream));
         a.xchg = m->xchg; a.xflag = m->xflag;
+        m->pair_used = true;
     }
     m->last_small = false;
     m->last_pair = v->pair;
@@ -809,11 +836,26 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
         a.l0_tab = m->l0[a.mode == DFF_MODE_DDPM ? 1 : 0].tab;
     }
     // Two workgroups per protein when one per protein would leave at least half the CUs idle (protein G at 128 per GPU:
-    // 1087 -> ~700 us / step): needs every block resident at once, i.e. at most 256 blocks, and the conservative, shipped
-    // input branch.  (The layer-0 table above is built by the one-workgroup variant: the stash layout is the same.)
-    if (G == 1 && !gen && m->cfg.conservative && !m->pair_off && 2 * 8 * ((a.B + 7) / 8) <= (m->max_wgs < 256 ? m->max_wgs : 256)) {
+    // 1087 -> ~700 us / step).  Both blocks of a pair must be RESIDENT at once, and the launch is not cooperative: the
+    // variant is used only when the whole grid fits the device's CUs one block each (hipDeviceAttributeMultiprocessorCount
+    // of THIS device -- a partitioned or CU-masked GPU reports fewer than 256 and gets the one-workgroup variant), and
+    // only on the conservative, shipped input branch.  A previous PAIR launch that gave up on a partner (co-tenancy: another
+    // process held the CUs) is reported here, before anything else is launched on top of its garbage.  (The layer-0 table
+    // above is built by the one-workgroup variant: the stash layout is the same.)
+    const int cu_cap = m->n_cus < m->max_wgs ? m->n_cus : m->max_wgs;
+    if (G == 1 && !gen && m->cfg.conservative && !m->pair_off && 2 * 8 * ((a.B + 7) / 8) <= cu_cap) {
         const Variant* vp = pick_pair(mt, v->spw);
-        if (vp) v = vp;
+        if (vp) {
+            if (m->pair_used) {
+                unsigned w = 0;
+                const int rc = read_status(m, &w, false);
+                if (rc) return rc;
+                if (w) return fail(DFF_EHIP, "an earlier two-workgroups-per-protein launch timed out waiting for its partner "
+                                             "workgroup (the GPU is shared or partitioned?): its results are invalid; "
+                                             "dff_debug_pair(m, 0) selects the one-workgroup kernels");
+            }
+            v = vp;
+        }
     }
     return launch_generic(m, a, G, v, stream);
 }

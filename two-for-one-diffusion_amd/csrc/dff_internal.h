@@ -101,7 +101,7 @@ struct DffRunArgs {
     // noise level: entry 0 (Langevin, fixed t) or entry t (DDPM).  Rows-<=16 kernel only.
     const float* l0_tab;
     // PAIR variants of the <= 64-row kernel (two workgroups per protein): partial-tile exchange slots
-    // [pair][half][parity][rows x (H + 4)] and flags [pair][half] + one error word at [2 * xpairs]
+    // [pair][half][parity][rows x (H + 4)]; xflag = one sticky error word at [0], then flags [pair][half]
     float* xchg;
     unsigned* xflag;
     int xpairs;

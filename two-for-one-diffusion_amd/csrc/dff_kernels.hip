@@ -1922,7 +1922,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             const size_t slot_floats = (size_t)(c.G * c.N) * (H + 4);
             float* const mine = a.xchg + ((size_t)(2 * unit + hf) * 2 + (xseq & 1)) * slot_floats;
             const float* const theirs = a.xchg + ((size_t)(2 * unit + (1 - hf)) * 2 + (xseq & 1)) * slot_floats;
-            unsigned* const flags = a.xflag + 2 * unit;
+            unsigned* const flags = a.xflag + 1 + 2 * unit;   // (word 0 is the sticky error word)
             const int n4 = ncols / 4;   // ncols % 4 == 0, ld % 4 == 0
             wg_sync<SPILL>();           // the tile is complete
             // The tile travels as agent-scope (sc1) 16-byte stores and loads: such a store is written through to the
@@ -1941,7 +1941,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             if (tid_ == 0) {
                 __hip_atomic_store(flags + hf, xseq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // never hang the GPU: the spin is bounded (~1 s), and once any pair has given up (error word set) nobody spins
-                unsigned* const err = a.xflag + 2 * a.xpairs;
+                unsigned* const err = a.xflag;
                 unsigned spins = 0;
                 while (__hip_atomic_load(flags + (1 - hf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < xseq + 1) {
                     __builtin_amdgcn_s_sleep(2);

@@ -40,7 +40,8 @@ class GaussianDiffusion:
     def __init__(self, model: GraphTransformer, features=None, num_atoms: Optional[int] = None,
                  timesteps: int = 1000, loss_type="l2", objective="pred_noise", beta_schedule="cosine",
                  p2_loss_weight_gamma: float = 0.0, p2_loss_weight_k: float = 1,   # training-only (ddpm.py:32-33): accepted in
-                 norm_factor: float = 1, loss_weights="ones", seed: int = 0):      # their reference positions, unused here
+                 norm_factor: float = 1, loss_weights="ones", seed: int = 0,       # their reference positions, unused here
+                 defer_checks: bool = False):
         if objective != "pred_noise" or beta_schedule != "cosine":
             raise ValueError("only objective='pred_noise', beta_schedule='cosine' (the shipped configs) are supported")
         self.dims = 3
@@ -63,6 +64,12 @@ class GaussianDiffusion:
         # kernels: bit 0 = the +-1000 clamp fired somewhere (ddpm.py:248-250 warns per step), bit 1 = a chain ended with
         # a centre of mass >= 1e-3 (assert_center_zero, ddpm.py:252).  check_clamp() reads and clears it.
         self._flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        # The reference warns about the clamp per step and asserts a centred result at the end of every p_sample_loop
+        # (ddpm.py:248-252).  Here every chain entry point (sample, p_sample_loop, p_sample_loop_from) ends with ONE
+        # check_clamp() -- one host sync per chain instead of three per step -- so a library user gets the warning and the
+        # assertion without having to remember anything.  defer_checks=True leaves the word alone until the caller's own
+        # check_clamp() (the CLI and bench.py run many batches back to back and check once at the end).
+        self.defer_checks = bool(defer_checks)
 
     def eval(self):
         return self
@@ -112,6 +119,8 @@ class GaussianDiffusion:
             noises = noises.detach().to(self.device, torch.float32).contiguous()
         self.model.native.ddpm_run(x, t_start, t_end, noise=noises, seed=self._seed,
                                    sample_offset=self._samples_drawn, clamp_flag=self._flag)
+        if not self.defer_checks:
+            self.check_clamp()
         return x
 
     @torch.no_grad()
@@ -122,6 +131,8 @@ class GaussianDiffusion:
         self.model.native.ddpm_run(x, self.num_timesteps - 1, 0, noise=None, seed=self._seed,
                                    sample_offset=self._samples_drawn, init_prior=True, clamp_flag=self._flag)
         self._samples_drawn += b
+        if not self.defer_checks:
+            self.check_clamp()                                                   # ddpm.py:249,252
         return x
 
     def check_clamp(self) -> bool:
@@ -130,6 +141,7 @@ class GaussianDiffusion:
         (ddpm.py:252) if any chain ended off-centre; clears the word."""
         word = int(self._flag.item())
         self._flag.zero_()
+        self.model.native.check()   # (the read above synchronised the device)
         self.last_clamped = bool(word & 1)
         if self.last_clamped:
             warnings.warn("Large molecule encountered in sampling")

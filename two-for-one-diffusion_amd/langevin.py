@@ -151,6 +151,7 @@ class LangevinDiffusion:
                 print(f"{done // self.save_interval}/{n_frames} time points saved")
         self.kinetic_energies = None if ke is None else ke.permute(1, 0).cpu().numpy()
         self.simulated_coords = frames.permute(1, 0, 2, 3).cpu().numpy()      # :605-629
+        self.native.check()   # the copies above synchronised: any device-side failure word of the launches is final now
         return self.simulated_coords
 
     def sample(self, noises=None, traj_offset: int = 0):

@@ -64,11 +64,37 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < extra else 0)
 
 
+_warned_knobs = False
+
+
 def dist_env() -> Tuple[int, int, int]:
-    """(rank, local_rank, world_size) from the torchrun environment (1-process default).  DFF_DEVICE overrides the
-    device index (several ranks on one GPU: how the multi-rank path is exercised on a one-GPU box)."""
-    local = int(os.environ.get("DFF_DEVICE", os.environ.get("LOCAL_RANK", 0)))
-    return (int(os.environ.get("RANK", 0)), local, int(os.environ.get("WORLD_SIZE", 1)))
+    """(rank, local_rank, world_size) from the torchrun environment (1-process default).
+
+    TEST KNOBS, honoured only together with DFF_TEST_KNOBS=1 (a variable leaked from a test shell must not silently put
+    every rank of a production job on one GPU): DFF_DEVICE overrides the device index (several ranks on ONE GPU: how the
+    multi-rank path is exercised on a one-GPU box) and DFF_DIST_BACKEND the process-group backend (`dist_backend`).
+    Rank 0 says so on stderr when they are in effect; without DFF_TEST_KNOBS they are ignored, also with a note."""
+    global _warned_knobs
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    knobs = {k: os.environ[k] for k in ("DFF_DEVICE", "DFF_DIST_BACKEND") if k in os.environ}
+    if knobs:
+        on = os.environ.get("DFF_TEST_KNOBS") == "1"
+        if on and "DFF_DEVICE" in knobs:
+            local = int(knobs["DFF_DEVICE"])
+        if rank == 0 and not _warned_knobs:
+            import sys
+            print(f"dff_amd: test knobs {knobs} are {'IN EFFECT (DFF_TEST_KNOBS=1)' if on else 'IGNORED (set DFF_TEST_KNOBS=1 to use them)'}",
+                  file=sys.stderr)
+            _warned_knobs = True
+    return (rank, local, int(os.environ.get("WORLD_SIZE", 1)))
+
+
+def dist_backend() -> str:
+    """Process-group backend: "nccl" (= RCCL over xGMI) unless the test knob DFF_DIST_BACKEND is in effect."""
+    if os.environ.get("DFF_TEST_KNOBS") == "1" and os.environ.get("DFF_DIST_BACKEND"):
+        return os.environ["DFF_DIST_BACKEND"]
+    return "nccl"
 
 
 def gather_variable(local: torch.Tensor, total: int, world: int, group=None) -> torch.Tensor:
