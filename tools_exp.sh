@@ -1,0 +1,31 @@
+#!/bin/bash
+# Development harness for kernel experiments on the <= 16-row kernel (not part of the product).
+#   tools_exp.sh build <name> "<extra hipcc flags>"   -> build/exp/<name>/libdff_amd.so  (dff_small.hip rebuilt with
+#                                                        -DDFF_FAST_BUILD + flags, linked with the objects of ./build.sh)
+#   tools_exp.sh run <name>...                         (on the GPU box) bench headline + smoke check per variant,
+#                                                        results appended to gpurun_out/exp.jsonl
+set -e
+cd "$(dirname "$(readlink -f "$0")")"
+cmd=$1; shift
+SRC=two-for-one-diffusion_amd/csrc
+if [ "$cmd" = build ]; then
+    name=$1; flags=$2
+    d=build/exp/$name; mkdir -p $d
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-result -DDFF_FAST_BUILD $flags -c $SRC/dff_small.hip -o $d/dff_small.o
+    hipcc --offload-arch=gfx950 -shared -fPIC build/obj/dff_kernels.o $d/dff_small.o build/obj/dff_host.o -o $d/libdff_amd.so
+    echo "$flags" > $d/flags
+    echo "built $d ($flags)"
+elif [ "$cmd" = run ]; then
+    mkdir -p gpurun_out
+    for name in "$@"; do
+        lib=$PWD/build/exp/$name/libdff_amd.so
+        [ "$name" = base ] && lib=$PWD/two-for-one-diffusion_amd/libdff_amd.so
+        for rep in 1 2; do
+            DFF_LIB_PATH=$lib ${DFF_EXP_ENV} python bench.py --no-cpu --no-extras --steps ${DFF_EXP_STEPS:-2000} ${DFF_EXP_ARGS} 2>gpurun_out/exp_$name.err | \
+                python -c "
+import json,sys
+r=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print(json.dumps({'name':'$name','rep':$rep,'us_per_step':1e3*r['ms_per_step'],'frac':r['roofline']['frac'],'finite':r.get('finite'),'kernel':r['config']['kernel'],'flags':open('build/exp/$name/flags').read().strip() if '$name'!='base' else ''}))" | tee -a gpurun_out/exp.jsonl
+        done
+    done
+fi

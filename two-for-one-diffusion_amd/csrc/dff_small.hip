@@ -28,22 +28,40 @@
 // regions in 160 KB the head buffers hold RLA = 11 rows (10 real + 1 dummy row that absorbs the
 // pad lanes' stores; MFMA operand reads of rows 11..15 run into the next buffer, which is finite
 // data multiplied by exact zeros of P / dS or landing in discarded output rows).
-template <int H, int NW>
+template <int H, int NW, bool FOLD = false>
 struct SmallLds {
     static constexpr int LH = H + 4;
     static constexpr int RLA = NW == 4 ? 16 : 11;
-    static constexpr unsigned WREG = 4 * RLA * DFF_XLD + 2 * 16 * DFF_PLD;   // floats per wave region
+    static constexpr int RS = RLA * DFF_XLD;         // floats of one head buffer (Q / K / V / G)
+    static constexpr int PT = 16 * DFF_PLD;          // ... of one P / dS tile
+    // FOLD variant (keys = values = the shared LayerNorm rows, dff_small_kernel below): no K / V regions.  A wave region is
+    //   [Q | P | G | dS | Qsave | Psave | GP0 | GP1]
+    // Qsave | Psave: q' and P of the layer before the last one parked between its forward and backward attention blocks
+    // (KEEP2); GP0 | GP1: GELU'(h_pre) of this wave's FFN hidden slice for the two layers before the last one, GPR rows x
+    // GPS floats each (row GPR - 1 absorbs the pad lanes' stores) -- the last layer's tile lives behind the wave's 11-row
+    // partial-sum tile inside G | dS, so that in the sampling loops of a <= 3-layer model GELU' never leaves the LDS (it was
+    // 57 % of the kernel's stash traffic, profiles/r02).  The one shared copy of the LayerNorm rows (K_ext = V_ext) has its
+    // own region `nx`; the fp32 K = H GEMM input `abuf` does not exist (the row stages write bf16 pieces into `asp`).
+    static constexpr int GPR = 11, GPS = 32;
+    static constexpr unsigned GPT = GPR * GPS;
+    static constexpr unsigned GP_LAST = RLA * LH;   // offset of the last layer's tile inside G | dS (behind the partial-sum tile)
+    static_assert(!FOLD || GP_LAST + GPT <= RS + PT, "the last layer's GELU' tile must fit G | dS behind the partial sums");
+    static constexpr unsigned WREG = FOLD ? 3 * RS + 3 * PT + 2 * GPT : 4 * RS + 2 * PT;   // floats per wave region
+    static_assert(RS + PT >= 16 * (H + 4) || !FOLD, "G | dS must hold a 16 x (H+4) tile");
     static_assert(WREG >= 16 * (H + 4), "wave region must hold a 16 x (H+4) partial-sum tile");
+    static constexpr int DMA_N = FOLD ? 5 : 13;      // head_dma: global_load_lds instructions per head ([Q | P] or [Q | K | V | P])
     static constexpr unsigned xst = 0, xs = 64, dxs = 128, vst = 192, cm = 256, tn = 384, prof = 400,
                               dxw = 448,                      // [NW][128] per-wave dx partials (+ dummies)
-                              abuf = 448 + NW * 128, resbuf = abuf + 16 * LH,
+                              abuf = 448 + NW * 128, resbuf = abuf + (FOLD ? 0 : 16 * LH),
                               // SPW variants (8 waves): the K = H GEMM input as bf16 pieces, written by the row stages:
                               // [piece 3][k-block H/32][kg 4][row 16][4 dwords] -- a wave's ds_read_b128 of (row, kg)
                               // then touches 16 rows x 4 dwords = every bank once, whatever the lane group
-                              asp = resbuf + 16 * LH, asp_size = (NW == 8 && H == 64) ? 3 * (H / 32) * 256 : 0,   // (only H = 64 has SPW variants)
-                              // source-offset table of the LDS-DMA head fetch (head_dma): 13 instructions x 64 lanes
-                              dmatab = asp + asp_size, dmatab_size = (NW == 8 && H == 64) ? 13 * 64 : 0,
-                              wreg = dmatab + dmatab_size, total = wreg + NW * WREG + 64;
+                              asp = resbuf + (FOLD ? RLA : 16) * LH, asp_size = (NW == 8 && H == 64) ? 3 * (H / 32) * 256 : 0,   // (only H = 64 has SPW variants)
+                              // source-offset table of the LDS-DMA head fetch (head_dma): DMA_N instructions x 64 lanes
+                              dmatab = asp + asp_size, dmatab_size = (NW == 8 && H == 64) ? DMA_N * 64 : 0,
+                              nx = dmatab + dmatab_size, nx_size = FOLD ? RS : 0,
+                              wreg = nx + nx_size, total = wreg + NW * WREG + 64;
+    static_assert(!FOLD || total * 4 <= 160 * 1024, "LDS budget");
 };
 
 // ---------------------------------------------------------------- wave-private MFMA engine
@@ -560,14 +578,14 @@ DEVI void lds_dma16(unsigned lds_byte, const gfloat* src) {
 DEVI void head_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // table entry of 16-byte slot `sl` of the contiguous [Q | K | V | P] regions: float offset of its source relative to the
 // head's stash rows (q_ext | k | v) or, with bit 31 set, to the head's P tile; 0xffffffff: no such slot
-template <int RLA, bool QONLY = false>
+template <int RLA, bool QP = false>
 DEVI unsigned head_dma_entry(int sl, int RA) {
     constexpr int RQ = RLA * (DFF_XLD / 4);                // 16-byte slots per Q / K / V region
     constexpr int NP = 16 * DFF_PLD / 4;                   // ... of the P tile
-    if (sl >= 3 * RQ + NP) return 0xffffffffu;
-    const int reg = (sl >= RQ) + (sl >= 2 * RQ) + (sl >= 3 * RQ);
-    const int r = sl - reg * RQ;
-    if (QONLY && (reg == 1 || reg == 2)) return 0xffffffffu;   // FOLD: the K / V regions are not loaded
+    constexpr int NREG = QP ? 1 : 3;                       // QP (FOLD layout): the regions are [Q | P], nothing else is loaded
+    if (sl >= NREG * RQ + NP) return 0xffffffffu;
+    const int reg = QP ? (sl >= RQ ? 3 : 0) : (sl >= RQ) + (sl >= 2 * RQ) + (sl >= 3 * RQ);
+    const int r = sl - (QP ? (reg ? RQ : 0) : reg * RQ);
     if (reg < 3) {
         const int row = r / (DFF_XLD / 4), c4 = r - row * (DFF_XLD / 4);
         // q_ext: 20 slots of data + 1 pad; k / v: 16 + 4 (extension columns, rewritten by write_xext) + 1 pad
@@ -577,13 +595,14 @@ DEVI unsigned head_dma_entry(int sl, int RA) {
     const int row = r / (DFF_PLD / 4), c4 = r - row * (DFF_PLD / 4);
     return 0x80000000u | (unsigned)(row * 16 + 4 * min(c4, 3));
 }
-DEVI void head_dma(const lu32* tab, const lfloat* Qx /* wave-uniform; Q | K | V | P contiguous */, const gfloat* sqkv, const gfloat* sp, int lane) {
+template <int NI>
+DEVI void head_dma(const lu32* tab, const lfloat* Qx /* wave-uniform; the regions the table describes start here */, const gfloat* sqkv, const gfloat* sp, int lane) {
     const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)Qx);
-    unsigned e[13];
+    unsigned e[NI];
 #pragma unroll
-    for (int k = 0; k < 13; ++k) e[k] = tab[64 * k + lane];
+    for (int k = 0; k < NI; ++k) e[k] = tab[64 * k + lane];
 #pragma unroll
-    for (int k = 0; k < 13; ++k) {
+    for (int k = 0; k < NI; ++k) {
         const bool isp = (e[k] >> 31) != 0;
         const gfloat* src = (isp ? sp : sqkv) + (e[k] & 0x7fffffffu);
         if (e[k] != 0xffffffffu && (!isp || sp)) lds_dma16(base + 1024u * k, src);
@@ -598,7 +617,7 @@ DEVI void head_dma(const lu32* tab, const lfloat* Qx /* wave-uniform; Q | K | V 
 template <int H, int NW, bool GEN, bool SPW = false, bool FOLD = false>
 __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m, const DffRunArgs a) {
     static_assert(!FOLD || (SPW && !GEN && H == DFF_DH), "FOLD: the split, shipped-branch, hidden == 64 variant");
-    using LL = SmallLds<H, NW>;
+    using LL = SmallLds<H, NW, FOLD>;
     constexpr int LH = LL::LH, F = 4 * H, E = H / 16;
     constexpr int NTHR = NW * 64;            // threads
     constexpr int HPW = DFF_HEADS / NW;      // heads per wave (2 or 1)
@@ -662,24 +681,27 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     };
     lfloat* const dxw = sm + LL::dxw + wave * 128;
     lfloat* const wr = sm + LL::wreg + wave * LL::WREG;
-    // FOLD: K_ext = V_ext = the shared LayerNorm rows, kept in wave 0's (otherwise unused) K region
-    lfloat* const Nx = sm + LL::wreg + RS;
+    // FOLD: K_ext = V_ext = ONE shared fp32 copy of the LayerNorm rows (+ x in the extension columns), region `nx`
+    lfloat* const Nx = sm + LL::nx;
     lfloat* const Qx = wr; lfloat* const Kx = FOLD ? Nx : wr + RS; lfloat* const Vx = FOLD ? Nx : wr + 2 * RS;
     auto n_store = [=](int row, int cl, float v) { if constexpr (FOLD) Nx[row * DFF_XLD + cl] = v; };
-    // RELAY (8 waves, H = 64): region order [Q | K | V | P | G | dS], and everything that is not an attention operand --
-    // o_ext = P V_ext, the FFN hidden slice, the wave's partial H-wide outputs -- lives in G | dS.  q_ext, k, v and P of
-    // the LAST layer then survive in LDS from its forward to its backward attention block: no stash reload (and no
-    // exposed HBM round trip) for one layer in three.  Otherwise [Q | K | V | G | P | dS] with those tiles aliasing Q | K.
+    // RELAY (8 waves, H = 64): region order [Q | K | V | P | G | dS] ([Q | P | G | dS | ...] in the FOLD layout, SmallLds),
+    // and everything that is not an attention operand -- o_ext = P V_ext, the FFN hidden slice, the wave's partial H-wide
+    // outputs -- lives in G | dS.  q_ext, k, v and P of the LAST layer then survive in LDS from its forward to its backward
+    // attention block: no stash reload (and no exposed HBM round trip) for one layer in three.  Otherwise
+    // [Q | K | V | G | P | dS] with those tiles aliasing Q | K.
     constexpr bool RELAY = NW == 8 && H == 64;
     constexpr bool KEEP_LAST = RELAY && !GEN;   // (the GEN variants re-derive their x-dependent extension columns on reload)
     constexpr bool HDMA = RELAY && !GEN;        // stash -> head buffers by LDS-DMA, requested a row stage ahead (head_dma)
-    // FOLD frees every wave's K / V region (but wave 0's K region: the shared LayerNorm rows), so the layer BEFORE the last
-    // one keeps its q' and P in LDS too: copied there after its forward attention, copied back before its backward one --
-    // with the layer-0 table and KEEP_LAST no q' / P of a 3-layer model ever goes through the stash in the sampling loops.
+    // FOLD has no K / V regions, and the layer BEFORE the last one keeps its q' and P in LDS too: copied to Qsave | Psave
+    // after its forward attention, copied back before its backward one -- with the layer-0 table and KEEP_LAST no q' / P of
+    // a 3-layer model ever goes through the stash in the sampling loops.
     constexpr bool KEEP2 = FOLD && KEEP_LAST;
-    lfloat* const Qsave = wr + 2 * RS;                                                        // own V region
-    lfloat* const Psave = wave == 0 ? sm + LL::wreg + LL::WREG + RS + 16 * DFF_PLD : wr + RS;   // own K region (wave 0: second slot of wave 1's)
-    static_assert(!KEEP2 || RS >= 2 * 16 * DFF_PLD, "two P tiles in a K region");
+    lfloat* const pb = FOLD ? wr + RS : RELAY ? wr + 3 * RS : wr + 4 * RS;
+    lfloat* const Gx = RELAY ? pb + 16 * DFF_PLD : wr + 3 * RS;
+    lfloat* const dsb = RELAY ? Gx + RS : pb + 16 * DFF_PLD;
+    lfloat* const Qsave = dsb + 16 * DFF_PLD;          // (FOLD layout only)
+    lfloat* const Psave = Qsave + RS;
     auto keep2_copy = [=](const lfloat* qs, lfloat* qd, const lfloat* ps, lfloat* pd, int lane) {
 #pragma unroll
         for (int u = 0; u < (RS / 4 + 63) / 64; ++u) {
@@ -693,14 +715,19 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         }
     };
     static_assert(!HDMA || DFF_XLD % 4 == 0, "16-byte slots");
-    lfloat* const pb = RELAY ? wr + 3 * RS : wr + 4 * RS;
-    lfloat* const Gx = RELAY ? pb + 16 * DFF_PLD : wr + 3 * RS;
-    lfloat* const dsb = RELAY ? Gx + RS : pb + 16 * DFF_PLD;
-    constexpr unsigned MPO = RELAY ? 3 * RS + 16 * DFF_PLD : 0;   // offset of the aliased tiles inside a wave region
+    constexpr unsigned MPO = FOLD ? RS + 16 * DFF_PLD : RELAY ? 3 * RS + 16 * DFF_PLD : 0;   // offset of G | dS (the aliased tiles) inside a wave region
     static_assert(!RELAY || RS + 16 * DFF_PLD >= 16 * (H + 4), "G | dS must hold a 16 x (H + 4) partial-sum tile");
     lfloat* const Ox = RELAY ? Gx : Qx;   // o_ext
     lfloat* const hbuf = wr + MPO;        // FFN hidden slice of this wave (aliases head buffers)
     lfloat* const mypart = wr + MPO;      // this wave's partial H-wide output (ditto; summed by the row stages)
+    // rows of the partial-sum tile: 16, or (FOLD) the RLA = 11 allocated ones -- pad rows collapse onto the last -- which
+    // leaves room behind it for the last layer's GELU' tile
+    constexpr int PRMAX = FOLD ? RLA - 1 : 15;
+    // GELU'(h_pre) of this wave's FFN hidden slice stays in LDS for the last three layers in the sampling loops (FOLD):
+    // layer L - 1 behind the partial sums in G | dS (its backward follows at once), layers L - 2 and L - 3 in GP0 / GP1
+    auto gp_tile = [=](int l, int L) -> lfloat* {
+        return l == L - 1 ? wr + MPO + LL::GP_LAST : wr + (3 * RS + 3 * 16 * DFF_PLD) + (unsigned)(L - 2 - l) * LL::GPT;
+    };
     // sum of the NW waves' partial outputs for this lane's HC columns of a row: ALL NW x HC LDS reads are
     // issued first (one latency), then added in wave order (left to itself the compiler issues one read,
     // waits, adds, issues the next: NW/2 serial LDS latencies inside a stage every other wave waits for)
@@ -721,10 +748,18 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         }
     };
     const SmallStash sl = dff_small_stash(N, G, H, m.L);
+#ifdef DFF_T_SHSTASH   // TIMING-ONLY experiment (results invalid): 8 shared, L2-resident stash slots
+    gfloat* const stash = (gfloat*)a.stash + (size_t)(blockIdx.x & 7) * a.stash_stride;
+#else
     gfloat* const stash = (gfloat*)a.stash + (size_t)blockIdx.x * a.stash_stride;
+#endif
     Ctx c;  // only what bead_mean() needs
     c.N = N; c.G = G; c.gcnt = gcnt; c.rows = rows;
 
+#ifdef DFF_X_PRIO
+    // static priority for one half of the waves (MI355X_MICROARCH.md "Two waves per SIMD", item 4)
+    if (DFF_X_PRIO == 1 ? wave >= NW / 2 : wave < NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     for (int i = tid; i < (int)LL::total; i += NTHR) smem[i] = 0.f;
     __syncthreads();
     if constexpr (LL::dmatab_size > 0) {
@@ -941,7 +976,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 sring_prefetch<SDR, KO, E>(sring, ss_wox(m.layer[0], wave), lane);
                 // layer 0's q_ext | k | v rows of this head (shared table entry): in flight during the centring below
                 // (measured: 86.8 vs 87.3 us / step with a register fetch inside the attention block)
-                if constexpr (HDMA) head_dma(dmatab, Qx, l0e + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, lane);
+                if constexpr (HDMA) head_dma<LL::DMA_N>(dmatab, Qx, l0e + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, lane);
             } else sring_prefetch<SDR, KQ, E>(sring, ss_qkv(m.layer[0], wave), lane);
         } else if (cached0) {
             const gfloat* sb0 = l0e;
@@ -1199,7 +1234,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     }
                 }
 #pragma unroll
-                for (int nt = 0; nt < E; ++nt) c_store_all(mypart, LH, 16 * nt, acc_o[nt], lane);
+                for (int nt = 0; nt < E; ++nt) c_store_all(mypart, LH, 16 * nt, acc_o[nt], lane, PRMAX);
             }
             __syncthreads();
             pf.tick(2);
@@ -1247,21 +1282,27 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 const gfloat* const b1p = (const gfloat*)lw.b1 + wave * FS + col;
 #pragma unroll
                 for (int d = 0; d < DR; ++d) b1r[d][0] = b1p[16 * d];
+                // FOLD, sampling loops: GELU'(h_pre) of the last three layers never leaves the LDS (gp_tile); otherwise it goes to
+                // the stash slot "h_pre" through a second LDS tile behind the hidden slice
+                const bool gp_lds = FOLD && a.mode != DFF_MODE_SCORE && l >= m.L - 3;
                 {
-                    gfloat* const shp = sb + sl.h_pre + wave * FS + col;
                     lfloat* const hb = hbuf + quad * 4 * LF + col;
-                    const int s0 = srow[0] * F, s1 = srow[1] * F, s2 = srow[2] * F, s3 = srow[3] * F;
+                    lfloat* const gq = (gp_lds ? gp_tile(l, m.L) : hbuf + 16 * LF) + col;
+                    int go[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) go[r] = gp_lds ? min(quad * 4 + r, LL::GPR - 1) * LL::GPS : (quad * 4 + r) * LF;
+                    const int go0 = go[0], go1 = go[1], go2 = go[2], go3 = go[3];
                     auto w1_pre = [=](int t, float (&ax)[1]) { ax[0] = b1p[16 * t]; };
                     auto w1_epi = [=](int t, const f32x4& acc, const float (&ax)[1]) {
                             float g0, g1, g2, g3, p0, p1, p2, p3;
                             gelu_both(acc[0] + ax[0], g0, p0); gelu_both(acc[1] + ax[0], g1, p1);
                             gelu_both(acc[2] + ax[0], g2, p2); gelu_both(acc[3] + ax[0], g3, p3);
-                            // the stash slot "h_pre" holds gelu'(h_pre) in this kernel.  It travels through a second LDS tile
-                            // and leaves as full 128-byte rows after the W2 GEMM (below): stored from here, 64 bytes per row and
-                            // instruction, each store was a partial-line write whose acknowledgement the W2 weights queued
-                            // behind in the in-order vmcnt queue (a timing-only build without the stores: -1.1 us / step)
+                            // On its way to the stash gelu'(h_pre) travels through the second LDS tile and leaves as full
+                            // 128-byte rows after the W2 GEMM (below): stored from here, 64 bytes per row and instruction, each
+                            // store was a partial-line write whose acknowledgement the W2 weights queued behind in the in-order
+                            // vmcnt queue (a timing-only build without the stores: -1.1 us / step)
                             hb[16 * t] = g0; hb[LF + 16 * t] = g1; hb[2 * LF + 16 * t] = g2; hb[3 * LF + 16 * t] = g3;
-                            hb[16 * LF + 16 * t] = p0; hb[17 * LF + 16 * t] = p1; hb[18 * LF + 16 * t] = p2; hb[19 * LF + 16 * t] = p3;
+                            gq[go0 + 16 * t] = p0; gq[go1 + 16 * t] = p1; gq[go2 + 16 * t] = p2; gq[go3 + 16 * t] = p3;
                         };
                     if constexpr (SPW) {
                         u32x4 ah[KB32], am[KB32], al[KB32];
@@ -1286,7 +1327,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     pf.tick(21);
                     // gelu'(h_pre) rows of this wave's hidden slice: LDS tile -> stash, 16 bytes per lane (rows beyond the real
                     // ones go to the dummy stash row); before the partial sums below reuse the tile
-                    {
+#ifndef DFF_T_NOHP
+                    if (!gp_lds) {
                         const lfloat* const gp = hbuf + 16 * LF;
                         gfloat* const dst = sb + sl.h_pre + wave * FS;
 #pragma unroll
@@ -1295,10 +1337,11 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                             if (row < 16) *(gf32x4*)(dst + (row < rows ? row : RA) * F + 4 * c4) = *(const lf32x4*)(gp + row * LF + 4 * c4);
                         }
                     }
+#endif
                 }
                 static_assert((2 * NTS) % DR == 0, "ring phase");
 #pragma unroll
-                for (int nt = 0; nt < E; ++nt) c_store_all(mypart, LH, 16 * nt, acc_f[nt], lane);
+                for (int nt = 0; nt < E; ++nt) c_store_all(mypart, LH, 16 * nt, acc_f[nt], lane, PRMAX);
             }
             __syncthreads();
             pf.tick(4);
@@ -1368,7 +1411,13 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #pragma unroll
             for (int d = 0; d < DR; ++d)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hpn[d][r] = ld_ntg(shp + srow[r] * F + 16 * d);
+                for (int r = 0; r < 4; ++r) {
+#ifdef DFF_T_NOHP   // TIMING-ONLY experiment (results invalid): no GELU' through the stash
+                    hpn[d][r] = 0.5f;
+#else
+                    hpn[d][r] = ld_ntg(shp + srow[r] * F + 16 * d);
+#endif
+                }
         };
         if (!m.conservative) {
             // force head (graph_transformer.py:62-63,112-113): node_decoder is Linear(H, 3) and forces = its output,
@@ -1391,7 +1440,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             }
             __syncthreads();
         }
-        if constexpr (HP_EARLY) { if (m.conservative) hp_prefetch(m.L - 1); }
+        if constexpr (HP_EARLY && !FOLD) { if (m.conservative) hp_prefetch(m.L - 1); }
         for (int l = m.conservative ? m.L - 1 : -1; l >= 0; --l) {
             const DffLayerDev& lw = m.layer[l];
             const gfloat* const sb = stash + (size_t)l * sl.layer_stride;
@@ -1438,7 +1487,20 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     ax[0] = ld_ntg(shp + s0 + 16 * t); ax[1] = ld_ntg(shp + s1 + 16 * t);
                     ax[2] = ld_ntg(shp + s2 + 16 * t); ax[3] = ld_ntg(shp + s3 + 16 * t);
                 };
-                if constexpr (HP_EARLY) {
+                if constexpr (FOLD) {
+                    // the tile the forward FFN left in LDS (read now, in flight under the first weight units), or -- score mode,
+                    // layers before the last three of a deep model -- the stash
+                    if (a.mode != DFF_MODE_SCORE && l >= m.L - 3) {
+                        const lfloat* const gq = gp_tile(l, m.L) + col;
+#pragma unroll
+                        for (int d = 0; d < DR; ++d)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) hp[d][r] = gq[min(quad * 4 + r, LL::GPR - 1) * LL::GPS + 16 * d];
+                    } else {
+#pragma unroll
+                        for (int d = 0; d < DR; ++d) hp_load(d, hp[d]);
+                    }
+                } else if constexpr (HP_EARLY) {
 #pragma unroll
                     for (int d = 0; d < DR; ++d)
 #pragma unroll
@@ -1470,14 +1532,14 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     else tall_run<NTS % DR, NTS, E, -1>(ring, acc_f, [=](int kb) { return ha + 16 * kb; }, s_w1t(lw), after, lane);
                 }
 #pragma unroll
-                for (int nt = 0; nt < E; ++nt) c_store_all(mypart, LH, 16 * nt, acc_f[nt], lane);
+                for (int nt = 0; nt < E; ++nt) c_store_all(mypart, LH, 16 * nt, acc_f[nt], lane, PRMAX);
             }
             __syncthreads();
             pf.tick(7);
             // first head of this layer's attention backward: start the stash read (hidden by row stage E)
             if constexpr (HDMA) {
                 if (!(KEEP_LAST && l == m.L - 1 && l > 0) && !(KEEP2 && l == m.L - 2 && l > 0 && a.mode != DFF_MODE_SCORE))
-                    head_dma(dmatab, Qx, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, lane_id());
+                    head_dma<LL::DMA_N>(dmatab, Qx, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, lane_id());
             }
             if constexpr (HPW == 2) {
                 const int lane = lane_id();
@@ -1713,7 +1775,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         pf.tick(18);
                     }
 #pragma unroll
-                    for (int nt = 0; nt < E; ++nt) c_store_all(mypart, LH, 16 * nt, acc_a[nt], lane);
+                    for (int nt = 0; nt < E; ++nt) c_store_all(mypart, LH, 16 * nt, acc_a[nt], lane, PRMAX);
                 } else if constexpr (HPW == 2) {
                     // layer 0 needs q_ext (for the dS^T u term) but not k
                     head_commit(hr, Qx, Kx, Vx, pb, false, true, lane, RLA);
@@ -1937,7 +1999,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 bool dff_small_pick(int H, int NW, bool gen, bool spw, const void** fn, unsigned* lds_floats, const char** name, bool fold) {
     if (H == 64 && NW == 8 && spw && fold && !gen) {
         *fn = (const void*)&dff_small_kernel<64, 8, false, true, true>;
-        *lds_floats = SmallLds<64, 8>::total;
+        *lds_floats = SmallLds<64, 8, true>::total;
         *name = "dff_small_kernel<64,8,split_bf16,fold_kv>";
         return true;
     }
