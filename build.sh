@@ -1,6 +1,7 @@
 #!/bin/bash
-# Build libdff_amd.so (HIP kernels + C ABI) for gfx950, in-tree.  Three translation units compiled in
-# parallel: the <= 64-row kernel, the <= 16-row kernel, and the host half (ABI, dispatch, PWD kernels).
+# Build libdff_amd.so (HIP kernels + C ABI) for gfx950, in-tree.  Five translation units compiled in
+# parallel: the <= 64-row kernel, the <= 16-row kernel once per sampler mode (score / Langevin / DDPM), and the host half
+# (ABI, dispatch, PWD kernels).
 #   DFF_EXTRA_FLAGS="-DDFF_FAST_BUILD"   development build: headline variants only (fast to compile)
 set -e
 cd "$(dirname "$(readlink -f "$0")")"
@@ -10,15 +11,19 @@ OBJ=build/obj
 mkdir -p $OBJ
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-result ${DFF_EXTRA_FLAGS}"
 pids=()
-for tu in dff_kernels dff_small dff_host; do
+for tu in dff_kernels dff_small_m0 dff_small_m1 dff_small_m2 dff_host; do
     # rebuild a unit only when one of the sources is newer than its object (or the flags changed)
     stamp="$OBJ/$tu.flags"
+    src=$tu; extra=""
+    case $tu in dff_small_m*) src=dff_small; extra="-DDFF_SMALL_MODE=${tu#dff_small_m}";; esac
     if [ ! -f "$OBJ/$tu.o" ] || [ "$(cat $stamp 2>/dev/null)" != "$FLAGS" ] || \
        [ -n "$(find $SRC include -newer $OBJ/$tu.o \( -name '*.hip' -o -name '*.h' \) | head -1)" ]; then
-        ( hipcc $FLAGS -c $SRC/$tu.hip -o $OBJ/$tu.o.tmp && mv $OBJ/$tu.o.tmp $OBJ/$tu.o && echo "$FLAGS" > $stamp ) &
+        ( hipcc $FLAGS $extra -c $SRC/$src.hip -o $OBJ/$tu.o.tmp && mv $OBJ/$tu.o.tmp $OBJ/$tu.o && echo "$FLAGS" > $stamp ) &
         pids+=($!)
     fi
 done
-for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC $OBJ/dff_kernels.o $OBJ/dff_small.o $OBJ/dff_host.o -o $OUT
+rc=0
+for p in "${pids[@]}"; do wait $p || rc=1; done
+[ $rc = 0 ] || { echo "compile failed"; exit 1; }
+hipcc --offload-arch=gfx950 -shared -fPIC $OBJ/dff_kernels.o $OBJ/dff_small_m0.o $OBJ/dff_small_m1.o $OBJ/dff_small_m2.o $OBJ/dff_host.o -o $OUT
 echo "built $OUT"

@@ -2,7 +2,7 @@
 # per-kernel register / scratch summary of the device code: tools_regs.sh [extra hipcc flags]
 set -e
 cd "$(dirname "$0")"
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Wno-unused-result "$@" -S --cuda-device-only \
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Wno-unused-result -DDFF_SMALL_MODE=${DFF_SMALL_MODE:-1} "$@" -S --cuda-device-only \
     two-for-one-diffusion_amd/csrc/${DFF_TU:-dff_small}.hip -o /tmp/dff_regs.s 2>/dev/null
 python3 - <<'PY'
 import re

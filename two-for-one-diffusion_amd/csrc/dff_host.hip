@@ -289,7 +289,7 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
         const char* ef = getenv("DFF_FOLD_KV");
         m->fold_kv = H == DFF_DH && !(ef && ef[0] == '0');
         const void* fn_; unsigned lds_; const char* nm_;
-        m->small_split = m->split && N <= 10 && dff_small_pick(H, 8, false, true, &fn_, &lds_, &nm_);
+        m->small_split = m->split && N <= 10 && dff_small_pick(DFF_MODE_SCORE, H, 8, false, true, &fn_, &lds_, &nm_);
     }
     memset(&m->dev, 0, sizeof m->dev);
     m->dev.N = N; m->dev.H = H; m->dev.L = L; m->dev.T = cfg->timesteps;
@@ -630,7 +630,7 @@ static int launch_small(dff_model* m, DffRunArgs& a, int G, hipStream_t stream) 
     const bool gen = !(m->cfg.use_intrinsic_coords == 1 && m->cfg.use_distances == 0 && m->cfg.use_abs_coords == 0);
     const int NW = eight ? 8 : 4;
     const bool spw = eight && m->small_split;
-    if (!dff_small_pick(H, NW, gen, spw, &fn, &lds, &name, m->fold_kv))
+    if (!dff_small_pick(a.mode, H, NW, gen, spw, &fn, &lds, &name, m->fold_kv))
         return fail(DFF_EINVAL, "no <= 16-row kernel for hidden=%d waves=%d in this build", H, NW);
     nthreads = NW * 64;
     lds *= (unsigned)sizeof(float);

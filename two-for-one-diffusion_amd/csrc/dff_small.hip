@@ -614,7 +614,11 @@ DEVI void head_dma(const lu32* tab, const lfloat* Qx /* wave-uniform; the region
 // so the QKV_ext GEMM has 5 tiles per head instead of 13 (q' | u), K_ext = V_ext is ONE shared fp32 copy of the LayerNorm
 // output (+ x), written by the row stages next to its bf16 pieces, dK and dV go straight into the wave's partial of
 // d(LayerNorm output) (identity back-projection) and the QKV_ext^T GEMM keeps only its dQ blocks; only q' is stashed.
-template <int H, int NW, bool GEN, bool SPW = false, bool FOLD = false>
+// MODE (DFF_MODE_SCORE / LANGEVIN / DDPM) is a template argument: one kernel per sampler mode.  With the three update stages
+// and their mode tests inside one step loop the register allocator and the scheduler paid for all of them everywhere
+// (the Langevin step ran 1.5 us slower next to the reverse-DDPM update's code than without it); each mode is its own
+// translation unit (build.sh compiles this file three times, -DDFF_SMALL_MODE=0|1|2).
+template <int H, int NW, bool GEN, bool SPW, bool FOLD, int MODE>
 __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m, const DffRunArgs a) {
     static_assert(!FOLD || (SPW && !GEN && H == DFF_DH), "FOLD: the split, shipped-branch, hidden == 64 variant");
     using LL = SmallLds<H, NW, FOLD>;
@@ -649,6 +653,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     lfloat* const sm = (lfloat*)smem;
     lfloat* const xst = sm + LL::xst; lfloat* const xs = sm + LL::xs; lfloat* const dxs = sm + LL::dxs;
     lfloat* const vst = sm + LL::vst; lfloat* const cm = sm + LL::cm; lfloat* const tn = sm + LL::tn;
+    lfloat* const xcb = cm;        // Langevin: the integrator's centred x_old of this step (written by the centring, read by the update)
+    lfloat* const xib = cm + 64;   // this step's standard normals, one per (bead, component) thread
     lfloat* const abuf = sm + LL::abuf; lfloat* const resbuf = sm + LL::resbuf;
     lu16* const asp16 = (lu16*)(sm + LL::asp);
     lu32* const dmatab = (lu32*)(sm + LL::dmatab);
@@ -791,24 +797,24 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 
     // ---- load state (as dff_fused_kernel) ----
     {
-        const float* xin = (a.mode == DFF_MODE_SCORE) ? a.x_in : a.x_io;
+        const float* xin = (MODE == DFF_MODE_SCORE) ? a.x_in : a.x_io;
         if (tid < rows * 4) {
             const int row = tid >> 2, cc = tid & 3;
             float xv = 0.f, vv = 0.f;
             if (cc < 3) {
                 const size_t gi = ((size_t)b0 * N + row) * 3 + cc;
-                if (a.mode == DFF_MODE_DDPM && a.init_prior)
+                if (MODE == DFF_MODE_DDPM && a.init_prior)
                     xv = philox_normal(a.seed, a.item_offset + b0 + row / N, 0xFFFFFFFFull, row % N, cc);
                 else
                     xv = xin[gi];
-                if (a.mode == DFF_MODE_LANGEVIN && !a.overdamped) vv = a.v_io[gi];
+                if (MODE == DFF_MODE_LANGEVIN && !a.overdamped) vv = a.v_io[gi];
             }
             xst[tid] = xv;
             vst[tid] = vv;
         }
-        if (tid < gcnt) tn[tid] = (a.mode == DFF_MODE_SCORE) ? a.tnorm[b0 + tid] : a.t_norm;
+        if (tid < gcnt) tn[tid] = (MODE == DFF_MODE_SCORE) ? a.tnorm[b0 + tid] : a.t_norm;
         __syncthreads();
-        if (a.mode == DFF_MODE_DDPM && a.init_prior) {
+        if (MODE == DFF_MODE_DDPM && a.init_prior) {
             bead_mean(c, (float*)xst, (float*)cm);
             __syncthreads();
             if (tid < rows * 4) xst[tid] -= cm[(tid >> 2) / N * 4 + (tid & 3)];
@@ -820,6 +826,13 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     // (all 16 possible rows then use the 512 threads) and halves the per-lane work of the 4-wave layout.
     constexpr int LPR = NW == 8 ? 32 : 16;
     constexpr int HC = H / LPR;
+    // In-kernel noise (Philox + Box-Muller: a ~300-instruction dependent chain per lane) does not depend on the forces: when
+    // the last wave has no rows in the row stages (chignolin: rows 0..9 are waves 0..4) it draws the step's normals during
+    // row stage A, off everybody's critical path, and the update just reads them.
+#ifndef DFF_XI_PRE
+#define DFF_XI_PRE 1
+#endif
+    const bool xi_pre = DFF_XI_PRE && MODE != DFF_MODE_SCORE && !a.noise && rows * LPR <= (NW - 1) * 64;
     static_assert(H % LPR == 0, "row layout");
     auto rsum = [](float v) {   // all-reduce over the LPR lanes of a row
         if constexpr (LPR == 32) {
@@ -956,7 +969,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 
     for (int step = 0; step < a.n_steps; ++step) {
         int t_int = 0;
-        if (a.mode == DFF_MODE_DDPM) {
+        if (MODE == DFF_MODE_DDPM) {
             t_int = a.t_start - step;
             if (tid < gcnt) tn[tid] = (1.0f * (float)t_int) / (float)m.T;
         }
@@ -965,10 +978,10 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         // very kernel, see ensure_l0_table) layer 0 never runs its QKV GEMM.  Without a table, Langevin
         // (fixed t) still re-reads what step 0 left in this workgroup's own stash.
         const bool tab = a.l0_tab != nullptr;
-        const gfloat* const l0e = tab ? (const gfloat*)a.l0_tab + (size_t)(a.mode == DFF_MODE_DDPM ? t_int : 0) * sl.layer_stride
+        const gfloat* const l0e = tab ? (const gfloat*)a.l0_tab + (size_t)(MODE == DFF_MODE_DDPM ? t_int : 0) * sl.layer_stride
                                       : (const gfloat*)stash;
         const bool full0 = GEN && m.in_abs;   // absolute coordinates: layer 0 depends on x (no caching, VJP through layer 0)
-        const bool cached0 = !full0 && (tab || ((a.mode == DFF_MODE_LANGEVIN) && step > 0));
+        const bool cached0 = !full0 && (tab || ((MODE == DFF_MODE_LANGEVIN) && step > 0));
         // first weights of the first block (hidden behind the centring below)
         { const int lane = lane_id();
         if constexpr (SPW) {
@@ -985,21 +998,36 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         } else {
             ring_prefetch<E>(ring, s_qkv(m.layer[0], wave), lane);
         } }
-        bead_mean(c, (float*)xst, (float*)cm);
-        __syncthreads();
-        if (tid < rows * 4) {
-            const float xc = xst[tid] - cm[(tid >> 2) / N * 4 + (tid & 3)];
-            if (a.mode == DFF_MODE_LANGEVIN) xst[tid] = xc;
-            xs[tid] = xc;
+        // Centring (utils.py:65-70; Langevin centres twice: the integrator's x_old, then the network's input).  Every
+        // (bead, component) thread -- all of them in wave 0 -- reads its protein's column once (one batch of LDS reads) and
+        // forms the means itself, summing in bead order exactly as bead_mean() does: same bits, ONE barrier instead of four
+        // and no serial one-thread-per-column loops in front of the whole workgroup.  The integrator's centred x_old goes to
+        // `xcb` (the update reads it there), the network's input to xs; xst itself is not written here.
+        { const int tq = tid_id();
+        if (tq < rows * 4) {
+            const int cc = tq & 3, pb0 = ((tq >> 2) / N) * N;
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = xst[(pb0 + min(i, N - 1)) * 4 + cc];
+            const float own = xst[tq];
+            float s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s1 += i < N ? v[i] : 0.f;
+            const float m1 = s1 / (float)N;
+            const float xc = own - m1;
+            float xn_in = xc;
+            if (MODE == DFF_MODE_LANGEVIN) {
+                float s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s2 += i < N ? v[i] - m1 : 0.f;
+                xn_in = xc - s2 / (float)N;
+                xcb[tq] = xc;
+            }
+            xs[tq] = xn_in;
+        }
         }
         { const int ln = lane_id(); dxw[ln] = 0.f; dxw[64 + ln] = 0.f; }
         __syncthreads();
-        if (a.mode == DFF_MODE_LANGEVIN) {
-            bead_mean(c, (float*)xs, (float*)cm);
-            __syncthreads();
-            if (tid < rows * 4) xs[tid] -= cm[(tid >> 2) / N * 4 + (tid & 3)];
-            __syncthreads();
-        }
         pf.tick(0);
 
         // =============================== forward ===============================
@@ -1060,6 +1088,14 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     }
                 }
                 if (ract) pre_B(lw, sub);
+                if (xi_pre && wave == NW - 1) {
+                    const int ln = lane_id();
+                    if (ln < rows * 4 && (ln & 3) < 3) {
+                        const int row = ln >> 2, g = row / N;
+                        xib[ln] = philox_normal(a.seed, a.item_offset + (size_t)b0 + g,
+                                                MODE == DFF_MODE_DDPM ? (uint64_t)t_int : a.step_offset + step, row - g * N, ln & 3);
+                    }
+                }
                 __syncthreads();
             }
             pf.tick(1);
@@ -1071,8 +1107,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 for (int nt = 0; nt < E; ++nt) acc_o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 const WStream after = s_w1(lw);   // the FFN block follows
                 // the sampling loops never read the last layer's q_ext | k | v | P back from the stash (KEEP_LAST)
-                const bool keep2 = KEEP2 && l == m.L - 2 && l > 0 && a.mode != DFF_MODE_SCORE;
-                const bool st_qkv = !(KEEP_LAST && l == m.L - 1 && l > 0 && a.mode != DFF_MODE_SCORE) && !keep2;
+                const bool keep2 = KEEP2 && l == m.L - 2 && l > 0 && MODE != DFF_MODE_SCORE;
+                const bool st_qkv = !(KEEP_LAST && l == m.L - 1 && l > 0 && MODE != DFF_MODE_SCORE) && !keep2;
                 const SStream sn0 = ss_w1(lw), sn1 = ss_w2(lw);   // the FFN block's units follow: W1 (U_W1), then W2
                 auto head_math = [&](int h) {
                     write_xext(lane);
@@ -1284,7 +1320,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 for (int d = 0; d < DR; ++d) b1r[d][0] = b1p[16 * d];
                 // FOLD, sampling loops: GELU'(h_pre) of the last three layers never leaves the LDS (gp_tile); otherwise it goes to
                 // the stash slot "h_pre" through a second LDS tile behind the hidden slice
-                const bool gp_lds = FOLD && a.mode != DFF_MODE_SCORE && l >= m.L - 3;
+                const bool gp_lds = FOLD && MODE != DFF_MODE_SCORE && l >= m.L - 3;
                 {
                     lfloat* const hb = hbuf + quad * 4 * LF + col;
                     lfloat* const gq = (gp_lds ? gp_tile(l, m.L) : hbuf + 16 * LF) + col;
@@ -1490,7 +1526,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 if constexpr (FOLD) {
                     // the tile the forward FFN left in LDS (read now, in flight under the first weight units), or -- score mode,
                     // layers before the last three of a deep model -- the stash
-                    if (a.mode != DFF_MODE_SCORE && l >= m.L - 3) {
+                    if (MODE != DFF_MODE_SCORE && l >= m.L - 3) {
                         const lfloat* const gq = gp_tile(l, m.L) + col;
 #pragma unroll
                         for (int d = 0; d < DR; ++d)
@@ -1538,7 +1574,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             pf.tick(7);
             // first head of this layer's attention backward: start the stash read (hidden by row stage E)
             if constexpr (HDMA) {
-                if (!(KEEP_LAST && l == m.L - 1 && l > 0) && !(KEEP2 && l == m.L - 2 && l > 0 && a.mode != DFF_MODE_SCORE))
+                if (!(KEEP_LAST && l == m.L - 1 && l > 0) && !(KEEP2 && l == m.L - 2 && l > 0 && MODE != DFF_MODE_SCORE))
                     head_dma<LL::DMA_N>(dmatab, Qx, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, lane_id());
             }
             if constexpr (HPW == 2) {
@@ -1609,7 +1645,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 // what follows this block: FFN backward of layer l-1, or (after layer 0) next step's first GEMM
                 const bool more = (step + 1 < a.n_steps);
                 const WStream after = l > 0 ? s_w2t(m.layer[l - 1])
-                                            : (a.mode == DFF_MODE_LANGEVIN ? s_wox(m.layer[0], wave) : s_qkv(m.layer[0], wave));
+                                            : (MODE == DFF_MODE_LANGEVIN ? s_wox(m.layer[0], wave) : s_qkv(m.layer[0], wave));
                 (void)more;
                 // what follows: FFN backward of layer l - 1 (W2^T, W1^T); after layer 0 the next step re-stages its own first units
                 const DffLayerDev& lwp = m.layer[l > 0 ? l - 1 : 0];
@@ -1754,7 +1790,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     } else {
                         if constexpr (HDMA) {
                             head_dma_wait();   // (requested before row stage E; nothing for the last layer)
-                            if constexpr (KEEP2) { if (l == m.L - 2 && l > 0 && a.mode != DFF_MODE_SCORE) keep2_copy(Qsave, Qx, Psave, pb, lane); }
+                            if constexpr (KEEP2) { if (l == m.L - 2 && l > 0 && MODE != DFF_MODE_SCORE) keep2_copy(Qsave, Qx, Psave, pb, lane); }
                         }
                         else if (!(KEEP_LAST && l == m.L - 1)) {   // the last layer's q_ext | k | v | P are still in the head buffers
                             head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, true, lane, m12p(wave));
@@ -1856,17 +1892,24 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             }
             pf.tick(10);
         }
-        // dxs = sum of the waves' partial x-gradients (the force head wrote dxs itself)
-        if (tid < 64 && m.conservative) {
+        { const int tq = tid_id();   // (opaque: the per-lane addresses below are re-derived every step, not hoisted and spilled)
+        // dxs = sum of the waves' partial x-gradients (the force head wrote dxs itself); supplied / not yet drawn noise -> xib
+        if (tq < 64 && m.conservative) {
             const lfloat* d0 = sm + LL::dxw;
             float pv[NW];
 #pragma unroll
-            for (int w = 0; w < NW; ++w) pv[w] = d0[w * 128 + tid];
+            for (int w = 0; w < NW; ++w) pv[w] = d0[w * 128 + tq];
             __builtin_amdgcn_sched_barrier(0);   // all reads in flight before the first add
             float t = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) t += pv[w];
-            dxs[tid] = t;
+            dxs[tq] = t;
+        }
+        if (MODE != DFF_MODE_SCORE && !xi_pre && tq < rows * 4 && (tq & 3) < 3) {
+            const int row = tq >> 2, cc = tq & 3, g = row / N, i = row - g * N;
+            const size_t item = (size_t)b0 + g;
+            if (a.noise) xib[tq] = a.noise[(((size_t)step * a.B + item) * N + i) * 3 + cc];
+            else xib[tq] = philox_normal(a.seed, a.item_offset + item, MODE == DFF_MODE_DDPM ? (uint64_t)t_int : a.step_offset + step, i, cc);
         }
         __syncthreads();
         if constexpr (GEN) {
@@ -1892,94 +1935,99 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         }
 
         // =============================== update (as dff_fused_kernel) ===============================
-        if (a.mode == DFF_MODE_SCORE) {
-            if (tid < rows * 4 && (tid & 3) < 3)
-                a.force_out[((size_t)b0 * N + (tid >> 2)) * 3 + (tid & 3)] = -dxs[tid];
-        } else if (a.mode == DFF_MODE_LANGEVIN) {
+        if (MODE == DFF_MODE_SCORE) {
+            if (tq < rows * 4 && (tq & 3) < 3)
+                a.force_out[((size_t)b0 * N + (tq >> 2)) * 3 + (tq & 3)] = -dxs[tq];
+        } else if (MODE == DFF_MODE_LANGEVIN) {
             const bool save = ((step + 1) % a.save_interval) == 0;
             const int fi = (step + 1) / a.save_interval - 1;
-            if (tid < rows * 4 && (tid & 3) < 3) {
-                const int row = tid >> 2, cc = tid & 3;
+            if (tq < rows * 4 && (tq & 3) < 3) {
+                const int row = tq >> 2, cc = tq & 3;
                 const int g = row / N, i = row - g * N;
                 const size_t item = (size_t)b0 + g;
-                float xi;
-                if (a.noise) xi = a.noise[(((size_t)step * a.B + item) * N + i) * 3 + cc];
-                else xi = philox_normal(a.seed, a.item_offset + item, a.step_offset + step, i, cc);
-                const float f = dxs[tid] * a.force_scale;
-                const float x = xst[tid];
+                const float xi = xib[tq];
+                const float f = dxs[tq] * a.force_scale;
+                const float x = xcb[tq];        // the centred x_old (langevin.py:75-92 centres before the force call)
                 float xn, vn = 0.f;
                 if (a.overdamped) {
                     xn = x + f * a.dtau + a.brown_sigma * xi;
                 } else {
-                    vn = vst[tid] + (a.dt * f) / a.mass[i];
+                    vn = vst[tq] + (a.dt * f) / a.mass[i];
                     xn = x + (vn * a.dt) / 2.0f;
                     const float nz = a.noise_sigma[i] * xi;
                     vn = vn * a.vscale;
                     vn = vn + a.noisescale * nz;
                     xn = xn + (vn * a.dt) / 2.0f;
                 }
-                xst[tid] = xn;
-                vst[tid] = vn;
+                xst[tq] = xn;
+                vst[tq] = vn;
                 if (save && a.frames) a.frames[(((size_t)fi * a.B + item) * N + i) * 3 + cc] = xn;
             }
-            __syncthreads();
-            if (save && a.ke && !a.overdamped && tid < gcnt) {
-                float ke = 0.f;
-                for (int i = 0; i < N; ++i) {
-                    const lfloat* vp = vst + (tid * N + i) * 4;
-                    ke += a.mass[i] * (vp[0] * vp[0] + vp[1] * vp[1] + vp[2] * vp[2]);
+            if (save && a.ke && !a.overdamped) {
+                __syncthreads();
+                if (tq < gcnt) {
+                    float ke = 0.f;
+                    for (int i = 0; i < N; ++i) {
+                        const lfloat* vp = vst + (tq * N + i) * 4;
+                        ke += a.mass[i] * (vp[0] * vp[0] + vp[1] * vp[1] + vp[2] * vp[2]);
+                    }
+                    a.ke[(size_t)fi * a.B + b0 + tq] = 0.5f * ke;
                 }
-                a.ke[(size_t)fi * a.B + b0 + tid] = 0.5f * ke;
             }
         } else {
-            const bool act = tid < rows * 4 && (tid & 3) < 3;
-            const int row = tid >> 2, cc = tid & 3;
-            const int g = act ? row / N : 0, i = act ? row - g * N : 0;
-            const size_t item = (size_t)b0 + g;
-            float eps = act ? -dxs[tid] : 0.f;
-            float xi = 0.f;
-            if (act) {
-                if (a.noise) xi = a.noise[(((size_t)step * a.B + item) * N + i) * 3 + cc];
-                else xi = philox_normal(a.seed, a.item_offset + item, (uint64_t)t_int, i, cc);
-            }
-            if (tid < rows * 4) { dxs[tid] = eps; xs[tid] = xi; }
-            __syncthreads();
-            bead_mean(c, (float*)dxs, (float*)cm);
-            bead_mean(c, (float*)xs, (float*)(cm + 64));
-            __syncthreads();
-            const float x = act ? xst[tid] : 0.f;
-            float x0 = 0.f;
-            if (act) {
-                eps -= cm[g * 4 + cc];
-                xi -= cm[64 + g * 4 + cc];
-                x0 = m.sqrt_recip_ac[t_int] * x - m.sqrt_recipm1_ac[t_int] * eps;
-            }
-            __syncthreads();
-            if (tid < rows * 4) dxs[tid] = x0;
-            __syncthreads();
-            bead_mean(c, (float*)dxs, (float*)cm);
-            __syncthreads();
-            float xn = 0.f;
-            if (act) {
-                x0 -= cm[g * 4 + cc];
-                const float mean = m.post_c1[t_int] * x0 + m.post_c2[t_int] * x;
-                const float nzm = (t_int == 0) ? 0.f : 1.f;
-                xn = mean + nzm * expf(0.5f * m.post_logvar[t_int]) * xi;
+            // Reverse DDPM step (ddpm.py:195-232) + clamp + centring (:248-251).  Four per-protein means sit between the
+            // element-wise stages; every (bead, component) thread -- all in wave 0, so its loads of the old xst precede every
+            // store of the new one -- runs the whole chain for its protein's column in registers and takes the means itself
+            // (summed in bead order as bead_mean() does): same arithmetic per element as the stage-by-stage form, no barriers.
+#ifndef DFF_T_LANGONLY   // (TIMING-ONLY experiment switch: code size)
+            if (tq < rows * 4 && (tq & 3) < 3) {
+                const int cc = tq & 3, pb0 = ((tq >> 2) / N) * N;
+                const float sr = m.sqrt_recip_ac[t_int], srm1 = m.sqrt_recipm1_ac[t_int];
+                const float c1 = m.post_c1[t_int], c2 = m.post_c2[t_int];
+                const float sig = ((t_int == 0) ? 0.f : 1.f) * expf(0.5f * m.post_logvar[t_int]);
+                const float invn = (float)N;
+                float ev[16], zv[16], xv[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int o = (pb0 + min(i, N - 1)) * 4 + cc;
+                    ev[i] = -dxs[o]; zv[i] = xib[o]; xv[i] = xst[o];
+                }
+                float e_own = -dxs[tq], z_own = xib[tq];
+                const float x_own = xst[tq];
+                auto colmean = [&](const float (&v)[16]) {
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) sacc += i < N ? v[i] : 0.f;
+                    return sacc / invn;
+                };
+                const float me = colmean(ev), mz = colmean(zv);
+                float x0v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { ev[i] -= me; zv[i] -= mz; x0v[i] = sr * xv[i] - srm1 * ev[i]; }
+                e_own -= me; z_own -= mz;
+                float x0_own = sr * x_own - srm1 * e_own;
+                const float m0 = colmean(x0v);
+                float xnv[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float mu = c1 * (x0v[i] - m0) + c2 * xv[i];
+                    xnv[i] = fminf(fmaxf(mu + sig * zv[i], -1000.f), 1000.f);
+                }
+                x0_own -= m0;
+                const float mu_own = c1 * x0_own + c2 * x_own;
+                float xn = mu_own + sig * z_own;
                 if (xn > 1000.f || xn < -1000.f) {
                     if (a.clamp_flag) atomicOr(a.clamp_flag, 1);
                     xn = fminf(fmaxf(xn, -1000.f), 1000.f);
                 }
+                xst[tq] = xn - colmean(xnv);
             }
-            __syncthreads();
-            if (tid < rows * 4) dxs[tid] = xn;
-            __syncthreads();
-            bead_mean(c, (float*)dxs, (float*)cm);
-            __syncthreads();
-            if (act) xst[tid] = xn - cm[g * 4 + cc];
+#endif
         }
         __syncthreads();
+        }
         // end of a reverse chain: assert_center_zero(mol) (models/ddpm.py:252) on the device -> bit 1 of the flag word
-        if (a.mode == DFF_MODE_DDPM && step == a.n_steps - 1 && a.clamp_flag) {
+        if (MODE == DFF_MODE_DDPM && step == a.n_steps - 1 && a.clamp_flag) {
             bead_mean(c, (float*)xst, (float*)cm);
             __syncthreads();
             if (tid < gcnt * 4 && (tid & 3) < 3 && !(fabsf(cm[tid]) < 1e-3f)) atomicOr(a.clamp_flag, 2);
@@ -1988,30 +2036,37 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     }
     if (pf.on)
         for (int i = 0; i < DFF_NPROF; ++i) a.prof[i] = pf.acc[i];
-    if (a.mode != DFF_MODE_SCORE && tid < rows * 4 && (tid & 3) < 3) {
+    if (MODE != DFF_MODE_SCORE && tid < rows * 4 && (tid & 3) < 3) {
         const size_t gi = ((size_t)b0 * N + (tid >> 2)) * 3 + (tid & 3);
         a.x_io[gi] = xst[tid];
-        if (a.mode == DFF_MODE_LANGEVIN && !a.overdamped) a.v_io[gi] = vst[tid];
+        if (MODE == DFF_MODE_LANGEVIN && !a.overdamped) a.v_io[gi] = vst[tid];
     }
 }
 
-// kernel lookup for the host dispatcher (dff_host.hip); taking the address instantiates the variant
-bool dff_small_pick(int H, int NW, bool gen, bool spw, const void** fn, unsigned* lds_floats, const char** name, bool fold) {
+// kernel lookup for the host dispatcher (dff_host.hip); taking the address instantiates the variant.  One translation unit
+// per sampler mode: this one exports dff_small_pick_m<DFF_SMALL_MODE>.
+#ifndef DFF_SMALL_MODE
+#error "compile dff_small.hip with -DDFF_SMALL_MODE=0|1|2 (DFF_MODE_SCORE / LANGEVIN / DDPM): build.sh builds all three"
+#endif
+#define DFF_CAT2(a, b) a##b
+#define DFF_CAT(a, b) DFF_CAT2(a, b)
+bool DFF_CAT(dff_small_pick_m, DFF_SMALL_MODE)(int H, int NW, bool gen, bool spw, const void** fn, unsigned* lds_floats, const char** name, bool fold) {
+    constexpr int MD = DFF_SMALL_MODE;
     if (H == 64 && NW == 8 && spw && fold && !gen) {
-        *fn = (const void*)&dff_small_kernel<64, 8, false, true, true>;
+        *fn = (const void*)&dff_small_kernel<64, 8, false, true, true, MD>;
         *lds_floats = SmallLds<64, 8, true>::total;
         *name = "dff_small_kernel<64,8,split_bf16,fold_kv>";
         return true;
     }
     if (H == 64 && NW == 8 && spw) {
-        *fn = gen ? (const void*)&dff_small_kernel<64, 8, true, true> : (const void*)&dff_small_kernel<64, 8, false, true>;
+        *fn = gen ? (const void*)&dff_small_kernel<64, 8, true, true, false, MD> : (const void*)&dff_small_kernel<64, 8, false, true, false, MD>;
         *lds_floats = SmallLds<64, 8>::total;
         *name = gen ? "dff_small_kernel<64,8,gen,split_bf16>" : "dff_small_kernel<64,8,split_bf16>";
         return true;
     }
 #define SMALL_CASE(H_, NW_)                                                                                          \
     if (H == H_ && NW == NW_ && !spw) {                                                                              \
-        *fn = gen ? (const void*)&dff_small_kernel<H_, NW_, true> : (const void*)&dff_small_kernel<H_, NW_, false>;  \
+        *fn = gen ? (const void*)&dff_small_kernel<H_, NW_, true, false, false, MD> : (const void*)&dff_small_kernel<H_, NW_, false, false, false, MD>;  \
         *lds_floats = SmallLds<H_, NW_>::total;                                                                      \
         *name = gen ? "dff_small_kernel<" #H_ "," #NW_ ",gen>" : "dff_small_kernel<" #H_ "," #NW_ ">";               \
         return true;                                                                                                 \
