@@ -23,6 +23,9 @@
 // LayerNorm, gates, GELU and the integrator update.
 #include "dff_device.h"
 
+#ifndef DFF_SDR
+#define DFF_SDR 4   // split-ring depth in units (SPW variants)
+#endif
 // NW = waves per workgroup.  NW = 4: one wave per SIMD, two heads per wave, 16-row head buffers.
 // NW = 8: two waves per SIMD (each hides the other's stalls), one head per wave; to fit 8 wave
 // regions in 160 KB the head buffers hold RLA = 11 rows (10 real + 1 dummy row that absorbs the
@@ -630,7 +633,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     constexpr int RS = RLA * DFF_XLD;        // floats between the Q / K / V / G buffers of a wave
     constexpr int FS = F / NW, NTS = FS / 16, LF = FS + 4;   // FFN hidden slice of a wave
     static_assert(HPW == 1 || HPW == 2, "4 or 8 waves");
-    constexpr int KB32 = H / 32, SDR = 4;   // SPW: 32-row k-blocks of a K = H GEMM, split-ring depth in units
+    constexpr int KB32 = H / 32, SDR = DFF_SDR;   // SPW: 32-row k-blocks of a K = H GEMM, split-ring depth in units
     static_assert(!SPW || (NW == 8 && H == 64 && FS == 32), "split-bf16 variant: one head per wave; the unit counts below are H = 64's");
     // units per GEMM of a wave (H = 64): QKV_ext 13 tiles x 2, [W_o;W_oc] 2 k-blocks x 4, W1 / W2^T 2 x 2, W2 / W1^T 1 x 4,
     // [W_o;W_oc]^T 5 x 2, QKV_ext^T 6 x 4
@@ -880,6 +883,29 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         for (int i = 0; i < HC; ++i) z += x[i] * ro[k][i] + res[i] * ro[k + 1][i] + (x[i] - res[i]) * ro[k + 2][i];
         return sigmoid_f(rsum(z));
     };
+    // KEEPROWS (FOLD, sampling loops): what the backward row stages need of the last three layers' forward row stages --
+    // attn_out, ff and nodes_in, two values per thread and array -- stays in the registers of the thread that made it (the
+    // thread <-> (row, column) mapping is the same in every row stage) instead of going through the stash: 18 VGPRs.  With
+    // GELU' in LDS and q' / P in LDS, a model of <= 3 layers then has NO stash traffic in its sampling loops: the HBM / MALL
+    // traffic of a launch drops to the trajectories themselves, and the per-XCD L2 working set (4 MB) to the 3.6 MB of
+    // weights a step streams (measured bound with an L2-resident stash: -2.9 us / step).  Slot k = L - 1 - l.
+    constexpr bool KEEPROWS = FOLD && MODE != DFF_MODE_SCORE;
+    float kp0[3][HC] = {}, kp1[3][HC] = {}, kp2[3][HC] = {};   // slot 0 / 1 / 2: [attn_out | ff | nodes_in][HC]  (separate arrays, constant indices: registers)
+    auto keep_put = [&](int k, auto ai, const float (&x)[HC]) {
+        constexpr int A = decltype(ai)::value;
+#pragma unroll
+        for (int i = 0; i < HC; ++i) {   // selects of VALUES (a branch or a select of addresses would put the arrays in scratch)
+            kp0[A][i] = k == 0 ? x[i] : kp0[A][i];
+            kp1[A][i] = k == 1 ? x[i] : kp1[A][i];
+            kp2[A][i] = k == 2 ? x[i] : kp2[A][i];
+        }
+    };
+    auto keep_get = [&](int k, auto ai, float (&x)[HC]) {
+        constexpr int A = decltype(ai)::value;
+#pragma unroll
+        for (int i = 0; i < HC; ++i) x[i] = k == 0 ? kp0[A][i] : k == 1 ? kp1[A][i] : kp2[A][i];
+    };
+    using KA = std::integral_constant<int, 0>; using KF = std::integral_constant<int, 1>; using KN = std::integral_constant<int, 2>;
     // stage B operands: bo, g1 (3), ln2 gamma, ln2 beta
     auto pre_B = [&](const DffLayerDev& w, int sub) {
         ro_load(0, w.bo, sub); ro_load3(1, w.g1, sub); ro_load(4, w.ln2_g, sub); ro_load(5, w.ln2_b, sub);
@@ -1285,8 +1311,9 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     const int cl = sub + LPR * i, o = rrow * LH + cl;
                     x[i] = ps[i] + ro[0][i];
                     res[i] = resbuf[o];
-                    st_ntg(sb + sl.attn_out + rrow * H + cl, x[i]);
+                    if (!(KEEPROWS && l >= m.L - 3)) st_ntg(sb + sl.attn_out + rrow * H + cl, x[i]);
                 }
+                if (KEEPROWS && l >= m.L - 3) keep_put(m.L - 1 - l, KA{}, x);
                 const float g = ro_gate(x, res, 1);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
@@ -1393,8 +1420,9 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     const int cl = sub + LPR * i, o = rrow * LH + cl;
                     x[i] = ps[i] + ro[0][i];
                     res[i] = resbuf[o];
-                    st_ntg(sb + sl.ff + rrow * H + cl, x[i]);
+                    if (!(KEEPROWS && l >= m.L - 3)) st_ntg(sb + sl.ff + rrow * H + cl, x[i]);
                 }
+                if (KEEPROWS && l >= m.L - 3) keep_put(m.L - 1 - l, KF{}, x);
                 const float g = ro_gate(x, res, 1);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) n2[i] = x[i] * g + res[i] * (1.0f - g);
@@ -1415,8 +1443,10 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     // g1 (3), g2 (3 -- already in ro[1..3], move up)
 #pragma unroll
                     for (int i = 0; i < HC; ++i) { ro[6][i] = ro[1][i]; ro[7][i] = ro[2][i]; ro[8][i] = ro[3][i]; ro[2][i] = x[i]; }
-                    ro_load(0, (const float*)(sb + sl.attn_out + rrow * H), sub);
-                    ro_load(1, (const float*)(sbq + sl.nodes_in + rrow * H), sub);
+                    if (KEEPROWS) keep_get(0, KA{}, ro[0]);
+                    else ro_load(0, (const float*)(sb + sl.attn_out + rrow * H), sub);
+                    if (KEEPROWS && l > 0) keep_get(0, KN{}, ro[1]);
+                    else ro_load(1, (const float*)(sbq + sl.nodes_in + rrow * H), sub);
                     ro_load3(3, lw.g1, sub);
                 } else {
                     gfloat* const sbn = stash + (size_t)(l + 1) * sl.layer_stride;
@@ -1426,11 +1456,12 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     for (int i = 0; i < HC; ++i) {
                         const int cl = sub + LPR * i;
                         resbuf[rrow * LH + cl] = n2[i];
-                        st_ntg(sbn + sl.nodes_in + rrow * H + cl, n2[i]);
+                        if (!(KEEPROWS && l + 1 >= m.L - 3)) st_ntg(sbn + sl.nodes_in + rrow * H + cl, n2[i]);
                         const float nv = (n2[i] - mean) * rstd * ro[4][i] + ro[5][i];
                         a_store(rrow, cl, nv);
                         n_store(rrow, cl, nv);
                     }
+                    if (KEEPROWS && l + 1 >= m.L - 3) keep_put(m.L - 2 - l, KN{}, n2);
                     pre_B(m.layer[l + 1], sub);
                 }
             } }
@@ -1882,9 +1913,16 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     if (l > 0) {   // stage D operands of layer l-1
                         const DffLayerDev& lp = m.layer[l - 1];
                         const gfloat* const sp = stash + (size_t)(l - 1) * sl.layer_stride;
-                        ro_load(0, (const float*)(sp + sl.attn_out + rrow * H), sub);
-                        ro_load(1, (const float*)((l == 1 ? l0e : sp) + sl.nodes_in + rrow * H), sub);
-                        ro_load(2, (const float*)(sp + sl.ff + rrow * H), sub);
+                        if (KEEPROWS && l - 1 >= m.L - 3) {   // the rows layer l - 1's forward stages left in this thread's registers
+                            keep_get(m.L - l, KA{}, ro[0]);
+                            keep_get(m.L - l, KF{}, ro[2]);
+                            if (l > 1) keep_get(m.L - l, KN{}, ro[1]);
+                            else ro_load(1, (const float*)(l0e + sl.nodes_in + rrow * H), sub);
+                        } else {
+                            ro_load(0, (const float*)(sp + sl.attn_out + rrow * H), sub);
+                            ro_load(1, (const float*)((l == 1 ? l0e : sp) + sl.nodes_in + rrow * H), sub);
+                            ro_load(2, (const float*)(sp + sl.ff + rrow * H), sub);
+                        }
                         ro_load3(3, lp.g1, sub); ro_load3(6, lp.g2, sub);
                     }
                 }
