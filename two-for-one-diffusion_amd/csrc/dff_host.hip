@@ -287,7 +287,9 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
         const char* e = getenv("DFF_SPLIT_BF16");
         m->split = !(e && e[0] == '0');
         const char* ef = getenv("DFF_FOLD_KV");
-        m->fold_kv = H == DFF_DH && !(ef && ef[0] == '0');
+        // (the <= 16-row FOLD kernel keeps a model's forward activations in LDS / registers: built for <= 3 layers, which is
+        // every shipped configuration; a deeper hidden-64 model runs the unfolded kernels)
+        m->fold_kv = H == DFF_DH && L <= 3 && !(ef && ef[0] == '0');
         const void* fn_; unsigned lds_; const char* nm_;
         m->small_split = m->split && N <= 10 && dff_small_pick(DFF_MODE_SCORE, H, 8, false, true, &fn_, &lds_, &nm_);
     }

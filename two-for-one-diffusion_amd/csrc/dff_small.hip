@@ -732,10 +732,11 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     // rows of the partial-sum tile: 16, or (FOLD) the RLA = 11 allocated ones -- pad rows collapse onto the last -- which
     // leaves room behind it for the last layer's GELU' tile
     constexpr int PRMAX = FOLD ? RLA - 1 : 15;
-    // GELU'(h_pre) of this wave's FFN hidden slice stays in LDS for the last three layers in the sampling loops (FOLD):
-    // layer L - 1 behind the partial sums in G | dS (its backward follows at once), layers L - 2 and L - 3 in GP0 / GP1
+    // GELU'(h_pre) of this wave's FFN hidden slice stays in LDS in the sampling loops (FOLD: the host uses this variant
+    // for models of <= 3 layers only): the last layer's tile behind the partial sums in G | dS (its backward follows at
+    // once), layers 0 and 1 of a deeper model in GP0 / GP1
     auto gp_tile = [=](int l, int L) -> lfloat* {
-        return l == L - 1 ? wr + MPO + LL::GP_LAST : wr + (3 * RS + 3 * 16 * DFF_PLD) + (unsigned)(L - 2 - l) * LL::GPT;
+        return l == L - 1 ? wr + MPO + LL::GP_LAST : wr + (3 * RS + 3 * 16 * DFF_PLD) + (unsigned)l * LL::GPT;
     };
     // sum of the NW waves' partial outputs for this lane's HC columns of a row: ALL NW x HC LDS reads are
     // issued first (one latency), then added in wave order (left to itself the compiler issues one read,
@@ -883,12 +884,14 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         for (int i = 0; i < HC; ++i) z += x[i] * ro[k][i] + res[i] * ro[k + 1][i] + (x[i] - res[i]) * ro[k + 2][i];
         return sigmoid_f(rsum(z));
     };
-    // KEEPROWS (FOLD, sampling loops): what the backward row stages need of the last three layers' forward row stages --
+    // KEEPROWS (FOLD, sampling loops; <= 3 layers): what the backward row stages need of the forward row stages --
     // attn_out, ff and nodes_in, two values per thread and array -- stays in the registers of the thread that made it (the
     // thread <-> (row, column) mapping is the same in every row stage) instead of going through the stash: 18 VGPRs.  With
-    // GELU' in LDS and q' / P in LDS, a model of <= 3 layers then has NO stash traffic in its sampling loops: the HBM / MALL
-    // traffic of a launch drops to the trajectories themselves, and the per-XCD L2 working set (4 MB) to the 3.6 MB of
-    // weights a step streams (measured bound with an L2-resident stash: -2.9 us / step).  Slot k = L - 1 - l.
+    // GELU' in LDS and q' / P in LDS, the only stash traffic left in the sampling loops is layer 0's P: the HBM / MALL
+    // traffic of a launch drops to (almost) the trajectories themselves, and the per-XCD L2 working set (4 MB) to the
+    // 3.6 MB of weights a step streams (measured bound with an L2-resident stash: -2.9 us / step).  Slot = layer.  The
+    // backward stages read their slot into fresh locals (keep_get at the point of use): a copy into the ro[] registers the
+    // parameter prefetches also target made the compiler guard every copy with an s_waitcnt vmcnt that drained the weight ring.
     constexpr bool KEEPROWS = FOLD && MODE != DFF_MODE_SCORE;
     float kp0[3][HC] = {}, kp1[3][HC] = {}, kp2[3][HC] = {};   // slot 0 / 1 / 2: [attn_out | ff | nodes_in][HC]  (separate arrays, constant indices: registers)
     auto keep_put = [&](int k, auto ai, const float (&x)[HC]) {
@@ -904,6 +907,16 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         constexpr int A = decltype(ai)::value;
 #pragma unroll
         for (int i = 0; i < HC; ++i) x[i] = k == 0 ? kp0[A][i] : k == 1 ? kp1[A][i] : kp2[A][i];
+    };
+    // attn_out / nodes_in / ff of layer l for a backward row stage: this thread's kept registers, or the prefetched ro[]
+    auto rows_of = [&](int l, float (&ao)[HC], float (&ni)[HC], float (*fv)[HC], int ffslot) {
+#pragma unroll
+        for (int i = 0; i < HC; ++i) { ao[i] = ro[0][i]; ni[i] = ro[1][i]; if (fv) (*fv)[i] = ro[ffslot][i]; }
+        if constexpr (KEEPROWS) {
+            keep_get(l, std::integral_constant<int, 0>{}, ao);
+            if (fv) keep_get(l, std::integral_constant<int, 1>{}, *fv);
+            if (l > 0) keep_get(l, std::integral_constant<int, 2>{}, ni);   // (layer 0's node inputs come from the table / the stash: ro[1])
+        }
     };
     using KA = std::integral_constant<int, 0>; using KF = std::integral_constant<int, 1>; using KN = std::integral_constant<int, 2>;
     // stage B operands: bo, g1 (3), ln2 gamma, ln2 beta
@@ -1311,9 +1324,9 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     const int cl = sub + LPR * i, o = rrow * LH + cl;
                     x[i] = ps[i] + ro[0][i];
                     res[i] = resbuf[o];
-                    if (!(KEEPROWS && l >= m.L - 3)) st_ntg(sb + sl.attn_out + rrow * H + cl, x[i]);
+                    if constexpr (!KEEPROWS) st_ntg(sb + sl.attn_out + rrow * H + cl, x[i]);
                 }
-                if (KEEPROWS && l >= m.L - 3) keep_put(m.L - 1 - l, KA{}, x);
+                if constexpr (KEEPROWS) keep_put(l, KA{}, x);
                 const float g = ro_gate(x, res, 1);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
@@ -1347,7 +1360,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 for (int d = 0; d < DR; ++d) b1r[d][0] = b1p[16 * d];
                 // FOLD, sampling loops: GELU'(h_pre) of the last three layers never leaves the LDS (gp_tile); otherwise it goes to
                 // the stash slot "h_pre" through a second LDS tile behind the hidden slice
-                const bool gp_lds = FOLD && MODE != DFF_MODE_SCORE && l >= m.L - 3;
+                constexpr bool gp_lds = FOLD && MODE != DFF_MODE_SCORE;
                 {
                     lfloat* const hb = hbuf + quad * 4 * LF + col;
                     lfloat* const gq = (gp_lds ? gp_tile(l, m.L) : hbuf + 16 * LF) + col;
@@ -1420,9 +1433,9 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     const int cl = sub + LPR * i, o = rrow * LH + cl;
                     x[i] = ps[i] + ro[0][i];
                     res[i] = resbuf[o];
-                    if (!(KEEPROWS && l >= m.L - 3)) st_ntg(sb + sl.ff + rrow * H + cl, x[i]);
+                    if constexpr (!KEEPROWS) st_ntg(sb + sl.ff + rrow * H + cl, x[i]);
                 }
-                if (KEEPROWS && l >= m.L - 3) keep_put(m.L - 1 - l, KF{}, x);
+                if constexpr (KEEPROWS) keep_put(l, KF{}, x);
                 const float g = ro_gate(x, res, 1);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) n2[i] = x[i] * g + res[i] * (1.0f - g);
@@ -1443,10 +1456,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     // g1 (3), g2 (3 -- already in ro[1..3], move up)
 #pragma unroll
                     for (int i = 0; i < HC; ++i) { ro[6][i] = ro[1][i]; ro[7][i] = ro[2][i]; ro[8][i] = ro[3][i]; ro[2][i] = x[i]; }
-                    if (KEEPROWS) keep_get(0, KA{}, ro[0]);
-                    else ro_load(0, (const float*)(sb + sl.attn_out + rrow * H), sub);
-                    if (KEEPROWS && l > 0) keep_get(0, KN{}, ro[1]);
-                    else ro_load(1, (const float*)(sbq + sl.nodes_in + rrow * H), sub);
+                    if constexpr (!KEEPROWS) ro_load(0, (const float*)(sb + sl.attn_out + rrow * H), sub);
+                    if (!KEEPROWS || l == 0) ro_load(1, (const float*)(sbq + sl.nodes_in + rrow * H), sub);
                     ro_load3(3, lw.g1, sub);
                 } else {
                     gfloat* const sbn = stash + (size_t)(l + 1) * sl.layer_stride;
@@ -1456,12 +1467,12 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     for (int i = 0; i < HC; ++i) {
                         const int cl = sub + LPR * i;
                         resbuf[rrow * LH + cl] = n2[i];
-                        if (!(KEEPROWS && l + 1 >= m.L - 3)) st_ntg(sbn + sl.nodes_in + rrow * H + cl, n2[i]);
+                        if constexpr (!KEEPROWS) st_ntg(sbn + sl.nodes_in + rrow * H + cl, n2[i]);
                         const float nv = (n2[i] - mean) * rstd * ro[4][i] + ro[5][i];
                         a_store(rrow, cl, nv);
                         n_store(rrow, cl, nv);
                     }
-                    if (KEEPROWS && l + 1 >= m.L - 3) keep_put(m.L - 2 - l, KN{}, n2);
+                    if constexpr (KEEPROWS) keep_put(l + 1, KN{}, n2);
                     pre_B(m.layer[l + 1], sub);
                 }
             } }
@@ -1516,16 +1527,17 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             // operands (prefetched): ro[0] attn_out, ro[1] nodes_in, ro[2] ff, ro[3..5] g1, ro[6..8] g2
             { DFF_ROW_CONSTS
             if (ract) {
-                float n1[HC], dn[HC];
+                float n1[HC], dn[HC], ao[HC], ni[HC], fv[HC];
+                rows_of(l, ao, ni, &fv, 2);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) dn[i] = resbuf[rrow * LH + sub + LPR * i];
-                const float g1 = ro_gate(ro[0], ro[1], 3);
+                const float g1 = ro_gate(ao, ni, 3);
 #pragma unroll
-                for (int i = 0; i < HC; ++i) n1[i] = ro[0][i] * g1 + ro[1][i] * (1.0f - g1);
-                const float g2 = ro_gate(ro[2], n1, 6);
+                for (int i = 0; i < HC; ++i) n1[i] = ao[i] * g1 + ni[i] * (1.0f - g1);
+                const float g2 = ro_gate(fv, n1, 6);
                 float dg = 0.f;
 #pragma unroll
-                for (int i = 0; i < HC; ++i) dg += dn[i] * (ro[2][i] - n1[i]);
+                for (int i = 0; i < HC; ++i) dg += dn[i] * (fv[i] - n1[i]);
                 dg = rsum(dg);
                 const float dz = dg * g2 * (1.0f - g2);
 #pragma unroll
@@ -1557,7 +1569,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 if constexpr (FOLD) {
                     // the tile the forward FFN left in LDS (read now, in flight under the first weight units), or -- score mode,
                     // layers before the last three of a deep model -- the stash
-                    if (MODE != DFF_MODE_SCORE && l >= m.L - 3) {
+                    if constexpr (MODE != DFF_MODE_SCORE) {
                         const lfloat* const gq = gp_tile(l, m.L) + col;
 #pragma unroll
                         for (int d = 0; d < DR; ++d)
@@ -1617,13 +1629,14 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             // operands: ro[0] attn_out, ro[1] nodes_in, ro[2] ln2 gamma, ro[3..5] g1
             { DFF_ROW_CONSTS
             if (ract) {
-                float n1[HC], d1[HC], dyg[HC], xh[HC], ps[HC];
+                float n1[HC], d1[HC], dyg[HC], xh[HC], ps[HC], ao[HC], ni[HC];
+                rows_of(l, ao, ni, nullptr, 0);
                 psum_all(ps, rrow * LH + sub);
                 pf.tick(22);
-                const float g1 = ro_gate(ro[0], ro[1], 3);
+                const float g1 = ro_gate(ao, ni, 3);
                 pf.tick(23);
 #pragma unroll
-                for (int i = 0; i < HC; ++i) n1[i] = ro[0][i] * g1 + ro[1][i] * (1.0f - g1);
+                for (int i = 0; i < HC; ++i) n1[i] = ao[i] * g1 + ni[i] * (1.0f - g1);
                 float mean, rstd;
                 ln_stats_row(n1, mean, rstd);
                 float s1 = 0.f, s2 = 0.f;
@@ -1641,7 +1654,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
                     d1[i] = resbuf[rrow * LH + sub + LPR * i] + rstd * (dyg[i] - s1 - xh[i] * s2);
-                    dg += d1[i] * (ro[0][i] - ro[1][i]);
+                    dg += d1[i] * (ao[i] - ni[i]);
                 }
                 dg = rsum(dg);
                 const float dz = dg * g1 * (1.0f - g1);
@@ -1653,11 +1666,11 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 }
                 if constexpr (FOLD) {   // this layer's LayerNorm rows (the keys / values of its attention block), as the forward pass made them
                     float mean1, rstd1;
-                    ln_stats_row(ro[1], mean1, rstd1);
+                    ln_stats_row(ni, mean1, rstd1);
 #pragma unroll
                     for (int i = 0; i < HC; ++i) {
                         const int cl = sub + LPR * i;
-                        n_store(rrow, cl, (ro[1][i] - mean1) * rstd1 * lw.ln1_g[cl] + lw.ln1_b[cl]);
+                        n_store(rrow, cl, (ni[i] - mean1) * rstd1 * lw.ln1_g[cl] + lw.ln1_b[cl]);
                     }
                 }
                 // stage F operands: nodes_in stays in ro[1]; LN1 gamma -> ro[2]
@@ -1893,15 +1906,16 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             if (l > 0 || full0) {
                 DFF_ROW_CONSTS
                 if (ract) {
-                    float dyg[HC], xh[HC], ps[HC];
+                    float dyg[HC], xh[HC], ps[HC], ao[HC], ni[HC];
+                    rows_of(l, ao, ni, nullptr, 0);
                     psum_all(ps, rrow * LH + sub);
                     float mean, rstd;
-                    ln_stats_row(ro[1], mean, rstd);
+                    ln_stats_row(ni, mean, rstd);
                     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                     for (int i = 0; i < HC; ++i) {
                         const int o = rrow * LH + sub + LPR * i;
-                        xh[i] = (ro[1][i] - mean) * rstd;
+                        xh[i] = (ni[i] - mean) * rstd;
                         dyg[i] = ps[i] * ro[2][i];
                         s1 += dyg[i];
                         s2 += dyg[i] * xh[i];
@@ -1913,11 +1927,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     if (l > 0) {   // stage D operands of layer l-1
                         const DffLayerDev& lp = m.layer[l - 1];
                         const gfloat* const sp = stash + (size_t)(l - 1) * sl.layer_stride;
-                        if (KEEPROWS && l - 1 >= m.L - 3) {   // the rows layer l - 1's forward stages left in this thread's registers
-                            keep_get(m.L - l, KA{}, ro[0]);
-                            keep_get(m.L - l, KF{}, ro[2]);
-                            if (l > 1) keep_get(m.L - l, KN{}, ro[1]);
-                            else ro_load(1, (const float*)(l0e + sl.nodes_in + rrow * H), sub);
+                        if constexpr (KEEPROWS) {   // (attn_out, ff and -- l > 1 -- nodes_in of layer l - 1: this thread's registers)
+                            if (l == 1) ro_load(1, (const float*)(l0e + sl.nodes_in + rrow * H), sub);
                         } else {
                             ro_load(0, (const float*)(sp + sl.attn_out + rrow * H), sub);
                             ro_load(1, (const float*)((l == 1 ? l0e : sp) + sl.nodes_in + rrow * H), sub);
