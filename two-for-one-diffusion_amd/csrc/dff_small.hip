@@ -711,16 +711,32 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     lfloat* const dsb = RELAY ? Gx + RS : pb + 16 * DFF_PLD;
     lfloat* const Qsave = dsb + 16 * DFF_PLD;          // (FOLD layout only)
     lfloat* const Psave = Qsave + RS;
+    // (q': the 68 data columns of every row -- columns 68.. of Qsave hold layer 0's P, below)
     auto keep2_copy = [=](const lfloat* qs, lfloat* qd, const lfloat* ps, lfloat* pd, int lane) {
 #pragma unroll
-        for (int u = 0; u < (RS / 4 + 63) / 64; ++u) {
-            const int it = lane + 64 * u;
-            if (it < RS / 4) *(lf32x4*)(qd + 4 * it) = *(const lf32x4*)(qs + 4 * it);
+        for (int u = 0; u < (RLA * 17 + 63) / 64; ++u) {
+            const int it = lane + 64 * u, row = it / 17, o = row * DFF_XLD + 4 * (it - row * 17);
+            if (it < RLA * 17) *(lf32x4*)(qd + o) = *(const lf32x4*)(qs + o);
         }
 #pragma unroll
         for (int u = 0; u < (16 * DFF_PLD / 4 + 63) / 64; ++u) {
             const int it = lane + 64 * u;
             if (it < 16 * DFF_PLD / 4) *(lf32x4*)(pd + 4 * it) = *(const lf32x4*)(ps + 4 * it);
+        }
+    };
+    // Layer 0's softmax rows P (10 x 10 real entries per head) also stay in LDS between its forward and its backward attention
+    // block when it is neither the last layer nor the one before (a 3-layer model): in columns 68..77 of the Qsave rows, which
+    // no q' uses.  With that the sampling loops of a 3-layer model have no stash traffic at all.
+    constexpr int P0C = 68;
+    static_assert(P0C + 10 <= DFF_XLD && RLA >= 10, "layer 0's P rows fit behind the q' columns of Qsave");
+    auto p0_copy = [=](bool save, int lane) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int it = lane + 64 * u, i = it / 10, j = it - i * 10;
+            if (it < 100) {
+                if (save) Qsave[i * DFF_XLD + P0C + j] = pb[i * DFF_PLD + j];
+                else pb[i * DFF_PLD + j] = Qsave[i * DFF_XLD + P0C + j];
+            }
         }
     };
     static_assert(!HDMA || DFF_XLD % 4 == 0, "16-byte slots");
@@ -1147,6 +1163,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 const WStream after = s_w1(lw);   // the FFN block follows
                 // the sampling loops never read the last layer's q_ext | k | v | P back from the stash (KEEP_LAST)
                 const bool keep2 = KEEP2 && l == m.L - 2 && l > 0 && MODE != DFF_MODE_SCORE;
+                const bool p0keep = KEEP2 && l == 0 && m.L > 2 && MODE != DFF_MODE_SCORE && rows <= 10;   // layer 0's P: p0_copy
                 const bool st_qkv = !(KEEP_LAST && l == m.L - 1 && l > 0 && MODE != DFF_MODE_SCORE) && !keep2;
                 const SStream sn0 = ss_w1(lw), sn1 = ss_w2(lw);   // the FFN block's units follow: W1 (U_W1), then W2
                 auto head_math = [&](int h) {
@@ -1165,7 +1182,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         pb[i * DFF_PLD + col] = p;
                     }
                     // the 16 x 16 tile to the stash as ONE 16-byte store per lane (was four scalar stores)
-                    if (st_qkv) *(gf32x4*)(sb + sl.P + (size_t)h * 256 + 4 * lane) = *(const lf32x4*)(pb + (lane >> 2) * DFF_PLD + 4 * (lane & 3));
+                    if (p0keep) p0_copy(true, lane);
+                    else if (st_qkv) *(gf32x4*)(sb + sl.P + (size_t)h * 256 + 4 * lane) = *(const lf32x4*)(pb + (lane >> 2) * DFF_PLD + 4 * (lane & 3));
                     // O_ext = P V_ext (5 tiles) -> Q region; extension columns become xrel = xbar - x_i
                     wv_mm<0, 5, false>(pb, Vx, lane, ks4, [&](int nt, const f32x4& acc) {
 #pragma unroll
@@ -1618,7 +1636,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             // first head of this layer's attention backward: start the stash read (hidden by row stage E)
             if constexpr (HDMA) {
                 if (!(KEEP_LAST && l == m.L - 1 && l > 0) && !(KEEP2 && l == m.L - 2 && l > 0 && MODE != DFF_MODE_SCORE))
-                    head_dma<LL::DMA_N>(dmatab, Qx, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, lane_id());
+                    head_dma<LL::DMA_N>(dmatab, Qx, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW,
+                                        KEEP2 && l == 0 && m.L > 2 && MODE != DFF_MODE_SCORE && rows <= 10 ? nullptr : sb + sl.P + (size_t)wave * 256, lane_id());
             }
             if constexpr (HPW == 2) {
                 const int lane = lane_id();
@@ -1886,8 +1905,10 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     dx_only();
                     // the next step (if any) re-stages its own first entries at phase 0
                 } else {
-                    if constexpr (HDMA) head_dma_wait();
-                    else {
+                    if constexpr (HDMA) {
+                        head_dma_wait();
+                        if constexpr (KEEP2) { if (m.L > 2 && MODE != DFF_MODE_SCORE && rows <= 10) p0_copy(false, lane); }
+                    } else {
                         head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, true, lane, m12p(wave));
                         head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
                     }
