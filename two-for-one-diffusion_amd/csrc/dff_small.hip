@@ -909,7 +909,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     // backward stages read their slot into fresh locals (keep_get at the point of use): a copy into the ro[] registers the
     // parameter prefetches also target made the compiler guard every copy with an s_waitcnt vmcnt that drained the weight ring.
     constexpr bool KEEPROWS = FOLD && MODE != DFF_MODE_SCORE;
-    float kp0[3][HC] = {}, kp1[3][HC] = {}, kp2[3][HC] = {};   // slot 0 / 1 / 2: [attn_out | ff | nodes_in][HC]  (separate arrays, constant indices: registers)
+    float kp0[4][HC] = {}, kp1[4][HC] = {}, kp2[4][HC] = {};   // layer 0 / 1 / 2: [attn_out | ff | nodes_in | LayerNorm-1 output][HC]  (separate arrays, constant indices: registers)
     auto keep_put = [&](int k, auto ai, const float (&x)[HC]) {
         constexpr int A = decltype(ai)::value;
 #pragma unroll
@@ -931,10 +931,11 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         if constexpr (KEEPROWS) {
             keep_get(l, std::integral_constant<int, 0>{}, ao);
             if (fv) keep_get(l, std::integral_constant<int, 1>{}, *fv);
-            if (l > 0) keep_get(l, std::integral_constant<int, 2>{}, ni);   // (layer 0's node inputs come from the table / the stash: ro[1])
+            keep_get(l, std::integral_constant<int, 2>{}, ni);
         }
     };
     using KA = std::integral_constant<int, 0>; using KF = std::integral_constant<int, 1>; using KN = std::integral_constant<int, 2>;
+    using KL = std::integral_constant<int, 3>;
     // stage B operands: bo, g1 (3), ln2 gamma, ln2 beta
     auto pre_B = [&](const DffLayerDev& w, int sub) {
         ro_load(0, w.bo, sub); ro_load3(1, w.g1, sub); ro_load(4, w.ln2_g, sub); ro_load(5, w.ln2_b, sub);
@@ -1107,26 +1108,37 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             // ---- row stage A (layer 0 only; later layers get LN1 fused into stage C) ----
             if (l == 0) {
                 DFF_ROW_CONSTS
+                // KEEPROWS: layer 0's node inputs and LayerNorm rows are kept in this thread's registers for the backward stages;
+                // with a fixed noise level (Langevin) they do not change from step to step: read / computed on step 0 only
+                const bool reuse0 = KEEPROWS && MODE == DFF_MODE_LANGEVIN && step > 0;
                 if (cached) {
                     if (ract) {
-                        float x[HC];
+                        float x[HC], nva[HC];
+                        if (reuse0) {
+                            keep_get(0, KN{}, x);
+                            keep_get(0, KL{}, nva);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < HC; ++i) x[i] = ld_ntg(sbq + sl.nodes_in + rrow * H + sub + LPR * i);
+                            if constexpr (FOLD) {   // the attention block needs layer 0's LayerNorm rows even when its q' comes from the table
+                                float mean, rstd;
+                                ln_stats_row(x, mean, rstd);
+#pragma unroll
+                                for (int i = 0; i < HC; ++i) {
+                                    const int cl = sub + LPR * i;
+                                    nva[i] = (x[i] - mean) * rstd * lw.ln1_g[cl] + lw.ln1_b[cl];
+                                }
+                            }
+                            if constexpr (KEEPROWS) { keep_put(0, KN{}, x); keep_put(0, KL{}, nva); }
+                        }
 #pragma unroll
                         for (int i = 0; i < HC; ++i) {
-                            x[i] = ld_ntg(sbq + sl.nodes_in + rrow * H + sub + LPR * i);
                             resbuf[rrow * LH + sub + LPR * i] = x[i];
-                        }
-                        if constexpr (FOLD) {   // the attention block needs layer 0's LayerNorm rows even when its q' comes from the table
-                            float mean, rstd;
-                            ln_stats_row(x, mean, rstd);
-#pragma unroll
-                            for (int i = 0; i < HC; ++i) {
-                                const int cl = sub + LPR * i;
-                                n_store(rrow, cl, (x[i] - mean) * rstd * lw.ln1_g[cl] + lw.ln1_b[cl]);
-                            }
+                            if constexpr (FOLD) n_store(rrow, sub + LPR * i, nva[i]);
                         }
                     }
                 } else if (ract) {
-                    float x[HC];
+                    float x[HC], nva[HC];
 #pragma unroll
                     for (int i = 0; i < HC; ++i) {
                         x[i] = resbuf[rrow * LH + sub + LPR * i];
@@ -1137,10 +1149,11 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #pragma unroll
                     for (int i = 0; i < HC; ++i) {
                         const int cl = sub + LPR * i;
-                        const float nv = (x[i] - mean) * rstd * lw.ln1_g[cl] + lw.ln1_b[cl];
-                        a_store(rrow, cl, nv);
-                        n_store(rrow, cl, nv);
+                        nva[i] = (x[i] - mean) * rstd * lw.ln1_g[cl] + lw.ln1_b[cl];
+                        a_store(rrow, cl, nva[i]);
+                        n_store(rrow, cl, nva[i]);
                     }
+                    if constexpr (KEEPROWS) { keep_put(0, KN{}, x); keep_put(0, KL{}, nva); }
                 }
                 if (ract) pre_B(lw, sub);
                 if (xi_pre && wave == NW - 1) {
@@ -1475,11 +1488,11 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #pragma unroll
                     for (int i = 0; i < HC; ++i) { ro[6][i] = ro[1][i]; ro[7][i] = ro[2][i]; ro[8][i] = ro[3][i]; ro[2][i] = x[i]; }
                     if constexpr (!KEEPROWS) ro_load(0, (const float*)(sb + sl.attn_out + rrow * H), sub);
-                    if (!KEEPROWS || l == 0) ro_load(1, (const float*)(sbq + sl.nodes_in + rrow * H), sub);
+                    if constexpr (!KEEPROWS) ro_load(1, (const float*)(sbq + sl.nodes_in + rrow * H), sub);
                     ro_load3(3, lw.g1, sub);
                 } else {
                     gfloat* const sbn = stash + (size_t)(l + 1) * sl.layer_stride;
-                    float mean, rstd;
+                    float mean, rstd, nva[HC];
                     ln_stats_row(n2, mean, rstd);
 #pragma unroll
                     for (int i = 0; i < HC; ++i) {
@@ -1489,8 +1502,9 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         const float nv = (n2[i] - mean) * rstd * ro[4][i] + ro[5][i];
                         a_store(rrow, cl, nv);
                         n_store(rrow, cl, nv);
+                        nva[i] = nv;
                     }
-                    if constexpr (KEEPROWS) keep_put(l + 1, KN{}, n2);
+                    if constexpr (KEEPROWS) { keep_put(l + 1, KN{}, n2); keep_put(l + 1, KL{}, nva); }
                     pre_B(m.layer[l + 1], sub);
                 }
             } }
@@ -1683,7 +1697,16 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     a_store(rrow, cl, d1[i] * g1 + dz * (ro[3][i] + ro[5][i]));
                     resbuf[rrow * LH + cl] = d1[i] * (1.0f - g1) + dz * (ro[4][i] - ro[5][i]);
                 }
-                if constexpr (FOLD) {   // this layer's LayerNorm rows (the keys / values of its attention block), as the forward pass made them
+                if constexpr (KEEPROWS) {
+                    // this layer's LayerNorm rows (the keys / values of its attention block) back into the shared buffer: kept in
+                    // registers since the forward stage made them; the last layer's are still there
+                    if (l < m.L - 1) {
+                        float nva[HC];
+                        keep_get(l, KL{}, nva);
+#pragma unroll
+                        for (int i = 0; i < HC; ++i) n_store(rrow, sub + LPR * i, nva[i]);
+                    }
+                } else if constexpr (FOLD) {   // ... re-derived from the stashed node inputs, as the forward pass made them
                     float mean1, rstd1;
                     ln_stats_row(ni, mean1, rstd1);
 #pragma unroll
@@ -1948,9 +1971,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     if (l > 0) {   // stage D operands of layer l-1
                         const DffLayerDev& lp = m.layer[l - 1];
                         const gfloat* const sp = stash + (size_t)(l - 1) * sl.layer_stride;
-                        if constexpr (KEEPROWS) {   // (attn_out, ff and -- l > 1 -- nodes_in of layer l - 1: this thread's registers)
-                            if (l == 1) ro_load(1, (const float*)(l0e + sl.nodes_in + rrow * H), sub);
-                        } else {
+                        if constexpr (!KEEPROWS) {   // (KEEPROWS: attn_out, ff and nodes_in of layer l - 1 are in this thread's registers)
                             ro_load(0, (const float*)(sp + sl.attn_out + rrow * H), sub);
                             ro_load(1, (const float*)((l == 1 ? l0e : sp) + sl.nodes_in + rrow * H), sub);
                             ro_load(2, (const float*)(sp + sl.ff + rrow * H), sub);
