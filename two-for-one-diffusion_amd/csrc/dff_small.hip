@@ -1023,6 +1023,40 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         return e + 2.0f * (col < 3 ? xs[rw * 4 + col] : 0.f) * w;
     };
 
+    // Centring (utils.py:65-70; Langevin centres twice: the integrator's x_old, then the network's input).  Every
+    // (bead, component) thread -- all of them in wave 0 -- reads its protein's column once (one batch of LDS reads) and
+    // forms the means itself, summing in bead order exactly as bead_mean() does: same bits, no serial one-thread-per-column
+    // loops in front of the whole workgroup.  The integrator's centred x_old goes to `xcb` (the update reads it there), the
+    // network's input to xs; xst itself is not written.  Step 0 centres at its start; every later step was centred by the
+    // update stage of the step before it (same wave: the column is read right after the new x was written, no workgroup
+    // barrier in between), so a step begins with its first row stage.
+    auto centre = [&]() {
+        const int tq = tid_id();
+        if (tq < rows * 4) {
+            const int cc = tq & 3, pb0 = ((tq >> 2) / N) * N;
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = xst[(pb0 + min(i, N - 1)) * 4 + cc];
+            const float own = xst[tq];
+            float s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s1 += i < N ? v[i] : 0.f;
+            const float m1 = s1 / (float)N;
+            const float xc = own - m1;
+            float xn_in = xc;
+            if (MODE == DFF_MODE_LANGEVIN) {
+                float s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s2 += i < N ? v[i] - m1 : 0.f;
+                xn_in = xc - s2 / (float)N;
+                xcb[tq] = xc;
+            }
+            xs[tq] = xn_in;
+            // FOLD: K_ext = V_ext is one shared buffer whose extension columns [x_j | 0 ...] no layer rewrites: once per step
+            // here instead of by every wave in every attention block (rows beyond the real ones and column 3 stay zero)
+            if constexpr (FOLD) { if (cc < 3) Nx[(tq >> 2) * DFF_XLD + 64 + cc] = xn_in; }
+        }
+    };
     for (int step = 0; step < a.n_steps; ++step) {
         int t_int = 0;
         if (MODE == DFF_MODE_DDPM) {
@@ -1054,36 +1088,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         } else {
             ring_prefetch<E>(ring, s_qkv(m.layer[0], wave), lane);
         } }
-        // Centring (utils.py:65-70; Langevin centres twice: the integrator's x_old, then the network's input).  Every
-        // (bead, component) thread -- all of them in wave 0 -- reads its protein's column once (one batch of LDS reads) and
-        // forms the means itself, summing in bead order exactly as bead_mean() does: same bits, ONE barrier instead of four
-        // and no serial one-thread-per-column loops in front of the whole workgroup.  The integrator's centred x_old goes to
-        // `xcb` (the update reads it there), the network's input to xs; xst itself is not written here.
-        { const int tq = tid_id();
-        if (tq < rows * 4) {
-            const int cc = tq & 3, pb0 = ((tq >> 2) / N) * N;
-            float v[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = xst[(pb0 + min(i, N - 1)) * 4 + cc];
-            const float own = xst[tq];
-            float s1 = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s1 += i < N ? v[i] : 0.f;
-            const float m1 = s1 / (float)N;
-            const float xc = own - m1;
-            float xn_in = xc;
-            if (MODE == DFF_MODE_LANGEVIN) {
-                float s2 = 0.f;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) s2 += i < N ? v[i] - m1 : 0.f;
-                xn_in = xc - s2 / (float)N;
-                xcb[tq] = xc;
-            }
-            xs[tq] = xn_in;
-        }
-        }
-        { const int ln = lane_id(); dxw[ln] = 0.f; dxw[64 + ln] = 0.f; }
-        __syncthreads();
+        if (step == 0) centre();
+        if (step == 0 || !cached0) __syncthreads();   // (later steps: the barrier that ended the previous update stage)
         pf.tick(0);
 
         // =============================== forward ===============================
@@ -1180,7 +1186,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 const bool st_qkv = !(KEEP_LAST && l == m.L - 1 && l > 0 && MODE != DFF_MODE_SCORE) && !keep2;
                 const SStream sn0 = ss_w1(lw), sn1 = ss_w2(lw);   // the FFN block's units follow: W1 (U_W1), then W2
                 auto head_math = [&](int h) {
-                    write_xext(lane);
+                    if constexpr (!FOLD) write_xext(lane);   // (FOLD: the shared buffer's x columns are written once per step, by the centring)
                     if constexpr (GEN) fix_q(lane);
                     const f32x4 S = wv_dot_rows(Qx, Kx, lane);
 #pragma unroll
@@ -1771,7 +1777,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 };
                 // dA = G_ext V_ext^T ; dS = scale * P (dA - sum_j P dA) -> dsb
                 auto ds_math = [&]() {
-                    write_xext(lane);
+                    if constexpr (!FOLD) write_xext(lane);   // (FOLD: the shared buffer's x columns are written once per step, by the centring)
                     const f32x4 dA = wv_dot_rows(Gx, Vx, lane);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -2003,6 +2009,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             else xib[tq] = philox_normal(a.seed, a.item_offset + item, MODE == DFF_MODE_DDPM ? (uint64_t)t_int : a.step_offset + step, i, cc);
         }
         __syncthreads();
+        { const int ln = lane_id(); dxw[ln] = 0.f; dxw[64 + ln] = 0.f; }   // (this wave's dx partials of the NEXT step start from zero)
         if constexpr (GEN) {
             if (full0 && m.conservative) {   // absolute coordinates: dE/dx_i += d(nodes_0)_i . W_node[:, x columns]
                 DFF_ROW_CONSTS
@@ -2054,6 +2061,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 vst[tq] = vn;
                 if (save && a.frames) a.frames[(((size_t)fi * a.B + item) * N + i) * 3 + cc] = xn;
             }
+            if (step + 1 < a.n_steps) { __builtin_amdgcn_wave_barrier(); centre(); }   // (wave 0 reads back what it just wrote)
             if (save && a.ke && !a.overdamped) {
                 __syncthreads();
                 if (tq < gcnt) {
@@ -2113,6 +2121,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 }
                 xst[tq] = xn - colmean(xnv);
             }
+            if (step + 1 < a.n_steps) { __builtin_amdgcn_wave_barrier(); centre(); }
 #endif
         }
         __syncthreads();
