@@ -936,6 +936,44 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     };
     using KA = std::integral_constant<int, 0>; using KF = std::integral_constant<int, 1>; using KN = std::integral_constant<int, 2>;
     using KL = std::integral_constant<int, 3>;
+    // ... and the two gate values of every layer (one number per row, the same in all lanes of the row)
+    float kg0[2] = {}, kg1[2] = {}, kg2[2] = {};
+    auto gate_put = [&](int k, int which, float g) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            kg0[q] = (k == 0 && which == q) ? g : kg0[q];
+            kg1[q] = (k == 1 && which == q) ? g : kg1[q];
+            kg2[q] = (k == 2 && which == q) ? g : kg2[q];
+        }
+    };
+    auto gate_get = [&](int k, auto wi) {
+        constexpr int Q = decltype(wi)::value;
+        return k == 0 ? kg0[Q] : k == 1 ? kg1[Q] : kg2[Q];
+    };
+    // KEEPROWS: row stage D of layer ld (gate-2 backward: dn -> dff as the FFN-backward GEMM's input, dn1 partial -> resbuf)
+    // on the kept rows and gate values.  It needs no partial sums, so it runs INSIDE the row stage that produces dn -- stage C
+    // of the last layer, stage F of layer ld + 1 -- instead of behind a barrier of its own: 3 barriers and 3 serial stages
+    // less per step.  W = ro[] slot of the gate-2 weights [x | res | x - res].
+    auto stage_D = [&](int ld, const float (&dn)[HC], auto wslot, int rrow, int sub) {
+        constexpr int W = decltype(wslot)::value;
+        float ao[HC], ni[HC], fv[HC], n1[HC];
+        keep_get(ld, KA{}, ao); keep_get(ld, KN{}, ni); keep_get(ld, KF{}, fv);
+        const float g1 = gate_get(ld, std::integral_constant<int, 0>{}), g2 = gate_get(ld, std::integral_constant<int, 1>{});
+        float dg = 0.f;
+#pragma unroll
+        for (int i = 0; i < HC; ++i) {
+            n1[i] = ao[i] * g1 + ni[i] * (1.0f - g1);
+            dg += dn[i] * (fv[i] - n1[i]);
+        }
+        dg = rsum(dg);
+        const float dz = dg * g2 * (1.0f - g2);
+#pragma unroll
+        for (int i = 0; i < HC; ++i) {
+            const int cl = sub + LPR * i;
+            a_store(rrow, cl, dn[i] * g2 + dz * (ro[W][i] + ro[W + 2][i]));
+            resbuf[rrow * LH + cl] = dn[i] * (1.0f - g2) + dz * (ro[W + 1][i] - ro[W + 2][i]);
+        }
+    };
     // stage B operands: bo, g1 (3), ln2 gamma, ln2 beta
     auto pre_B = [&](const DffLayerDev& w, int sub) {
         ro_load(0, w.bo, sub); ro_load3(1, w.g1, sub); ro_load(4, w.ln2_g, sub); ro_load(5, w.ln2_b, sub);
@@ -1365,6 +1403,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 }
                 if constexpr (KEEPROWS) keep_put(l, KA{}, x);
                 const float g = ro_gate(x, res, 1);
+                if constexpr (KEEPROWS) gate_put(l, 0, g);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
                     n1[i] = x[i] * g + res[i] * (1.0f - g);
@@ -1474,27 +1513,37 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 }
                 if constexpr (KEEPROWS) keep_put(l, KF{}, x);
                 const float g = ro_gate(x, res, 1);
+                if constexpr (KEEPROWS) gate_put(l, 1, g);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) n2[i] = x[i] * g + res[i] * (1.0f - g);
                 if (last) {
-                    float e = 0.f;
+                    float e = 0.f, wdv[HC];
 #pragma unroll
                     for (int i = 0; i < HC; ++i) {
                         const int cl = sub + LPR * i;
                         const float wd = m.wdec[cl];
+                        wdv[i] = wd;
                         e += n2[i] * wd;
-                        resbuf[rrow * LH + cl] = m.conservative ? wd : n2[i];   // dn = d(sum e)/d nodes_L (or nodes_L for the force head)
+                        if (!(KEEPROWS && m.conservative)) resbuf[rrow * LH + cl] = m.conservative ? wd : n2[i];   // dn = d(sum e)/d nodes_L (or nodes_L for the force head)
                     }
                     if (a.energy_out) {
                         e = rsum(e);
                         if (sub == 0) a.energy_out[(size_t)b0 * N + rrow] = e + m.bdec;
                     }
+                    if constexpr (KEEPROWS) {
+                        // stage D of this (last) layer right here: dn = the energy head's weights; gate-2 weights are in ro[1..3]
+                        if (m.conservative) stage_D(l, wdv, std::integral_constant<int, 1>{}, rrow, sub);
+                    }
                     // stage D operands of this (last) layer: attn_out, nodes_in from the stash, ff (kept),
                     // g1 (3), g2 (3 -- already in ro[1..3], move up)
+                    if constexpr (KEEPROWS) {   // stage E operands: LN2 gamma -> ro[2], g1 (3) -> ro[3..5]
+                        ro_load(2, lw.ln2_g, sub);
+                    } else {
 #pragma unroll
-                    for (int i = 0; i < HC; ++i) { ro[6][i] = ro[1][i]; ro[7][i] = ro[2][i]; ro[8][i] = ro[3][i]; ro[2][i] = x[i]; }
-                    if constexpr (!KEEPROWS) ro_load(0, (const float*)(sb + sl.attn_out + rrow * H), sub);
-                    if constexpr (!KEEPROWS) ro_load(1, (const float*)(sbq + sl.nodes_in + rrow * H), sub);
+                        for (int i = 0; i < HC; ++i) { ro[6][i] = ro[1][i]; ro[7][i] = ro[2][i]; ro[8][i] = ro[3][i]; ro[2][i] = x[i]; }
+                        ro_load(0, (const float*)(sb + sl.attn_out + rrow * H), sub);
+                        ro_load(1, (const float*)(sbq + sl.nodes_in + rrow * H), sub);
+                    }
                     ro_load3(3, lw.g1, sub);
                 } else {
                     gfloat* const sbn = stash + (size_t)(l + 1) * sl.layer_stride;
@@ -1563,7 +1612,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             const gfloat* const sbq = l == 0 ? l0e : sb;
             // ---- row stage D: gate2 backward: dn (resbuf) -> dff (abuf), dn1 partial (resbuf) ----
             // operands (prefetched): ro[0] attn_out, ro[1] nodes_in, ro[2] ff, ro[3..5] g1, ro[6..8] g2
-            { DFF_ROW_CONSTS
+            // (KEEPROWS: done inside the stage that made dn -- stage_D)
+            if constexpr (!KEEPROWS) { DFF_ROW_CONSTS
             if (ract) {
                 float n1[HC], dn[HC], ao[HC], ni[HC], fv[HC];
                 rows_of(l, ao, ni, &fv, 2);
@@ -1586,8 +1636,9 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 }
                 // stage E operands: attn_out, nodes_in, g1 stay; LN2 gamma -> ro[2]
                 ro_load(2, lw.ln2_g, sub);
-            } }
+            }
             __syncthreads();
+            }
             pf.tick(6);
             // ---- FFN backward slice: dh = dff W2[:, slice] ; * gelu'(h_pre) ; partial df = dh_pre W1[slice, :] ----
             {
@@ -1672,7 +1723,9 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 rows_of(l, ao, ni, nullptr, 0);
                 psum_all(ps, rrow * LH + sub);
                 pf.tick(22);
-                const float g1 = ro_gate(ao, ni, 3);
+                float g1;
+                if constexpr (KEEPROWS) g1 = gate_get(l, std::integral_constant<int, 0>{});
+                else g1 = ro_gate(ao, ni, 3);
                 pf.tick(23);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) n1[i] = ao[i] * g1 + ni[i] * (1.0f - g1);
@@ -1721,8 +1774,9 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         n_store(rrow, cl, (ni[i] - mean1) * rstd1 * lw.ln1_g[cl] + lw.ln1_b[cl]);
                     }
                 }
-                // stage F operands: nodes_in stays in ro[1]; LN1 gamma -> ro[2]
+                // stage F operands: nodes_in stays in ro[1]; LN1 gamma -> ro[2]  (KEEPROWS: + gate-2 weights of layer l - 1 for its stage D)
                 if (l > 0 || full0) ro_load(2, lw.ln1_g, sub);
+                if constexpr (KEEPROWS) { if (l > 0) ro_load3(6, m.layer[l - 1].g2, sub); }
             } }
             __syncthreads();
             pf.tick(8);
@@ -1972,17 +2026,26 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     }
                     s1 = rsum(s1) * (1.0f / H);
                     s2 = rsum(s2) * (1.0f / H);
+                    if constexpr (KEEPROWS) {
+                        // dn of layer l - 1 stays in registers and goes straight through that layer's stage D (gate-2 weights in
+                        // ro[6..8], prefetched by stage E); then its stage E operands: LN2 gamma -> ro[2], g1 (3) -> ro[3..5]
+                        float dnv[HC];
+#pragma unroll
+                        for (int i = 0; i < HC; ++i) dnv[i] = resbuf[rrow * LH + sub + LPR * i] + rstd * (dyg[i] - s1 - xh[i] * s2);
+                        stage_D(l - 1, dnv, std::integral_constant<int, 6>{}, rrow, sub);
+                        ro_load(2, m.layer[l - 1].ln2_g, sub);
+                        ro_load3(3, m.layer[l - 1].g1, sub);
+                    } else {
 #pragma unroll
                     for (int i = 0; i < HC; ++i) resbuf[rrow * LH + sub + LPR * i] += rstd * (dyg[i] - s1 - xh[i] * s2);
                     if (l > 0) {   // stage D operands of layer l-1
                         const DffLayerDev& lp = m.layer[l - 1];
                         const gfloat* const sp = stash + (size_t)(l - 1) * sl.layer_stride;
-                        if constexpr (!KEEPROWS) {   // (KEEPROWS: attn_out, ff and nodes_in of layer l - 1 are in this thread's registers)
-                            ro_load(0, (const float*)(sp + sl.attn_out + rrow * H), sub);
-                            ro_load(1, (const float*)((l == 1 ? l0e : sp) + sl.nodes_in + rrow * H), sub);
-                            ro_load(2, (const float*)(sp + sl.ff + rrow * H), sub);
-                        }
+                        ro_load(0, (const float*)(sp + sl.attn_out + rrow * H), sub);
+                        ro_load(1, (const float*)((l == 1 ? l0e : sp) + sl.nodes_in + rrow * H), sub);
+                        ro_load(2, (const float*)(sp + sl.ff + rrow * H), sub);
                         ro_load3(3, lp.g1, sub); ro_load3(6, lp.g2, sub);
+                    }
                     }
                 }
                 __syncthreads();
