@@ -974,6 +974,18 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             resbuf[rrow * LH + cl] = dn[i] * (1.0f - g2) + dz * (ro[W + 1][i] - ro[W + 2][i]);
         }
     };
+    // The empty asm READS every row-stage operand register: the compiler takes whatever s_waitcnt their loads still need
+    // here.  Called at the START of each wave-private block -- the operands were requested by the row stage before it and
+    // are older than everything but the block's own first weight units, which the first MFMA needs anyway: free -- it
+    // makes the operands "known complete" for the NEXT row stage, which otherwise starts with an s_waitcnt vmcnt(<= 2)
+    // that also waits for the next block's prefetched weight units (loads retire in order) to land: measured 0.8 us / step.
+    // (The alternative -- let the row stage itself request the next block's units after reading its operands -- was built
+    // and measured 1.5 us SLOWER: the request is then late by the whole tail of the block before.)
+    auto ro_touch = [&]() {
+        asm volatile("" ::"v"(ro[0][0]), "v"(ro[0][HC - 1]), "v"(ro[1][0]), "v"(ro[1][HC - 1]), "v"(ro[2][0]), "v"(ro[2][HC - 1]),
+                     "v"(ro[3][0]), "v"(ro[3][HC - 1]), "v"(ro[4][0]), "v"(ro[4][HC - 1]), "v"(ro[5][0]), "v"(ro[5][HC - 1]),
+                     "v"(ro[6][0]), "v"(ro[6][HC - 1]), "v"(ro[7][0]), "v"(ro[7][HC - 1]), "v"(ro[8][0]), "v"(ro[8][HC - 1]));
+    };
     // stage B operands: bo, g1 (3), ln2 gamma, ln2 beta
     auto pre_B = [&](const DffLayerDev& w, int sub) {
         ro_load(0, w.bo, sub); ro_load3(1, w.g1, sub); ro_load(4, w.ln2_g, sub); ro_load(5, w.ln2_b, sub);
@@ -1214,6 +1226,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             // ---- attention block: wave w owns heads w and w+4 (ring holds the first entries) ----
             {
                 DFF_LANE_CONSTS
+                ro_touch();
                 f32x4 acc_o[E];
 #pragma unroll
                 for (int nt = 0; nt < E; ++nt) acc_o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1422,6 +1435,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             // ---- FFN: wave w owns hidden columns [w H, (w+1) H) ----
             {
                 DFF_LANE_CONSTS
+                ro_touch();
                 const bool lastl = l == m.L - 1;
                 const WStream after = lastl ? s_w2t(lw) : s_qkv(m.layer[lastl ? l : l + 1], wave);
                 // what follows: the last layer's FFN backward (W2^T, W1^T) or the next layer's QKV_ext (whose units MW.. are "n1")
@@ -1643,6 +1657,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             // ---- FFN backward slice: dh = dff W2[:, slice] ; * gelu'(h_pre) ; partial df = dh_pre W1[slice, :] ----
             {
                 DFF_LANE_CONSTS
+                ro_touch();
                 const WStream after = s_woxt(lw, wave);
                 const SStream gn = ss_woxt(lw, wave);   // this layer's attention backward follows (G_ext GEMM: U_GX >= SDR units)
                 const SSeq<U_W1, U_W2, SDR, 0, 0, 0, 0, E> sqb{ss_w2t(lw), ss_w1t(lw), gn, gn};
@@ -1783,6 +1798,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             // ---- attention backward: wave w owns heads w and w+4 ----
             {
                 DFF_LANE_CONSTS
+                ro_touch();
                 f32x4 afr[E];
                 if constexpr (!SPW) load_afrag<E>(afr, abuf, LH, lane);   // dattn
                 f32x4 acc_a[E];
