@@ -35,12 +35,17 @@ template <int H, int NW, bool FOLD = false>
 struct SmallLds {
     static constexpr int LH = H + 4;
     static constexpr int RLA = NW == 4 ? 16 : 11;
-    static constexpr int RS = RLA * DFF_XLD;         // floats of one head buffer (Q / K / V / G)
+    // Row stride of the head buffers.  84 floats: 80 + one 16-byte pad slot.  FOLD: 88 -- 8 dwords mod 64, which makes the
+    // ds_read_b128 operand fragments of the attention products conflict-free (a read group is rows {0-3, 12-15} of one
+    // k-group and rows {4-11} of the next: bank slots (2 row + kg) mod 16 all even | all odd; with 84 row 11 of one k-group
+    // lands on row 12 of the other) -- and leaves 20 spare columns per row, where the saved P tiles of layers 0 and L - 2 live.
+    static constexpr int XLD = FOLD ? 88 : DFF_XLD;
+    static constexpr int RS = RLA * XLD;             // floats of one head buffer (Q / K / V / G)
     static constexpr int PT = 16 * DFF_PLD;          // ... of one P / dS tile
     // FOLD variant (keys = values = the shared LayerNorm rows, dff_small_kernel below): no K / V regions.  A wave region is
-    //   [Q | P | G | dS | Qsave | Psave | GP0 | GP1]
-    // Qsave | Psave: q' and P of the layer before the last one parked between its forward and backward attention blocks
-    // (KEEP2); GP0 | GP1: GELU'(h_pre) of this wave's FFN hidden slice for the two layers before the last one, GPR rows x
+    //   [Q | P | G | dS | Qsave | GP0 | GP1]
+    // Qsave: q' of the layer before the last one parked between its forward and backward attention blocks (KEEP2), and, in
+    // the spare columns 68.. of its rows, the 10 x 10 real entries of that layer's and of layer 0's softmax tiles; GP0 | GP1: GELU'(h_pre) of this wave's FFN hidden slice for the two layers before the last one, GPR rows x
     // GPS floats each (row GPR - 1 absorbs the pad lanes' stores) -- the last layer's tile lives behind the wave's 11-row
     // partial-sum tile inside G | dS, so that in the sampling loops of a <= 3-layer model GELU' never leaves the LDS (it was
     // 57 % of the kernel's stash traffic, profiles/r02).  The one shared copy of the LayerNorm rows (K_ext = V_ext) has its
@@ -49,10 +54,10 @@ struct SmallLds {
     static constexpr unsigned GPT = GPR * GPS;
     static constexpr unsigned GP_LAST = RLA * LH;   // offset of the last layer's tile inside G | dS (behind the partial-sum tile)
     static_assert(!FOLD || GP_LAST + GPT <= RS + PT, "the last layer's GELU' tile must fit G | dS behind the partial sums");
-    static constexpr unsigned WREG = FOLD ? 3 * RS + 3 * PT + 2 * GPT : 4 * RS + 2 * PT;   // floats per wave region
+    static constexpr unsigned WREG = FOLD ? 3 * RS + 2 * PT + 2 * GPT : 4 * RS + 2 * PT;   // floats per wave region
     static_assert(RS + PT >= 16 * (H + 4) || !FOLD, "G | dS must hold a 16 x (H+4) tile");
     static_assert(WREG >= 16 * (H + 4), "wave region must hold a 16 x (H+4) partial-sum tile");
-    static constexpr int DMA_N = FOLD ? 5 : 13;      // head_dma: global_load_lds instructions per head ([Q | P] or [Q | K | V | P])
+    static constexpr int DMA_N = FOLD ? 6 : 13;      // head_dma: global_load_lds instructions per head ([Q | P] or [Q | K | V | P])
     static constexpr unsigned xst = 0, xs = 64, dxs = 128, vst = 192, cm = 256, tn = 384, prof = 400,
                               dxw = 448,                      // [NW][128] per-wave dx partials (+ dummies)
                               abuf = 448 + NW * 128, resbuf = abuf + (FOLD ? 0 : 16 * LH),
@@ -447,9 +452,10 @@ DEVI void load_afrag(f32x4 (&a)[KB], const lfloat* A, int lda, int lane) {
 }
 
 // C[i][j] = sum_k A[i][k] B[j][k], K = 80 (5 k-blocks), both operands rows of a head buffer
+template <int XLD = DFF_XLD>
 DEVI f32x4 wv_dot_rows(const lfloat* A, const lfloat* B, int lane) {
-    const lfloat* ap = A + (lane & 15) * DFF_XLD + 4 * (lane >> 4);
-    const lfloat* bp = B + (lane & 15) * DFF_XLD + 4 * (lane >> 4);
+    const lfloat* ap = A + (lane & 15) * XLD + 4 * (lane >> 4);
+    const lfloat* bp = B + (lane & 15) * XLD + 4 * (lane >> 4);
     f32x4 av[4], bv[4];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) { av[kb] = *(const lf32x4*)(ap + 16 * kb); bv[kb] = *(const lf32x4*)(bp + 16 * kb); }
@@ -473,7 +479,7 @@ DEVI f32x4 wv_dot_rows(const lfloat* A, const lfloat* B, int lane) {
 // C[m][16nt+n] = sum_{k<16} Aop[m][k] B[k][16nt+n] for tiles nt in [NT0, NT1).
 // TRANS = false: Aop[m][k] = T[m][k] (T = 16x16 tile, ld DFF_PLD);  true: Aop[m][k] = T[k][m].
 // ks = k-steps that can be non-zero: columns / rows of T at or beyond the real rows are exact zeros (P, dS).
-template <int NT0, int NT1, bool TRANS, class Epi>
+template <int NT0, int NT1, bool TRANS, int XLD = DFF_XLD, class Epi>
 DEVI void wv_mm(const lfloat* T, const lfloat* B, int lane, int ks, Epi epi) {
     const int kk = lane >> 4, mm = lane & 15;
     // k-step s covers k = 4 s .. 4 s + 3 (lane: k = 4 s + kk), so trailing all-zero k-steps can be dropped
@@ -484,7 +490,7 @@ DEVI void wv_mm(const lfloat* T, const lfloat* B, int lane, int ks, Epi epi) {
 #pragma unroll
     for (int nt = NT0; nt < NT1; ++nt)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) bv[nt - NT0][s] = B[(4 * s + kk) * DFF_XLD + 16 * nt + mm];
+        for (int s = 0; s < 4; ++s) bv[nt - NT0][s] = B[(4 * s + kk) * XLD + 16 * nt + mm];
     f32x4 acc[NT1 - NT0];
 #pragma unroll
     for (int nt = 0; nt < NT1 - NT0; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -524,20 +530,20 @@ DEVI void head_fetch(HeadRegs& r, const gfloat* sqkv, const gfloat* sp, int RA, 
     if (sp) r.p = ld_ntg4(sp + 4 * lane);
 }
 DEVI void head_commit(const HeadRegs& r, lfloat* Qx, lfloat* Kx, lfloat* Vx, lfloat* pb, bool need_qk, bool need_p, int lane,
-                      int rla = 16) {
+                      int rla = 16, int xld = DFF_XLD) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int it = lane + 64 * u, row = it >> 4, c4 = it & 15;
         if (row < rla) {
-            *(lf32x4*)(Vx + row * DFF_XLD + 4 * c4) = r.v[u];
-            if (need_qk) *(lf32x4*)(Kx + row * DFF_XLD + 4 * c4) = r.k[u];
+            *(lf32x4*)(Vx + row * xld + 4 * c4) = r.v[u];
+            if (need_qk) *(lf32x4*)(Kx + row * xld + 4 * c4) = r.k[u];
         }
     }
     if (need_qk) {
 #pragma unroll
         for (int u = 0; u < 5; ++u) {
             const int it = lane + 64 * u, row = it / 20, c4 = it % 20;
-            if (row < rla) *(lf32x4*)(Qx + row * DFF_XLD + 4 * c4) = r.q[u];
+            if (row < rla) *(lf32x4*)(Qx + row * xld + 4 * c4) = r.q[u];
         }
     }
     if (need_p) *(lf32x4*)(pb + (lane >> 2) * DFF_PLD + 4 * (lane & 3)) = r.p;
@@ -548,19 +554,19 @@ DEVI void head_commit(const HeadRegs& r, lfloat* Qx, lfloat* Kx, lfloat* Vx, lfl
 // with the GEMM's weight loads in its tile epilogues: loads and stores share the in-order vmcnt queue, and a timing-only
 // build without these stores ran 2.2 us / step faster.  Rows beyond the allocated ones go to the dummy stash row.
 template <bool QONLY = false>
-DEVI void head_store(const lfloat* Qx, const lfloat* Kx, const lfloat* Vx, gfloat* sqkv, int RA, int lane, int rla) {
+DEVI void head_store(const lfloat* Qx, const lfloat* Kx, const lfloat* Vx, gfloat* sqkv, int RA, int lane, int rla, int xld = DFF_XLD) {
 #pragma unroll
     for (int u = 0; u < 5; ++u) {
         const int it = lane + 64 * u, row = it / 20, c4 = it - row * 20;
-        if (row < rla) *(gf32x4*)(sqkv + min(row, RA) * DFF_QKVW + 4 * c4) = *(const lf32x4*)(Qx + row * DFF_XLD + 4 * c4);
+        if (row < rla) *(gf32x4*)(sqkv + min(row, RA) * DFF_QKVW + 4 * c4) = *(const lf32x4*)(Qx + row * xld + 4 * c4);
     }
     if (QONLY) return;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int it = lane + 64 * u, row = it >> 4, c4 = it & 15;
         if (row < rla) {
-            *(gf32x4*)(sqkv + min(row, RA) * DFF_QKVW + 80 + 4 * c4) = *(const lf32x4*)(Kx + row * DFF_XLD + 4 * c4);
-            *(gf32x4*)(sqkv + min(row, RA) * DFF_QKVW + 144 + 4 * c4) = *(const lf32x4*)(Vx + row * DFF_XLD + 4 * c4);
+            *(gf32x4*)(sqkv + min(row, RA) * DFF_QKVW + 80 + 4 * c4) = *(const lf32x4*)(Kx + row * xld + 4 * c4);
+            *(gf32x4*)(sqkv + min(row, RA) * DFF_QKVW + 144 + 4 * c4) = *(const lf32x4*)(Vx + row * xld + 4 * c4);
         }
     }
 }
@@ -581,16 +587,16 @@ DEVI void lds_dma16(unsigned lds_byte, const gfloat* src) {
 DEVI void head_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // table entry of 16-byte slot `sl` of the contiguous [Q | K | V | P] regions: float offset of its source relative to the
 // head's stash rows (q_ext | k | v) or, with bit 31 set, to the head's P tile; 0xffffffff: no such slot
-template <int RLA, bool QP = false>
+template <int RLA, bool QP = false, int XLD = DFF_XLD>
 DEVI unsigned head_dma_entry(int sl, int RA) {
-    constexpr int RQ = RLA * (DFF_XLD / 4);                // 16-byte slots per Q / K / V region
+    constexpr int RQ = RLA * (XLD / 4);                    // 16-byte slots per Q / K / V region
     constexpr int NP = 16 * DFF_PLD / 4;                   // ... of the P tile
     constexpr int NREG = QP ? 1 : 3;                       // QP (FOLD layout): the regions are [Q | P], nothing else is loaded
     if (sl >= NREG * RQ + NP) return 0xffffffffu;
     const int reg = QP ? (sl >= RQ ? 3 : 0) : (sl >= RQ) + (sl >= 2 * RQ) + (sl >= 3 * RQ);
     const int r = sl - (QP ? (reg ? RQ : 0) : reg * RQ);
     if (reg < 3) {
-        const int row = r / (DFF_XLD / 4), c4 = r - row * (DFF_XLD / 4);
+        const int row = r / (XLD / 4), c4 = r - row * (XLD / 4);
         // q_ext: 20 slots of data + 1 pad; k / v: 16 + 4 (extension columns, rewritten by write_xext) + 1 pad
         const int lim = reg == 0 ? 19 : 15, off = reg == 0 ? 0 : reg == 1 ? 80 : 144;
         return (unsigned)(min(row, RA) * DFF_QKVW + off + 4 * min(c4, lim));
@@ -630,7 +636,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     constexpr int HPW = DFF_HEADS / NW;      // heads per wave (2 or 1)
     constexpr int DR = NW == 4 ? 4 : 2;      // weight-ring depth (2 waves/SIMD need less run-ahead)
     constexpr int RLA = LL::RLA;             // rows allocated per head buffer
-    constexpr int RS = RLA * DFF_XLD;        // floats between the Q / K / V / G buffers of a wave
+    constexpr int XLD = LL::XLD;             // row stride of the head buffers
+    constexpr int RS = RLA * XLD;            // floats between the Q / K / V / G buffers of a wave
     constexpr int FS = F / NW, NTS = FS / 16, LF = FS + 4;   // FFN hidden slice of a wave
     static_assert(HPW == 1 || HPW == 2, "4 or 8 waves");
     constexpr int KB32 = H / 32, SDR = DFF_SDR;   // SPW: 32-row k-blocks of a K = H GEMM, split-ring depth in units
@@ -693,7 +700,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     // FOLD: K_ext = V_ext = ONE shared fp32 copy of the LayerNorm rows (+ x in the extension columns), region `nx`
     lfloat* const Nx = sm + LL::nx;
     lfloat* const Qx = wr; lfloat* const Kx = FOLD ? Nx : wr + RS; lfloat* const Vx = FOLD ? Nx : wr + 2 * RS;
-    auto n_store = [=](int row, int cl, float v) { if constexpr (FOLD) Nx[row * DFF_XLD + cl] = v; };
+    auto n_store = [=](int row, int cl, float v) { if constexpr (FOLD) Nx[row * XLD + cl] = v; };
     // RELAY (8 waves, H = 64): region order [Q | K | V | P | G | dS] ([Q | P | G | dS | ...] in the FOLD layout, SmallLds),
     // and everything that is not an attention operand -- o_ext = P V_ext, the FFN hidden slice, the wave's partial H-wide
     // outputs -- lives in G | dS.  q_ext, k, v and P of the LAST layer then survive in LDS from its forward to its backward
@@ -710,36 +717,32 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     lfloat* const Gx = RELAY ? pb + 16 * DFF_PLD : wr + 3 * RS;
     lfloat* const dsb = RELAY ? Gx + RS : pb + 16 * DFF_PLD;
     lfloat* const Qsave = dsb + 16 * DFF_PLD;          // (FOLD layout only)
-    lfloat* const Psave = Qsave + RS;
-    // (q': the 68 data columns of every row -- columns 68.. of Qsave hold layer 0's P, below)
-    auto keep2_copy = [=](const lfloat* qs, lfloat* qd, const lfloat* ps, lfloat* pd, int lane) {
-#pragma unroll
-        for (int u = 0; u < (RLA * 17 + 63) / 64; ++u) {
-            const int it = lane + 64 * u, row = it / 17, o = row * DFF_XLD + 4 * (it - row * 17);
-            if (it < RLA * 17) *(lf32x4*)(qd + o) = *(const lf32x4*)(qs + o);
-        }
-#pragma unroll
-        for (int u = 0; u < (16 * DFF_PLD / 4 + 63) / 64; ++u) {
-            const int it = lane + 64 * u;
-            if (it < 16 * DFF_PLD / 4) *(lf32x4*)(pd + 4 * it) = *(const lf32x4*)(ps + 4 * it);
-        }
-    };
-    // Layer 0's softmax rows P (10 x 10 real entries per head) also stay in LDS between its forward and its backward attention
-    // block when it is neither the last layer nor the one before (a 3-layer model): in columns 68..77 of the Qsave rows, which
-    // no q' uses.  With that the sampling loops of a 3-layer model have no stash traffic at all.
-    constexpr int P0C = 68;
-    static_assert(P0C + 10 <= DFF_XLD && RLA >= 10, "layer 0's P rows fit behind the q' columns of Qsave");
-    auto p0_copy = [=](bool save, int lane) {
+    // Saved softmax tiles: the 10 x 10 real entries of a head's P live in the spare columns of the Qsave rows -- layer 0's in
+    // columns 68..77, layer (L - 2)'s in 78..87 -- between the layer's forward and its backward attention block.  With the last
+    // layer's tile left in place, no q' / P of a 3-layer model goes through the stash in the sampling loops.
+    constexpr int P0C = 68, P1C = 78;
+    static_assert(!FOLD || (P1C + 10 <= XLD && RLA >= 10), "the saved P rows fit behind the q' columns of Qsave");
+    auto p_copy = [=](int c0, bool save, int lane) {   // pb (zero outside the real entries: left alone) <-> Qsave columns c0..c0+9
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int it = lane + 64 * u, i = it / 10, j = it - i * 10;
             if (it < 100) {
-                if (save) Qsave[i * DFF_XLD + P0C + j] = pb[i * DFF_PLD + j];
-                else pb[i * DFF_PLD + j] = Qsave[i * DFF_XLD + P0C + j];
+                if (save) Qsave[i * XLD + c0 + j] = pb[i * DFF_PLD + j];
+                else pb[i * DFF_PLD + j] = Qsave[i * XLD + c0 + j];
             }
         }
     };
-    static_assert(!HDMA || DFF_XLD % 4 == 0, "16-byte slots");
+    auto p0_copy = [=](bool save, int lane) { p_copy(P0C, save, lane); };
+    // (q': the 68 data columns of every row)
+    auto keep2_copy = [=](const lfloat* qs, lfloat* qd, bool save, int lane) {
+#pragma unroll
+        for (int u = 0; u < (RLA * 17 + 63) / 64; ++u) {
+            const int it = lane + 64 * u, row = it / 17, o = row * XLD + 4 * (it - row * 17);
+            if (it < RLA * 17) *(lf32x4*)(qd + o) = *(const lf32x4*)(qs + o);
+        }
+        p_copy(P1C, save, lane);
+    };
+    static_assert(!HDMA || XLD % 4 == 0, "16-byte slots");
     constexpr unsigned MPO = FOLD ? RS + 16 * DFF_PLD : RELAY ? 3 * RS + 16 * DFF_PLD : 0;   // offset of G | dS (the aliased tiles) inside a wave region
     static_assert(!RELAY || RS + 16 * DFF_PLD >= 16 * (H + 4), "G | dS must hold a 16 x (H + 4) partial-sum tile");
     lfloat* const Ox = RELAY ? Gx : Qx;   // o_ext
@@ -752,7 +755,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     // for models of <= 3 layers only): the last layer's tile behind the partial sums in G | dS (its backward follows at
     // once), layers 0 and 1 of a deeper model in GP0 / GP1
     auto gp_tile = [=](int l, int L) -> lfloat* {
-        return l == L - 1 ? wr + MPO + LL::GP_LAST : wr + (3 * RS + 3 * 16 * DFF_PLD) + (unsigned)l * LL::GPT;
+        return l == L - 1 ? wr + MPO + LL::GP_LAST : wr + (3 * RS + 2 * 16 * DFF_PLD) + (unsigned)l * LL::GPT;
     };
     // sum of the NW waves' partial outputs for this lane's HC columns of a row: ALL NW x HC LDS reads are
     // issued first (one latency), then added in wave order (left to itself the compiler issues one read,
@@ -789,7 +792,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     for (int i = tid; i < (int)LL::total; i += NTHR) smem[i] = 0.f;
     __syncthreads();
     if constexpr (LL::dmatab_size > 0) {
-        for (int i = tid; i < (int)LL::dmatab_size; i += NTHR) dmatab[i] = head_dma_entry<LL::RLA, FOLD>(i, G * m.N);
+        for (int i = tid; i < (int)LL::dmatab_size; i += NTHR) dmatab[i] = head_dma_entry<LL::RLA, FOLD, LL::XLD>(i, G * m.N);
         __syncthreads();
     }
     Prof pf;
@@ -805,7 +808,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     _Pragma("unroll") for (int r = 0; r < 4; ++r) {                          \
         const int row_ = quad * 4 + r;                                       \
         srow[r] = row_ < rows ? row_ : RA;                                   \
-        lro[r] = min(row_, RLA - 1) * DFF_XLD;                               \
+        lro[r] = min(row_, RLA - 1) * XLD;                               \
         dxi[r] = (row_ < rows && col < 3) ? row_ * 4 + col : 64 + lane;      \
     }                                                                        \
     const int pj = col / N;                                                  \
@@ -1033,8 +1036,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 }
             }
             if (row < RLA) {
-                Kx[row * DFF_XLD + 64 + cc] = xv;
-                if constexpr (!FOLD) Vx[row * DFF_XLD + 64 + cc] = xv;   // (FOLD: the same buffer)
+                Kx[row * XLD + 64 + cc] = xv;
+                if constexpr (!FOLD) Vx[row * XLD + 64 + cc] = xv;   // (FOLD: the same buffer)
             }
         }
     };
@@ -1044,14 +1047,14 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     auto fix_q = [&](int lane) {
         const int row = lane >> 2, c3 = lane & 3;
         if (row < rows && c3 < 3) {
-            lfloat* q = Qx + row * DFF_XLD + 64;
+            lfloat* q = Qx + row * XLD + 64;
             q[c3] = q[c3] - 2.0f * q[3] * xs[row * 4 + c3];
         }
     };
     auto fix_g = [&](int lane, float mv) {   // mv = [m1 | m2] element of this lane; dE/dx_i += gD (2 x_i - 2 m1_i)
         const int row = lane >> 2, c3 = lane & 3;
         if (row < rows && c3 < 3) {
-            lfloat* gp = Gx + row * DFF_XLD + 64;
+            lfloat* gp = Gx + row * XLD + 64;
             const float gD = gp[3], xc = xs[row * 4 + c3];
             dxw[row * 4 + c3] += gD * (2.0f * xc - 2.0f * mv);
             gp[c3] = gp[c3] - 2.0f * gD * xc;
@@ -1063,7 +1066,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         const float xr = col < 3 ? xs[rw * 4 + col] : 0.f;
         const float tq = col < 3 ? -2.0f * xr * e : col == 3 ? e : 0.f;
         const float dsv = quad_sum(tq);
-        if (row < rows && col < 3) dxw[row * 4 + col] += -2.0f * Qx[row * DFF_XLD + 67] * e;
+        if (row < rows && col < 3) dxw[row * 4 + col] += -2.0f * Qx[row * XLD + 67] * e;
         return col == 3 ? dsv : e;
     };
     // extension tile of dV_ext / dK_ext: [c | w] -> dE/dx_j += c + 2 x_j w
@@ -1104,7 +1107,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             xs[tq] = xn_in;
             // FOLD: K_ext = V_ext is one shared buffer whose extension columns [x_j | 0 ...] no layer rewrites: once per step
             // here instead of by every wave in every attention block (rows beyond the real ones and column 3 stay zero)
-            if constexpr (FOLD) { if (cc < 3) Nx[(tq >> 2) * DFF_XLD + 64 + cc] = xn_in; }
+            if constexpr (FOLD) { if (cc < 3) Nx[(tq >> 2) * XLD + 64 + cc] = xn_in; }
         }
     };
     for (int step = 0; step < a.n_steps; ++step) {
@@ -1239,7 +1242,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 auto head_math = [&](int h) {
                     if constexpr (!FOLD) write_xext(lane);   // (FOLD: the shared buffer's x columns are written once per step, by the centring)
                     if constexpr (GEN) fix_q(lane);
-                    const f32x4 S = wv_dot_rows(Qx, Kx, lane);
+                    const f32x4 S = wv_dot_rows<XLD>(Qx, Kx, lane);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int i = quad * 4 + r;
@@ -1255,7 +1258,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     if (p0keep) p0_copy(true, lane);
                     else if (st_qkv) *(gf32x4*)(sb + sl.P + (size_t)h * 256 + 4 * lane) = *(const lf32x4*)(pb + (lane >> 2) * DFF_PLD + 4 * (lane & 3));
                     // O_ext = P V_ext (5 tiles) -> Q region; extension columns become xrel = xbar - x_i
-                    wv_mm<0, 5, false>(pb, Vx, lane, ks4, [&](int nt, const f32x4& acc) {
+                    wv_mm<0, 5, false, XLD>(pb, Vx, lane, ks4, [&](int nt, const f32x4& acc) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             float v = acc[r];
@@ -1276,16 +1279,16 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         }
                     });
                 };
-                const lfloat* const wox_a = Ox + col * DFF_XLD + 4 * quad;
+                const lfloat* const wox_a = Ox + col * XLD + 4 * quad;
                 auto wox_fa = [=](int kb) { return wox_a + 16 * kb; };
                 auto wox_fa32 = [=](int kb) { return wox_a + 32 * kb; };
-                const lfloat* const wox_xa = Ox + col * DFF_XLD + 64 + quad;   // extension column `quad` of row `col`
+                const lfloat* const wox_xa = Ox + col * XLD + 64 + quad;   // extension column `quad` of row `col`
                 if constexpr (SPW) {
                     if (cached) {
                         if constexpr (HDMA) head_dma_wait();
                         else {
                             head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
-                            head_commit(hr, Qx, Kx, Vx, pb, true, false, lane, RLA);
+                            head_commit(hr, Qx, Kx, Vx, pb, true, false, lane, RLA, XLD);
                         }
                         pf.tick(12);
                         head_math(wave);
@@ -1313,10 +1316,10 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                                 const float v0 = acc[0] + ax[0], v1 = acc[1] + ax[0], v2 = acc[2] + ax[0], v3 = acc[3] + ax[0];
                                 dl[l0] = v0; dl[l1] = v1; dl[l2] = v2; dl[l3] = v3;
                             });
-                        if (st_qkv) head_store<FOLD>(Qx, Kx, Vx, sb + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, RA, lane, RLA);
+                        if (st_qkv) head_store<FOLD>(Qx, Kx, Vx, sb + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, RA, lane, RLA, XLD);
                         pf.tick(12);
                         head_math(wave);
-                        if constexpr (KEEP2) { if (keep2) keep2_copy(Qx, Qsave, pb, Psave, lane); }
+                        if constexpr (KEEP2) { if (keep2) keep2_copy(Qx, Qsave, true, lane); }
                         pf.tick(13);
                         stall_run<U_QKV, 2, E, true>(sring, acc_o, wox_fa32, sq, lane, wox_xa, wox_ext(lw, wave, lane), DFF_HEADS * 5 * 256);
                         pf.tick(14);
@@ -1324,16 +1327,16 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 } else if (cached) {
                     // layer-0 q_ext / k / v are x-independent and t is fixed: re-read, no GEMM
                     if constexpr (HPW == 2) {
-                        head_commit(hr, Qx, Kx, Vx, pb, true, false, lane, RLA);
+                        head_commit(hr, Qx, Kx, Vx, pb, true, false, lane, RLA, XLD);
                         head_fetch(hr, sbq + sl.qkv + (size_t)(wave + 4) * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
                         head_math(wave);
                         tall_run<0, 5, E, 4>(ring, acc_o, wox_fa, s_wox(lw, wave), s_wox(lw, wave + 4), lane);
-                        head_commit(hr, Qx, Kx, Vx, pb, true, false, lane, RLA);
+                        head_commit(hr, Qx, Kx, Vx, pb, true, false, lane, RLA, XLD);
                         head_math(wave + 4);
                         tall_run<1, 5, E, 4>(ring, acc_o, wox_fa, s_wox(lw, wave + 4), after, lane);
                     } else {
                         head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
-                        head_commit(hr, Qx, Kx, Vx, pb, true, false, lane, RLA);
+                        head_commit(hr, Qx, Kx, Vx, pb, true, false, lane, RLA, XLD);
                         head_math(wave);
                         tall_run<0, 5, E, 4>(ring, acc_o, wox_fa, s_wox(lw, wave), after, lane);
                     }
@@ -1848,7 +1851,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 // dA = G_ext V_ext^T ; dS = scale * P (dA - sum_j P dA) -> dsb
                 auto ds_math = [&]() {
                     if constexpr (!FOLD) write_xext(lane);   // (FOLD: the shared buffer's x columns are written once per step, by the centring)
-                    const f32x4 dA = wv_dot_rows(Gx, Vx, lane);
+                    const f32x4 dA = wv_dot_rows<XLD>(Gx, Vx, lane);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int i = quad * 4 + r;
@@ -1857,7 +1860,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         dsb[i * DFF_PLD + col] = 0.125f * p * (dA[r] - sm);
                     }
                 };
-                const int fa_off = col * DFF_XLD + 4 * quad;
+                const int fa_off = col * XLD + 4 * quad;
                 lfloat* const gx_ = Gx; lfloat* const kx_ = Kx; lfloat* const vx_ = Vx;
                 auto qkvt_fa = [=](int kb) {
                     const lfloat* base = kb < 5 ? gx_ + 16 * kb : kb < 9 ? kx_ + 16 * (kb - 5) : vx_ + 16 * (kb - 9);
@@ -1867,10 +1870,10 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     const lfloat* base = kb < 2 ? gx_ + 32 * kb : kb < 4 ? kx_ + 32 * (kb - 2) : vx_ + 32 * (kb - 4);
                     return base + fa_off;
                 };
-                const lfloat* const qkvt_xa = Gx + col * DFF_XLD + 64 + quad;
+                const lfloat* const qkvt_xa = Gx + col * XLD + 64 + quad;
                 auto dqkv = [&]() {
                     // dV_ext = P^T G_ext -> V region (ext columns: dx term sum_i a_ij r_i)
-                    wv_mm<0, 5, true>(pb, Gx, lane, ks4, [&](int nt, const f32x4& acc) {
+                    wv_mm<0, 5, true, XLD>(pb, Gx, lane, ks4, [&](int nt, const f32x4& acc) {
                         if constexpr (FOLD) { if (nt < 4) acc_a[nt < 4 ? nt : 0] += acc; }   // v = n: dV IS a term of d(LayerNorm output)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -1879,7 +1882,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         }
                     });
                     // dQ_ext = dS K_ext -> G region (ext columns: du, and ds in the GEN variants)
-                    wv_mm<0, 5, false>(dsb, Kx, lane, ks4, [&](int nt, const f32x4& acc) {
+                    wv_mm<0, 5, false, XLD>(dsb, Kx, lane, ks4, [&](int nt, const f32x4& acc) {
                         f32x4 v = acc;
                         if constexpr (GEN) {
                             if (nt == 4) {
@@ -1887,10 +1890,10 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                                 for (int r = 0; r < 4; ++r) v[r] = dq_ext(quad * 4 + r, col, acc[r]);
                             }
                         }
-                        c_store_all(Gx, DFF_XLD, 16 * nt, v, lane, RLA - 1);
+                        c_store_all(Gx, XLD, 16 * nt, v, lane, RLA - 1);
                     });
                     // dK_ext = dS^T Q_ext -> K region (ext columns: dx term sum_i dS_ij u_i)
-                    wv_mm<0, 5, true>(dsb, Qx, lane, ks4, [&](int nt, const f32x4& acc) {
+                    wv_mm<0, 5, true, XLD>(dsb, Qx, lane, ks4, [&](int nt, const f32x4& acc) {
                         if constexpr (FOLD) { if (nt < 4) acc_a[nt < 4 ? nt : 0] += acc; }   // k = n: so is dK
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -1900,16 +1903,16 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     });
                 };
                 auto dx_only = [&]() {   // layer 0: node inputs do not depend on x
-                    wv_mm<4, 5, true>(pb, Gx, lane, ks4, [&](int, const f32x4& acc) {
+                    wv_mm<4, 5, true, XLD>(pb, Gx, lane, ks4, [&](int, const f32x4& acc) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) dxw[dxi[r]] += GEN ? dx_ext(quad * 4 + r, col, acc[r]) : acc[r];
                     });
-                    wv_mm<4, 5, true>(dsb, Qx, lane, ks4, [&](int, const f32x4& acc) {
+                    wv_mm<4, 5, true, XLD>(dsb, Qx, lane, ks4, [&](int, const f32x4& acc) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) dxw[dxi[r]] += GEN ? dx_ext(quad * 4 + r, col, acc[r]) : acc[r];
                     });
                     if constexpr (GEN) {   // the distance term of the logits reaches x_i through Q_ext: -2 s_i sum_j dS_ij x_j
-                        wv_mm<4, 5, false>(dsb, Kx, lane, ks4, [&](int, const f32x4& acc) {
+                        wv_mm<4, 5, false, XLD>(dsb, Kx, lane, ks4, [&](int, const f32x4& acc) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) (void)dq_ext(quad * 4 + r, col, acc[r]);
                         });
@@ -1925,7 +1928,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 auto gfix = [&]() { if constexpr (GEN) fix_g(lane, m_cur); };
                 if (l > 0 || full0) {
                     if constexpr (HPW == 2) {
-                        head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
+                        head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA, XLD);
                         committed();
                         head_fetch(hr, sbq + sl.qkv + (size_t)h1 * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)h1 * 256, RA, true, lane, m12p(h1));
                         pf.tick(8);
@@ -1938,7 +1941,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         pf.tick(17);
                         tall_run<1, 13, E, 4>(ring, acc_a, qkvt_fa, s_qkvt(lw, wave), s_woxt(lw, h1), lane);
                         pf.tick(18);
-                        head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
+                        head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA, XLD);
                         committed();
                         gext(std::integral_constant<int, 2>{}, h1, s_qkvt(lw, h1));
                         gfix();
@@ -1952,11 +1955,11 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     } else {
                         if constexpr (HDMA) {
                             head_dma_wait();   // (requested before row stage E; nothing for the last layer)
-                            if constexpr (KEEP2) { if (l == m.L - 2 && l > 0 && MODE != DFF_MODE_SCORE) keep2_copy(Qsave, Qx, Psave, pb, lane); }
+                            if constexpr (KEEP2) { if (l == m.L - 2 && l > 0 && MODE != DFF_MODE_SCORE) keep2_copy(Qsave, Qx, false, lane); }
                         }
                         else if (!(KEEP_LAST && l == m.L - 1)) {   // the last layer's q_ext | k | v | P are still in the head buffers
                             head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, true, lane, m12p(wave));
-                            head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
+                            head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA, XLD);
                         }
                         committed();
                         pf.tick(8);
@@ -1976,7 +1979,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     for (int nt = 0; nt < E; ++nt) c_store_all(mypart, LH, 16 * nt, acc_a[nt], lane, PRMAX);
                 } else if constexpr (HPW == 2) {
                     // layer 0 needs q_ext (for the dS^T u term) but not k
-                    head_commit(hr, Qx, Kx, Vx, pb, false, true, lane, RLA);
+                    head_commit(hr, Qx, Kx, Vx, pb, false, true, lane, RLA, XLD);
                     {   // q_ext of head `wave`
                         const gfloat* sq = sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW;
 #pragma unroll
@@ -1987,7 +1990,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #pragma unroll
                         for (int u = 0; u < 5; ++u) {
                             const int it = lane + 64 * u, row = it / 20, c4 = it % 20;
-                            if (row < RLA) *(lf32x4*)(Qx + row * DFF_XLD + 4 * c4) = hr.q[u];
+                            if (row < RLA) *(lf32x4*)(Qx + row * XLD + 4 * c4) = hr.q[u];
                         }
                     }
                     committed();
@@ -1996,7 +1999,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     gfix();
                     ds_math();
                     dx_only();
-                    head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
+                    head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA, XLD);
                     committed();
                     gext(std::integral_constant<int, 1>{}, h1, after);
                     gfix();
@@ -2009,7 +2012,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         if constexpr (KEEP2) { if (m.L > 2 && MODE != DFF_MODE_SCORE && rows <= 10) p0_copy(false, lane); }
                     } else {
                         head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, true, lane, m12p(wave));
-                        head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA);
+                        head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA, XLD);
                     }
                     committed();
                     if constexpr (SPW) sgext(sqa0);
