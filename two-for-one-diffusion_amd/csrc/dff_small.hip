@@ -1110,6 +1110,15 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             if constexpr (FOLD) { if (cc < 3) Nx[(tq >> 2) * XLD + 64 + cc] = xn_in; }
         }
     };
+    auto step_prefetch = [&](bool cached0_, const gfloat* l0e_) {
+        if constexpr (SPW) {
+            const int lane = lane_id();
+            if (cached0_) {
+                sring_prefetch<SDR, KO, E>(sring, ss_wox(m.layer[0], wave), lane);
+                if constexpr (HDMA) head_dma<LL::DMA_N>(dmatab, Qx, l0e_ + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, lane);
+            } else sring_prefetch<SDR, KQ, E>(sring, ss_qkv(m.layer[0], wave), lane);
+        }
+    };
     for (int step = 0; step < a.n_steps; ++step) {
         int t_int = 0;
         if (MODE == DFF_MODE_DDPM) {
@@ -1125,15 +1134,12 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                                       : (const gfloat*)stash;
         const bool full0 = GEN && m.in_abs;   // absolute coordinates: layer 0 depends on x (no caching, VJP through layer 0)
         const bool cached0 = !full0 && (tab || ((MODE == DFF_MODE_LANGEVIN) && step > 0));
-        // first weights of the first block (hidden behind the centring below)
+        // First weights of the first block, and layer 0's q_ext | k | v rows of this head (shared table entry) by LDS-DMA
+        // (measured: 86.8 vs 87.3 us / step with a register fetch inside the attention block).  SPW: step 0 only -- every
+        // later step's were requested in the shadow of the update stage of the step before it (step_prefetch).
         { const int lane = lane_id();
         if constexpr (SPW) {
-            if (cached0) {
-                sring_prefetch<SDR, KO, E>(sring, ss_wox(m.layer[0], wave), lane);
-                // layer 0's q_ext | k | v rows of this head (shared table entry): in flight during the centring below
-                // (measured: 86.8 vs 87.3 us / step with a register fetch inside the attention block)
-                if constexpr (HDMA) head_dma<LL::DMA_N>(dmatab, Qx, l0e + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, lane);
-            } else sring_prefetch<SDR, KQ, E>(sring, ss_qkv(m.layer[0], wave), lane);
+            if (step == 0) step_prefetch(cached0, l0e);
         } else if (cached0) {
             const gfloat* sb0 = l0e;
             if constexpr (HPW == 2) head_fetch(hr, sb0 + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
@@ -2205,6 +2211,18 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             }
             if (step + 1 < a.n_steps) { __builtin_amdgcn_wave_barrier(); centre(); }
 #endif
+        }
+        // The next step's first weight units and layer-0 head rows: requested here, where seven waves have nothing to do but
+        // wait for wave 0's integrator update (wave 0 requests its own once it is through); the ring and the Q region are
+        // dead since the last attention block.
+        if constexpr (SPW) {
+            if (step + 1 < a.n_steps) {
+                const bool tab_ = a.l0_tab != nullptr;
+                const bool c0n = !(GEN && m.in_abs) && (tab_ || MODE == DFF_MODE_LANGEVIN);
+                const gfloat* const l0n = tab_ ? (const gfloat*)a.l0_tab + (size_t)(MODE == DFF_MODE_DDPM ? a.t_start - step - 1 : 0) * sl.layer_stride
+                                               : (const gfloat*)stash;
+                step_prefetch(c0n, l0n);
+            }
         }
         __syncthreads();
         }
