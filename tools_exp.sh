@@ -18,6 +18,13 @@ if [ "$cmd" = build ]; then
     hipcc --offload-arch=gfx950 -shared -fPIC build/obj/dff_kernels.o $objs build/obj/dff_host.o -o $d/libdff_amd.so
     echo "$flags" > $d/flags
     echo "built $d ($flags)"
+elif [ "$cmd" = buildk ]; then   # the <= 64-row kernel TU instead (e.g. flags: -DDFF_FAST_BUILD -DDFF_ONLY="VAR_SPW(128,3,1)")
+    name=$1; flags=$2
+    d=build/exp/$name; mkdir -p $d
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-result $flags -c $SRC/dff_kernels.hip -o $d/dff_kernels.o
+    hipcc --offload-arch=gfx950 -shared -fPIC $d/dff_kernels.o build/obj/dff_small_m0.o build/obj/dff_small_m1.o build/obj/dff_small_m2.o build/obj/dff_host.o -o $d/libdff_amd.so
+    echo "$flags" > $d/flags
+    echo "built $d ($flags)"
 elif [ "$cmd" = run ]; then
     mkdir -p gpurun_out
     for name in "$@"; do

@@ -452,15 +452,14 @@ DEVI void load_afrag(f32x4 (&a)[KB], const lfloat* A, int lda, int lane) {
 }
 
 // C[i][j] = sum_k A[i][k] B[j][k], K = 80 (5 k-blocks), both operands rows of a head buffer
+// The 64 regular columns (two accumulator chains) ...
 template <int XLD = DFF_XLD>
-DEVI f32x4 wv_dot_rows(const lfloat* A, const lfloat* B, int lane) {
+DEVI f32x4 wv_dot_base(const lfloat* A, const lfloat* B, int lane) {
     const lfloat* ap = A + (lane & 15) * XLD + 4 * (lane >> 4);
     const lfloat* bp = B + (lane & 15) * XLD + 4 * (lane >> 4);
     f32x4 av[4], bv[4];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) { av[kb] = *(const lf32x4*)(ap + 16 * kb); bv[kb] = *(const lf32x4*)(bp + 16 * kb); }
-    // extension block: only its first 4 columns are ever non-zero (u | s, x | |x|^2, r | g_D): one k-step, exact
-    const float ax = ap[64 - 3 * (lane >> 4)], bx = bp[64 - 3 * (lane >> 4)];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -472,8 +471,17 @@ DEVI f32x4 wv_dot_rows(const lfloat* A, const lfloat* B, int lane) {
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2][s], bv[2][s], acc, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3][s], bv[3][s], acc2, 0, 0, 0);
     }
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, bx, acc, 0, 0, 0);
     return acc + acc2;
+}
+// ... and the extension block on top: only its first 4 columns are ever non-zero (u | s, x | |x|^2, r | g_D): one k-step, exact
+template <int XLD = DFF_XLD>
+DEVI f32x4 wv_dot_ext(const lfloat* A, const lfloat* B, int lane, const f32x4 base) {
+    const float ax = A[(lane & 15) * XLD + 64 + (lane >> 4)], bx = B[(lane & 15) * XLD + 64 + (lane >> 4)];
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(ax, bx, base, 0, 0, 0);
+}
+template <int XLD = DFF_XLD>
+DEVI f32x4 wv_dot_rows(const lfloat* A, const lfloat* B, int lane) {
+    return wv_dot_ext<XLD>(A, B, lane, wv_dot_base<XLD>(A, B, lane));
 }
 
 // C[m][16nt+n] = sum_{k<16} Aop[m][k] B[k][16nt+n] for tiles nt in [NT0, NT1).
@@ -941,6 +949,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     using KL = std::integral_constant<int, 3>;
     // ... and the two gate values of every layer (one number per row, the same in all lanes of the row)
     float kg0[2] = {}, kg1[2] = {}, kg2[2] = {};
+    f32x4 s0keep = {0.f, 0.f, 0.f, 0.f};   // layer 0's q' . n logits of this wave's head (Langevin: constant over a launch)
     auto gate_put = [&](int k, int which, float g) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -1248,7 +1257,16 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 auto head_math = [&](int h) {
                     if constexpr (!FOLD) write_xext(lane);   // (FOLD: the shared buffer's x columns are written once per step, by the centring)
                     if constexpr (GEN) fix_q(lane);
-                    const f32x4 S = wv_dot_rows<XLD>(Qx, Kx, lane);
+                    // Layer 0 at a fixed noise level (Langevin): q' and the LayerNorm rows are the same every step, so the 64
+                    // regular columns of the logits are too -- computed on step 0 of the launch, kept in 4 registers; only the
+                    // extension k-step (u . x_j) is redone
+                    f32x4 Sb;
+                    if (KEEPROWS && MODE == DFF_MODE_LANGEVIN && l == 0 && step > 0) Sb = s0keep;
+                    else {
+                        Sb = wv_dot_base<XLD>(Qx, Kx, lane);
+                        if (KEEPROWS && MODE == DFF_MODE_LANGEVIN && l == 0) s0keep = Sb;
+                    }
+                    const f32x4 S = wv_dot_ext<XLD>(Qx, Kx, lane, Sb);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int i = quad * 4 + r;
