@@ -194,6 +194,10 @@ def test_bench_finds_the_profiled_traffic_for_the_shipped_kernels():
     # round 2: the split-bf16 headline kernel (rocprofv3 prints "<64, 8, false, true>") has its own, smaller, traffic figure
     t2 = bench.hbm_traffic_from_profile("dff_small_kernel<64,8,split_bf16>", "chignolin", 256, 250)
     assert t2 is not None and t2 < t
+    # round 3: the headline kernel (rocprofv3: "<64, 8, false, true, true, 1>" -- the sampler mode is a template argument now)
+    # keeps its activations in LDS / registers: its figure is the latest round's, two orders of magnitude below round 2's
+    t3 = bench.hbm_traffic_from_profile("dff_small_kernel<64,8,split_bf16,fold_kv>", "chignolin", 256, 250)
+    assert t3 is not None and t3 < 0.1 * t2
     r = bench.roofline("chignolin", 256, 250, [20.8, 20.9], "dff_small_kernel<64,8,split_bf16>")
     assert abs(r["frac"] - 1.408e12 / 20.85e-3 / 157.3e12) < 1e-3 and r["peak_split_gemms"] == 2500.0 / 6 and r["traffic"] == t2
     assert "3-way bf16 split" in bench.kernel_dtype("dff_small_kernel<64,8,split_bf16>")

@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Per-stage cycle breakdown of the fused kernel (workgroup 0), via dff_debug_profile."""
+"""Per-stage cycle breakdown of the fused kernel (workgroup 0), via dff_debug_profile.
+
+Needs a library built with the stage ticks compiled in (-DDFF_PROF=1: `DFF_EXTRA_FLAGS=-DDFF_PROF=1 ./build.sh`, or
+`./tools_exp.sh build prof -DDFF_PROF=1` and DFF_LIB_PATH=build/exp/prof/libdff_amd.so); the product build leaves them out."""
 import argparse, sys, os, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

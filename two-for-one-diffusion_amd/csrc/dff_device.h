@@ -332,6 +332,11 @@ DEVI void split8(const f32x4& x0, const f32x4& x1, u32x4& h, u32x4& m, u32x4& l)
 }
 
 // ------------------------------------------------------------------------------------------
+// DFF_PROF=1 (./build.sh with DFF_EXTRA_FLAGS=-DDFF_PROF=1; tools_profile_stages.py needs such a build): the stage ticks are
+// compiled in.  The product build leaves them out: ~30 exec-masked branch sites per layer in every wave's instruction stream.
+#ifndef DFF_PROF
+#define DFF_PROF 0
+#endif
 // optional per-stage cycle accounting (a.prof != null): thread 0 of block 0 accumulates
 // s_memtime deltas per stage id at stage boundaries; written out at kernel end.
 // ------------------------------------------------------------------------------------------
@@ -341,6 +346,10 @@ struct Prof {
     unsigned long long* acc;   // LDS
     bool on;
     DEVI void tick(int id) {
+#if !DFF_PROF
+        (void)id;
+        return;
+#endif
         if (on) {
             const unsigned long long t = __builtin_readcyclecounter();
             acc[id] += t - last;

@@ -504,13 +504,6 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
         UP(pack_b(H, 8 * 80, [&](int k, int n) { return wox(n, k); }), d.WoxT_p);
         UP(pack_b(8 * 208, H, [&](int k, int n) { return wqkvx(k, n); }, 13), d.WqkvxT_p);
     }
-    if (getenv("DFF_T_ALIAS")) {   // TIMING-ONLY experiment (results invalid): every layer streams layer 0's split images
-        for (int l = 1; l < L; ++l) {
-            DffLayerDev& d = m->dev.layer[l]; const DffLayerDev& z = m->dev.layer[0];
-            d.Wqkvx_w = z.Wqkvx_w; d.W1_w = z.W1_w; d.W2T_w = z.W2T_w; d.WoxT_w = z.WoxT_w;
-            d.Wox_t = z.Wox_t; d.W2_t = z.W2_t; d.W1T_t = z.W1T_t; d.WqkvxT_t = z.WqkvxT_t;
-        }
-    }
     build_schedule(cfg->timesteps, m->sched);
     UP(m->sched[6], m->dev.sqrt_recip_ac);
     UP(m->sched[7], m->dev.sqrt_recipm1_ac);

@@ -785,18 +785,10 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         }
     };
     const SmallStash sl = dff_small_stash(N, G, H, m.L);
-#ifdef DFF_T_SHSTASH   // TIMING-ONLY experiment (results invalid): 8 shared, L2-resident stash slots
-    gfloat* const stash = (gfloat*)a.stash + (size_t)(blockIdx.x & 7) * a.stash_stride;
-#else
     gfloat* const stash = (gfloat*)a.stash + (size_t)blockIdx.x * a.stash_stride;
-#endif
     Ctx c;  // only what bead_mean() needs
     c.N = N; c.G = G; c.gcnt = gcnt; c.rows = rows;
 
-#ifdef DFF_X_PRIO
-    // static priority for one half of the waves (MI355X_MICROARCH.md "Two waves per SIMD", item 4)
-    if (DFF_X_PRIO == 1 ? wave >= NW / 2 : wave < NW / 2) __builtin_amdgcn_s_setprio(1);
-#endif
     for (int i = tid; i < (int)LL::total; i += NTHR) smem[i] = 0.f;
     __syncthreads();
     if constexpr (LL::dmatab_size > 0) {
@@ -1520,7 +1512,6 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     pf.tick(21);
                     // gelu'(h_pre) rows of this wave's hidden slice: LDS tile -> stash, 16 bytes per lane (rows beyond the real
                     // ones go to the dummy stash row); before the partial sums below reuse the tile
-#ifndef DFF_T_NOHP
                     if (!gp_lds) {
                         const lfloat* const gp = hbuf + 16 * LF;
                         gfloat* const dst = sb + sl.h_pre + wave * FS;
@@ -1530,7 +1521,6 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                             if (row < 16) *(gf32x4*)(dst + (row < rows ? row : RA) * F + 4 * c4) = *(const lf32x4*)(gp + row * LF + 4 * c4);
                         }
                     }
-#endif
                 }
                 static_assert((2 * NTS) % DR == 0, "ring phase");
 #pragma unroll
@@ -1617,13 +1607,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #pragma unroll
             for (int d = 0; d < DR; ++d)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-#ifdef DFF_T_NOHP   // TIMING-ONLY experiment (results invalid): no GELU' through the stash
-                    hpn[d][r] = 0.5f;
-#else
-                    hpn[d][r] = ld_ntg(shp + srow[r] * F + 16 * d);
-#endif
-                }
+                for (int r = 0; r < 4; ++r) hpn[d][r] = ld_ntg(shp + srow[r] * F + 16 * d);
         };
         if (!m.conservative) {
             // force head (graph_transformer.py:62-63,112-113): node_decoder is Linear(H, 3) and forces = its output,
@@ -2184,7 +2168,6 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             // element-wise stages; every (bead, component) thread -- all in wave 0, so its loads of the old xst precede every
             // store of the new one -- runs the whole chain for its protein's column in registers and takes the means itself
             // (summed in bead order as bead_mean() does): same arithmetic per element as the stage-by-stage form, no barriers.
-#ifndef DFF_T_LANGONLY   // (TIMING-ONLY experiment switch: code size)
             if (tq < rows * 4 && (tq & 3) < 3) {
                 const int cc = tq & 3, pb0 = ((tq >> 2) / N) * N;
                 const float sr = m.sqrt_recip_ac[t_int], srm1 = m.sqrt_recipm1_ac[t_int];
@@ -2228,7 +2211,6 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 xst[tq] = xn - colmean(xnv);
             }
             if (step + 1 < a.n_steps) { __builtin_amdgcn_wave_barrier(); centre(); }
-#endif
         }
         // The next step's first weight units and layer-0 head rows: requested here, where seven waves have nothing to do but
         // wait for wave 0's integrator update (wave 0 requests its own once it is through); the ring and the Q region are
