@@ -1010,278 +1010,302 @@ DEVI void node_embed(const Ctx& c, const DffModelDev& m) {
         c.resbuf[row * (H + 4) + col] = v;
     }
 }
+// ------------------------------------------------------------------------------------------
+// Row stages (LayerNorm, gates and their backward forms).  LP lanes share a row, HC = H / LP columns per lane, in groups of
+// VW consecutive columns (element e = j VW + k of a lane is column VW sub + VW LP j + k): every LDS / stash / parameter
+// access of a lane is a 16- (or 8-) byte vector, the LP lanes of a row cover 4 LP consecutive floats per access.  LP is
+// a template argument (512 / LP rows per pass; the kernel uses 16), and each
+// stage issues every global load it needs (stashed rows, gate weights, LayerNorm gains) BEFORE the first reduction: round 2's
+// stages loaded a scalar, waited, used it, 16 to 100 times per pass (b_ln2+gate1: 36 k cycles per call on protein G).
+// ------------------------------------------------------------------------------------------
+template <int H, int LP>
+struct RowMap {
+    static constexpr int HC = H / LP, VW = (HC % 4 == 0) ? 4 : 2, NV = HC / VW, RPP = DFF_NTHREADS / LP;   // rows per pass
+    static_assert(H % LP == 0 && HC % 2 == 0, "row layout");
+};
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// HC values of a row-shaped array (p = the row's first element: LDS tile row, stash row or a parameter vector)
+template <int H, int LP>
+DEVI void rload(float (&x)[H / LP], const float* p, int sub) {
+    using M = RowMap<H, LP>;
+#pragma unroll
+    for (int j = 0; j < M::NV; ++j) {
+        const float* q = p + M::VW * sub + M::VW * LP * j;
+        if constexpr (M::VW == 4) { const f32x4 v = *(const f32x4*)q; x[4 * j] = v[0]; x[4 * j + 1] = v[1]; x[4 * j + 2] = v[2]; x[4 * j + 3] = v[3]; }
+        else { const f32x2 v = *(const f32x2*)q; x[2 * j] = v[0]; x[2 * j + 1] = v[1]; }
+    }
+}
+template <int H, int LP>
+DEVI void rstore(float* p, const float (&x)[H / LP], int sub) {
+    using M = RowMap<H, LP>;
+#pragma unroll
+    for (int j = 0; j < M::NV; ++j) {
+        float* q = p + M::VW * sub + M::VW * LP * j;
+        if constexpr (M::VW == 4) *(f32x4*)q = (f32x4){x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3]};
+        else *(f32x2*)q = (f32x2){x[2 * j], x[2 * j + 1]};
+    }
+}
+template <int LP>
+DEVI float grp_sum_lp(float v) {   // all-reduce over the LP (8 or 16) lanes of a row
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    if constexpr (LP == 16) v += dpp_mov<0x140>(v);
+    return v;
+}
 // absolute coordinates: dE/dx_i += d(nodes_0)_i . W_node[:, x columns]   (dn_0 is in resbuf after layer 0's backward)
-template <int H>
+template <int H, int LP>
 DEVI void node_embed_bwd(const Ctx& c, const DffModelDev& m) {
     const int tid_ = tid_now();
-    constexpr int HC = H / 16, LH = H + 4;
-    const int grp = tid_ >> 4, sub = tid_ & 15;
-    for (int row = grp; row < c.rows; row += DFF_NTHREADS / 16) {
-        float f[3] = {0.f, 0.f, 0.f};
+    constexpr int HC = H / LP, LH = H + 4;
+    const int grp = tid_ / LP, sub = tid_ % LP;
+    for (int row = grp; row < c.rows; row += RowMap<H, LP>::RPP) {
+        float dn[HC], w[3][HC];
+        rload<H, LP>(dn, c.resbuf + row * LH, sub);
 #pragma unroll
-        for (int i = 0; i < HC; ++i) {
-            const int col = sub + 16 * i;
-            const float dn = c.resbuf[row * LH + col];
-#pragma unroll
-            for (int c3 = 0; c3 < 3; ++c3) f[c3] += dn * m.WnT[(c.N + c3) * H + col];
-        }
+        for (int c3 = 0; c3 < 3; ++c3) rload<H, LP>(w[c3], m.WnT + (c.N + c3) * H, sub);
 #pragma unroll
         for (int c3 = 0; c3 < 3; ++c3) {
-            f[c3] = grp16_sum(f[c3]);
-            if (sub == 0) c.dxs[row * 4 + c3] += f[c3];
+            float f = 0.f;
+#pragma unroll
+            for (int i = 0; i < HC; ++i) f += dn[i] * w[c3][i];
+            f = grp_sum_lp<LP>(f);
+            if (sub == 0) c.dxs[row * 4 + c3] += f;
         }
     }
 }
 
-// LayerNorm of one row held as HC values per lane of a 16-lane group
-template <int H>
-DEVI void ln_stats(const float (&x)[H / 16], float& mean, float& rstd) {
+// LayerNorm of one row held as HC values per lane of an LP-lane group
+template <int H, int LP>
+DEVI void ln_stats(const float (&x)[H / LP], float& mean, float& rstd) {
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < H / 16; ++i) s += x[i];
-    mean = grp16_sum(s) * (1.0f / H);
+    for (int i = 0; i < H / LP; ++i) s += x[i];
+    mean = grp_sum_lp<LP>(s) * (1.0f / H);
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < H / 16; ++i) { const float d = x[i] - mean; q += d * d; }
-    const float var = grp16_sum(q) * (1.0f / H);
+    for (int i = 0; i < H / LP; ++i) { const float d = x[i] - mean; q += d * d; }
+    const float var = grp_sum_lp<LP>(q) * (1.0f / H);
     rstd = fast_rsqrt(var + 1e-5f);
 }
 
-// gate = sigmoid(w . [x, res, x-res])   (graph_transformer.py:197-205)
-template <int H>
-DEVI float gate_value(const float (&x)[H / 16], const float (&res)[H / 16], const float* __restrict__ w, int sub) {
+// gate = sigmoid(w . [x, res, x-res])   (graph_transformer.py:197-205); w = the three weight vectors, already in registers
+template <int H, int LP>
+DEVI float gate_value(const float (&x)[H / LP], const float (&res)[H / LP], const float (&w)[3][H / LP]) {
     float z = 0.f;
 #pragma unroll
-    for (int i = 0; i < H / 16; ++i) {
-        const int col = sub + 16 * i;
-        z += x[i] * w[col] + res[i] * w[H + col] + (x[i] - res[i]) * w[2 * H + col];
-    }
-    return sigmoid_f(grp16_sum(z));
+    for (int i = 0; i < H / LP; ++i) z += x[i] * w[0][i] + res[i] * w[1][i] + (x[i] - res[i]) * w[2][i];
+    return sigmoid_f(grp_sum_lp<LP>(z));
+}
+template <int H, int LP>
+DEVI void gate_weights(float (&w)[3][H / LP], const float* g, int sub) {
+    rload<H, LP>(w[0], g, sub); rload<H, LP>(w[1], g + H, sub); rload<H, LP>(w[2], g + 2 * H, sub);
 }
 
 // R0: nodes (resbuf) -> stash nodes_in ; LN1 -> abuf
-template <int H>
+template <int H, int LP>
 DEVI void row_ln1(const Ctx& c, const DffLayerDev& lw, int l) {
     const int tid_ = tid_now();
-    constexpr int HC = H / 16, LH = H + 4;
-    const int grp = tid_ >> 4, sub = tid_ & 15;
+    constexpr int HC = H / LP, LH = H + 4;
+    const int grp = tid_ / LP, sub = tid_ % LP;
     float* s_nodes = c.stash + (size_t)l * c.sl.layer_stride + c.sl.nodes_in;
-    for (int row = grp; row < c.rows; row += DFF_NTHREADS / 16) {
-        float x[HC];
-#pragma unroll
-        for (int i = 0; i < HC; ++i) {
-            x[i] = c.resbuf[row * LH + sub + 16 * i];
-            st_nt(s_nodes + row * H + sub + 16 * i, x[i]);
-        }
+    for (int row = grp; row < c.rows; row += RowMap<H, LP>::RPP) {
+        float x[HC], gam[HC], bet[HC];
+        rload<H, LP>(gam, lw.ln1_g, sub); rload<H, LP>(bet, lw.ln1_b, sub);
+        rload<H, LP>(x, c.resbuf + row * LH, sub);
+        rstore<H, LP>(s_nodes + row * H, x, sub);
         float mean, rstd;
-        ln_stats<H>(x, mean, rstd);
+        ln_stats<H, LP>(x, mean, rstd);
 #pragma unroll
-        for (int i = 0; i < HC; ++i) {
-            const int col = sub + 16 * i;
-            c.abuf[row * LH + col] = (x[i] - mean) * rstd * lw.ln1_g[col] + lw.ln1_b[col];
-        }
+        for (int i = 0; i < HC; ++i) x[i] = (x[i] - mean) * rstd * gam[i] + bet[i];
+        rstore<H, LP>(c.abuf + row * LH, x, sub);
     }
 }
 
 // R1: tbuf = attn_out, resbuf = nodes -> nodes1 (resbuf), stash attn_out, LN2 -> abuf
-template <int H>
+template <int H, int LP>
 DEVI void row_gate1_ln2(const Ctx& c, const DffLayerDev& lw, int l, const float* tbuf) {
     const int tid_ = tid_now();
-    constexpr int HC = H / 16, LH = H + 4;
-    const int grp = tid_ >> 4, sub = tid_ & 15;
+    constexpr int HC = H / LP, LH = H + 4;
+    const int grp = tid_ / LP, sub = tid_ % LP;
     float* s_att = c.stash + (size_t)l * c.sl.layer_stride + c.sl.attn_out;
-    for (int row = grp; row < c.rows; row += DFF_NTHREADS / 16) {
-        float x[HC], res[HC], n1[HC];
+    for (int row = grp; row < c.rows; row += RowMap<H, LP>::RPP) {
+        float x[HC], res[HC], n1[HC], w[3][HC], gam[HC], bet[HC];
+        gate_weights<H, LP>(w, lw.g1, sub);
+        rload<H, LP>(gam, lw.ln2_g, sub); rload<H, LP>(bet, lw.ln2_b, sub);
+        rload<H, LP>(x, tbuf + row * LH, sub);
+        rload<H, LP>(res, c.resbuf + row * LH, sub);
+        rstore<H, LP>(s_att + row * H, x, sub);
+        const float g = gate_value<H, LP>(x, res, w);
 #pragma unroll
-        for (int i = 0; i < HC; ++i) {
-            x[i] = tbuf[row * LH + sub + 16 * i];
-            res[i] = c.resbuf[row * LH + sub + 16 * i];
-            st_nt(s_att + row * H + sub + 16 * i, x[i]);
-        }
-        const float g = gate_value<H>(x, res, lw.g1, sub);
-#pragma unroll
-        for (int i = 0; i < HC; ++i) {
-            n1[i] = x[i] * g + res[i] * (1.0f - g);
-            c.resbuf[row * LH + sub + 16 * i] = n1[i];
-        }
+        for (int i = 0; i < HC; ++i) n1[i] = x[i] * g + res[i] * (1.0f - g);
+        rstore<H, LP>(c.resbuf + row * LH, n1, sub);
         float mean, rstd;
-        ln_stats<H>(n1, mean, rstd);
+        ln_stats<H, LP>(n1, mean, rstd);
 #pragma unroll
-        for (int i = 0; i < HC; ++i) {
-            const int col = sub + 16 * i;
-            c.abuf[row * LH + col] = (n1[i] - mean) * rstd * lw.ln2_g[col] + lw.ln2_b[col];
-        }
+        for (int i = 0; i < HC; ++i) n1[i] = (n1[i] - mean) * rstd * gam[i] + bet[i];
+        rstore<H, LP>(c.abuf + row * LH, n1, sub);
     }
 }
 
 // R2: tbuf = ff, resbuf = nodes1 -> nodes2 (resbuf), stash ff.  Last layer: energy + dn = w_dec.
-template <int H>
+template <int H, int LP>
 DEVI void row_gate2(const Ctx& c, const DffModelDev& m, const DffLayerDev& lw, int l, const float* tbuf,
                     bool last, float* energy_out) {
     const int tid_ = tid_now();
-    constexpr int HC = H / 16, LH = H + 4;
-    const int grp = tid_ >> 4, sub = tid_ & 15;
+    constexpr int HC = H / LP, LH = H + 4;
+    const int grp = tid_ / LP, sub = tid_ % LP;
     float* s_ff = c.stash + (size_t)l * c.sl.layer_stride + c.sl.ff;
-    for (int row = grp; row < c.rows; row += DFF_NTHREADS / 16) {
-        float x[HC], res[HC];
-#pragma unroll
-        for (int i = 0; i < HC; ++i) {
-            x[i] = tbuf[row * LH + sub + 16 * i];
-            res[i] = c.resbuf[row * LH + sub + 16 * i];
-            st_nt(s_ff + row * H + sub + 16 * i, x[i]);
-        }
-        const float g = gate_value<H>(x, res, lw.g2, sub);
+    for (int row = grp; row < c.rows; row += RowMap<H, LP>::RPP) {
+        float x[HC], res[HC], w[3][HC];
+        gate_weights<H, LP>(w, lw.g2, sub);
+        rload<H, LP>(x, tbuf + row * LH, sub);
+        rload<H, LP>(res, c.resbuf + row * LH, sub);
+        rstore<H, LP>(s_ff + row * H, x, sub);
+        const float g = gate_value<H, LP>(x, res, w);
         if (last && !m.conservative) {
             // force head (graph_transformer.py:62-63,112-113): forces = node_decoder(nodes), no VJP;
             // the update stage takes dE/dx, so the negated forces go there
-            float f[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < HC; ++i) {
-                const int col = sub + 16 * i;
-                const float n2 = x[i] * g + res[i] * (1.0f - g);
-#pragma unroll
-                for (int c3 = 0; c3 < 3; ++c3) f[c3] += n2 * m.wdec[c3 * H + col];
-            }
 #pragma unroll
             for (int c3 = 0; c3 < 3; ++c3) {
-                f[c3] = grp16_sum(f[c3]);
-                if (sub == 0) c.dxs[row * 4 + c3] = -(f[c3] + m.bdec3[c3]);
+                float wd[HC], f = 0.f;
+                rload<H, LP>(wd, m.wdec + c3 * H, sub);
+#pragma unroll
+                for (int i = 0; i < HC; ++i) f += (x[i] * g + res[i] * (1.0f - g)) * wd[i];
+                f = grp_sum_lp<LP>(f);
+                if (sub == 0) c.dxs[row * 4 + c3] = -(f + m.bdec3[c3]);
             }
             continue;
         }
-        float e = 0.f;
+        if (last) {
+            float wd[HC], e = 0.f;
+            rload<H, LP>(wd, m.wdec, sub);
 #pragma unroll
-        for (int i = 0; i < HC; ++i) {
-            const int col = sub + 16 * i;
-            const float n2 = x[i] * g + res[i] * (1.0f - g);
-            if (last) {
-                e += n2 * m.wdec[col];
-                c.resbuf[row * LH + col] = m.wdec[col];  // d(sum_i e_i)/d nodes_L
-            } else {
-                c.resbuf[row * LH + col] = n2;
+            for (int i = 0; i < HC; ++i) e += (x[i] * g + res[i] * (1.0f - g)) * wd[i];
+            rstore<H, LP>(c.resbuf + row * LH, wd, sub);   // d(sum_i e_i)/d nodes_L
+            if (energy_out) {
+                e = grp_sum_lp<LP>(e);
+                if (sub == 0) energy_out[(size_t)c.b0 * c.N + row] = e + m.bdec;
             }
-        }
-        if (last && energy_out) {
-            e = grp16_sum(e);
-            if (sub == 0) energy_out[(size_t)c.b0 * c.N + row] = e + m.bdec;
+        } else {
+#pragma unroll
+            for (int i = 0; i < HC; ++i) x[i] = x[i] * g + res[i] * (1.0f - g);
+            rstore<H, LP>(c.resbuf + row * LH, x, sub);
         }
     }
 }
 
 // RB1: dn (resbuf) through gate2 -> dff (abuf), dn1 partial (resbuf)
-template <int H>
+template <int H, int LP>
 DEVI void rowb_gate2(const Ctx& c, const DffLayerDev& lw, int l) {
     const int tid_ = tid_now();
-    constexpr int HC = H / 16, LH = H + 4;
-    const int grp = tid_ >> 4, sub = tid_ & 15;
+    constexpr int HC = H / LP, LH = H + 4;
+    const int grp = tid_ / LP, sub = tid_ % LP;
     const float* sb = c.stash + (size_t)l * c.sl.layer_stride;
-    for (int row = grp; row < c.rows; row += DFF_NTHREADS / 16) {
-        float ao[HC], nin[HC], n1[HC], ff[HC], dn[HC];
-#pragma unroll
-        for (int i = 0; i < HC; ++i) {
-            const int col = sub + 16 * i;
-            ao[i] = ld_nt(sb + c.sl.attn_out + row * H + col);
-            nin[i] = ld_nt((l == 0 ? c.l0 : sb) + c.sl.nodes_in + row * H + col);
-            ff[i] = ld_nt(sb + c.sl.ff + row * H + col);
-            dn[i] = c.resbuf[row * LH + col];
-        }
-        const float g1 = gate_value<H>(ao, nin, lw.g1, sub);
+    for (int row = grp; row < c.rows; row += RowMap<H, LP>::RPP) {
+        float ao[HC], nin[HC], n1[HC], ff[HC], dn[HC], w1[3][HC], w2[3][HC];
+        rload<H, LP>(ao, sb + c.sl.attn_out + row * H, sub);
+        rload<H, LP>(nin, (l == 0 ? c.l0 : sb) + c.sl.nodes_in + row * H, sub);
+        rload<H, LP>(ff, sb + c.sl.ff + row * H, sub);
+        gate_weights<H, LP>(w1, lw.g1, sub);
+        gate_weights<H, LP>(w2, lw.g2, sub);
+        rload<H, LP>(dn, c.resbuf + row * LH, sub);
+        const float g1 = gate_value<H, LP>(ao, nin, w1);
 #pragma unroll
         for (int i = 0; i < HC; ++i) n1[i] = ao[i] * g1 + nin[i] * (1.0f - g1);
-        const float g2 = gate_value<H>(ff, n1, lw.g2, sub);
+        const float g2 = gate_value<H, LP>(ff, n1, w2);
         float dg = 0.f;
 #pragma unroll
         for (int i = 0; i < HC; ++i) dg += dn[i] * (ff[i] - n1[i]);
-        dg = grp16_sum(dg);
+        dg = grp_sum_lp<LP>(dg);
         const float dz = dg * g2 * (1.0f - g2);
 #pragma unroll
         for (int i = 0; i < HC; ++i) {
-            const int col = sub + 16 * i;
-            c.abuf[row * LH + col] = dn[i] * g2 + dz * (lw.g2[col] + lw.g2[2 * H + col]);
-            c.resbuf[row * LH + col] = dn[i] * (1.0f - g2) + dz * (lw.g2[H + col] - lw.g2[2 * H + col]);
+            ao[i] = dn[i] * g2 + dz * (w2[0][i] + w2[2][i]);
+            nin[i] = dn[i] * (1.0f - g2) + dz * (w2[1][i] - w2[2][i]);
         }
+        rstore<H, LP>(c.abuf + row * LH, ao, sub);
+        rstore<H, LP>(c.resbuf + row * LH, nin, sub);
     }
 }
 
 // RB2: tbuf = df ; dn1 = resbuf + LN2bwd(df) ; gate1 bwd -> dattn (abuf), dn_in partial (resbuf)
-template <int H>
+template <int H, int LP>
 DEVI void rowb_ln2_gate1(const Ctx& c, const DffLayerDev& lw, int l, const float* tbuf) {
     const int tid_ = tid_now();
-    constexpr int HC = H / 16, LH = H + 4;
-    const int grp = tid_ >> 4, sub = tid_ & 15;
+    constexpr int HC = H / LP, LH = H + 4;
+    const int grp = tid_ / LP, sub = tid_ % LP;
     const float* sb = c.stash + (size_t)l * c.sl.layer_stride;
-    for (int row = grp; row < c.rows; row += DFF_NTHREADS / 16) {
-        float ao[HC], nin[HC], n1[HC], d1[HC];
-#pragma unroll
-        for (int i = 0; i < HC; ++i) {
-            const int col = sub + 16 * i;
-            ao[i] = ld_nt(sb + c.sl.attn_out + row * H + col);
-            nin[i] = ld_nt((l == 0 ? c.l0 : sb) + c.sl.nodes_in + row * H + col);
-        }
-        const float g1 = gate_value<H>(ao, nin, lw.g1, sub);
+    for (int row = grp; row < c.rows; row += RowMap<H, LP>::RPP) {
+        float ao[HC], nin[HC], n1[HC], d1[HC], w[3][HC], gam[HC], df[HC], dnp[HC];
+        rload<H, LP>(ao, sb + c.sl.attn_out + row * H, sub);
+        rload<H, LP>(nin, (l == 0 ? c.l0 : sb) + c.sl.nodes_in + row * H, sub);
+        gate_weights<H, LP>(w, lw.g1, sub);
+        rload<H, LP>(gam, lw.ln2_g, sub);
+        rload<H, LP>(df, tbuf + row * LH, sub);
+        rload<H, LP>(dnp, c.resbuf + row * LH, sub);
+        const float g1 = gate_value<H, LP>(ao, nin, w);
 #pragma unroll
         for (int i = 0; i < HC; ++i) n1[i] = ao[i] * g1 + nin[i] * (1.0f - g1);
         float mean, rstd;
-        ln_stats<H>(n1, mean, rstd);
+        ln_stats<H, LP>(n1, mean, rstd);
         float s1 = 0.f, s2 = 0.f;
         float dyg[HC], xh[HC];
 #pragma unroll
         for (int i = 0; i < HC; ++i) {
-            const int col = sub + 16 * i;
             xh[i] = (n1[i] - mean) * rstd;
-            dyg[i] = tbuf[row * LH + col] * lw.ln2_g[col];
+            dyg[i] = df[i] * gam[i];
             s1 += dyg[i];
             s2 += dyg[i] * xh[i];
         }
-        s1 = grp16_sum(s1) * (1.0f / H);
-        s2 = grp16_sum(s2) * (1.0f / H);
+        s1 = grp_sum_lp<LP>(s1) * (1.0f / H);
+        s2 = grp_sum_lp<LP>(s2) * (1.0f / H);
         float dg = 0.f;
 #pragma unroll
         for (int i = 0; i < HC; ++i) {
-            const int col = sub + 16 * i;
-            d1[i] = c.resbuf[row * LH + col] + rstd * (dyg[i] - s1 - xh[i] * s2);
+            d1[i] = dnp[i] + rstd * (dyg[i] - s1 - xh[i] * s2);
             dg += d1[i] * (ao[i] - nin[i]);
         }
-        dg = grp16_sum(dg);
+        dg = grp_sum_lp<LP>(dg);
         const float dz = dg * g1 * (1.0f - g1);
 #pragma unroll
         for (int i = 0; i < HC; ++i) {
-            const int col = sub + 16 * i;
-            c.abuf[row * LH + col] = d1[i] * g1 + dz * (lw.g1[col] + lw.g1[2 * H + col]);
-            c.resbuf[row * LH + col] = d1[i] * (1.0f - g1) + dz * (lw.g1[H + col] - lw.g1[2 * H + col]);
+            ao[i] = d1[i] * g1 + dz * (w[0][i] + w[2][i]);
+            nin[i] = d1[i] * (1.0f - g1) + dz * (w[1][i] - w[2][i]);
         }
+        rstore<H, LP>(c.abuf + row * LH, ao, sub);
+        rstore<H, LP>(c.resbuf + row * LH, nin, sub);
     }
 }
 
 // RB3: tbuf = d(LN1 out) ; dn = resbuf + LN1bwd
-template <int H>
+template <int H, int LP>
 DEVI void rowb_ln1(const Ctx& c, const DffLayerDev& lw, int l, const float* tbuf) {
     const int tid_ = tid_now();
-    constexpr int HC = H / 16, LH = H + 4;
-    const int grp = tid_ >> 4, sub = tid_ & 15;
+    constexpr int HC = H / LP, LH = H + 4;
+    const int grp = tid_ / LP, sub = tid_ % LP;
     const float* sb = c.stash + (size_t)l * c.sl.layer_stride;
-    for (int row = grp; row < c.rows; row += DFF_NTHREADS / 16) {
-        float nin[HC];
-#pragma unroll
-        for (int i = 0; i < HC; ++i) nin[i] = ld_nt((l == 0 ? c.l0 : sb) + c.sl.nodes_in + row * H + sub + 16 * i);
+    for (int row = grp; row < c.rows; row += RowMap<H, LP>::RPP) {
+        float nin[HC], gam[HC], dy[HC], dnp[HC];
+        rload<H, LP>(nin, (l == 0 ? c.l0 : sb) + c.sl.nodes_in + row * H, sub);
+        rload<H, LP>(gam, lw.ln1_g, sub);
+        rload<H, LP>(dy, tbuf + row * LH, sub);
+        rload<H, LP>(dnp, c.resbuf + row * LH, sub);
         float mean, rstd;
-        ln_stats<H>(nin, mean, rstd);
+        ln_stats<H, LP>(nin, mean, rstd);
         float s1 = 0.f, s2 = 0.f, dyg[HC], xh[HC];
 #pragma unroll
         for (int i = 0; i < HC; ++i) {
-            const int col = sub + 16 * i;
             xh[i] = (nin[i] - mean) * rstd;
-            dyg[i] = tbuf[row * LH + col] * lw.ln1_g[col];
+            dyg[i] = dy[i] * gam[i];
             s1 += dyg[i];
             s2 += dyg[i] * xh[i];
         }
-        s1 = grp16_sum(s1) * (1.0f / H);
-        s2 = grp16_sum(s2) * (1.0f / H);
+        s1 = grp_sum_lp<LP>(s1) * (1.0f / H);
+        s2 = grp_sum_lp<LP>(s2) * (1.0f / H);
 #pragma unroll
-        for (int i = 0; i < HC; ++i) {
-            const int col = sub + 16 * i;
-            c.resbuf[row * LH + col] += rstd * (dyg[i] - s1 - xh[i] * s2);
-        }
+        for (int i = 0; i < HC; ++i) dnp[i] += rstd * (dyg[i] - s1 - xh[i] * s2);
+        rstore<H, LP>(c.resbuf + row * LH, dnp, sub);
     }
 }
 
@@ -1887,6 +1911,10 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
     constexpr int NTW = (NT_H + DFF_NWAVES - 1) / DFF_NWAVES;
     constexpr int NHG = DFF_HEADS / HGS;
     constexpr int NCH = F / FC;
+    // lanes per row of the row stages (RowMap).  16: up to 32 rows per pass; 8 lanes (64 rows per pass: villin's 35 and
+    // protein G's 56 rows in one) was built and measured: 16 values per lane and array spill (412 B of scratch on villin's
+    // variant), villin +5 %, protein G no better than the two 16-lane passes.
+    constexpr int LPG = 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     Ctx c;
@@ -2083,7 +2111,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     c.resbuf[row * LH + col] = ld_nt(c.l0 + c.sl.nodes_in + it);
                 }
             } else {
-                row_ln1<H>(c, lw, l);
+                row_ln1<H, LPG>(c, lw, l);
                 wg_sync<SPILL>();
             }
             if constexpr (SPW) {
@@ -2226,7 +2254,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             store_tall<MT, NTW>(acc_o, tbuf, LH, rows, NT_H, hf == 0 ? lw.bo : nullptr);
             pair_exchange(tbuf, H, LH);
             wg_sync<SPILL>();
-            row_gate1_ln2<H>(c, lw, l, tbuf);
+            row_gate1_ln2<H, LPG>(c, lw, l, tbuf);
             wg_sync<SPILL>();
             if constexpr (SPW) { split_rows<H>(abufL, asplit, RN); wg_sync<SPILL>(); }
             pf.tick(7);
@@ -2272,7 +2300,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             store_tall<MT, NTW>(acc_f, tbuf, LH, rows, NT_H, hf == 0 ? lw.b2 : nullptr);
             pair_exchange(tbuf, H, LH);
             wg_sync<SPILL>();
-            row_gate2<H>(c, m, lw, l, tbuf, l == m.L - 1, a.energy_out);
+            row_gate2<H, LPG>(c, m, lw, l, tbuf, l == m.L - 1, a.energy_out);
             wg_sync<SPILL>();
             pf.tick(10);
         }
@@ -2281,7 +2309,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
         for (int l = m.conservative ? m.L - 1 : -1; l >= 0; --l) {
             const DffLayerDev& lw = m.layer[l];
             const float* sb = c.stash + (size_t)l * c.sl.layer_stride;
-            rowb_gate2<H>(c, lw, l);
+            rowb_gate2<H, LPG>(c, lw, l);
             wg_sync<SPILL>();
             if constexpr (SPW) { split_rows<H>(abufL, asplit, RN); wg_sync<SPILL>(); }
             pf.tick(11);
@@ -2334,7 +2362,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             CoReload<MT, HGS> rl;
             co_reload_plan<MT, HGS>(rl, geo, true, tid_now());
             co_reload_issue<MT, HGS>(rl, sqkv + (size_t)hg_lo * HGS * RN * DFF_QKVW, sPl + (size_t)hg_lo * HGS * RN * c.sl.PS);
-            rowb_ln2_gate1<H>(c, lw, l, tbuf);
+            rowb_ln2_gate1<H, LPG>(c, lw, l, tbuf);
             wg_sync<SPILL>();
             if constexpr (SPW) { split_rows<H>(abufL, asplit, RN); wg_sync<SPILL>(); }
             pf.tick(14);
@@ -2499,7 +2527,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 store_tall<MT, NTW>(acc_a, tbuf, LH, rows, NT_H, nullptr);
                 pair_exchange(tbuf, H, LH);
                 wg_sync<SPILL>();
-                rowb_ln1<H>(c, lw, l, tbuf);
+                rowb_ln1<H, LPG>(c, lw, l, tbuf);
                 wg_sync<SPILL>();
                 pf.tick(20);
             }
@@ -2516,7 +2544,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
         }
         wg_sync<SPILL>();
         if (full0 && m.conservative) {
-            node_embed_bwd<H>(c, m);
+            node_embed_bwd<H, LPG>(c, m);
             wg_sync<SPILL>();
         }
 
