@@ -139,7 +139,9 @@ def main():
     lines.append(f"- HBM traffic per launch: read {fetch / 1e9:.2f} GB (FETCH_SIZE x 1024 x 2, gfx950 correction of "
                  f"MI355X_MICROARCH.md) + write {write / 1e9:.2f} GB = {(fetch + write) / 1e9:.2f} GB -> "
                  f"{(fetch + write) / (avg_ms * 1e-3) / 1e12:.2f} TB/s; algorithmic state traffic is only "
-                 f"{state / 1e9:.2f} GB: the rest is the per-workgroup activation stash spilling out of L2")
+                 f"{state / 1e9:.2f} GB" + (": the rest is the per-workgroup activation stash spilling out of L2" if fetch + write > 20 * state else
+                                           ": what is left on top of it is the weights' first touch per XCD, the layer-0 table and the saved frames "
+                                           "(no activation goes through the stash in this kernel's sampling loops)"))
     if "SQ_LDS_BANK_CONFLICT" in C:
         lines.append(f"- LDS: bank-conflict cycles / active cycles = "
                      f"{C['SQ_LDS_BANK_CONFLICT'] / max(C.get('SQ_LDS_IDX_ACTIVE', 1.0), 1.0):.2f}")
