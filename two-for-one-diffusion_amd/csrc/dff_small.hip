@@ -730,25 +730,26 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     // layer's tile left in place, no q' / P of a 3-layer model goes through the stash in the sampling loops.
     constexpr int P0C = 68, P1C = 78;
     static_assert(!FOLD || (P1C + 10 <= XLD && RLA >= 10), "the saved P rows fit behind the q' columns of Qsave");
-    auto p_copy = [=](int c0, bool save, int lane) {   // pb (zero outside the real entries: left alone) <-> Qsave columns c0..c0+9
+    // (ij = the lane's two entries as (row, column) nibbles: `pcij`, set up once per kernel)
+    auto p_copy = [=](int c0, bool save, unsigned ij) {   // pb (zero outside the real entries: left alone) <-> Qsave columns c0..c0+9
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int it = lane + 64 * u, i = it / 10, j = it - i * 10;
-            if (it < 100) {
+            const int i = (ij >> (8 * u)) & 15, j = (ij >> (8 * u + 4)) & 15;
+            if (u == 0 || (ij >> 16)) {
                 if (save) Qsave[i * XLD + c0 + j] = pb[i * DFF_PLD + j];
                 else pb[i * DFF_PLD + j] = Qsave[i * XLD + c0 + j];
             }
         }
     };
-    auto p0_copy = [=](bool save, int lane) { p_copy(P0C, save, lane); };
+    auto p0_copy = [=](bool save, unsigned ij) { p_copy(P0C, save, ij); };
     // (q': the 68 data columns of every row)
-    auto keep2_copy = [=](const lfloat* qs, lfloat* qd, bool save, int lane) {
+    auto keep2_copy = [=](const lfloat* qs, lfloat* qd, bool save, int lane, unsigned ij) {
 #pragma unroll
         for (int u = 0; u < (RLA * 17 + 63) / 64; ++u) {
             const int it = lane + 64 * u, row = it / 17, o = row * XLD + 4 * (it - row * 17);
             if (it < RLA * 17) *(lf32x4*)(qd + o) = *(const lf32x4*)(qs + o);
         }
-        p_copy(P1C, save, lane);
+        p_copy(P1C, save, ij);
     };
     static_assert(!HDMA || XLD % 4 == 0, "16-byte slots");
     constexpr unsigned MPO = FOLD ? RS + 16 * DFF_PLD : RELAY ? 3 * RS + 16 * DFF_PLD : 0;   // offset of G | dS (the aliased tiles) inside a wave region
@@ -1084,6 +1085,23 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     // network's input to xs; xst itself is not written.  Step 0 centres at its start; every later step was centred by the
     // update stage of the step before it (same wave: the column is read right after the new x was written, no workgroup
     // barrier in between), so a step begins with its first row stage.
+    // Kernel-lifetime per-lane constants of the attention blocks (one VGPR each): which of the lane's four logits of a head's
+    // 16 x 16 tile are real, same-protein pairs (block-diagonal softmax), and where the lane's two entries of a saved 10 x 10
+    // softmax tile live.  Re-derived per block they were ~60 integer VALU instructions per head and layer (three divisions by
+    // N, two by 10) in a phase where the two waves of a SIMD run back to back.
+    unsigned okmask = 0, pcij = 0;
+    {
+        const int ln_ = tid & 63, q_ = ln_ >> 4, c_ = ln_ & 15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = q_ * 4 + r;
+            if (c_ < rows && i < rows && i / N == c_ / N) okmask |= 1u << r;
+        }
+        // entries ln_ and ln_ + 64 of a 10 x 10 tile as (row, column) nibbles; bit 16: the second one exists (< 100)
+        const int i0 = ln_ / 10, i1 = (ln_ + 64) / 10;
+        pcij = (unsigned)i0 | ((unsigned)(ln_ - 10 * i0) << 4) | ((unsigned)(i1 & 15) << 8) | ((unsigned)((ln_ + 64 - 10 * i1) & 15) << 12) |
+               (ln_ + 64 < 100 ? 1u << 16 : 0u);
+    }
     auto centre = [&]() {
         const int tq = tid_id();
         if (tq < rows * 4) {
@@ -1262,7 +1280,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int i = quad * 4 + r;
-                        const bool ok = (col < rows) && (i < rows) && (i / N == pj);
+                        const bool ok = (okmask >> r) & 1u;   // (col < rows) && (i < rows) && (i / N == col / N), once per kernel
                         const float s = ok ? S[r] * 0.125f : -INFINITY;
                         const float mx = row16_max(s);
                         const float e = ok ? fast_exp(s - mx) : 0.f;
@@ -1271,7 +1289,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         pb[i * DFF_PLD + col] = p;
                     }
                     // the 16 x 16 tile to the stash as ONE 16-byte store per lane (was four scalar stores)
-                    if (p0keep) p0_copy(true, lane);
+                    if (p0keep) p0_copy(true, pcij);
                     else if (st_qkv) *(gf32x4*)(sb + sl.P + (size_t)h * 256 + 4 * lane) = *(const lf32x4*)(pb + (lane >> 2) * DFF_PLD + 4 * (lane & 3));
                     // O_ext = P V_ext (5 tiles) -> Q region; extension columns become xrel = xbar - x_i
                     wv_mm<0, 5, false, XLD>(pb, Vx, lane, ks4, [&](int nt, const f32x4& acc) {
@@ -1335,7 +1353,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         if (st_qkv) head_store<FOLD>(Qx, Kx, Vx, sb + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, RA, lane, RLA, XLD);
                         pf.tick(12);
                         head_math(wave);
-                        if constexpr (KEEP2) { if (keep2) keep2_copy(Qx, Qsave, true, lane); }
+                        if constexpr (KEEP2) { if (keep2) keep2_copy(Qx, Qsave, true, lane, pcij); }
                         pf.tick(13);
                         stall_run<U_QKV, 2, E, true>(sring, acc_o, wox_fa32, sq, lane, wox_xa, wox_ext(lw, wave, lane), DFF_HEADS * 5 * 256);
                         pf.tick(14);
@@ -1963,7 +1981,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     } else {
                         if constexpr (HDMA) {
                             head_dma_wait();   // (requested before row stage E; nothing for the last layer)
-                            if constexpr (KEEP2) { if (l == m.L - 2 && l > 0 && MODE != DFF_MODE_SCORE) keep2_copy(Qsave, Qx, false, lane); }
+                            if constexpr (KEEP2) { if (l == m.L - 2 && l > 0 && MODE != DFF_MODE_SCORE) keep2_copy(Qsave, Qx, false, lane, pcij); }
                         }
                         else if (!(KEEP_LAST && l == m.L - 1)) {   // the last layer's q_ext | k | v | P are still in the head buffers
                             head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, true, lane, m12p(wave));
@@ -2017,7 +2035,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 } else {
                     if constexpr (HDMA) {
                         head_dma_wait();
-                        if constexpr (KEEP2) { if (m.L > 2 && MODE != DFF_MODE_SCORE && rows <= 10) p0_copy(false, lane); }
+                        if constexpr (KEEP2) { if (m.L > 2 && MODE != DFF_MODE_SCORE && rows <= 10) p0_copy(false, pcij); }
                     } else {
                         head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, RA, true, lane, m12p(wave));
                         head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA, XLD);
