@@ -803,17 +803,33 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 
     // per-lane constants of the MFMA C layout, re-derived inside each block (see lane_id()):
     // stash row (pad rows -> dummy row RA), dx slot, protein of column j (block-diagonal attention)
-#define DFF_LANE_CONSTS                                                      \
-    const int lane = lane_id(), quad = lane >> 4, col = lane & 15;           \
-    int srow[4], dxi[4], lro[4];                                             \
-    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                          \
-        const int row_ = quad * 4 + r;                                       \
-        srow[r] = row_ < rows ? row_ : RA;                                   \
-        lro[r] = min(row_, RLA - 1) * XLD;                               \
-        dxi[r] = (row_ < rows && col < 3) ? row_ * 4 + col : 64 + lane;      \
-    }                                                                        \
-    const int pj = col / N;                                                  \
-    (void)srow; (void)dxi; (void)pj; (void)lro;
+    // (packed once per kernel into four VGPRs -- lcP0/1: lro[0..3] as 16-bit fields, lcD: dxi[0..3] as bytes, lcS: srow[0..3]
+    // as bytes -- and unpacked with one bit-field extract each where a block uses them: re-deriving them cost ~45 integer
+    // VALU instructions at the head of every wave-private block, hoisting them raw would pin 12 registers)
+    unsigned lcP0 = 0, lcP1 = 0, lcD = 0, lcS = 0;
+    {
+        const int ln_ = tid & 63, q_ = ln_ >> 4, c_ = ln_ & 15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row_ = q_ * 4 + r;
+            const unsigned lro_ = (unsigned)(min(row_, RLA - 1) * XLD);
+            const unsigned dxi_ = (row_ < rows && c_ < 3) ? (unsigned)(row_ * 4 + c_) : 64u + (unsigned)ln_;
+            const unsigned srow_ = (unsigned)(row_ < rows ? row_ : RA);
+            if (r < 2) lcP0 |= lro_ << (16 * r); else lcP1 |= lro_ << (16 * (r - 2));
+            lcD |= dxi_ << (8 * r);
+            lcS |= srow_ << (8 * r);
+        }
+    }
+    static_assert(16 * XLD < 65536, "lro fits 16 bits");
+#define DFF_LANE_CONSTS                                                                  \
+    const int lane = lane_id(), quad = lane >> 4, col = lane & 15;                       \
+    int srow[4], dxi[4], lro[4];                                                         \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                      \
+        srow[r] = (int)((lcS >> (8 * r)) & 255u);                                        \
+        lro[r] = (int)(((r < 2 ? lcP0 : lcP1) >> (16 * (r & 1))) & 65535u);              \
+        dxi[r] = (int)((lcD >> (8 * r)) & 255u);                                         \
+    }                                                                                    \
+    (void)srow; (void)dxi; (void)lro; (void)quad; (void)col;
 #define DFF_ROW_CONSTS                                  \
     const int tq_ = tid_id();                           \
     const int rrow = tq_ / LPR, sub = tq_ % LPR;        \
