@@ -19,8 +19,11 @@
 //     du and both x-gradient terms of SURVEY.md section 8a "Derived math" fall out of the same
 //     16x16x4 MFMA tiles; no VALU contraction is left in the attention block.
 //
-// Everything dense runs on v_mfma_f32_16x16x4_f32; VALU work is softmax (in the MFMA C layout),
-// LayerNorm, gates, GELU and the integrator update.
+// The attention products run on v_mfma_f32_16x16x4_f32, the weight GEMMs of the SPW variants on v_mfma_f32_16x16x32_bf16
+// through an exact three-way bf16 split (split engine below); VALU work is softmax (in the MFMA C layout), LayerNorm,
+// gates, GELU and the integrator update.  One kernel per sampler mode (MODE template argument).
+// The FOLD variant (hidden == head dimension, <= 3 layers: chignolin) keeps everything a step produces in LDS / registers
+// in the sampling loops: no stash traffic (SmallLds<..., FOLD>, KEEPROWS).
 #include "dff_device.h"
 
 #ifndef DFF_SDR
@@ -444,6 +447,13 @@ DEVI void c_store_all(lfloat* dst, int ld, int col0, const f32x4& acc, int lane,
     for (int r = 0; r < 4; ++r) dst[min(quad * 4 + r, rmax) * ld + col0 + col] = acc[r];
 }
 
+// the same with the lane's four row offsets (floats, pad rows already collapsed) supplied
+DEVI void c_store_offs(lfloat* dst, const int (&ro4)[4], int col0, const f32x4& acc, int lane) {
+    const int col = lane & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[ro4[r] + col0 + col] = acc[r];
+}
+
 template <int KB>
 DEVI void load_afrag(f32x4 (&a)[KB], const lfloat* A, int lda, int lane) {
     const lfloat* ap = A + (lane & 15) * lda + 4 * (lane >> 4);
@@ -806,7 +816,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     // (packed once per kernel into four VGPRs -- lcP0/1: lro[0..3] as 16-bit fields, lcD: dxi[0..3] as bytes, lcS: srow[0..3]
     // as bytes -- and unpacked with one bit-field extract each where a block uses them: re-deriving them cost ~45 integer
     // VALU instructions at the head of every wave-private block, hoisting them raw would pin 12 registers)
-    unsigned lcP0 = 0, lcP1 = 0, lcD = 0, lcS = 0;
+    unsigned lcP0 = 0, lcP1 = 0, lcD = 0, lcS = 0, lcM0 = 0, lcM1 = 0;   // (lcM0/1: row offsets of the partial-sum tile, 16-bit fields)
     {
         const int ln_ = tid & 63, q_ = ln_ >> 4, c_ = ln_ & 15;
 #pragma unroll
@@ -818,18 +828,21 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             if (r < 2) lcP0 |= lro_ << (16 * r); else lcP1 |= lro_ << (16 * (r - 2));
             lcD |= dxi_ << (8 * r);
             lcS |= srow_ << (8 * r);
+            const unsigned mro_ = (unsigned)(min(row_, FOLD ? RLA - 1 : 15) * (H + 4));
+            if (r < 2) lcM0 |= mro_ << (16 * r); else lcM1 |= mro_ << (16 * (r - 2));
         }
     }
     static_assert(16 * XLD < 65536, "lro fits 16 bits");
 #define DFF_LANE_CONSTS                                                                  \
     const int lane = lane_id(), quad = lane >> 4, col = lane & 15;                       \
-    int srow[4], dxi[4], lro[4];                                                         \
+    int srow[4], dxi[4], lro[4], mro[4];                                                 \
     _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                      \
         srow[r] = (int)((lcS >> (8 * r)) & 255u);                                        \
         lro[r] = (int)(((r < 2 ? lcP0 : lcP1) >> (16 * (r & 1))) & 65535u);              \
         dxi[r] = (int)((lcD >> (8 * r)) & 255u);                                         \
+        mro[r] = (int)(((r < 2 ? lcM0 : lcM1) >> (16 * (r & 1))) & 65535u);              \
     }                                                                                    \
-    (void)srow; (void)dxi; (void)lro; (void)quad; (void)col;
+    (void)srow; (void)dxi; (void)lro; (void)quad; (void)col; (void)mro;
 #define DFF_ROW_CONSTS                                  \
     const int tq_ = tid_id();                           \
     const int rrow = tq_ / LPR, sub = tq_ % LPR;        \
@@ -1450,7 +1463,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     }
                 }
 #pragma unroll
-                for (int nt = 0; nt < E; ++nt) c_store_all(mypart, LH, 16 * nt, acc_o[nt], lane, PRMAX);
+                for (int nt = 0; nt < E; ++nt) c_store_offs(mypart, mro, 16 * nt, acc_o[nt], lane);
             }
             __syncthreads();
             pf.tick(2);
@@ -1558,7 +1571,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 }
                 static_assert((2 * NTS) % DR == 0, "ring phase");
 #pragma unroll
-                for (int nt = 0; nt < E; ++nt) c_store_all(mypart, LH, 16 * nt, acc_f[nt], lane, PRMAX);
+                for (int nt = 0; nt < E; ++nt) c_store_offs(mypart, mro, 16 * nt, acc_f[nt], lane);
             }
             __syncthreads();
             pf.tick(4);
@@ -1760,7 +1773,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     else tall_run<NTS % DR, NTS, E, -1>(ring, acc_f, [=](int kb) { return ha + 16 * kb; }, s_w1t(lw), after, lane);
                 }
 #pragma unroll
-                for (int nt = 0; nt < E; ++nt) c_store_all(mypart, LH, 16 * nt, acc_f[nt], lane, PRMAX);
+                for (int nt = 0; nt < E; ++nt) c_store_offs(mypart, mro, 16 * nt, acc_f[nt], lane);
             }
             __syncthreads();
             pf.tick(7);
@@ -1932,7 +1945,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                                 for (int r = 0; r < 4; ++r) v[r] = dq_ext(quad * 4 + r, col, acc[r]);
                             }
                         }
-                        c_store_all(Gx, XLD, 16 * nt, v, lane, RLA - 1);
+                        c_store_offs(Gx, lro, 16 * nt, v, lane);
                     });
                     // dK_ext = dS^T Q_ext -> K region (ext columns: dx term sum_i dS_ij u_i)
                     wv_mm<0, 5, true, XLD>(dsb, Qx, lane, ks4, [&](int nt, const f32x4& acc) {
@@ -2018,7 +2031,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         pf.tick(18);
                     }
 #pragma unroll
-                    for (int nt = 0; nt < E; ++nt) c_store_all(mypart, LH, 16 * nt, acc_a[nt], lane, PRMAX);
+                    for (int nt = 0; nt < E; ++nt) c_store_offs(mypart, mro, 16 * nt, acc_a[nt], lane);
                 } else if constexpr (HPW == 2) {
                     // layer 0 needs q_ext (for the dS^T u term) but not k
                     head_commit(hr, Qx, Kx, Vx, pb, false, true, lane, RLA, XLD);
