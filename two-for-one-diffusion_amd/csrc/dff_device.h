@@ -83,6 +83,9 @@ __host__ __device__ inline StashLayout dff_stash_layout(int N, int G, int H, int
 // Head-group region Rg: four (R x LQ) buffers Q_ext | K_ext | V_ext | G_ext, a head being 80
 // columns [64 | 16 extension]; Pbuf / dSbuf: per head of the group a (16MT x PL) tile array.
 // ------------------------------------------------------------------------------------------
+#ifndef DFF_KVSPLIT
+#define DFF_KVSPLIT 1
+#endif
 template <int H, int MT, int HGS, bool SPILL>
 struct LdsLayout {
     static constexpr int LH = H + 4;
@@ -94,7 +97,13 @@ struct LdsLayout {
     static constexpr int LF = FC + 4;
     static constexpr int NREG = MT < 4 ? 5 : 4;   // a fifth head-group buffer (backward: dQ_ext) where LDS allows
     static constexpr int LHS2 = (H + DFF_SPAD) / 2;   // dwords per row of a bf16 piece of the split A operand (SPW variants)
-    unsigned xst, xs, dxs, vst, cm, tn, prof, prow, dxw, m12, abuf, resbuf, Pbuf, dSbuf, Rg, asplit, total;
+    // SPW variants with the fifth buffer: dK / dV leave their producer as bf16 pieces (co_dv_dk), [h | m] in place of the
+    // fp32 row, dK's l pieces in the extension columns of the R1 / R2 rows, dV's in `lsplit` (LSV dwords per row) where the
+    // LDS has room for it (DFF_KVSPLIT, VSP)
+    static constexpr bool KVS = NREG == 5 && DFF_KVSPLIT;
+    static constexpr bool VSP = KVS && !(H == 96 && MT == 2);
+    static constexpr int LSV = 32 * HGS + 4;
+    unsigned xst, xs, dxs, vst, cm, tn, prof, prow, dxw, m12, abuf, resbuf, Pbuf, dSbuf, Rg, asplit, lsplit, junk, total;
     __host__ __device__ LdsLayout(int N, int G, bool spw = false) {
         const unsigned R = (unsigned)(G * N);
         unsigned o = 0;
@@ -119,6 +128,9 @@ struct LdsLayout {
         o += rsz + 64;  // slack: clamped A-fragment reads never leave the allocation
         asplit = o;
         if (spw) o += 3u * R * LHS2;   // [h | m | l] bf16 pieces of abuf (R x H each, row stride H + 8)
+        lsplit = o;
+        if (spw && VSP) o += R * LSV;
+        junk = o;  o += 64;                    // landing pad of the L2 warm-up loads (l2_touch)
         total = o;
     }
 };

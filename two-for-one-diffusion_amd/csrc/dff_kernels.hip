@@ -697,14 +697,63 @@ DEVI void gemm_tall_split_st(f32x4 (&acc)[NTW][MT], int LS2 /* dwords per piece 
     }
 }
 
+#ifndef DFF_QPRE
+#define DFF_QPRE 0   // (measured: even one k-block of the ring held across the barrier spills -- 571 -> 592 us on villin)
+#endif
+#ifndef DFF_L2W
+#define DFF_L2W 1
+#endif
+// L2 warm-up.  The weights of a phase are what all 32 workgroups of an XCD ask their L2 for at about the same time; they are
+// 15 MB per step (villin) against 4 MB of L2, so whoever is first pays the trip to memory and the others queue behind the
+// same lines: the convoy moves at the pace of a miss per phase.  Here each workgroup requests 1/32 of the NEXT phase's lines
+// while the current phase runs (line i by the workgroup with (blockIdx.x >> 3) % 32 == i % 32: blocks b and b + 8 share an
+// XCD under the observed placement -- used for speed only): one instruction of one wave covers 256 KiB of weights.  The
+// requests are LDS-DMA loads into a 256-byte junk pad: no register waits for the data and nothing reads it.  (Touching
+// whole regions from every workgroup was measured too: the texture unit takes a cycle per line, villin 577 -> 641 us.)
+// Region: `ntiles` pieces of `lpt` 128-byte lines, `stride` bytes apart.
+DEVI void l2_touch(unsigned junk_byte, const void* base, int ntiles, size_t stride, int lpt) {
+    const int lane = tid_now() & 63;
+    const int q = (int)(blockIdx.x >> 3) & 31;
+    const int total = ntiles * lpt;
+    for (int l0 = 0; l0 < total; l0 += 2048) {
+        const int ln = l0 + lane * 32 + q;
+        if (ln < total) {
+            const int t = ln / lpt, w = ln - t * lpt;
+            const char __attribute__((address_space(1)))* p =
+                (const char __attribute__((address_space(1)))*)base + (size_t)t * stride + (size_t)w * 128;
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, off" ::"s"(junk_byte), "v"(p) : "memory");
+        }
+    }
+}
+
 // d(LN1 out) += [dq | dk | dv] [W_q | W_k | W_v] of HGS heads on the split engine.  The operand rows live in LDS as fp32
 // (dQ_ext in head buffer regQ, dK in 1, dV in 2: there is no room for their bf16 pieces), so every wave splits the
 // fragments it reads in registers (split8): ~130 VALU next to 18 bf16 MFMAs per 32-column block, against the
 // 24 fp32 MFMAs (32 cycles each, vector port blocked) of the fp32 engine.  Ws = pack_b_split image of the 192 regular
 // rows per head; the extension rows (du) stay on the fp32 image (gemm_tall_kb, one k-step per head).
-template <int MT, int NTW, int HGS>
+// KVS / VSP: dK (and dV) are bf16 pieces already (co_dv_dk) -- their fragments are three 16-byte reads.
+// The first D k-blocks of a wave's tiles for gemm_tall_qkvT_split, requested a phase early (PRE): the ring then crosses
+// the barrier in registers and the GEMM starts on landed operands instead of on a trip to the L2.
+template <int NTW>
+DEVI void qkvT_ring_fill(u32x4 (&b)[4][NTW][3], const unsigned* __restrict__ Ws, int head0, int ntiles) {
+    constexpr int KBtot = 6 * DFF_HEADS;
+    const int tid_ = tid_now();
+    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+    const gu32x4* wp = (const gu32x4*)Ws + lane;
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int nt = wave + DFF_NWAVES * i;
+        const size_t tb = ((size_t)(nt < ntiles ? nt : 0) * KBtot + 6 * head0) * 3;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) b[d][i][p] = wp[(tb + 3 * d + p) * 64];
+    }
+    asm volatile("" ::: "memory");
+}
+template <int MT, int NTW, int HGS, bool KVS = false, bool VSP = false, int PRE = 0>
 DEVI void gemm_tall_qkvT_split(f32x4 (&acc)[NTW][MT], const lfloat* Rg, int regQ, int RN, const unsigned* __restrict__ Ws,
-                               int head0, int ntiles) {
+                               int head0, int ntiles, const lu32* lsp, u32x4 (&b)[4][NTW][3]) {
     constexpr int LQ = 80 * HGS + 4, NKB = 6 * HGS, D = 4, KBtot = 6 * DFF_HEADS;
     const int tid_ = tid_now();
     const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
@@ -722,25 +771,60 @@ DEVI void gemm_tall_qkvT_split(f32x4 (&acc)[NTW][MT], const lfloat* Rg, int regQ
         tbase[i] = ((size_t)(tok[i] ? nt : 0) * KBtot + 6 * head0) * 3;
     }
     if (!tok[0]) return;
-    u32x4 b[D][NTW][3];
+    {
 #pragma unroll
-    for (int d = 0; d < D; ++d)
+        for (int d = PRE; d < D; ++d)
 #pragma unroll
-        for (int i = 0; i < NTW; ++i)
+            for (int i = 0; i < NTW; ++i)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) b[d][i][p] = wp[(tbase[i] + 3 * d + p) * 64];
+#ifdef DFF_TX_NOB
+                for (int p = 0; p < 3; ++p) b[d][i][p] = d == 0 ? wp[(tbase[i] + 3 * d + p) * 64] : b[0][i][p];
+#else
+                for (int p = 0; p < 3; ++p) b[d][i][p] = wp[(tbase[i] + 3 * d + p) * 64];
+#endif
+    }
     __builtin_amdgcn_sched_barrier(0);
+#ifdef DFF_TX_NOLDS
+    u32x4 ah0[MT], am0[MT], al0[MT];
+#endif
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
         const int d = kb % D;
         const int hh = kb / 6, part = (kb % 6) / 2, half = kb % 2;
         const int aoff = (part == 0 ? regQ : part) * RN * LQ + hh * 80 + 32 * half;
         u32x4 ah[MT], am[MT], al[MT];
+#ifdef DFF_TX_NOLDS
+        static_assert(HGS == 1, "");
+#endif
+        if (KVS && (part == 1 || (VSP && part == 2))) {
+            constexpr int LSV = 32 * HGS + 4;
+            const lu32* const hb = (const lu32*)(Rg + part * RN * LQ + hh * 80) + 16 * half;
+            const lu32* const lb = part == 1 ? (const lu32*)(Rg + (1 + half) * RN * LQ + hh * 80 + 64) : lsp + hh * 32 + 16 * half;
+            const int lmul = part == 1 ? LQ : LSV;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const lfloat* ap = Rg + aoff + rowoff[mt];
-            const f32x4 x0 = *(const lf32x4*)ap, x1 = *(const lf32x4*)(ap + 4);
-            split8(x0, x1, ah[mt], am[mt], al[mt]);
+            for (int mt = 0; mt < MT; ++mt) {
+#ifdef DFF_TX_NOLDS
+                if (kb != 2) { ah[mt] = ah0[mt]; am[mt] = am0[mt]; al[mt] = al0[mt]; continue; }
+#endif
+                const int ro = rowoff[mt] - 4 * kg;   // row * LQ + 4 kg
+                ah[mt] = *(const lu32x4*)(hb + ro);
+                am[mt] = *(const lu32x4*)(hb + 32 + ro);
+                al[mt] = *(const lu32x4*)(lb + min(mt * 16 + mm, RN - 1) * lmul + 4 * kg);
+#ifdef DFF_TX_NOLDS
+                ah0[mt] = ah[mt]; am0[mt] = am[mt]; al0[mt] = al[mt];
+#endif
+            }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const lfloat* ap = Rg + aoff + rowoff[mt];
+                const f32x4 x0 = *(const lf32x4*)ap, x1 = *(const lf32x4*)(ap + 4);
+#ifdef DFF_TX_NOQ
+                ah[mt] = __builtin_bit_cast(u32x4, x0); am[mt] = __builtin_bit_cast(u32x4, x1); al[mt] = ah[mt];
+#else
+                split8(x0, x1, ah[mt], am[mt], al[mt]);
+#endif
+            }
         }
 #pragma unroll
         for (int i = 0; i < NTW; ++i)
@@ -758,6 +842,7 @@ DEVI void gemm_tall_qkvT_split(f32x4 (&acc)[NTW][MT], const lfloat* Rg, int regQ
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][0], ah[mt], acc[i][mt]);
             }
+#ifndef DFF_TX_NOB
         if (kb + D < NKB) {
 #pragma unroll
             for (int i = 0; i < NTW; ++i)
@@ -765,6 +850,7 @@ DEVI void gemm_tall_qkvT_split(f32x4 (&acc)[NTW][MT], const lfloat* Rg, int regQ
                 for (int p = 0; p < 3; ++p) b[d][i][p] = wp[(tbase[i] + 3 * (kb + D) + p) * 64];
             __builtin_amdgcn_sched_barrier(0);
         }
+#endif
     }
 }
 
@@ -1381,8 +1467,11 @@ DEVI f32x4 co_mm(const lfloat* T, int mo, const lfloat* B, int ldb, int RN, int 
 // the same for the five 16-column tiles of a head at once (B points at the head's column 0): the A
 // operand is read once and five independent accumulator chains keep the MFMA pipe busy while the
 // next operands arrive.
-template <int MT, bool TRANS>
-DEVI void co_mm5(f32x4 (&c)[5], const lfloat* T, int mo, const lfloat* B, int ldb, int RN, int rows, int lane) {
+// hook(step), step = 0 .. 4 MT - 1, runs once per k-step: a place to spread another phase's weight requests over this one's
+// MFMAs (a burst of them stalls the wave at issue while the CU's one texture-address unit takes 16 cycles per KiB).
+struct NoStepHook { DEVI void operator()(int) const {} };
+template <int MT, bool TRANS, class SH = NoStepHook>
+DEVI void co_mm5(f32x4 (&c)[5], const lfloat* T, int mo, const lfloat* B, int ldb, int RN, int rows, int lane, SH hook = SH()) {
     constexpr int PL = 16 * MT + 4;
     const int kk = lane >> 4, mm = lane & 15;
 #pragma unroll
@@ -1396,12 +1485,14 @@ DEVI void co_mm5(f32x4 (&c)[5], const lfloat* T, int mo, const lfloat* B, int ld
             as[s] = TRANS ? T[k * PL + 16 * mo + mm] : T[(16 * mo + mm) * PL + k];
         }
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < 4; ++s) {
             if (s == 0 || 16 * kt + 4 * s < rows) {
                 const lfloat* bp = B + min(16 * kt + 4 * s + kk, RN - 1) * ldb + mm;
 #pragma unroll
                 for (int nt = 0; nt < 5; ++nt) c[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[s], bp[16 * nt], c[nt], 0, 0, 0);
             }
+            hook(4 * kt + s);
+        }
     }
 }
 
@@ -1413,6 +1504,7 @@ DEVI void co_mm5(f32x4 (&c)[5], const lfloat* T, int mo, const lfloat* B, int ld
 // by the wave that owns the row tile, right before it uses them.
 struct CoGeo {
     lfloat *Rg, *Pbuf, *dSbuf, *xs, *dxw;   // dxw: this wave's partial dE/dx
+    lu32* lsp;                              // l pieces of dV (LdsLayout::lsplit)
     lfloat* m12;                            // GEN: [m1 | m2] rows of the head group (backward)
     const int __attribute__((address_space(3))) * prow;   // protein index of each row, -1 for pad rows
     int N, RN, rows;
@@ -1730,8 +1822,43 @@ DEVI void co_ds(const CoGeo& g) {
 // backward, with the fifth buffer: dV_ext = P^T G_ext (-> R2) and dK_ext = dS^T Q_ext (-> R1) in ONE phase
 // (nothing reads R1 / R2 any more); their extension tiles are dE/dx_j -> this wave's dxw.
 // EXT_ONLY (layer 0: nothing upstream of q, k, v depends on x): only those extension tiles.
-template <int MT, int HGS, bool EXT_ONLY, bool GEN>
-DEVI void co_dv_dk(const CoGeo& g) {
+// KVS (SPW variants): the 64 regular columns of a dK / dV row leave as the bf16 pieces the back-projection multiplies
+// (gemm_tall_qkvT_split): split ONCE here instead of by each of the eight waves that read them.  [h | m] take the place of
+// the fp32 row (2 x 128 B); the l pieces of dK go to the extension columns of the same head in the R1 row (columns 0..31)
+// and the R2 row (32..63) -- K_ext's / V_ext's x columns are dead by now and rewritten with the next head (co_fill_x) --
+// and those of dV to g.lsp (VSP; otherwise dV stays fp32).
+// requests of qkvT_ring_fill, 12 NTW of them, dealt out over NS steps
+template <int NTW, int NS, int PD = 4>
+struct QkvTRingHook {
+    u32x4 (&b)[4][NTW][3];
+    const gu32x4* wp;
+    size_t tb[NTW];
+    DEVI QkvTRingHook(u32x4 (&b_)[4][NTW][3], const unsigned* __restrict__ Ws, int head0, int ntiles) : b(b_) {
+        const int tid_ = tid_now();
+        const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+        wp = (const gu32x4*)Ws + lane;
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            const int nt = wave + DFF_NWAVES * i;
+            tb[i] = ((size_t)(nt < ntiles ? nt : 0) * (6 * DFF_HEADS) + 6 * head0) * 3;
+        }
+    }
+    DEVI void operator()(int step) const {
+        constexpr int NL = 3 * PD * NTW;
+#pragma unroll
+        for (int q = 0; q < NL; ++q)
+            if (q * NS / NL == step) {   // load q belongs to step floor(q NS / NL)
+                const int d = q / (3 * NTW), i = (q / 3) % NTW, p = q % 3;
+                b[d][i][p] = wp[(tb[i] + 3 * d + p) * 64];
+            }
+    }
+    DEVI void all() const {
+#pragma unroll
+        for (int st = 0; st < NS; ++st) (*this)(st);
+    }
+};
+template <int MT, int HGS, bool EXT_ONLY, bool GEN, bool KVS = false, bool VSP = false, class SH = NoStepHook>
+DEVI void co_dv_dk(const CoGeo& g, SH hook = SH()) {
     const int tid_ = tid_now(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     constexpr int LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL;
     const int quad = lane >> 4, col = lane & 15;
@@ -1762,14 +1889,34 @@ DEVI void co_dv_dk(const CoGeo& g) {
             const int hh = r0 / MT, mo = r0 - hh * MT;
             const lfloat* T = (which ? g.dSbuf : g.Pbuf) + hh * PT;
             f32x4 acc[5];
-            co_mm5<MT, true>(acc, T, mo, g.Rg + (which ? 0 : 3) * g.RN * LQ + hh * 80, LQ, g.RN, g.rows, lane);
+            co_mm5<MT, true>(acc, T, mo, g.Rg + (which ? 0 : 3) * g.RN * LQ + hh * 80, LQ, g.RN, g.rows, lane, hook);
             lfloat* const dst = g.Rg + (which ? 1 : 2) * g.RN * LQ + hh * 80 + col;
+            lu16* const hm = (lu16*)(g.Rg + (which ? 1 : 2) * g.RN * LQ + hh * 80) + col;
+            constexpr int LSV = 32 * HGS + 4;
+            // l pieces: columns 0..31 from lb0, 32..63 from lb1, row stride ls (16-bit units)
+            lu16* const lb0 = (which ? (lu16*)(g.Rg + 1 * g.RN * LQ + hh * 80 + 64) : (lu16*)(g.lsp + hh * 32)) + col;
+            lu16* const lb1 = (which ? (lu16*)(g.Rg + 2 * g.RN * LQ + hh * 80 + 64) : (lu16*)(g.lsp + hh * 32 + 16)) + col;
+            const int ls = which ? 2 * LQ : 2 * LSV;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * mo + 4 * quad + r;
                 if (row < g.rows) {
+                    if (KVS && (VSP || which)) {
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) dst[row * LQ + 16 * nt] = acc[nt][r];
+                        for (int nt = 0; nt < 4; ++nt) {
+                            const float v = acc[nt][r];
+                            const unsigned uh = __float_as_uint(v) & 0xffff0000u;
+                            const float r1 = v - __uint_as_float(uh);
+                            const unsigned um = __float_as_uint(r1) & 0xffff0000u;
+                            const float r2 = r1 - __uint_as_float(um);
+                            hm[row * 2 * LQ + 16 * nt] = (unsigned short)(uh >> 16);
+                            hm[row * 2 * LQ + 64 + 16 * nt] = (unsigned short)(um >> 16);
+                            (nt < 2 ? lb0 : lb1)[row * ls + 16 * (nt & 1)] = (unsigned short)(__float_as_uint(r2) >> 16);
+                        }
+                    } else {
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) dst[row * LQ + 16 * nt] = acc[nt][r];
+                    }
                 }
                 const float e = GEN ? co_dx_ext(g, row, col, acc[4][r]) : acc[4][r];
                 if (row < g.rows && col < 3) g.dxw[row * 4 + col] += e;
@@ -1929,6 +2076,26 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
     c.NP = c.N <= 8 ? 8 : c.N <= 16 ? 16 : c.N <= 32 ? 32 : 64;
     const LL ll(c.N, c.G, SPW);
     lu32* const asplit = (lu32*)(smem + ll.asplit);
+    const unsigned junk_b = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lfloat*)((lfloat*)smem + ll.junk));
+    // SPW variants: the weights of the NEXT GEMM phase are pulled into the XCD's L2 while the current phase runs (l2_touch);
+    // `ntiles` pieces of `bytes` each, `stride` bytes apart, dealt out over the waves.  KB3 = bytes of one (tile, k-block)
+    // unit of a split image.
+    constexpr size_t KB3 = 3072;
+    const int wave_l2 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    // The last wave asks.  When matters: vmcnt retires in order, so the wave's next wait for a load of its own also waits
+    // for the (missing) warm-up lines -- in the attention phases it asks after its own work, in the slack the row-tile waves
+    // leave it before the barrier.
+    constexpr int l2wave = DFF_NWAVES - 1;
+    auto l2w = [&](const unsigned* base, size_t off, int ntiles, size_t stride, int bytes) {
+        if constexpr (SPW && DFF_L2W)
+            if (wave_l2 == l2wave) l2_touch(junk_b, (const char*)base + off, ntiles, stride, bytes >> 7);
+    };
+    constexpr size_t QKV_HG = (size_t)HGS * 13 * (H / 32) * KB3;    // Wqkvx_s: a head group's tiles, contiguous
+    constexpr size_t GX_HG = (size_t)HGS * 5 * (H / 32) * KB3;      // WoxT_s: likewise
+    constexpr size_t FFW_CH = (size_t)(LL::FC / 16) * (H / 32) * KB3;   // W1_s / W2T_s: a chunk's tiles, contiguous
+    auto l2w_ffn_tall = [&](const unsigned* w, int ch) {           // W2_s / W1T_s: FC / 32 k-blocks of every H-tile
+        l2w(w, (size_t)ch * (LL::FC / 32) * KB3, H / 16, (size_t)(LL::F / 32) * KB3, (LL::FC / 32) * (int)KB3);
+    };
     c.xst = smem + ll.xst; c.xs = smem + ll.xs; c.dxs = smem + ll.dxs; c.vst = smem + ll.vst;
     c.cm = smem + ll.cm; c.tn = smem + ll.tn;
     c.abuf = smem + ll.abuf;
@@ -2015,6 +2182,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
         geo.Rg = sm + ll.Rg; geo.Pbuf = sm + ll.Pbuf; geo.dSbuf = sm + ll.dSbuf; geo.xs = sm + ll.xs;
         geo.dxw = sm + ll.dxw + wave_ * RN * 4;
         geo.m12 = sm + ll.m12;
+        geo.lsp = (lu32*)(sm + ll.lsplit);
         geo.prow = (const int __attribute__((address_space(3)))*)(sm + ll.prow);
         geo.N = N; geo.RN = RN; geo.rows = rows;
     }
@@ -2111,6 +2279,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     c.resbuf[row * LH + col] = ld_nt(c.l0 + c.sl.nodes_in + it);
                 }
             } else {
+                l2w(lw.Wqkvx_s, hg_lo * QKV_HG, 8, QKV_HG / 8, (int)(QKV_HG / 8));
                 row_ln1<H, LPG>(c, lw, l);
                 wg_sync<SPILL>();
             }
@@ -2174,6 +2343,11 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                             [](int, float (&)[1]) {},
                             [&](int, int mt, const f32x4& acc, const float (&)[1], bool, int i) { held[i][mt] = acc; });
                     }
+                    // (the GEMM waves are done before the softmax waves: the last one asks for the next phases' weights
+                    // in the slack, and its next wait for a load of its own is a barrier away)
+                    l2w(lw.Wox_s, (size_t)hg * HGS * 2 * KB3, NT_H, 2 * DFF_HEADS * KB3, 2 * HGS * (int)KB3);
+                    if (hg + 2 < hg_hi) l2w(lw.Wqkvx_s, (hg + 2) * QKV_HG, 8, QKV_HG / 8, (int)(QKV_HG / 8));
+                    else if (!more) l2w(lw.W1_s, ch_lo * FFW_CH, 8, FFW_CH / 8, (int)(FFW_CH / 8));
                     wg_sync<SPILL>();
                     pf.tick(4);
                     float bias4[CNTH][4];
@@ -2229,6 +2403,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 co_fill_x<HGS, GEN>(geo);
                 wg_sync<SPILL>();
                 pf.tick(3);
+                l2w(lw.Wox_s, (size_t)hg * HGS * 2 * KB3, NT_H, 2 * DFF_HEADS * KB3, 2 * HGS * (int)KB3);
                 if constexpr (GEN || MT == 4)   // MT = 4 (protein G): measured 1.3 % slower transposed (16 probabilities per lane)
                     co_softmax_pv<MT, HGS, GEN, SPW>(geo, sPl + (size_t)hg * HGS * RN * c.sl.PS,
                                                      (gfloat*)sb + c.sl.m12 + (size_t)hg * HGS * RN * 4, oxt);
@@ -2239,6 +2414,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 pf.tick(4);
                 // attn_out += o_ext [W_o ; W_oc]   (K = 80 per head)
                 if constexpr (SPW) {   // 64 regular rows per head on the split path, the extension block on the fp32 one
+                    if (hg + 1 < hg_hi) { if (!cached) l2w(lw.Wqkvx_s, (hg + 1) * QKV_HG, 8, QKV_HG / 8, (int)(QKV_HG / 8)); }
+                    else l2w(lw.W1_s, ch_lo * FFW_CH, 8, FFW_CH / 8, (int)(FFW_CH / 8));
                     wo_gemm(hg);
                 } else
                 gemm_tall_kb_st<MT, NTW, 5, 5 * HGS>(acc_o,
@@ -2281,6 +2458,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                                 else *(lf32x4*)(hl + row * LF + cl) = gv;
                             }
                         };
+                    l2w_ffn_tall(lw.W2_s, ch);
                     if constexpr (SPW)
                         gemm_wide_split_st<MT, H / 32, FC / 16, 4>(asplit, RN, RN, lw.W1_s, ch * (FC / 16), w1_pre, w1_epi);
                     else
@@ -2288,6 +2466,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 }
                 wg_sync<SPILL>();
                 pf.tick(8);
+                if (ch + 1 < ch_hi) l2w(lw.W1_s, (ch + 1) * FFW_CH, 8, FFW_CH / 8, (int)(FFW_CH / 8));
+                else if (l == m.L - 1 && m.conservative) l2w(lw.W2T_s, ch_lo * FFW_CH, 8, FFW_CH / 8, (int)(FFW_CH / 8));
                 if constexpr (SPW)
                     gemm_tall_split_st<MT, NTW, FC / 32>(acc_f, (FC + DFF_SPAD) / 2, (const lu32*)geo.Rg, RN, RN, lw.W2_s, F / 32, ch * (FC / 32), NT_H);
                 else
@@ -2309,6 +2489,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
         for (int l = m.conservative ? m.L - 1 : -1; l >= 0; --l) {
             const DffLayerDev& lw = m.layer[l];
             const float* sb = c.stash + (size_t)l * c.sl.layer_stride;
+            if (l < m.L - 1) l2w(lw.W2T_s, ch_lo * FFW_CH, 8, FFW_CH / 8, (int)(FFW_CH / 8));
             rowb_gate2<H, LPG>(c, lw, l);
             wg_sync<SPILL>();
             if constexpr (SPW) { split_rows<H>(abufL, asplit, RN); wg_sync<SPILL>(); }
@@ -2335,6 +2516,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                                 else *(lf32x4*)(hl + row * LF + cl) = v;
                             }
                         };
+                    l2w_ffn_tall(lw.W1T_s, ch);
                     if constexpr (SPW)
                         gemm_wide_split_st<MT, H / 32, FC / 16, 4 * MT>(asplit, RN, RN, lw.W2T_s, ch * (FC / 16), w2t_pre, w2t_epi);
                     else
@@ -2342,6 +2524,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 }
                 wg_sync<SPILL>();
                 pf.tick(12);
+                if (ch + 1 < ch_hi) l2w(lw.W2T_s, (ch + 1) * FFW_CH, 8, FFW_CH / 8, (int)(FFW_CH / 8));
+                else l2w(lw.WoxT_s, hg_lo * GX_HG, 8, GX_HG / 8, (int)(GX_HG / 8));
                 if constexpr (SPW)
                     gemm_tall_split_st<MT, NTW, FC / 32>(acc_f, (FC + DFF_SPAD) / 2, (const lu32*)geo.Rg, RN, RN, lw.W1T_s, F / 32, ch * (FC / 32), NT_H);
                 else
@@ -2414,13 +2598,25 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     } else if (more) {
                         gx_units_hold<MT, H / 32, NTG, NI, NWH>(asplit, RN, RN, lw.WoxT_s, (hg + 1) * NTG, gheld);
                     }
+                    if (deep) l2w(lw.WqkvxT_s, (size_t)hg * HGS * 6 * KB3, NT_H, 6 * DFF_HEADS * KB3, 6 * HGS * (int)KB3);
+                    if (hg + 2 < hg_hi) l2w(lw.WoxT_s, (hg + 2) * GX_HG, 8, GX_HG / 8, (int)(GX_HG / 8));
+                    else if (!more && l > 0) l2w(m.layer[l - 1].W2T_s, ch_lo * FFW_CH, 8, FFW_CH / 8, (int)(FFW_CH / 8));
                     wg_sync<SPILL>();
                     pf.tick(17);
                     if (deep) {
-                        co_dv_dk<MT, HGS, false, GEN>(geo);
+                        u32x4 bq[4][NTW][3];
+                        constexpr int QPRE = DFF_QPRE;   // k-blocks of the ring requested a phase early
+                        if constexpr (QPRE > 0) {
+                            // (one item per wave at most: waves without one have nothing to hide the requests behind, and nothing to delay)
+                            static_assert(2 * HGS * MT <= DFF_NWAVES, "");
+                            QkvTRingHook<NTW, 4 * MT, QPRE> rh(bq, lw.WqkvxT_s, hg * HGS, NT_H);
+                            if (wave_ >= 2 * HGS * MT) rh.all();
+                            co_dv_dk<MT, HGS, false, GEN, LL::KVS, LL::VSP>(geo, rh);
+                        } else
+                        co_dv_dk<MT, HGS, false, GEN, LL::KVS, LL::VSP>(geo);
                         wg_sync<SPILL>();
                         pf.tick(18);
-                        gemm_tall_qkvT_split<MT, NTW, HGS>(acc_a, geo.Rg, 4, RN, lw.WqkvxT_s, hg * HGS, NT_H);
+                        gemm_tall_qkvT_split<MT, NTW, HGS, LL::KVS, LL::VSP, QPRE>(acc_a, geo.Rg, 4, RN, lw.WqkvxT_s, hg * HGS, NT_H, geo.lsp, bq);
                         gemm_tall_kb<MT, NTW, 13>(acc_a, HGS,
                             [=](int i, int& aoff, int& wkb) { aoff = 4 * RN * LQ + i * 80 + 64; wkb = (hg * HGS + i) * 13 + 4; },
                             geo.Rg, LQ, RN, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
@@ -2462,6 +2658,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                                 }
                             }
                         };
+                    if (l > 0 || full0) l2w(lw.WqkvxT_s, (size_t)hg * HGS * 6 * KB3, NT_H, 6 * DFF_HEADS * KB3, 6 * HGS * (int)KB3);
                     if constexpr (SPW)
                         gemm_wide_units_split<MT, H / 32, HGS * 5>(asplit, RN, RN, lw.WoxT_s, hg * HGS * 5, gx_epi);
                     else
@@ -2485,7 +2682,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     wg_sync<SPILL>();
                     pf.tick(17);
                     if (FIVE) {
-                        co_dv_dk<MT, HGS, false, GEN>(geo);
+                        co_dv_dk<MT, HGS, false, GEN, SPW && LL::KVS, SPW && LL::VSP>(geo);
                     } else {
                         co_dqkv<MT, HGS, 0, GEN>(geo);
                         wg_sync<SPILL>();
@@ -2497,7 +2694,10 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     pf.tick(18);
                     // d(LN1 out) += [dq|du] W_qu + dk W_k + dv W_v   (K order per head [q64|u16|k64|v64])
                     if constexpr (SPW) {
-                        gemm_tall_qkvT_split<MT, NTW, HGS>(acc_a, geo.Rg, FIVE ? 4 : 3, RN, lw.WqkvxT_s, hg * HGS, NT_H);
+                        if (hg + 1 < hg_hi) l2w(lw.WoxT_s, (hg + 1) * GX_HG, 8, GX_HG / 8, (int)(GX_HG / 8));
+                        else if (l > 0) l2w(m.layer[l - 1].W2T_s, ch_lo * FFW_CH, 8, FFW_CH / 8, (int)(FFW_CH / 8));
+                        u32x4 bq[4][NTW][3];
+                        gemm_tall_qkvT_split<MT, NTW, HGS, LL::KVS, LL::VSP>(acc_a, geo.Rg, FIVE ? 4 : 3, RN, lw.WqkvxT_s, hg * HGS, NT_H, geo.lsp, bq);
                         gemm_tall_kb<MT, NTW, 13>(acc_a, HGS,
                             [=](int i, int& aoff, int& wkb) {
                                 aoff = (FIVE ? 4 : 3) * RN * LQ + i * 80 + 64;
