@@ -25,6 +25,7 @@
 // their transposes for the VJP) run on v_mfma_f32_16x16x4_f32 (exact fp32 == fmaf chain);
 // softmax / LayerNorm / GELU / gates / the N x N contractions run on the VALU out of LDS.
 #include "dff_device.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------
 // MFMA GEMM stages.  A (rows x K) lives in LDS with leading dimension lda (multiple of 4);
@@ -632,9 +633,26 @@ DEVI void gemm_tall_split(f32x4 (&acc)[NTW][MT], int nkb, int LS2 /* dwords per 
 }
 
 // The same with a compile-time k-block count: loop-free, so that the ring (D k-blocks ahead) is waited for exactly.
-template <int MT, int NTW, int NKB>
-DEVI void gemm_tall_split_st(f32x4 (&acc)[NTW][MT], int LS2 /* dwords per piece row */, const lu32* as, int R, int rowsA,
-                             const unsigned* __restrict__ Wp, int KBtot, int kb0, int ntiles) {
+// (PRE: the ring's first D k-blocks were requested by tall_ring_fill before the barrier in front of this GEMM)
+template <int NTW, int D>
+DEVI void tall_ring_fill(u32x4 (&b)[D][NTW][3], const unsigned* __restrict__ Wp, int KBtot, int kb0, int ntiles) {
+    const int tid_ = tid_now();
+    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+    const gu32x4* wp = (const gu32x4*)Wp + lane;
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int nt = wave + DFF_NWAVES * i;
+        const size_t tb = ((size_t)(nt < ntiles ? nt : 0) * KBtot + kb0) * 3;
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) b[d][i][p] = wp[(tb + 3 * d + p) * 64];
+    }
+    asm volatile("" ::: "memory");
+}
+template <int MT, int NTW, int NKB, bool PRE = false>
+DEVI void gemm_tall_split_st_b(f32x4 (&acc)[NTW][MT], int LS2 /* dwords per piece row */, const lu32* as, int R, int rowsA,
+                             const unsigned* __restrict__ Wp, int KBtot, int kb0, int ntiles, u32x4 (&b)[NKB < 4 ? NKB : 4][NTW][3]) {
     const int tid_ = tid_now();
     constexpr int D = NKB < 4 ? NKB : 4;
     const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
@@ -652,13 +670,14 @@ DEVI void gemm_tall_split_st(f32x4 (&acc)[NTW][MT], int LS2 /* dwords per piece 
         tbase[i] = ((size_t)(tok[i] ? nt : 0) * KBtot + kb0) * 3;
     }
     if (!tok[0]) return;
-    u32x4 b[D][NTW][3];
+    if (!PRE) {
 #pragma unroll
-    for (int d = 0; d < D; ++d)
+        for (int d = 0; d < D; ++d)
 #pragma unroll
-        for (int i = 0; i < NTW; ++i)
+            for (int i = 0; i < NTW; ++i)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) b[d][i][p] = wp[(tbase[i] + 3 * d + p) * 64];
+                for (int p = 0; p < 3; ++p) b[d][i][p] = wp[(tbase[i] + 3 * d + p) * 64];
+    }
     __builtin_amdgcn_sched_barrier(0);   // issue the ring's loads here (see gemm_wide_split_st)
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
@@ -697,6 +716,16 @@ DEVI void gemm_tall_split_st(f32x4 (&acc)[NTW][MT], int LS2 /* dwords per piece 
     }
 }
 
+template <int MT, int NTW, int NKB>
+DEVI void gemm_tall_split_st(f32x4 (&acc)[NTW][MT], int LS2, const lu32* as, int R, int rowsA,
+                             const unsigned* __restrict__ Wp, int KBtot, int kb0, int ntiles) {
+    u32x4 b[NKB < 4 ? NKB : 4][NTW][3];
+    gemm_tall_split_st_b<MT, NTW, NKB>(acc, LS2, as, R, rowsA, Wp, KBtot, kb0, ntiles, b);
+}
+
+#ifndef DFF_WOPRE
+#define DFF_WOPRE 1
+#endif
 #ifndef DFF_QPRE
 #define DFF_QPRE 0   // (measured: even one k-block of the ring held across the barrier spills -- 571 -> 592 us on villin)
 #endif
@@ -2077,25 +2106,33 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
     const LL ll(c.N, c.G, SPW);
     lu32* const asplit = (lu32*)(smem + ll.asplit);
     const unsigned junk_b = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lfloat*)((lfloat*)smem + ll.junk));
-    // SPW variants: the weights of the NEXT GEMM phase are pulled into the XCD's L2 while the current phase runs (l2_touch);
-    // `ntiles` pieces of `bytes` each, `stride` bytes apart, dealt out over the waves.  KB3 = bytes of one (tile, k-block)
-    // unit of a split image.
-    constexpr size_t KB3 = 3072;
-    const int wave_l2 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    // The weights of the NEXT GEMM phase are pulled into the XCD's L2 while the current phase runs (l2_touch).  One lambda per
+    // weight image; the fp32 images are [tile][k-block of 16] x 1 KiB, the split ones [tile][k-block of 32] x 3 KiB.
     // The last wave asks.  When matters: vmcnt retires in order, so the wave's next wait for a load of its own also waits
-    // for the (missing) warm-up lines -- in the attention phases it asks after its own work, in the slack the row-tile waves
-    // leave it before the barrier.
-    constexpr int l2wave = DFF_NWAVES - 1;
-    auto l2w = [&](const unsigned* base, size_t off, int ntiles, size_t stride, int bytes) {
-        if constexpr (SPW && DFF_L2W)
-            if (wave_l2 == l2wave) l2_touch(junk_b, (const char*)base + off, ntiles, stride, bytes >> 7);
+    // for the (missing) warm-up lines -- in the pipelined attention phases it asks after its own work, in the slack the
+    // row-tile waves leave it before the barrier.
+    constexpr size_t UB = SPW ? 3072 : 1024;          // bytes of one (tile, k-block) unit
+    constexpr int KQ = SPW ? 32 : 16;                 // rows of a k-block
+    const int wave_l2 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    auto l2w = [&](const void* base, size_t off, int ntiles, size_t stride, size_t bytes) {
+        if constexpr (SPW && DFF_L2W)   // (the fp32 variants are MFMA-bound: protein G measured 578.8 with, 578.6 us without)
+            if (wave_l2 == DFF_NWAVES - 1) l2_touch(junk_b, (const char*)base + off, ntiles, stride, (int)(bytes >> 7));
     };
-    constexpr size_t QKV_HG = (size_t)HGS * 13 * (H / 32) * KB3;    // Wqkvx_s: a head group's tiles, contiguous
-    constexpr size_t GX_HG = (size_t)HGS * 5 * (H / 32) * KB3;      // WoxT_s: likewise
-    constexpr size_t FFW_CH = (size_t)(LL::FC / 16) * (H / 32) * KB3;   // W1_s / W2T_s: a chunk's tiles, contiguous
-    auto l2w_ffn_tall = [&](const unsigned* w, int ch) {           // W2_s / W1T_s: FC / 32 k-blocks of every H-tile
-        l2w(w, (size_t)ch * (LL::FC / 32) * KB3, H / 16, (size_t)(LL::F / 32) * KB3, (LL::FC / 32) * (int)KB3);
-    };
+    auto l2w_flat = [&](const void* base, size_t off, size_t bytes) { l2w(base, off, 8, bytes / 8, bytes / 8); };
+    constexpr size_t QKV_HG = (size_t)HGS * 13 * (H / KQ) * UB;     // Wqkvx: a head group's 13 HGS tiles, contiguous
+    constexpr size_t GX_HG = (size_t)HGS * 5 * (H / KQ) * UB;       // WoxT: its 5 HGS tiles
+    constexpr size_t FFW_CH = (size_t)(LL::FC / 16) * (H / KQ) * UB;   // W1 / W2T: a chunk's tiles
+    auto l2_wqkv = [&](const DffLayerDev& w, int hg) { l2w_flat(SPW ? (const void*)w.Wqkvx_s : (const void*)w.Wqkvx_p, hg * QKV_HG, QKV_HG); };
+    auto l2_wgx = [&](const DffLayerDev& w, int hg) { l2w_flat(SPW ? (const void*)w.WoxT_s : (const void*)w.WoxT_p, hg * GX_HG, GX_HG); };
+    auto l2_w1 = [&](const DffLayerDev& w, int ch) { l2w_flat(SPW ? (const void*)w.W1_s : (const void*)w.W1_p, ch * FFW_CH, FFW_CH); };
+    auto l2_w2t = [&](const DffLayerDev& w, int ch) { l2w_flat(SPW ? (const void*)w.W2T_s : (const void*)w.W2T_p, ch * FFW_CH, FFW_CH); };
+    // "tall" images (Nout = H): a few k-blocks of every one of the H / 16 tiles
+    auto l2_tall = [&](const void* base, int kb0, int nkb, int kbtot) { l2w(base, (size_t)kb0 * UB, H / 16, (size_t)kbtot * UB, (size_t)nkb * UB); };
+    auto l2_w2 = [&](const DffLayerDev& w, int ch) { l2_tall(SPW ? (const void*)w.W2_s : (const void*)w.W2_p, ch * (LL::FC / KQ), LL::FC / KQ, LL::F / KQ); };
+    auto l2_w1t = [&](const DffLayerDev& w, int ch) { l2_tall(SPW ? (const void*)w.W1T_s : (const void*)w.W1T_p, ch * (LL::FC / KQ), LL::FC / KQ, LL::F / KQ); };
+    constexpr int WO_KB = SPW ? 2 : 5, WQT_KB = SPW ? 6 : 13;       // k-blocks per head (split: the 64 regular rows only)
+    auto l2_wo = [&](const DffLayerDev& w, int hg) { l2_tall(SPW ? (const void*)w.Wox_s : (const void*)w.Wox_p, hg * HGS * WO_KB, HGS * WO_KB, DFF_HEADS * WO_KB); };
+    auto l2_wqkvT = [&](const DffLayerDev& w, int hg) { l2_tall(SPW ? (const void*)w.WqkvxT_s : (const void*)w.WqkvxT_p, hg * HGS * WQT_KB, HGS * WQT_KB, DFF_HEADS * WQT_KB); };
     c.xst = smem + ll.xst; c.xs = smem + ll.xs; c.dxs = smem + ll.dxs; c.vst = smem + ll.vst;
     c.cm = smem + ll.cm; c.tn = smem + ll.tn;
     c.abuf = smem + ll.abuf;
@@ -2279,7 +2316,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     c.resbuf[row * LH + col] = ld_nt(c.l0 + c.sl.nodes_in + it);
                 }
             } else {
-                l2w(lw.Wqkvx_s, hg_lo * QKV_HG, 8, QKV_HG / 8, (int)(QKV_HG / 8));
+                l2_wqkv(lw, hg_lo);
                 row_ln1<H, LPG>(c, lw, l);
                 wg_sync<SPILL>();
             }
@@ -2296,9 +2333,10 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             // (idle in the forward pass) so that R0 is free by then.
             constexpr bool PIPE = SPW && !GEN && HGS == 1 && MT < DFF_NWAVES;   // HGS = 2: the parked tiles (7 x MT) do not fit the register file
             lfloat* const oxt = PIPE ? geo.dSbuf : nullptr;
-            auto wo_gemm = [&](int hg) {
-                gemm_tall_split_st<MT, NTW, 2 * HGS>(acc_o, (64 * HGS + DFF_SPAD) / 2, (const lu32*)(geo.Rg + 3 * RN * LQ), RN, RN,
-                                                     lw.Wox_s, 2 * DFF_HEADS, hg * HGS * 2, NT_H);
+            constexpr int DWO = 2 * HGS < 4 ? 2 * HGS : 4;
+            auto wo_gemm = [&](int hg, auto pre, u32x4 (&bw)[DWO][NTW][3]) {
+                gemm_tall_split_st_b<MT, NTW, 2 * HGS, decltype(pre)::value>(acc_o, (64 * HGS + DFF_SPAD) / 2, (const lu32*)(geo.Rg + 3 * RN * LQ), RN, RN,
+                                                     lw.Wox_s, 2 * DFF_HEADS, hg * HGS * 2, NT_H, bw);
                 if (oxt)
                     gemm_tall_kb<MT, NTW, 5>(acc_o, HGS,
                         [=](int i, int& aoff, int& wkb) { aoff = i * 16; wkb = (hg * HGS + i) * 5 + 4; },
@@ -2345,9 +2383,12 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     }
                     // (the GEMM waves are done before the softmax waves: the last one asks for the next phases' weights
                     // in the slack, and its next wait for a load of its own is a barrier away)
-                    l2w(lw.Wox_s, (size_t)hg * HGS * 2 * KB3, NT_H, 2 * DFF_HEADS * KB3, 2 * HGS * (int)KB3);
-                    if (hg + 2 < hg_hi) l2w(lw.Wqkvx_s, (hg + 2) * QKV_HG, 8, QKV_HG / 8, (int)(QKV_HG / 8));
-                    else if (!more) l2w(lw.W1_s, ch_lo * FFW_CH, 8, FFW_CH / 8, (int)(FFW_CH / 8));
+                    l2_wo(lw, hg);
+                    if (hg + 2 < hg_hi) l2_wqkv(lw, hg + 2);
+                    else if (!more) l2_w1(lw, ch_lo);
+                    u32x4 bw[DWO][NTW][3];
+                    constexpr bool WOPRE = DFF_WOPRE;   // W_o's operands cross the barrier in registers
+                    if constexpr (WOPRE) tall_ring_fill<NTW, DWO>(bw, lw.Wox_s, 2 * DFF_HEADS, hg * HGS * 2, NT_H);
                     wg_sync<SPILL>();
                     pf.tick(4);
                     float bias4[CNTH][4];
@@ -2356,7 +2397,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
 #pragma unroll
                         for (int i = 0; i < CNTH; ++i) pre(min(wave_ - NI + NWH * i, NTQ - 1), bias4[i]);
                     }
-                    wo_gemm(hg);
+                    wo_gemm(hg, std::integral_constant<bool, WOPRE>(), bw);
                     if (more && wave_ >= NI) {
                         auto epi = mk_epi(hg + 1);
 #pragma unroll
@@ -2403,7 +2444,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 co_fill_x<HGS, GEN>(geo);
                 wg_sync<SPILL>();
                 pf.tick(3);
-                l2w(lw.Wox_s, (size_t)hg * HGS * 2 * KB3, NT_H, 2 * DFF_HEADS * KB3, 2 * HGS * (int)KB3);
+                l2_wo(lw, hg);
                 if constexpr (GEN || MT == 4)   // MT = 4 (protein G): measured 1.3 % slower transposed (16 probabilities per lane)
                     co_softmax_pv<MT, HGS, GEN, SPW>(geo, sPl + (size_t)hg * HGS * RN * c.sl.PS,
                                                      (gfloat*)sb + c.sl.m12 + (size_t)hg * HGS * RN * 4, oxt);
@@ -2413,10 +2454,10 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 wg_sync<SPILL>();
                 pf.tick(4);
                 // attn_out += o_ext [W_o ; W_oc]   (K = 80 per head)
+                if (hg + 1 < hg_hi) { if (!cached) l2_wqkv(lw, hg + 1); }
+                else l2_w1(lw, ch_lo);
                 if constexpr (SPW) {   // 64 regular rows per head on the split path, the extension block on the fp32 one
-                    if (hg + 1 < hg_hi) { if (!cached) l2w(lw.Wqkvx_s, (hg + 1) * QKV_HG, 8, QKV_HG / 8, (int)(QKV_HG / 8)); }
-                    else l2w(lw.W1_s, ch_lo * FFW_CH, 8, FFW_CH / 8, (int)(FFW_CH / 8));
-                    wo_gemm(hg);
+                    { u32x4 bw[DWO][NTW][3]; wo_gemm(hg, std::false_type(), bw); }
                 } else
                 gemm_tall_kb_st<MT, NTW, 5, 5 * HGS>(acc_o,
                     [=](int i, int& aoff, int& wkb) {
@@ -2458,7 +2499,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                                 else *(lf32x4*)(hl + row * LF + cl) = gv;
                             }
                         };
-                    l2w_ffn_tall(lw.W2_s, ch);
+                    l2_w2(lw, ch);
                     if constexpr (SPW)
                         gemm_wide_split_st<MT, H / 32, FC / 16, 4>(asplit, RN, RN, lw.W1_s, ch * (FC / 16), w1_pre, w1_epi);
                     else
@@ -2466,8 +2507,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 }
                 wg_sync<SPILL>();
                 pf.tick(8);
-                if (ch + 1 < ch_hi) l2w(lw.W1_s, (ch + 1) * FFW_CH, 8, FFW_CH / 8, (int)(FFW_CH / 8));
-                else if (l == m.L - 1 && m.conservative) l2w(lw.W2T_s, ch_lo * FFW_CH, 8, FFW_CH / 8, (int)(FFW_CH / 8));
+                if (ch + 1 < ch_hi) l2_w1(lw, ch + 1);
+                else if (l == m.L - 1 && m.conservative) l2_w2t(lw, ch_lo);
                 if constexpr (SPW)
                     gemm_tall_split_st<MT, NTW, FC / 32>(acc_f, (FC + DFF_SPAD) / 2, (const lu32*)geo.Rg, RN, RN, lw.W2_s, F / 32, ch * (FC / 32), NT_H);
                 else
@@ -2489,7 +2530,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
         for (int l = m.conservative ? m.L - 1 : -1; l >= 0; --l) {
             const DffLayerDev& lw = m.layer[l];
             const float* sb = c.stash + (size_t)l * c.sl.layer_stride;
-            if (l < m.L - 1) l2w(lw.W2T_s, ch_lo * FFW_CH, 8, FFW_CH / 8, (int)(FFW_CH / 8));
+            if (l < m.L - 1) l2_w2t(lw, ch_lo);
             rowb_gate2<H, LPG>(c, lw, l);
             wg_sync<SPILL>();
             if constexpr (SPW) { split_rows<H>(abufL, asplit, RN); wg_sync<SPILL>(); }
@@ -2516,7 +2557,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                                 else *(lf32x4*)(hl + row * LF + cl) = v;
                             }
                         };
-                    l2w_ffn_tall(lw.W1T_s, ch);
+                    l2_w1t(lw, ch);
                     if constexpr (SPW)
                         gemm_wide_split_st<MT, H / 32, FC / 16, 4 * MT>(asplit, RN, RN, lw.W2T_s, ch * (FC / 16), w2t_pre, w2t_epi);
                     else
@@ -2524,8 +2565,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 }
                 wg_sync<SPILL>();
                 pf.tick(12);
-                if (ch + 1 < ch_hi) l2w(lw.W2T_s, (ch + 1) * FFW_CH, 8, FFW_CH / 8, (int)(FFW_CH / 8));
-                else l2w(lw.WoxT_s, hg_lo * GX_HG, 8, GX_HG / 8, (int)(GX_HG / 8));
+                if (ch + 1 < ch_hi) l2_w2t(lw, ch + 1);
+                else l2_wgx(lw, hg_lo);
                 if constexpr (SPW)
                     gemm_tall_split_st<MT, NTW, FC / 32>(acc_f, (FC + DFF_SPAD) / 2, (const lu32*)geo.Rg, RN, RN, lw.W1T_s, F / 32, ch * (FC / 32), NT_H);
                 else
@@ -2598,9 +2639,9 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     } else if (more) {
                         gx_units_hold<MT, H / 32, NTG, NI, NWH>(asplit, RN, RN, lw.WoxT_s, (hg + 1) * NTG, gheld);
                     }
-                    if (deep) l2w(lw.WqkvxT_s, (size_t)hg * HGS * 6 * KB3, NT_H, 6 * DFF_HEADS * KB3, 6 * HGS * (int)KB3);
-                    if (hg + 2 < hg_hi) l2w(lw.WoxT_s, (hg + 2) * GX_HG, 8, GX_HG / 8, (int)(GX_HG / 8));
-                    else if (!more && l > 0) l2w(m.layer[l - 1].W2T_s, ch_lo * FFW_CH, 8, FFW_CH / 8, (int)(FFW_CH / 8));
+                    if (deep) l2_wqkvT(lw, hg);
+                    if (hg + 2 < hg_hi) l2_wgx(lw, hg + 2);
+                    else if (!more && l > 0) l2_w2t(m.layer[l - 1], ch_lo);
                     wg_sync<SPILL>();
                     pf.tick(17);
                     if (deep) {
@@ -2658,7 +2699,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                                 }
                             }
                         };
-                    if (l > 0 || full0) l2w(lw.WqkvxT_s, (size_t)hg * HGS * 6 * KB3, NT_H, 6 * DFF_HEADS * KB3, 6 * HGS * (int)KB3);
+                    if (l > 0 || full0) l2_wqkvT(lw, hg);
                     if constexpr (SPW)
                         gemm_wide_units_split<MT, H / 32, HGS * 5>(asplit, RN, RN, lw.WoxT_s, hg * HGS * 5, gx_epi);
                     else
@@ -2693,9 +2734,9 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     wg_sync<SPILL>();
                     pf.tick(18);
                     // d(LN1 out) += [dq|du] W_qu + dk W_k + dv W_v   (K order per head [q64|u16|k64|v64])
+                    if (hg + 1 < hg_hi) l2_wgx(lw, hg + 1);
+                    else if (l > 0) l2_w2t(m.layer[l - 1], ch_lo);
                     if constexpr (SPW) {
-                        if (hg + 1 < hg_hi) l2w(lw.WoxT_s, (hg + 1) * GX_HG, 8, GX_HG / 8, (int)(GX_HG / 8));
-                        else if (l > 0) l2w(m.layer[l - 1].W2T_s, ch_lo * FFW_CH, 8, FFW_CH / 8, (int)(FFW_CH / 8));
                         u32x4 bq[4][NTW][3];
                         gemm_tall_qkvT_split<MT, NTW, HGS, LL::KVS, LL::VSP>(acc_a, geo.Rg, FIVE ? 4 : 3, RN, lw.WqkvxT_s, hg * HGS, NT_H, geo.lsp, bq);
                         gemm_tall_kb<MT, NTW, 13>(acc_a, HGS,
