@@ -1501,27 +1501,41 @@ DEVI f32x4 co_mm(const lfloat* T, int mo, const lfloat* B, int ldb, int RN, int 
 struct NoStepHook { DEVI void operator()(int) const {} };
 template <int MT, bool TRANS, class SH = NoStepHook>
 DEVI void co_mm5(f32x4 (&c)[5], const lfloat* T, int mo, const lfloat* B, int ldb, int RN, int rows, int lane, SH hook = SH()) {
-    constexpr int PL = 16 * MT + 4;
+    constexpr int PL = 16 * MT + 4, NS = 4 * MT;
     const int kk = lane >> 4, mm = lane & 15;
 #pragma unroll
     for (int nt = 0; nt < 5; ++nt) c[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // k-step st contracts k = 4 st + kk.  The steps beyond the workgroup's rows are skipped by a (uniform) branch, and the
+    // compiler will not lift an LDS read over a branch: the operands of step st + 1 are therefore requested BEFORE the
+    // products of step st -- otherwise every product waits out the LDS latency of its own operands (3 of 5 did: the
+    // phases built on this ran at 40 % of their MFMA time).  Reads of skipped steps are harmless (clamped rows).
+    // (volatile: a plain read that is only used inside the next step's branch gets sunk into it again)
+    typedef const volatile lfloat* vlp;
+    auto a_of = [&](int st) { const int k = 4 * st + kk; return TRANS ? *(vlp)(T + k * PL + 16 * mo + mm) : *(vlp)(T + (16 * mo + mm) * PL + k); };
+    auto b_of = [&](int st) { return (vlp)(B + min(4 * st + kk, RN - 1) * ldb + mm); };
+    float a_n = a_of(0), b_n[5];
+    {
+        vlp bp = b_of(0);
 #pragma unroll
-    for (int kt = 0; kt < MT; ++kt) {
-        float as[4];
+        for (int nt = 0; nt < 5; ++nt) b_n[nt] = bp[16 * nt];
+    }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int k = 16 * kt + 4 * s + kk;
-            as[s] = TRANS ? T[k * PL + 16 * mo + mm] : T[(16 * mo + mm) * PL + k];
+    for (int st = 0; st < NS; ++st) {
+        const float a_c = a_n;
+        float b_c[5];
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt) b_c[nt] = b_n[nt];
+        if (st + 1 < NS) {
+            a_n = a_of(st + 1);
+            vlp bp = b_of(st + 1);
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) b_n[nt] = bp[16 * nt];
         }
+        if (st % 4 == 0 || 4 * st < rows) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            if (s == 0 || 16 * kt + 4 * s < rows) {
-                const lfloat* bp = B + min(16 * kt + 4 * s + kk, RN - 1) * ldb + mm;
-#pragma unroll
-                for (int nt = 0; nt < 5; ++nt) c[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[s], bp[16 * nt], c[nt], 0, 0, 0);
-            }
-            hook(4 * kt + s);
+            for (int nt = 0; nt < 5; ++nt) c[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_c, b_c[nt], c[nt], 0, 0, 0);
         }
+        hook(st);
     }
 }
 
@@ -1757,15 +1771,29 @@ DEVI void co_softmax_pv_t(const CoGeo& g, gfloat* sP /* P block of head hg*HGS *
 #pragma unroll
         for (int nt = 0; nt < 5; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const lfloat* const vb = g.Rg + 2 * g.RN * LQ + hh * 80 + rl;
+        // (operands of k-step st + 1 requested before the products of step st: see co_mm5)
+        float v_n[5];
+        typedef const volatile lfloat* vlp;   // (volatile: see co_mm5)
+        {
+            vlp vp = vb + min(quad, g.RN - 1) * LQ;
 #pragma unroll
-        for (int kt = 0; kt < MT; ++kt)
+            for (int nt = 0; nt < 5; ++nt) v_n[nt] = vp[16 * nt];
+        }
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (r == 0 || 16 * kt + 4 * r < g.rows) {
-                    const lfloat* vp = vb + min(16 * kt + 4 * r + quad, g.RN - 1) * LQ;
+        for (int st = 0; st < 4 * MT; ++st) {
+            float v_c[5];
 #pragma unroll
-                    for (int nt = 0; nt < 5; ++nt) o[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[16 * nt], p[kt][r], o[nt], 0, 0, 0);
-                }
+            for (int nt = 0; nt < 5; ++nt) v_c[nt] = v_n[nt];
+            if (st + 1 < 4 * MT) {
+                vlp vp = vb + min(4 * (st + 1) + quad, g.RN - 1) * LQ;
+#pragma unroll
+                for (int nt = 0; nt < 5; ++nt) v_n[nt] = vp[16 * nt];
+            }
+            if (st % 4 == 0 || 4 * st < g.rows) {
+#pragma unroll
+                for (int nt = 0; nt < 5; ++nt) o[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v_c[nt], p[st / 4][st % 4], o[nt], 0, 0, 0);
+            }
+        }
         if (i < g.rows) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
