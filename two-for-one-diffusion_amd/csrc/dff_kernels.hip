@@ -26,6 +26,9 @@
 // softmax / LayerNorm / GELU / gates / the N x N contractions run on the VALU out of LDS.
 #include "dff_device.h"
 #include <type_traits>
+#ifndef DFF_ARES
+#define DFF_ARES 1
+#endif
 
 // ------------------------------------------------------------------------------------------
 // MFMA GEMM stages.  A (rows x K) lives in LDS with leading dimension lda (multiple of 4);
@@ -378,6 +381,11 @@ DEVI void gemm_wide_split_st(const lu32* as, int R, int rowsA, const unsigned* _
     constexpr bool HALVES = KB32 % 2 == 0 && KB32 >= 4;
     constexpr int NHALF = HALVES ? 2 : 1, HB = KB32 / NHALF, LHS2 = (32 * KB32 + DFF_SPAD) / 2;
     constexpr int CNT = (NTN + NWV - 1) / NWV, NE = CNT * NHALF;
+    // ARES (two row tiles at most): the whole split A operand -- 12 MT KB32 registers -- is read from LDS ONCE and stays in
+    // registers while the wave's tiles stream by.  Otherwise every wave re-reads all of A for every tile: at MT = 2 that is
+    // as many LDS cycles as the GEMM has MFMA cycles, and the two do not overlap (trp-cage's QKV_ext GEMM: 14.5 k cycles per
+    // call against 5 k of products).
+    constexpr bool ARES = MT * KB32 <= 8 && DFF_ARES;
     constexpr int DR0 = HALVES ? (DRMAX < 3 ? DRMAX : 3) : 2, DR = NE < DR0 ? NE : DR0;
     constexpr int NA = 3;
     const int tid_ = tid_now();
@@ -405,6 +413,18 @@ DEVI void gemm_wide_split_st(const lu32* as, int R, int rowsA, const unsigned* _
     // the loads above are issued HERE: left alone, the scheduler sinks each next to its first use (one L2 latency
     // per k-block instead of one per GEMM)
     __builtin_amdgcn_sched_barrier(0);
+    u32x4 ares[ARES ? MT : 1][ARES ? KB32 : 1][3];
+    if constexpr (ARES) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int kb = 0; kb < KB32; ++kb) {
+                const int o = rowoff[mt] + 16 * kb;
+                ares[mt][kb][0] = *(const lu32x4*)(as + o);
+                ares[mt][kb][1] = *(const lu32x4*)(as + R * LHS2 + o);
+                ares[mt][kb][2] = *(const lu32x4*)(as + 2 * R * LHS2 + o);
+            }
+    }
     f32x4 cs[MT], cb[MT];
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
@@ -421,9 +441,14 @@ DEVI void gemm_wide_split_st(const lu32* as, int R, int rowsA, const unsigned* _
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const int o = rowoff[mt] + 16 * (half * HB + kb);
-                    const u32x4 ah = *(const lu32x4*)(as + o);
-                    const u32x4 am = *(const lu32x4*)(as + R * LHS2 + o);
-                    const u32x4 al = *(const lu32x4*)(as + 2 * R * LHS2 + o);
+                    u32x4 ah, am, al;
+                    if constexpr (ARES) {
+                        ah = ares[mt][half * HB + kb][0]; am = ares[mt][half * HB + kb][1]; al = ares[mt][half * HB + kb][2];
+                    } else {
+                        ah = *(const lu32x4*)(as + o);
+                        am = *(const lu32x4*)(as + R * LHS2 + o);
+                        al = *(const lu32x4*)(as + 2 * R * LHS2 + o);
+                    }
                     cs[mt] = mfma_bf16(b[slot][kb][0], al, cs[mt]);
                     cb[mt] = mfma_bf16(b[slot][kb][0], am, cb[mt]);
                     cs[mt] = mfma_bf16(b[slot][kb][2], ah, cs[mt]);
