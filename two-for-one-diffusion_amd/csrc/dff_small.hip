@@ -497,18 +497,28 @@ DEVI f32x4 wv_dot_rows(const lfloat* A, const lfloat* B, int lane) {
 // C[m][16nt+n] = sum_{k<16} Aop[m][k] B[k][16nt+n] for tiles nt in [NT0, NT1).
 // TRANS = false: Aop[m][k] = T[m][k] (T = 16x16 tile, ld DFF_PLD);  true: Aop[m][k] = T[k][m].
 // ks = k-steps that can be non-zero: columns / rows of T at or beyond the real rows are exact zeros (P, dS).
+#ifndef DFF_WVMM_VOL
+#define DFF_WVMM_VOL 1
+#endif
 template <int NT0, int NT1, bool TRANS, int XLD = DFF_XLD, class Epi>
 DEVI void wv_mm(const lfloat* T, const lfloat* B, int lane, int ks, Epi epi) {
     const int kk = lane >> 4, mm = lane & 15;
     // k-step s covers k = 4 s .. 4 s + 3 (lane: k = 4 s + kk), so trailing all-zero k-steps can be dropped
+    // (volatile: the operands of k-steps 1..3 are only used inside the row-count branches below, and the compiler sinks a
+    // plain LDS read into the branch that uses it -- every product then waits out the latency of its own operands)
+#if DFF_WVMM_VOL
+    typedef const volatile lfloat* vlp;
+#else
+    typedef const lfloat* vlp;
+#endif
     float as[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) as[s] = TRANS ? T[(4 * s + kk) * DFF_PLD + mm] : T[mm * DFF_PLD + 4 * s + kk];
+    for (int s = 0; s < 4; ++s) as[s] = TRANS ? *(vlp)(T + (4 * s + kk) * DFF_PLD + mm) : *(vlp)(T + mm * DFF_PLD + 4 * s + kk);
     float bv[NT1 - NT0][4];
 #pragma unroll
     for (int nt = NT0; nt < NT1; ++nt)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) bv[nt - NT0][s] = B[(4 * s + kk) * XLD + 16 * nt + mm];
+        for (int s = 0; s < 4; ++s) bv[nt - NT0][s] = *(vlp)(B + (4 * s + kk) * XLD + 16 * nt + mm);
     f32x4 acc[NT1 - NT0];
 #pragma unroll
     for (int nt = 0; nt < NT1 - NT0; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
