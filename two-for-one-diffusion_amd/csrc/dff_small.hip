@@ -1309,6 +1309,13 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     // Layer 0 at a fixed noise level (Langevin): q' and the LayerNorm rows are the same every step, so the 64
                     // regular columns of the logits are too -- computed on step 0 of the launch, kept in 4 registers; only the
                     // extension k-step (u . x_j) is redone
+                    // x_i of this lane's four C-layout rows (for xrel below), requested before the products instead of
+                    // after them (volatile: the compiler would sink the reads to their use in the last tile's epilogue)
+                    float xsub[4];
+                    if constexpr (!GEN) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) xsub[r] = *(const volatile lfloat*)(xs + (quad * 4 + r) * 4 + (col & 3));
+                    }
                     f32x4 Sb;
                     if (KEEPROWS && MODE == DFF_MODE_LANGEVIN && l == 0 && step > 0) Sb = s0keep;
                     else {
@@ -1346,7 +1353,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                                     v = col < 3 ? v - xr : col == 3 ? D : 0.f;
                                 }
                             } else {
-                                if (nt == 4) v -= (col < 3) ? xs[(quad * 4 + r) * 4 + col] : 0.f;
+                                if (nt == 4) v -= (col < 3) ? xsub[r] : 0.f;
                             }
                             Ox[lro[r] + 16 * nt + col] = v;
                         }
@@ -1883,19 +1890,23 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 const SSeq<U_GX, 0, MW, 0, 0, 0, 0, E, 4 * KB32> sqa0{ss_woxt(lw, wave), ss_woxt(lw, wave), ss_w2t(lwp), ss_w1t(lwp)};
                 u32x4 dah[KB32], dam[KB32], dal[KB32];   // SPW: dattn as bf16 pieces
                 if constexpr (SPW) a_load(dah, dam, dal, lane);
+                // this lane's share of the head's dE/dx terms (extension tiles of G_ext, dV_ext, dK_ext: rows quad * 4 + r,
+                // column col): summed in registers and added to the wave's dxw ONCE per layer -- as three LDS
+                // read-modify-writes per layer they were four dependent round trips each (the compiler cannot tell that
+                // dxi[0..3] differ)
+                f32x4 dxr = {0.f, 0.f, 0.f, 0.f};
                 // G_ext = dattn W_o_ext[h]^T  (5 tiles: [G 64 | r 3 | 0]) -> G region ; dx_i -= r_i
                 auto gext = [&](auto ph, int h, const WStream& wnext) {
                     float none[DR][1] = {};
                     lfloat* const gb = Gx + col;
                     const int l0 = lro[0], l1 = lro[1], l2 = lro[2], l3 = lro[3];
-                    lfloat* const dxp = dxw;
-                    const int d0 = dxi[0], d1 = dxi[1], d2 = dxi[2], d3 = dxi[3];
+                    f32x4* const dxrp = &dxr;
                     wide_run<decltype(ph)::value, 5, E, 1>(ring, none, afr, s_woxt(lw, h), wnext, lane,
                         [=](int, float (&)[1]) {},
                         [=](int t, const f32x4& acc, const float (&)[1]) {
                             gb[l0 + 16 * t] = acc[0]; gb[l1 + 16 * t] = acc[1];
                             gb[l2 + 16 * t] = acc[2]; gb[l3 + 16 * t] = acc[3];
-                            if (t == 4) { dxp[d0] -= acc[0]; dxp[d1] -= acc[1]; dxp[d2] -= acc[2]; dxp[d3] -= acc[3]; }
+                            if (t == 4) *dxrp -= acc;
                         });
                 };
                 // the same on the split operands; phn = ring phase of the GEMM that follows (2: this head's QKV_ext^T back-projection)
@@ -1903,14 +1914,13 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     float none[2][1] = {};
                     lfloat* const gb = Gx + col;
                     const int l0 = lro[0], l1 = lro[1], l2 = lro[2], l3 = lro[3];
-                    lfloat* const dxp = dxw;
-                    const int d0 = dxi[0], d1 = dxi[1], d2 = dxi[2], d3 = dxi[3];
+                    f32x4* const dxrp = &dxr;
                     swide_run<0, 5, KB32, 1>(sring, none, dah, dam, dal, sq, lane,
                         [=](int, float (&)[1]) {},
                         [=](int t, const f32x4& acc, const float (&)[1]) {
                             gb[l0 + 16 * t] = acc[0]; gb[l1 + 16 * t] = acc[1];
                             gb[l2 + 16 * t] = acc[2]; gb[l3 + 16 * t] = acc[3];
-                            if (t == 4) { dxp[d0] -= acc[0]; dxp[d1] -= acc[1]; dxp[d2] -= acc[2]; dxp[d3] -= acc[3]; }
+                            if (t == 4) *dxrp -= acc;
                         });
                 };
                 // dA = G_ext V_ext^T ; dS = scale * P (dA - sum_j P dA) -> dsb
@@ -1943,7 +1953,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             if constexpr (!FOLD) Vx[lro[r] + 16 * nt + col] = acc[r];
-                            if (nt == 4) dxw[dxi[r]] += GEN ? dx_ext(quad * 4 + r, col, acc[r]) : acc[r];
+                            if (nt == 4) dxr[r] += GEN ? dx_ext(quad * 4 + r, col, acc[r]) : acc[r];
                         }
                     });
                     // dQ_ext = dS K_ext -> G region (ext columns: du, and ds in the GEN variants)
@@ -1963,18 +1973,18 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             if constexpr (!FOLD) Kx[lro[r] + 16 * nt + col] = acc[r];
-                            if (nt == 4) dxw[dxi[r]] += GEN ? dx_ext(quad * 4 + r, col, acc[r]) : acc[r];
+                            if (nt == 4) dxr[r] += GEN ? dx_ext(quad * 4 + r, col, acc[r]) : acc[r];
                         }
                     });
                 };
                 auto dx_only = [&]() {   // layer 0: node inputs do not depend on x
                     wv_mm<4, 5, true, XLD>(pb, Gx, lane, ks4, [&](int, const f32x4& acc) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) dxw[dxi[r]] += GEN ? dx_ext(quad * 4 + r, col, acc[r]) : acc[r];
+                        for (int r = 0; r < 4; ++r) dxr[r] += GEN ? dx_ext(quad * 4 + r, col, acc[r]) : acc[r];
                     });
                     wv_mm<4, 5, true, XLD>(dsb, Qx, lane, ks4, [&](int, const f32x4& acc) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) dxw[dxi[r]] += GEN ? dx_ext(quad * 4 + r, col, acc[r]) : acc[r];
+                        for (int r = 0; r < 4; ++r) dxr[r] += GEN ? dx_ext(quad * 4 + r, col, acc[r]) : acc[r];
                     });
                     if constexpr (GEN) {   // the distance term of the logits reaches x_i through Q_ext: -2 s_i sum_j dS_ij x_j
                         wv_mm<4, 5, false, XLD>(dsb, Kx, lane, ks4, [&](int, const f32x4& acc) {
@@ -2085,6 +2095,13 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     gfix();
                     ds_math();
                     dx_only();
+                }
+                {
+                    float t4[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t4[r] = dxw[dxi[r]];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dxw[dxi[r]] = t4[r] + dxr[r];
                 }
             }
             __syncthreads();
