@@ -26,6 +26,9 @@
 // softmax / LayerNorm / GELU / gates / the N x N contractions run on the VALU out of LDS.
 #include "dff_device.h"
 #include <type_traits>
+#ifndef DFF_APRE
+#define DFF_APRE 1
+#endif
 #ifndef DFF_ARES
 #define DFF_ARES 1
 #endif
@@ -425,6 +428,13 @@ DEVI void gemm_wide_split_st(const lu32* as, int R, int rowsA, const unsigned* _
                 ares[mt][kb][2] = *(const lu32x4*)(as + 2 * R * LHS2 + o);
             }
     }
+    constexpr bool APRE = !ARES && DFF_APRE;
+    u32x4 apre[3];
+    if constexpr (APRE) {
+        apre[0] = *(const volatile lu32x4*)(as + rowoff[0]);
+        apre[1] = *(const volatile lu32x4*)(as + R * LHS2 + rowoff[0]);
+        apre[2] = *(const volatile lu32x4*)(as + 2 * R * LHS2 + rowoff[0]);
+    }
     f32x4 cs[MT], cb[MT];
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
@@ -444,6 +454,17 @@ DEVI void gemm_wide_split_st(const lu32* as, int R, int rowsA, const unsigned* _
                     u32x4 ah, am, al;
                     if constexpr (ARES) {
                         ah = ares[mt][half * HB + kb][0]; am = ares[mt][half * HB + kb][1]; al = ares[mt][half * HB + kb][2];
+                    } else if constexpr (APRE) {
+                        // this unit's fragments were requested a unit ago; request the next unit's (the first of the next
+                        // entry after the last of this one: A is the same for every tile) before this unit's products
+                        ah = apre[0]; am = apre[1]; al = apre[2];
+                        constexpr int dummy = 0; (void)dummy;
+                        const int mtn = (mt + 1) % MT, kbn = (mt + 1 == MT) ? kb + 1 : kb;
+                        const int kabs = (kbn == HB) ? ((half + 1) % NHALF) * HB : half * HB + kbn;
+                        const int on = rowoff[mtn] + 16 * kabs;
+                        apre[0] = *(const volatile lu32x4*)(as + on);
+                        apre[1] = *(const volatile lu32x4*)(as + R * LHS2 + on);
+                        apre[2] = *(const volatile lu32x4*)(as + 2 * R * LHS2 + on);
                     } else {
                         ah = *(const lu32x4*)(as + o);
                         am = *(const lu32x4*)(as + R * LHS2 + o);
@@ -708,13 +729,14 @@ DEVI void gemm_tall_split_st_b(f32x4 (&acc)[NTW][MT], int LS2 /* dwords per piec
     for (int kb = 0; kb < NKB; ++kb) {
         const int d = kb % D;
         u32x4 ah[MT], am[MT], al[MT];
+        // (requested in the order the products consume them -- l, h, m pieces -- so that the first product waits for one
+        // read, not for nine)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int o = rowoff[mt] + 16 * kb;
-            ah[mt] = *(const lu32x4*)(as + o);
-            am[mt] = *(const lu32x4*)(as + R * LS2 + o);
-            al[mt] = *(const lu32x4*)(as + 2 * R * LS2 + o);
-        }
+        for (int mt = 0; mt < MT; ++mt) al[mt] = *(const volatile lu32x4*)(as + 2 * R * LS2 + rowoff[mt] + 16 * kb);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) ah[mt] = *(const volatile lu32x4*)(as + rowoff[mt] + 16 * kb);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) am[mt] = *(const volatile lu32x4*)(as + R * LS2 + rowoff[mt] + 16 * kb);
 #pragma unroll
         for (int i = 0; i < NTW; ++i)
             if (i == 0 || tok[i]) {
