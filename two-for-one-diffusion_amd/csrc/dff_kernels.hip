@@ -853,53 +853,33 @@ DEVI void gemm_tall_qkvT_split(f32x4 (&acc)[NTW][MT], const lfloat* Rg, int regQ
 #pragma unroll
             for (int i = 0; i < NTW; ++i)
 #pragma unroll
-#ifdef DFF_TX_NOB
-                for (int p = 0; p < 3; ++p) b[d][i][p] = d == 0 ? wp[(tbase[i] + 3 * d + p) * 64] : b[0][i][p];
-#else
                 for (int p = 0; p < 3; ++p) b[d][i][p] = wp[(tbase[i] + 3 * d + p) * 64];
-#endif
     }
     __builtin_amdgcn_sched_barrier(0);
-#ifdef DFF_TX_NOLDS
-    u32x4 ah0[MT], am0[MT], al0[MT];
-#endif
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
         const int d = kb % D;
         const int hh = kb / 6, part = (kb % 6) / 2, half = kb % 2;
         const int aoff = (part == 0 ? regQ : part) * RN * LQ + hh * 80 + 32 * half;
         u32x4 ah[MT], am[MT], al[MT];
-#ifdef DFF_TX_NOLDS
-        static_assert(HGS == 1, "");
-#endif
         if (KVS && (part == 1 || (VSP && part == 2))) {
             constexpr int LSV = 32 * HGS + 4;
             const lu32* const hb = (const lu32*)(Rg + part * RN * LQ + hh * 80) + 16 * half;
             const lu32* const lb = part == 1 ? (const lu32*)(Rg + (1 + half) * RN * LQ + hh * 80 + 64) : lsp + hh * 32 + 16 * half;
             const int lmul = part == 1 ? LQ : LSV;
+            // (l, h, m: the order the products consume them)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-#ifdef DFF_TX_NOLDS
-                if (kb != 2) { ah[mt] = ah0[mt]; am[mt] = am0[mt]; al[mt] = al0[mt]; continue; }
-#endif
-                const int ro = rowoff[mt] - 4 * kg;   // row * LQ + 4 kg
-                ah[mt] = *(const lu32x4*)(hb + ro);
-                am[mt] = *(const lu32x4*)(hb + 32 + ro);
-                al[mt] = *(const lu32x4*)(lb + min(mt * 16 + mm, RN - 1) * lmul + 4 * kg);
-#ifdef DFF_TX_NOLDS
-                ah0[mt] = ah[mt]; am0[mt] = am[mt]; al0[mt] = al[mt];
-#endif
-            }
+            for (int mt = 0; mt < MT; ++mt) al[mt] = *(const volatile lu32x4*)(lb + min(mt * 16 + mm, RN - 1) * lmul + 4 * kg);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) ah[mt] = *(const volatile lu32x4*)(hb + rowoff[mt] - 4 * kg);   // row * LQ + 4 kg
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) am[mt] = *(const volatile lu32x4*)(hb + 32 + rowoff[mt] - 4 * kg);
         } else {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const lfloat* ap = Rg + aoff + rowoff[mt];
                 const f32x4 x0 = *(const lf32x4*)ap, x1 = *(const lf32x4*)(ap + 4);
-#ifdef DFF_TX_NOQ
-                ah[mt] = __builtin_bit_cast(u32x4, x0); am[mt] = __builtin_bit_cast(u32x4, x1); al[mt] = ah[mt];
-#else
                 split8(x0, x1, ah[mt], am[mt], al[mt]);
-#endif
             }
         }
 #pragma unroll
@@ -918,7 +898,6 @@ DEVI void gemm_tall_qkvT_split(f32x4 (&acc)[NTW][MT], const lfloat* Rg, int regQ
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][0], ah[mt], acc[i][mt]);
             }
-#ifndef DFF_TX_NOB
         if (kb + D < NKB) {
 #pragma unroll
             for (int i = 0; i < NTW; ++i)
@@ -926,7 +905,6 @@ DEVI void gemm_tall_qkvT_split(f32x4 (&acc)[NTW][MT], const lfloat* Rg, int regQ
                 for (int p = 0; p < 3; ++p) b[d][i][p] = wp[(tbase[i] + 3 * (kb + D) + p) * 64];
             __builtin_amdgcn_sched_barrier(0);
         }
-#endif
     }
 }
 
