@@ -310,6 +310,17 @@ struct SSeq {
     SStream s0, s1, n0, n1;
     static constexpr int kind(int i) { return i < N0 ? K0 : K1; }   // of unit i of this block
 };
+// The ring's refill loads must be ISSUED where they are written: left alone, the scheduler sinks a load whose slot is free
+// down to the products that consume it a ring's depth later (it saves the slot's live range -- and exposes an L2 latency
+// per unit).  A scheduling barrier that everything but VMEM may cross pins the load without fencing the products.
+#ifndef DFF_PIN
+#define DFF_PIN 1
+#endif
+#if DFF_PIN
+#define DFF_PIN_VMEM() __builtin_amdgcn_sched_barrier(0x078F)
+#else
+#define DFF_PIN_VMEM() ((void)0)
+#endif
 template <int DR, int I, class Q>
 DEVI void seq_refill(SRing<DR>& ring, const Q& q, int lane) {   // slot of unit I <- unit I + DR (or the next block's)
     constexpr int slot = I % DR, J = I + DR;
@@ -318,6 +329,7 @@ DEVI void seq_refill(SRing<DR>& ring, const Q& q, int lane) {   // slot of unit 
     else if constexpr (J < Q::N0 + Q::N1) sfill_k<Q::K1>(ring.b[slot], unit_addr<Q::K1, Q::E>(q.s1, J - Q::N0), lane);
     else if constexpr (slot < Q::M0) sfill_k<Q::KN0>(ring.b[slot], unit_addr<Q::KN0, Q::E>(q.n0, slot), lane);
     else sfill_k<Q::KN1>(ring.b[slot], unit_addr<Q::KN1, Q::E>(q.n1, slot - Q::M0), lane);
+    DFF_PIN_VMEM();
 }
 // first DR units of a block (step start), all from one stream of kind KIND
 template <int DR, int KIND, int E>
