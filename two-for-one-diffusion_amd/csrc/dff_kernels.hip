@@ -1501,15 +1501,25 @@ DEVI f32x4 co_mm(const lfloat* T, int mo, const lfloat* B, int ldb, int RN, int 
     constexpr int PL = 16 * MT + 4;
     const int kk = lane >> 4, mm = lane & 15;
     f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+    // (the operands of row tile kt + 1 are requested before the products of tile kt, as volatile reads: the compiler sinks
+    // plain ones into the row-count branches that use them -- see co_mm5)
+    typedef const volatile lfloat* vlp;
+    float an[4], bn[4];
+    auto load = [&](int kt) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = 16 * kt + 4 * s + kk;
+            an[s] = TRANS ? *(vlp)(T + k * PL + 16 * mo + mm) : *(vlp)(T + (16 * mo + mm) * PL + k);
+            bn[s] = *(vlp)(B + min(k, RN - 1) * ldb + mm);
+        }
+    };
+    load(0);
 #pragma unroll
     for (int kt = 0; kt < MT; ++kt) {
         float as[4], bs[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int k = 16 * kt + 4 * s + kk;
-            as[s] = TRANS ? T[k * PL + 16 * mo + mm] : T[(16 * mo + mm) * PL + k];
-            bs[s] = B[min(k, RN - 1) * ldb + mm];
-        }
+        for (int s = 0; s < 4; ++s) { as[s] = an[s]; bs[s] = bn[s]; }
+        if (kt + 1 < MT) load(kt + 1);
         c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(as[0], bs[0], c0, 0, 0, 0);
         if (16 * kt + 4 < rows) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(as[1], bs[1], c1, 0, 0, 0);
         if (16 * kt + 8 < rows) c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(as[2], bs[2], c0, 0, 0, 0);
