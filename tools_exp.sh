@@ -12,7 +12,7 @@ if [ "$cmd" = build ]; then
     name=$1; flags=$2
     d=build/exp/$name; mkdir -p $d
     md=${DFF_EXP_MODE:-1}   # the sampler mode whose kernel is rebuilt (1 = Langevin, the headline); the others come from ./build.sh
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-result -DDFF_FAST_BUILD -DDFF_SMALL_MODE=$md $flags -c $SRC/dff_small.hip -o $d/dff_small_m$md.o
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-result -DDFF_FAST_BUILD -DDFF_SMALL_MODE=$md ${DFF_SMALL_SCHED--mllvm -amdgpu-sched-strategy=max-ilp -mllvm -amdgpu-use-amdgpu-trackers} $flags -c $SRC/dff_small.hip -o $d/dff_small_m$md.o
     objs=""
     for k in 0 1 2; do if [ $k = $md ]; then objs="$objs $d/dff_small_m$k.o"; else objs="$objs build/obj/dff_small_m$k.o"; fi; done
     hipcc --offload-arch=gfx950 -shared -fPIC build/obj/dff_kernels.o $objs build/obj/dff_host.o -o $d/libdff_amd.so
