@@ -20,8 +20,10 @@ ALGORITHMIC FLOPs of SURVEY.md section 8d (22.00 MFLOP per chignolin score call,
 durations from HIP events on the launch stream.  `cpu_baseline`: the oracle twin of the reference
 (oracle/reference_twin.py, materialised formulation, torch CPU) on a bounded number of the same steps.
 `also`: the other figures BASELINE.json's north_star names -- villin (35 beads) Langevin at 256 per GPU, protein G (56
-beads) at 128 per GPU, chignolin / villin i.i.d. samples/s -- each a first-class entry with its own `roofline` object
-(and a `cpu_baseline` for villin), measured after the headline's timed region.
+beads) at 128 per GPU, chignolin / villin i.i.d. samples/s -- each a first-class entry (<= 700 bytes) with its own `roofline`
+object (and a `cpu_baseline`), measured after the headline's timed region.  What every entry would repeat (dtype, how frac /
+traffic / mfma_busy / hbm_tbps are defined) is said once, in `notes`, the LAST key: the whole line stays under 6 KB so that
+the driver's stdout tail holds all of it.
 """
 import argparse
 import glob
@@ -47,9 +49,11 @@ PEAK_BF16_DENSE_TFLOPS = 2500.0     # dense bf16 MFMA peak; an exact fp32 produc
 MIN_LAUNCHES = 8
 
 
-def hbm_traffic_from_profile(kname, cfg, P, chunk):
-    """HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes,
-    gfx950 x2 read correction) for this exact kernel + workload: profiles/<round>/**/traffic.json (latest round wins)."""
+def profile_figures(kname, cfg, P, chunk):
+    """rocprofv3 figures for this exact kernel + workload from profiles/<round>/**/traffic.json (latest round wins;
+    written by tools_profile_report.py from separate --pmc passes): HBM bytes per launch (FETCH_SIZE x 2 on gfx950 +
+    WRITE_SIZE), HBM TB/s, MFMA pipe busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GUI cycles)), L2 hit rate.
+    Older traffic.json files carry the bytes only: the rest is derived from the summary.json next to them."""
     best = None
 
     def norm(n):   # rocprofv3 prints the full template argument list, the library its own short name
@@ -70,40 +74,66 @@ def hbm_traffic_from_profile(kname, cfg, P, chunk):
         except Exception:
             continue
         if norm(t.get("kernel", "")) == norm(kname) and t.get("workload") == f"{cfg} P={P} chunk={chunk}":
-            best = t
-    return None if best is None else float(best["hbm_bytes_per_launch"])
+            best = (t, os.path.dirname(f))
+    if best is None:
+        return {"traffic": None, "hbm_tbps": None, "mfma_busy": None, "l2_hit": None, "profile": None}
+    t, d = best
+    out = {"traffic": float(t["hbm_bytes_per_launch"]),
+           "hbm_tbps": t.get("hbm_tbps", float(t["hbm_bytes_per_launch"]) / (float(t["avg_launch_ms"]) * 1e-3) / 1e12),
+           "mfma_busy": t.get("mfma_busy"), "l2_hit": t.get("l2_hit"), "profile": os.path.relpath(d, ROOT)}
+    if out["mfma_busy"] is None or out["l2_hit"] is None:
+        try:
+            c = {k: v["mean_per_launch"] for k, v in json.load(open(os.path.join(d, "summary.json")))["counters"].items()}
+            if out["mfma_busy"] is None and c.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+                out["mfma_busy"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * c["GRBM_GUI_ACTIVE"] / 8)
+            if out["l2_hit"] is None and "TCC_HIT_sum" in c:
+                out["l2_hit"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+        except Exception:
+            pass
+    for k in ("hbm_tbps", "mfma_busy", "l2_hit"):
+        if out[k] is not None:
+            out[k] = round(out[k], 4)
+    return out
+
+
+# Said ONCE per line (`notes`), not once per entry: the driver keeps only the tail of stdout.
+NOTES = {
+    "dtype": "f32 everywhere.  Kernels named split_bf16 run the weight GEMMs as an exact 3-way bf16 split of every fp32 operand "
+             "(six v_mfma_f32_16x16x32_bf16 per fp32 product, fp32 accumulate; held to the fp32 reference's own error); attention "
+             "products and the other kernels: v_mfma_f32_16x16x4_f32 / fp32 VALU",
+    "roofline": "bound = fp32 compute (SURVEY 8d): frac = algorithmic TFLOP/s (official factorised FLOP count x proteins x steps / "
+                "HIP-event launch time) / 157.3.  split_peak_frac: against the split GEMMs' own roof, dense bf16 / 6 = 416.7.  "
+                "traffic = HBM bytes per launch, hbm_tbps, mfma_busy, l2_hit: rocprofv3 PMC passes of the same workload under "
+                "`profile` (FETCH_SIZE x2 + WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GUI cycles))",
+    "fold_kv": "hidden == head dim: k / v projections folded into q / out (exact); ~26 % fewer MFMAs issued than the FLOP count used",
+    "timing": "persistent launches of `chunk` fused steps; --steps / --warmup are rounded up to whole launches, >= 8 timed launches",
+    "cpu": "oracle/reference_twin.py (torch CPU port of the reference, materialised formulation), thread count picked by a probe",
+    "also": "roofline objects there omit bound / peak / unit (= the headline's: mfma, 157.3, TFLOP/s)",
+}
 
 
 def kernel_dtype(kname):
-    if "split_bf16" in kname:
-        return ("f32 (weight GEMMs: exact 3-way bf16 split of every fp32 operand, six v_mfma_f32_16x16x32_bf16 products "
-                "per term, fp32 accumulate; attention products and everything else: v_mfma_f32_16x16x4_f32 / fp32 VALU)")
-    return "f32 (v_mfma_f32_16x16x4_f32 and fp32 VALU)"
+    return "f32"
 
 
-def roofline(cfg, P, steps_per_launch, launch_ms, kname):
+def roofline(cfg, P, steps_per_launch, launch_ms, kname, brief=False):
     """bound = fp32 compute: achieved algorithmic TFLOP/s of one launch against 157.3."""
     avg = float(np.mean(launch_ms))
     flops = MFLOP_PER_CALL[cfg] * 1e6 * P * steps_per_launch
     ach = flops / (avg * 1e-3) / 1e12
-    r = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
-         "traffic": hbm_traffic_from_profile(kname, cfg, P, steps_per_launch), "kernel": kname, "avg_launch_ms": avg,
-         "min_launch_ms": float(np.min(launch_ms)), "launches": len(launch_ms), "algorithmic_flops_per_launch": flops,
-         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/)"}
-    if "split_bf16" in kname:
-        r["peak_split_gemms"] = PEAK_BF16_DENSE_TFLOPS / 6.0
-        r["frac_vs_split_peak"] = ach / (PEAK_BF16_DENSE_TFLOPS / 6.0)
-        r["note"] = ("frac is against the fp32 peak (157.3): the arithmetic delivered is fp32-exact.  The weight GEMMs (87% of "
-                     "the MFMA work) run as six bf16 products per fp32 product, whose own roof is the dense bf16 peak / 6 = "
-                     "416.7 TFLOP/s (peak_split_gemms); the attention products stay on the fp32 MFMA (157.3).  Algorithmic "
-                     "HBM bytes are ~600 B per trajectory-step; measured traffic is the activation stash")
-        if "fold_kv" in kname:
-            r["note"] += (".  algorithmic_flops_per_launch is SURVEY 8d's official count for the factorised formulation; this "
-                          "kernel issues ~26 % fewer MFMA instructions than that formulation needs, because with hidden == "
-                          "head dimension the key / value projections are folded into the query / output projections "
-                          "(exact algebra, DESIGN.md section 2)")
+    pf = profile_figures(kname, cfg, P, steps_per_launch)
+    r = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+         "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": pf["traffic"], "hbm_tbps": pf["hbm_tbps"],
+         "mfma_busy": pf["mfma_busy"], "l2_hit": pf["l2_hit"], "kernel": kname, "avg_launch_ms": round(avg, 4),
+         "min_launch_ms": round(float(np.min(launch_ms)), 4), "launches": len(launch_ms)}
+    if brief:   # `also` entries: bound / peak / unit are the headline's
+        for k in ("bound", "peak", "unit", "min_launch_ms", "launches"):
+            del r[k]
     else:
-        r["note"] = "fp32-compute bound: algorithmic HBM bytes are ~600 B per trajectory-step; measured traffic is the activation stash"
+        r["algorithmic_flops_per_launch"] = flops
+        r["profile"] = pf["profile"]
+    if "split_bf16" in kname:
+        r["split_peak_frac"] = round(ach / (PEAK_BF16_DENSE_TFLOPS / 6.0), 4)
     return r
 
 
@@ -150,8 +180,7 @@ def cpu_baseline(cfg, P, t_level, budget_s=12.0, max_steps=40, threads=None):
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": f"MD-steps/s (batch {P})", "cores": torch.get_num_threads(),
             "kind": "port", "ms_per_step": 1e3 * dt / n,
-            "sample": f"{n} Langevin steps of the same workload (P={P}, {cfg}) after warm-up and a thread-count probe, "
-                      f"oracle/reference_twin.py on {torch.get_num_threads()} threads of {os.cpu_count()} logical cores"}
+            "sample": f"{n} Langevin steps, same workload (P={P}, {cfg}), {torch.get_num_threads()} of {os.cpu_count()} logical cores"}
 
 
 def cpu_baseline_iid(cfg, P, budget_s=8.0, max_steps=20, threads=8):
@@ -177,9 +206,7 @@ def cpu_baseline_iid(cfg, P, budget_s=8.0, max_steps=20, threads=8):
     dt = (time.perf_counter() - t0) / n
     return {"value": P / (1000.0 * dt), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
             "ms_per_reverse_step": 1e3 * dt,
-            "sample": f"{n} reverse DDPM steps (t = 998 .. {t}) of the same workload (batch {P}, {cfg}) after one warm-up step, "
-                      f"oracle/reference_twin.py p_sample on {torch.get_num_threads()} threads of {os.cpu_count()} logical cores; "
-                      f"a sample = 1000 such steps"}
+            "sample": f"{n} reverse steps (t = 998 .. {t}), batch {P}, {cfg}; a sample = 1000 such steps"}
 
 
 def make_model(cfg, dev):
@@ -338,22 +365,21 @@ def main():
                                           ("protein_g_langevin", "protein_g", 128, 250, MIN_LAUNCHES)):
                 e = langevin_entry(c2, P2, ch2, 1, nt, dev, rank, world)
                 also[name] = {
-                    "metric": f"Langevin MD-steps/sec at batch {P2} per GPU ({c2}, {e['N']} beads, H={e['H']}, L={e['L']})",
-                    "value": world * P2 * e["K"] / e["elapsed"] / P2, "unit": f"MD-steps/s (batch-{P2} steps, whole job)",
-                    "ms_per_step": 1e3 * e["elapsed"] / e["K"], "steps": e["K"], "finite": e["finite"],
-                    "trajectory_steps_per_s": world * P2 * e["K"] / e["elapsed"],
-                    "roofline": roofline(c2, P2, ch2, e["launch_ms"], e["kernel"]), "dtype": kernel_dtype(e["kernel"])}
+                    "workload": f"{c2} ({e['N']} beads, H={e['H']}, L={e['L']}) Langevin, {P2}/GPU",
+                    "value": round(world * e["K"] / e["elapsed"], 2), "unit": f"MD-steps/s (batch {P2}, whole job)",
+                    "ms_per_step": round(1e3 * e["elapsed"] / e["K"], 5), "steps": e["K"], "finite": e["finite"],
+                    "roofline": roofline(c2, P2, ch2, e["launch_ms"], e["kernel"], brief=True)}
             # chignolin_iid_512: BASELINE configs[2] in its own per-GPU shape (batch 4096 over 8 GPUs, sample.py:185-189)
             for name, c2, P2, nt in (("chignolin_iid", "chignolin", 256, MIN_LAUNCHES), ("chignolin_iid_512", "chignolin", 512, 4),
                                      ("villin_iid", "villin", 256, 4)):
                 e = iid_entry(c2, P2, 1, nt, dev, rank, world)
                 also[name] = {
-                    "metric": f"i.i.d. samples/sec at batch {P2} per GPU ({c2}: complete 1000-step reverse DDPM chains)",
-                    "value": world * P2 * nt / e["elapsed"], "unit": "samples/s (whole job)",
-                    "ms_per_reverse_step": 1e3 * e["elapsed"] / (nt * 1000), "chains_timed": nt,
-                    "roofline": roofline(c2, P2, 1000, e["launch_ms"], e["kernel"]), "dtype": kernel_dtype(e["kernel"])}
+                    "workload": f"{c2} iid, batch {P2}/GPU, complete 1000-step reverse chains",
+                    "value": round(world * P2 * nt / e["elapsed"], 2), "unit": "samples/s (whole job)",
+                    "ms_per_reverse_step": round(1e3 * e["elapsed"] / (nt * 1000), 5), "chains_timed": nt,
+                    "roofline": roofline(c2, P2, 1000, e["launch_ms"], e["kernel"], brief=True)}
         except Exception as ex:  # noqa: BLE001
-            also["error"] = f"{type(ex).__name__}: {ex}"
+            also["error"] = f"{type(ex).__name__}: {ex}"[:300]
 
     if rank == 0:
         N, H, L = h["N"], h["H"], h["L"]
@@ -366,33 +392,31 @@ def main():
             "vs_baseline": None, "dtype": kernel_dtype(h["kernel"]),
             "data": "synthetic (seeded weights, N(0,1) centred x0, in-kernel Philox noise)",
             "steps_requested": args.steps, "warmup_requested": args.warmup,
-            "timing_note": f"steps are issued as persistent launches of {chunk} fused steps; the request is rounded up to whole "
-                           f"launches and the timed region is never shorter than {MIN_LAUNCHES} launches ({n_timed} timed, {n_warm} warm-up)",
             "config": {"workload": f"BASELINE configs[1]: {cfg} ({N} beads, H={H}, L={L}) Langevin, parallel_sim={P}/GPU, "
                                    f"noise_level={args.noise_level}, save_interval={chunk}, 1 persistent launch per {chunk} steps",
                        "parallelism": f"{world} x independent trajectory shards (no data-path collective)",
-                       "kernel": h["kernel"], "grid": h["grid"], "lds_bytes": h["lds"]},
+                       "kernel": h["kernel"], "grid": h["grid"], "lds_bytes": h["lds"], "launches_timed": n_timed},
             "trajectory_steps_per_s": traj_steps, "finite": h["finite"], "gather_ms": gather_ms,
             "roofline": roofline(cfg, P, chunk, h["launch_ms"], h["kernel"]),
         }
-        if also is not None:
-            res["also"] = also
         if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(cfg, P, args.noise_level)
-            res["speedup_vs_cpu_port"] = value / res["cpu_baseline"]["value"]
+            res["speedup_vs_cpu_port"] = round(value / res["cpu_baseline"]["value"], 1)
+            thr = res["cpu_baseline"]["cores"]
+
+            def brief(cb):   # the `also` entries carry the figures only (kind / unit: see notes.cpu and the entry's own unit)
+                return {"value": round(cb["value"], 4), "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"]}
             if also is not None and "villin_langevin" in also:    # ~5 s per step on the host: three steps, same thread count
-                also["villin_langevin"]["cpu_baseline"] = cpu_baseline("villin", 256, 20, budget_s=10.0, max_steps=3,
-                                                                         threads=res["cpu_baseline"]["cores"])
+                also["villin_langevin"]["cpu_baseline"] = brief(cpu_baseline("villin", 256, 20, budget_s=10.0, max_steps=3, threads=thr))
             if also is not None:    # the i.i.d. metric's CPU legs (north_star: "alongside the CPU-reference number")
                 for name, c2, bud, mx in (("chignolin_iid", "chignolin", 8.0, 20), ("villin_iid", "villin", 8.0, 2)):
                     if name in also:
-                        also[name]["cpu_baseline"] = cpu_baseline_iid(c2, 256, budget_s=bud, max_steps=mx,
-                                                                      threads=res["cpu_baseline"]["cores"])
-                        also[name]["speedup_vs_cpu_port"] = also[name]["value"] / also[name]["cpu_baseline"]["value"]
-                if "chignolin_iid_512" in also and "chignolin_iid" in also and "cpu_baseline" in also["chignolin_iid"]:
-                    also["chignolin_iid_512"]["cpu_baseline"] = dict(also["chignolin_iid"]["cpu_baseline"],
-                                                                     note="measured at batch 256 (the CPU port's samples/s does not grow with the batch)")
-        print(json.dumps(res))
+                        also[name]["cpu_baseline"] = brief(cpu_baseline_iid(c2, 256, budget_s=bud, max_steps=mx, threads=thr))
+        if also is not None:
+            res["also"] = also
+        res["notes"] = NOTES
+        line = json.dumps(res)
+        print(line)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -187,20 +187,33 @@ def test_bench_finds_the_profiled_traffic_for_the_shipped_kernels():
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    t = bench.hbm_traffic_from_profile("dff_small_kernel<64,8>", "chignolin", 256, 250)
+    tr = lambda *a: bench.profile_figures(*a)["traffic"]   # noqa: E731
+    t = tr("dff_small_kernel<64,8>", "chignolin", 256, 250)
     assert t is not None and 1e9 < t < 1e12
-    assert bench.hbm_traffic_from_profile("dff_fused_kernel<128,3,1,false>", "villin", 256, 250) is not None
-    assert bench.hbm_traffic_from_profile("dff_small_kernel<64,8>", "chignolin", 128, 250) is None   # other workload
+    assert tr("dff_fused_kernel<128,3,1,false>", "villin", 256, 250) is not None
+    assert tr("dff_small_kernel<64,8>", "chignolin", 128, 250) is None   # other workload
     # round 2: the split-bf16 headline kernel (rocprofv3 prints "<64, 8, false, true>") has its own, smaller, traffic figure
-    t2 = bench.hbm_traffic_from_profile("dff_small_kernel<64,8,split_bf16>", "chignolin", 256, 250)
+    t2 = tr("dff_small_kernel<64,8,split_bf16>", "chignolin", 256, 250)
     assert t2 is not None and t2 < t
     # round 3: the headline kernel (rocprofv3: "<64, 8, false, true, true, 1>" -- the sampler mode is a template argument now)
     # keeps its activations in LDS / registers: its figure is the latest round's, two orders of magnitude below round 2's
-    t3 = bench.hbm_traffic_from_profile("dff_small_kernel<64,8,split_bf16,fold_kv>", "chignolin", 256, 250)
+    t3 = tr("dff_small_kernel<64,8,split_bf16,fold_kv>", "chignolin", 256, 250)
     assert t3 is not None and t3 < 0.1 * t2
     r = bench.roofline("chignolin", 256, 250, [20.8, 20.9], "dff_small_kernel<64,8,split_bf16>")
-    assert abs(r["frac"] - 1.408e12 / 20.85e-3 / 157.3e12) < 1e-3 and r["peak_split_gemms"] == 2500.0 / 6 and r["traffic"] == t2
-    assert "3-way bf16 split" in bench.kernel_dtype("dff_small_kernel<64,8,split_bf16>")
-    assert "split" not in bench.kernel_dtype("dff_fused_kernel<128,4,1,true>")
+    assert abs(r["frac"] - 1.408e12 / 20.85e-3 / 157.3e12) < 1e-3 and r["traffic"] == t2
+    assert abs(r["split_peak_frac"] - r["achieved"] / (2500.0 / 6)) < 1e-3
+    # round 4: the rocprof-reported MFMA utilisation and HBM rate ride in the roofline object (north_star), read from the
+    # same profile directory as the traffic
+    h = bench.roofline("chignolin", 256, 250, [13.3] * 8, "dff_small_kernel<64,8,split_bf16,fold_kv>")
+    assert 0.05 < h["mfma_busy"] < 1.0 and 0.0 < h["hbm_tbps"] < 8.0 and h["l2_hit"] > 0.5 and h["profile"].startswith("profiles/r")
+    v = bench.roofline("villin", 256, 250, [131.0] * 8, "dff_fused_kernel<128,3,1,false,split_bf16>", brief=True)
+    assert 0.05 < v["mfma_busy"] < 1.0 and v["hbm_tbps"] > 0.1 and "peak" not in v
+    # ... and the line must fit the driver's stdout tail: every `also` entry <= 700 bytes, what they share said once
+    import json
+    entry = {"workload": "villin (35 beads, H=128, L=3) Langevin, 256/GPU", "value": 1897.33, "unit": "MD-steps/s (batch 256, whole job)",
+             "ms_per_step": 0.52712, "steps": 2000, "finite": True, "roofline": v,
+             "cpu_baseline": {"value": 0.3312, "cores": 16, "kind": "port", "sample": "3 Langevin steps, same workload (P=256, villin), 16 of 256 logical cores"}}
+    assert len(json.dumps(entry)) <= 700 and len(json.dumps(bench.NOTES)) <= 1400
+    assert bench.kernel_dtype("dff_small_kernel<64,8,split_bf16>") == "f32" and "3-way bf16 split" in bench.NOTES["dtype"]
     # algorithmic FLOPs per launch of the headline config: 22.00 MFLOP x 256 x 250
     assert abs(bench.MFLOP_PER_CALL["chignolin"] * 1e6 * 256 * 250 - 1.408e12) < 1e6
