@@ -47,6 +47,10 @@ TEMP = {"chignolin": 340, "villin": 360, "protein_g": 350, "ala2": 300, "trp_cag
 PEAK_FP32_TFLOPS = 157.3            # MI355X_MICROARCH.md: f32 vector = f32 MFMA peak
 PEAK_BF16_DENSE_TFLOPS = 2500.0     # dense bf16 MFMA peak; an exact fp32 product costs six bf16 products
 MIN_LAUNCHES = 8
+# DFF_FORCE_DIST=1: run the N > 1 code (process group over RCCL, barriers, max-over-ranks all_reduce, the frame all_gather)
+# at ANY world size -- with one rank under torchrun this loads RCCL and executes every collective of the job on the one GPU
+# a test box has (tests/test_gpu_parity.py::test_bench_rccl_world_one), before the first 8-GPU run does.
+FORCE_DIST = os.environ.get("DFF_FORCE_DIST") == "1"
 
 
 def profile_figures(kname, cfg, P, chunk):
@@ -225,9 +229,10 @@ class Timer:
 
     def __init__(self, dev, world):
         self.dev, self.world = dev, world
+        self.dist = world > 1 or FORCE_DIST
 
     def barrier(self):
-        if self.world > 1:
+        if self.dist:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -244,7 +249,7 @@ class Timer:
             ev[j][1].record()
         self.barrier()
         elapsed = time.perf_counter() - t0
-        if self.world > 1:
+        if self.dist:
             import torch.distributed as dist
             tmax = torch.tensor([elapsed], device=self.dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -317,7 +322,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or FORCE_DIST
+    backend = None
+    if use_dist:
         import torch.distributed as dist
         backend = dist_backend()
         if backend == "nccl":
@@ -337,7 +344,7 @@ def main():
                               "data": "synthetic (seeded weights, in-kernel Philox noise)",
                               "config": {"workload": f"{cfg} iid, batch {P}/GPU, 1000 reverse steps per launch", "kernel": e["kernel"]},
                               "roofline": roofline(cfg, P, 1000, e["launch_ms"], e["kernel"])}))
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             dist.destroy_process_group()
         return
@@ -347,7 +354,7 @@ def main():
     K, W = h["K"], n_warm * chunk
     # the job's only collective: gather the saved frames (xGMI); not part of a "step"
     gather_ms = 0.0
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -395,7 +402,8 @@ def main():
             "config": {"workload": f"BASELINE configs[1]: {cfg} ({N} beads, H={H}, L={L}) Langevin, parallel_sim={P}/GPU, "
                                    f"noise_level={args.noise_level}, save_interval={chunk}, 1 persistent launch per {chunk} steps",
                        "parallelism": f"{world} x independent trajectory shards (no data-path collective)",
-                       "kernel": h["kernel"], "grid": h["grid"], "lds_bytes": h["lds"], "launches_timed": n_timed},
+                       "kernel": h["kernel"], "grid": h["grid"], "lds_bytes": h["lds"], "launches_timed": n_timed,
+                       "collective_backend": backend},
             "trajectory_steps_per_s": traj_steps, "finite": h["finite"], "gather_ms": gather_ms,
             "roofline": roofline(cfg, P, chunk, h["launch_ms"], h["kernel"]),
         }
@@ -417,7 +425,7 @@ def main():
         res["notes"] = NOTES
         line = json.dumps(res)
         print(line)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.destroy_process_group()
 

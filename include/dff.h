@@ -131,11 +131,16 @@ int dff_ddpm_run(dff_model* m, int batch, float* x_dev, const float* noise_dev, 
  * dff_debug_pair) gave up waiting for a partner workgroup -- possible only when the GPU is shared with another process or
  * partitioned below the CU count the driver reports; the results of that launch are invalid.  The samplers call this at
  * their host synchronisation points (end of LangevinDiffusion.simulate, GaussianDiffusion.check_clamp, the CLI) and raise;
- * the next such launch on the same model also refuses with DFF_EHIP.  The reference has no counterpart (one process, one
- * kernel per op).  NOTE: which variant runs depends on the per-call batch (<= n_CUs / 2 proteins), and the two variants sum
+ * once the host has seen the word, the next such launch on the same model refuses with DFF_EHIP; one queued before that
+ * leaves at kernel entry (the word is read on the device), so nothing runs on top of invalid results.  The entry points
+ * themselves never read it: they only enqueue on the caller's stream (round 4; they used to synchronise the device before
+ * every two-workgroups launch).  The reference has no counterpart (one process, one kernel per op).  NOTE: which variant runs depends on the per-call batch (<= n_CUs / 2 proteins), and the two variants sum
  * in different orders: trajectories are bit-reproducible for a fixed per-rank batch, not across batch splits that cross
  * that threshold. */
 int dff_model_status(dff_model* m, unsigned* status);
+/* Clear the sticky word (synchronises the device): re-arms the two-workgroups variants after the caller has dealt with a
+ * reported failure (e.g. the co-tenant that held the CUs is gone).  dff_debug_pair(m, 0) clears it as well. */
+int dff_model_status_clear(dff_model* m);
 
 /* ---- introspection / debugging (used by tests and bench.py, not by samplers) ---- */
 
@@ -157,6 +162,9 @@ int dff_debug_l0_table(dff_model* m, int on);
 int dff_debug_pair(dff_model* m, int on);
 /* dff_model_status for tests: *status = the sticky word, which is then CLEARED.  Synchronises the device. */
 int dff_debug_pair_status(dff_model* m, int* status);
+/* Tests: overwrite the sticky word ON THE DEVICE as a kernel that lost its partner would (the host's cached copy is not
+ * touched), to exercise the failure path: queued two-workgroups launches leave at entry, dff_model_status reports. */
+int dff_debug_poke_status(dff_model* m, unsigned word);
 /* Name of the kernel the last call launched, grid size and dynamic LDS bytes. */
 int dff_last_launch(const dff_model* m, const char** kernel_name, int* grid, int* lds_bytes);
 /* Run one MFMA GEMM stage out(M,Nout) = A(M,K) W(K,Nout) through the same device routine and

@@ -796,6 +796,73 @@ def test_bench_two_ranks_on_one_gpu(dff):
 
 
 @pytest.mark.gpu
+def test_pair_failure_word_is_sticky_reported_once_and_never_syncs_the_launch_path(dff):
+    """The two-workgroups-per-protein variants' failure word (round 4): the launch path does not read it (stays
+    asynchronous); a launch queued on top of a failure leaves at kernel entry (outputs untouched), the host's next status
+    check raises ONCE and clears, after which the same model works again; once the host has seen the word, a further
+    two-workgroups launch is refused without touching the device; Model.pair(False) clears it too."""
+    cfg = "protein_g"
+    g = golden(f"score_{cfg}.npz")
+    model, _ = get_model(dff, cfg)
+    x, t = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["t"]).cuda()
+    try:
+        model.native.pair(True)
+        good = model.native.score(x, t).cpu().numpy()
+        assert "pair" in model.native.last_launch()[0] and model.native.status() == 0
+        model.native.poke_status(1)                       # as a kernel that lost its partner would
+        sent = torch.full_like(x, 123.0)
+        import dff_amd.binding as B
+        _ = model.native.score(x, t)                      # accepted (the host has not looked), leaves at entry
+        # its output buffer is whatever torch.empty handed out; run again into a sentinel through the raw ABI instead
+        rc = model.native.lib.dff_score(model.native.handle, B._ptr(x), B._ptr(t), x.shape[0], B._ptr(sent), None, model.native._stream())
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert bool((sent == 123.0).all()), "a two-workgroups launch ran on top of a reported failure"
+        with pytest.raises(RuntimeError, match="partner workgroup"):
+            model.native.check()
+        model.native.check()                              # reported once, cleared
+        again = model.native.score(x, t).cpu().numpy()
+        assert np.array_equal(again, good)
+        model.native.poke_status(1)
+        assert model.native.status() == 1                 # the host has seen it now: refused on the host side
+        with pytest.raises(RuntimeError):
+            model.native.score(x, t)
+        model.native.pair(False)                          # selects the one-workgroup kernels AND clears the word
+        assert model.native.status() == 0
+        one = model.native.score(x, t).cpu().numpy()
+        assert rel(one, good) <= 5e-6
+    finally:
+        model.native.status_clear()
+        model.native.pair(True)
+
+
+@pytest.mark.gpu
+def test_bench_rccl_world_one(dff):
+    """The RCCL code path itself, executed before the first multi-GPU run does: bench.py under torchrun with ONE rank and
+    DFF_FORCE_DIST=1 -> init_process_group("nccl", device_id=...) (RCCL is loaded), the barriers, the max-over-ranks
+    all_reduce on a device tensor and the frame all_gather (sample.py:180-190's gather) all run on the one GPU."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DFF_TEST_KNOBS", "DFF_DIST_BACKEND", "DFF_DEVICE")}
+    env.update(DFF_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "500", "--warmup", "250",
+                        "--no-cpu", "--no-extras"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["finite"] and j["config"]["collective_backend"] == "nccl"
+    assert j["gather_ms"] > 0.0 and j["steps"] == 2000 and j["value"] > 1000.0
+    print(f"bench over RCCL at world 1: {j['value']:.0f} MD-steps/s, gather {j['gather_ms']:.2f} ms")
+
+
+@pytest.mark.gpu
 def test_device_flag_word_persists_and_reports_centre(dff):
     """One flag word per GaussianDiffusion: a clamp in an EARLIER batch is still reported after later clean batches
     (the reference warns per step, ddpm.py:248-250), and a chain that ends off-centre -- here: NaNs, which slip through the

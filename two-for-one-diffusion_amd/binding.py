@@ -70,6 +70,8 @@ SYMBOLS = {
     "dff_debug_pair": (C.c_int, [_P, C.c_int]),
     "dff_debug_pair_status": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "dff_model_status": (C.c_int, [_P, C.POINTER(C.c_uint)]),
+    "dff_model_status_clear": (C.c_int, [_P]),
+    "dff_debug_poke_status": (C.c_int, [_P, C.c_uint]),
     "dff_version": (C.c_char_p, []),
 }
 
@@ -195,9 +197,18 @@ class Model:
         two-workgroups-per-protein launch lost its partner workgroup).  Called at the samplers' host sync points."""
         w = self.status()
         if w:
+            # reported once: the word is cleared, so the model is usable again (a transient co-tenant must not poison every
+            # later run); the launches since the failure produced nothing -- the kernels leave at entry while the word is set
+            self.status_clear()
             raise RuntimeError(f"libdff_amd: device-side failure word {w:#x}: a two-workgroups-per-protein kernel launch timed "
-                               f"out waiting for its partner workgroup (GPU shared or partitioned?); results are invalid. "
-                               f"Model.pair(False) selects the one-workgroup kernels.")
+                               f"out waiting for its partner workgroup (GPU shared or partitioned?); the results since then "
+                               f"are invalid.  The word has been cleared; Model.pair(False) selects the one-workgroup kernels.")
+
+    def poke_status(self, word: int):
+        _check(self.lib, self.lib.dff_debug_poke_status(self.handle, int(word)), "dff_debug_poke_status")
+
+    def status_clear(self):
+        _check(self.lib, self.lib.dff_model_status_clear(self.handle), "dff_model_status_clear")
 
     def l0_table(self, on: bool = True):
         _check(self.lib, self.lib.dff_debug_l0_table(self.handle, int(on)), "dff_debug_l0_table")

@@ -183,7 +183,8 @@ struct dff_model {
     size_t xflag_n = 0;
     bool pair_off = false;                     // debugging: never use a PAIR variant
     bool last_pair = false;
-    bool pair_used = false;                    // a PAIR launch has run since the sticky error word was last read
+    unsigned sticky = 0;                       // the sticky error word as the host last read it (read_status): a non-zero one
+                                               // refuses further PAIR launches WITHOUT touching the device
     int n_cus = 0;                             // hipDeviceAttributeMultiprocessorCount of `device`
 };
 
@@ -551,16 +552,22 @@ extern "C" int dff_debug_max_workgroups(dff_model* m, int n) {
     return DFF_OK;
 }
 
+static int clear_status(dff_model* m);
 extern "C" int dff_debug_pair(dff_model* m, int on) {
     if (!m) return fail(DFF_EINVAL, "null model");
     m->pair_off = on == 0;
+    // turning the PAIR variants off is how a caller recovers from a partner timeout: the one-workgroup kernels do not look
+    // at the word, so it is cleared here (it would otherwise fail every later status check of a model that works again)
+    if (m->pair_off && m->sticky) return clear_status(m);
     return DFF_OK;
 }
 
 // Sticky status of the model's launches so far: bit 0 = a PAIR launch (two workgroups per protein) gave up waiting for a
 // partner workgroup (bounded spin instead of a hang; the results of that launch are invalid).  The word lives at
 // xflag[0], is only ever OR-ed by the kernels and is never cleared by a launch, so an error in ANY launch of a chunked
-// run is still there when the caller looks.  Synchronises the device.
+// run is still there when the caller looks.  Synchronises the device -- which is why only the status calls come here: the
+// launch path never does (a PAIR kernel that finds the word set at entry leaves at once, and launch() refuses PAIR on the
+// host's cached copy), so dff_score / dff_langevin_run / dff_ddpm_run stay asynchronous on the caller's stream.
 static int read_status(dff_model* m, unsigned* word, bool clear) {
     *word = 0;
     if (!m->xflag) return DFF_OK;
@@ -568,13 +575,32 @@ static int read_status(dff_model* m, unsigned* word, bool clear) {
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(word, m->xflag, sizeof(unsigned), hipMemcpyDeviceToHost));
     if (clear && *word) HIPCHK(hipMemset(m->xflag, 0, sizeof(unsigned)));
-    m->pair_used = false;
+    m->sticky = clear ? 0u : *word;
     return DFF_OK;
+}
+static int clear_status(dff_model* m) {
+    unsigned w = 0;
+    return read_status(m, &w, true);
 }
 
 extern "C" int dff_model_status(dff_model* m, unsigned* status) {
     if (!m || !status) return fail(DFF_EINVAL, "null argument");
     return read_status(m, status, false);
+}
+
+extern "C" int dff_model_status_clear(dff_model* m) {
+    if (!m) return fail(DFF_EINVAL, "null model");
+    return clear_status(m);
+}
+
+// tests: set the DEVICE word behind the host's back (as a kernel that lost its partner would), host cache untouched
+extern "C" int dff_debug_poke_status(dff_model* m, unsigned word) {
+    if (!m) return fail(DFF_EINVAL, "null model");
+    if (!m->xflag) return fail(DFF_EINVAL, "no two-workgroups launch has run on this model yet");
+    ON_DEVICE(m->device);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(m->xflag, &word, sizeof(unsigned), hipMemcpyHostToDevice));
+    return DFF_OK;
 }
 
 // debugging form: reads AND clears
@@ -677,23 +703,17 @@ static int launch_generic(dff_model* m, DffRunArgs& a, int G, const Variant* v, 
             HIPCHK(hipMalloc((void**)&m->xchg, need * sizeof(float)));
             m->xchg_floats = need;
         }
-        if (nflag > m->xflag_n) {   // word 0 (sticky error word) survives the re-allocation
-            unsigned keep = 0;
-            if (m->xflag) {
-                HIPCHK(hipStreamSynchronize(stream));
-                HIPCHK(hipMemcpy(&keep, m->xflag, sizeof(unsigned), hipMemcpyDeviceToHost));
-                HIPCHK(hipFree(m->xflag));
-            }
-            m->xflag = nullptr; m->xflag_n = 0;
-            const size_t cap = nflag < 513 ? 513 : nflag;
+        if (!m->xflag) {   // once per model, sized for the largest grid a PAIR launch can have (one block per CU): no
+                           // re-allocation -- and so no synchronisation -- on the launch path afterwards
+            const size_t cap = (size_t)(m->n_cus > 512 ? m->n_cus : 512) + 1;
             HIPCHK(hipMalloc((void**)&m->xflag, cap * sizeof(unsigned)));
-            HIPCHK(hipMemcpy(m->xflag, &keep, sizeof(unsigned), hipMemcpyHostToDevice));
+            HIPCHK(hipMemsetAsync(m->xflag, 0, sizeof(unsigned), stream));
             m->xflag_n = cap;
         }
+        if (nflag > m->xflag_n) return fail(DFF_EINVAL, "PAIR grid of %d pairs exceeds the flag array", npairs);
         // sequence numbers restart at every launch; the error word at [0] is NOT touched
         HIPCHK(hipMemsetAsync(m->xflag + 1, 0, (nflag - 1) * sizeof(unsigned), stream));
         a.xchg = m->xchg; a.xflag = m->xflag;
-        m->pair_used = true;
     }
     m->last_small = false;
     m->last_pair = v->pair;
@@ -848,14 +868,12 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
     if (G == 1 && !gen && m->cfg.conservative && !m->pair_off && 2 * 8 * ((a.B + 7) / 8) <= cu_cap) {
         const Variant* vp = pick_pair(mt, v->spw);
         if (vp) {
-            if (m->pair_used) {
-                unsigned w = 0;
-                const int rc = read_status(m, &w, false);
-                if (rc) return rc;
-                if (w) return fail(DFF_EHIP, "an earlier two-workgroups-per-protein launch timed out waiting for its partner "
-                                             "workgroup (the GPU is shared or partitioned?): its results are invalid; "
-                                             "dff_debug_pair(m, 0) selects the one-workgroup kernels");
-            }
+            // (no device access here: the launch path stays asynchronous.  The word the HOST last saw refuses; one it has
+            // not seen yet makes the kernel itself leave at entry, and the next status call reports it.)
+            if (m->sticky)
+                return fail(DFF_EHIP, "an earlier two-workgroups-per-protein launch timed out waiting for its partner "
+                                      "workgroup (the GPU is shared or partitioned?): its results are invalid; "
+                                      "dff_model_status_clear(m) re-arms, dff_debug_pair(m, 0) selects the one-workgroup kernels");
             v = vp;
         }
     }
@@ -1008,6 +1026,9 @@ extern "C" int dff_debug_stash(dff_model* m, int b, int layer, int what, float* 
 
 extern "C" int dff_debug_profile(dff_model* m, int enable) {
     if (!m) return fail(DFF_EINVAL, "null model");
+#if !DFF_PROF
+    if (enable) return fail(DFF_EINVAL, "this library was built without the stage ticks (./build.sh with DFF_EXTRA_FLAGS=-DDFF_PROF=1)");
+#endif
     ON_DEVICE(m->device);
     if (enable && !m->prof) {
         HIPCHK(hipMalloc((void**)&m->prof, DFF_NPROF * sizeof(unsigned long long)));

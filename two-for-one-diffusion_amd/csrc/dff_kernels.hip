@@ -797,7 +797,7 @@ DEVI void l2_touch(unsigned junk_byte, const void* base, int ntiles, size_t stri
             const int t = ln / lpt, w = ln - t * lpt;
             const char __attribute__((address_space(1)))* p =
                 (const char __attribute__((address_space(1)))*)base + (size_t)t * stride + (size_t)w * 128;
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, off" ::"s"(junk_byte), "v"(p) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, off" ::"s"(junk_byte), "v"(p) : "memory", "m0");
         }
     }
 }
@@ -2290,6 +2290,16 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
     // zero LDS once (pad columns of the 32-wide buffers must be 0; pad rows must be finite)
     for (int i = tid; i < (int)ll.total; i += DFF_NTHREADS) smem[i] = 0.f;
     wg_sync<SPILL>();
+    if constexpr (PAIR) {
+        // A launch on top of a failed one (sticky error word set: an earlier PAIR launch lost a partner) leaves at once
+        // -- the host does not look at the word on the launch path (that would synchronise the stream), it reads it at its
+        // own synchronisation points (dff_model_status).  One thread reads, everybody agrees through LDS.
+        if (tid == 0) ((unsigned*)smem)[ll.junk] = __hip_atomic_load(a.xflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned failed = ((const unsigned*)smem)[ll.junk];
+        __syncthreads();
+        if (failed) return;
+    }
     if (tid < 64) ((int*)smem)[ll.prow + tid] = tid < rows ? tid / N : -1;
 
     Prof pf;

@@ -140,9 +140,15 @@ class GaussianDiffusion:
         times per step): warns like ddpm.py:249 if the clamp fired in ANY batch, raises like assert_center_zero
         (ddpm.py:252) if any chain ended off-centre; clears the word."""
         word = int(self._flag.item())
-        self._flag.zero_()
-        self.model.native.check()   # (the read above synchronised the device)
         self.last_clamped = bool(word & 1)
+        self._flag.zero_()
+        try:
+            self.model.native.check()   # (the read above synchronised the device)
+        except RuntimeError:
+            # the chains since the last check are invalid, but what their flag word said is not lost with the exception
+            if self.last_clamped:
+                warnings.warn("Large molecule encountered in sampling")
+            raise
         if self.last_clamped:
             warnings.warn("Large molecule encountered in sampling")
         if word & 2:
