@@ -796,7 +796,7 @@ def test_bench_two_ranks_on_one_gpu(dff):
 
 
 @pytest.mark.gpu
-def test_pair_failure_word_is_sticky_reported_once_and_never_syncs_the_launch_path(dff):
+def test_pair_failure_word_is_sticky_reported_once_and_never_syncs_the_launch_path(dff, golden):
     """The two-workgroups-per-protein variants' failure word (round 4): the launch path does not read it (stays
     asynchronous); a launch queued on top of a failure leaves at kernel entry (outputs untouched), the host's next status
     check raises ONCE and clears, after which the same model works again; once the host has seen the word, a further

@@ -117,7 +117,7 @@ struct LdsLayout {
         prow = o;  o += 64;                    // protein index of each row (-1: pad row)
         dxw = o;   o += DFF_NWAVES * R * 4;   // per-wave partial dE/dx (summed once per step)
         m12 = o;   o += HGS * R * 4;          // GEN: reloaded [m1 | m2] of the head group (backward)
-        abuf = o;  o += R * LH;
+        abuf = o;  if (!spw) o += R * LH;   // (split engine: the row stages write the bf16 pieces themselves, no fp32 copy)
         resbuf = o; if (!SPILL) o += R * LH;
         Pbuf = o;  o += HGS * PT;
         dSbuf = o; o += HGS * PT;
@@ -377,6 +377,8 @@ struct Ctx {
     int N, G, gcnt, rows, NP, L;
     int b0;
     float *xst, *xs, *dxs, *vst, *cm, *tn, *abuf, *resbuf, *Pbuf, *dSbuf, *Rg;
+    lu32* asp;     // split engine: the bf16 pieces of the K = H GEMM input (LdsLayout::asplit), RNa allocated rows
+    int RNa;
     float* stash;  // this workgroup's slot
     const float* l0;   // layer-0 slot the x-independent nodes_in / q|u|k|v are READ from (table entry or own stash)
     StashLayout sl;

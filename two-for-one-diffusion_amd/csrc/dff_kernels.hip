@@ -797,7 +797,7 @@ DEVI void l2_touch(unsigned junk_byte, const void* base, int ntiles, size_t stri
             const int t = ln / lpt, w = ln - t * lpt;
             const char __attribute__((address_space(1)))* p =
                 (const char __attribute__((address_space(1)))*)base + (size_t)t * stride + (size_t)w * 128;
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, off" ::"s"(junk_byte), "v"(p) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, off" ::"s"(junk_byte), "v"(p) : "memory");
         }
     }
 }
@@ -1185,6 +1185,39 @@ DEVI void rstore(float* p, const float (&x)[H / LP], int sub) {
         else *(f32x2*)q = (f32x2){x[2 * j], x[2 * j + 1]};
     }
 }
+// A row stage's K = H GEMM input.  fp32 engine: the fp32 row into abuf.  Split engine (round 4): the three bf16 pieces
+// straight into the split A operand (as[piece][row][LHS2], what split_rows used to make of abuf in a pass -- and a workgroup
+// barrier -- of its own, four times per layer); abuf does not exist in those variants.
+template <int H, int LP, bool SPW>
+DEVI void rstore_a(const Ctx& c, int row, const float (&x)[H / LP], int sub) {
+    using M = RowMap<H, LP>;
+    if constexpr (!SPW) {
+        rstore<H, LP>(c.abuf + row * (H + 4), x, sub);
+    } else {
+        constexpr int LHS2 = (H + DFF_SPAD) / 2;
+#pragma unroll
+        for (int j = 0; j < M::NV; ++j) {
+            const int col = M::VW * sub + M::VW * LP * j;
+            if constexpr (M::VW == 4) {
+                store_split4(c.asp, c.RNa, LHS2, row, col, (f32x4){x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3]});
+            } else {
+                unsigned hh[2], mm[2], ll[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float v = x[2 * j + q];
+                    const unsigned uh = __float_as_uint(v) & 0xffff0000u;
+                    const float r = v - __uint_as_float(uh);
+                    const unsigned um = __float_as_uint(r) & 0xffff0000u;
+                    hh[q] = uh; mm[q] = um; ll[q] = __float_as_uint(r - __uint_as_float(um));
+                }
+                const int o = row * LHS2 + (col >> 1);
+                c.asp[0 * c.RNa * LHS2 + o] = __builtin_amdgcn_perm(hh[1], hh[0], 0x07060302u);
+                c.asp[1 * c.RNa * LHS2 + o] = __builtin_amdgcn_perm(mm[1], mm[0], 0x07060302u);
+                c.asp[2 * c.RNa * LHS2 + o] = __builtin_amdgcn_perm(ll[1], ll[0], 0x07060302u);
+            }
+        }
+    }
+}
 template <int LP>
 DEVI float grp_sum_lp(float v) {   // all-reduce over the LP (8 or 16) lanes of a row
     v += dpp_mov<0xB1>(v);
@@ -1243,7 +1276,7 @@ DEVI void gate_weights(float (&w)[3][H / LP], const float* g, int sub) {
 }
 
 // R0: nodes (resbuf) -> stash nodes_in ; LN1 -> abuf
-template <int H, int LP>
+template <int H, int LP, bool SPW>
 DEVI void row_ln1(const Ctx& c, const DffLayerDev& lw, int l) {
     const int tid_ = tid_now();
     constexpr int HC = H / LP, LH = H + 4;
@@ -1258,12 +1291,12 @@ DEVI void row_ln1(const Ctx& c, const DffLayerDev& lw, int l) {
         ln_stats<H, LP>(x, mean, rstd);
 #pragma unroll
         for (int i = 0; i < HC; ++i) x[i] = (x[i] - mean) * rstd * gam[i] + bet[i];
-        rstore<H, LP>(c.abuf + row * LH, x, sub);
+        rstore_a<H, LP, SPW>(c, row, x, sub);
     }
 }
 
 // R1: tbuf = attn_out, resbuf = nodes -> nodes1 (resbuf), stash attn_out, LN2 -> abuf
-template <int H, int LP>
+template <int H, int LP, bool SPW>
 DEVI void row_gate1_ln2(const Ctx& c, const DffLayerDev& lw, int l, const float* tbuf) {
     const int tid_ = tid_now();
     constexpr int HC = H / LP, LH = H + 4;
@@ -1284,7 +1317,7 @@ DEVI void row_gate1_ln2(const Ctx& c, const DffLayerDev& lw, int l, const float*
         ln_stats<H, LP>(n1, mean, rstd);
 #pragma unroll
         for (int i = 0; i < HC; ++i) n1[i] = (n1[i] - mean) * rstd * gam[i] + bet[i];
-        rstore<H, LP>(c.abuf + row * LH, n1, sub);
+        rstore_a<H, LP, SPW>(c, row, n1, sub);
     }
 }
 
@@ -1336,7 +1369,7 @@ DEVI void row_gate2(const Ctx& c, const DffModelDev& m, const DffLayerDev& lw, i
 }
 
 // RB1: dn (resbuf) through gate2 -> dff (abuf), dn1 partial (resbuf)
-template <int H, int LP>
+template <int H, int LP, bool SPW>
 DEVI void rowb_gate2(const Ctx& c, const DffLayerDev& lw, int l) {
     const int tid_ = tid_now();
     constexpr int HC = H / LP, LH = H + 4;
@@ -1364,13 +1397,13 @@ DEVI void rowb_gate2(const Ctx& c, const DffLayerDev& lw, int l) {
             ao[i] = dn[i] * g2 + dz * (w2[0][i] + w2[2][i]);
             nin[i] = dn[i] * (1.0f - g2) + dz * (w2[1][i] - w2[2][i]);
         }
-        rstore<H, LP>(c.abuf + row * LH, ao, sub);
+        rstore_a<H, LP, SPW>(c, row, ao, sub);
         rstore<H, LP>(c.resbuf + row * LH, nin, sub);
     }
 }
 
 // RB2: tbuf = df ; dn1 = resbuf + LN2bwd(df) ; gate1 bwd -> dattn (abuf), dn_in partial (resbuf)
-template <int H, int LP>
+template <int H, int LP, bool SPW>
 DEVI void rowb_ln2_gate1(const Ctx& c, const DffLayerDev& lw, int l, const float* tbuf) {
     const int tid_ = tid_now();
     constexpr int HC = H / LP, LH = H + 4;
@@ -1413,7 +1446,7 @@ DEVI void rowb_ln2_gate1(const Ctx& c, const DffLayerDev& lw, int l, const float
             ao[i] = d1[i] * g1 + dz * (w[0][i] + w[2][i]);
             nin[i] = d1[i] * (1.0f - g1) + dz * (w[1][i] - w[2][i]);
         }
-        rstore<H, LP>(c.abuf + row * LH, ao, sub);
+        rstore_a<H, LP, SPW>(c, row, ao, sub);
         rstore<H, LP>(c.resbuf + row * LH, nin, sub);
     }
 }
@@ -2199,6 +2232,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
     c.xst = smem + ll.xst; c.xs = smem + ll.xs; c.dxs = smem + ll.dxs; c.vst = smem + ll.vst;
     c.cm = smem + ll.cm; c.tn = smem + ll.tn;
     c.abuf = smem + ll.abuf;
+    c.asp = asplit; c.RNa = c.G * c.N;
     c.Pbuf = smem + ll.Pbuf; c.dSbuf = smem + ll.dSbuf; c.Rg = smem + ll.Rg;
     c.sl = dff_stash_layout(c.N, c.G, H, m.L);
     c.stash = a.stash + (size_t)blockIdx.x * a.stash_stride;
@@ -2390,11 +2424,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 }
             } else {
                 l2_wqkv(lw, hg_lo);
-                row_ln1<H, LPG>(c, lw, l);
+                row_ln1<H, LPG, SPW>(c, lw, l);
                 wg_sync<SPILL>();
-            }
-            if constexpr (SPW) {
-                if (!cached) { split_rows<H>(abufL, asplit, RN); wg_sync<SPILL>(); }
             }
             pf.tick(1);
             f32x4 acc_o[NTW][MT];
@@ -2545,9 +2576,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             store_tall<MT, NTW>(acc_o, tbuf, LH, rows, NT_H, hf == 0 ? lw.bo : nullptr);
             pair_exchange(tbuf, H, LH);
             wg_sync<SPILL>();
-            row_gate1_ln2<H, LPG>(c, lw, l, tbuf);
+            row_gate1_ln2<H, LPG, SPW>(c, lw, l, tbuf);
             wg_sync<SPILL>();
-            if constexpr (SPW) { split_rows<H>(abufL, asplit, RN); wg_sync<SPILL>(); }
             pf.tick(7);
             // FFN: Linear(H,4H) -> GELU(erf) -> Linear(4H,H)   (graph_transformer.py:264-267)
             f32x4 acc_f[NTW][MT];
@@ -2604,9 +2634,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             const DffLayerDev& lw = m.layer[l];
             const float* sb = c.stash + (size_t)l * c.sl.layer_stride;
             if (l < m.L - 1) l2_w2t(lw, ch_lo);
-            rowb_gate2<H, LPG>(c, lw, l);
+            rowb_gate2<H, LPG, SPW>(c, lw, l);
             wg_sync<SPILL>();
-            if constexpr (SPW) { split_rows<H>(abufL, asplit, RN); wg_sync<SPILL>(); }
             pf.tick(11);
             // dh = dff W2 ; dh_pre = dh * gelu'(h_pre) ; df = dh_pre W1
             f32x4 acc_f[NTW][MT];
@@ -2660,9 +2689,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             CoReload<MT, HGS> rl;
             co_reload_plan<MT, HGS>(rl, geo, true, tid_now());
             co_reload_issue<MT, HGS>(rl, sqkv + (size_t)hg_lo * HGS * RN * DFF_QKVW, sPl + (size_t)hg_lo * HGS * RN * c.sl.PS);
-            rowb_ln2_gate1<H, LPG>(c, lw, l, tbuf);
+            rowb_ln2_gate1<H, LPG, SPW>(c, lw, l, tbuf);
             wg_sync<SPILL>();
-            if constexpr (SPW) { split_rows<H>(abufL, asplit, RN); wg_sync<SPILL>(); }
             pf.tick(14);
             f32x4 acc_a[NTW][MT];
             acc_zero<MT, NTW>(acc_a);

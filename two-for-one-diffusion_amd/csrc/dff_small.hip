@@ -620,8 +620,10 @@ DEVI void head_store(const lfloat* Qx, const lfloat* Kx, const lfloat* Vx, gfloa
 // compiler would order EVERY later LDS read of the wave behind a builtin LDS-DMA (it has no alias information); its own
 // s_waitcnt bookkeeping stays safe: vmcnt retires in order, so the extra loads can only make its waits longer.
 DEVI void lds_dma16(unsigned lds_byte, const gfloat* src) {
-    // (m0 is declared clobbered: the compiler re-materialises whatever it keeps there for its own LDS-DMA / GWS / s_movrel uses)
-    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte), "v"(src) : "memory", "m0");
+    // (m0 cannot go on the clobber list: hipcc rejects it as a RESERVED register -- "inline asm clobber list contains reserved
+    // registers: m0", ROCm 7.2 -- which is also why the write is safe: the compiler never keeps a value in a reserved register
+    // across statements, it sets m0 right before each instruction of its own that reads it)
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte), "v"(src) : "memory");
 }
 DEVI void head_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // table entry of 16-byte slot `sl` of the contiguous [Q | K | V | P] regions: float offset of its source relative to the
