@@ -90,8 +90,6 @@ template <int H, int MT, int HGS, bool SPILL>
 struct LdsLayout {
     static constexpr int LH = H + 4;
     static constexpr int LQ = 80 * HGS + 4;
-    static constexpr int PL = 16 * MT + 4;
-    static constexpr int PT = 16 * MT * PL;   // one head's tile array
     static constexpr int F = 4 * H;
     static constexpr int FC = (F % 256 == 0) ? 256 : 128;
     static constexpr int LF = FC + 4;
@@ -103,9 +101,23 @@ struct LdsLayout {
     static constexpr bool KVS = NREG == 5 && DFF_KVSPLIT;
     static constexpr bool VSP = KVS && !(H == 96 && MT == 2);
     static constexpr int LSV = 32 * HGS + 4;
+    // P / dS tile arrays.  Default: 16 MT rows x (16 MT + 4) floats per head.  TIGHT (split engine at four row tiles, i.e.
+    // protein G: 56 rows; round 4): the workgroup's ALLOCATED rows only, 16 MT - 4 = 60 floats each -- columns 60..63 do not
+    // exist (the phases that would touch them are guarded: they hold pad beads, exact zeros) -- and the regions are ordered
+    //   [... | asplit | Rg = R0 R1 R2 R3 | dSbuf | Pbuf]
+    // so that what outgrows R3 / Rg in this variant continues into buffers that are idle then: the bf16 pieces of o (forward,
+    // 3 x R x 40 dwords from R3 on: dSbuf is idle) and of the FFN hidden chunk (3 x R x 136 dwords from R0 on: dSbuf and Pbuf
+    // are idle).  That, and the fp32 abuf the split engine no longer has, is what lets the split A operand (48 KB at 56
+    // rows) into the 160 KB next to four head buffers.
+    static constexpr bool TIGHT_OK = MT == 4 && HGS == 1;
+    static constexpr int PL_WIDE = 16 * MT + 4, PL_TIGHT = 16 * MT - 4;
+    template <bool SPW> static constexpr int pl() { return (SPW && TIGHT_OK) ? PL_TIGHT : PL_WIDE; }
     unsigned xst, xs, dxs, vst, cm, tn, prof, prow, dxw, m12, abuf, resbuf, Pbuf, dSbuf, Rg, asplit, lsplit, junk, total;
+    unsigned PT;   // floats of one head's P (or dS) tile array
     __host__ __device__ LdsLayout(int N, int G, bool spw = false) {
         const unsigned R = (unsigned)(G * N);
+        const bool tight = spw && TIGHT_OK;
+        PT = tight ? R * PL_TIGHT : 16u * MT * PL_WIDE;
         unsigned o = 0;
         xst = o;   o += R * 4;
         xs = o;    o += R * 4;
@@ -116,9 +128,20 @@ struct LdsLayout {
         prof = o;  o += 2 * DFF_NPROF;
         prow = o;  o += 64;                    // protein index of each row (-1: pad row)
         dxw = o;   o += DFF_NWAVES * R * 4;   // per-wave partial dE/dx (summed once per step)
-        m12 = o;   o += HGS * R * 4;          // GEN: reloaded [m1 | m2] of the head group (backward)
+        m12 = o;   if (!tight) o += HGS * R * 4;   // GEN: reloaded [m1 | m2] of the head group (backward); no GEN variant is TIGHT
         abuf = o;  if (!spw) o += R * LH;   // (split engine: the row stages write the bf16 pieces themselves, no fp32 copy)
         resbuf = o; if (!SPILL) o += R * LH;
+        if (tight) {
+            asplit = o; o += 3u * R * LHS2;
+            Rg = o;     o += (unsigned)NREG * R * LQ;
+            dSbuf = o;  o += HGS * PT;
+            Pbuf = o;   o += HGS * PT;
+            // (slack: clamped / skipped operand reads of the last tile rows run a few floats past Pbuf)
+            lsplit = o;
+            junk = o;   o += 64;
+            total = o;
+            return;
+        }
         Pbuf = o;  o += HGS * PT;
         dSbuf = o; o += HGS * PT;
         Rg = o;

@@ -835,7 +835,10 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
         const Variant* vs = dff_fused_variants(&nv);
         for (int q = 0; q < nv; ++q) {
             const Variant& c = vs[q];
-            if (c.H == H && c.MT == mt_ && c.gen == gen && !c.pair && (!c.spw || m->split) && (!r || c.spw)) r = &c;
+            // (a split-engine variant must also fit the 160 KB of LDS at this row count: the four-row-tile one does up to
+            // 56 rows -- protein G --, beyond that the fp32 engine of the same shape runs)
+            if (c.H == H && c.MT == mt_ && c.gen == gen && !c.pair && (!c.spw || m->split) && (!r || c.spw) &&
+                (!c.spw || c.lds_floats(N, G) * sizeof(float) <= 160u * 1024u)) r = &c;
         }
         return r;
     };

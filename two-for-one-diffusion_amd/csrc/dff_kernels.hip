@@ -492,26 +492,27 @@ DEVI void gemm_wide_split_st(const lu32* as, int R, int rowsA, const unsigned* _
     }
 }
 
-// gemm_wide_units on the split operands (few output tiles: (tile, row-tile) units round-robin over the waves, loop-free)
+// gemm_wide_units on the split operands (few output tiles: (tile, row-tile) units round-robin over the waves, loop-free).
+// Up to two units per wave: all weights requested up front.  More (four row tiles: 5 tiles x 4 = 20 units, three per
+// wave): a ring of two units -- three units of K = 128 weights at once are 144 registers.
 template <int MT, int KB32, int NTN, class Epi>
 DEVI void gemm_wide_units_split(const lu32* as, int R, int rowsA, const unsigned* __restrict__ Wp, int nt0, Epi epi) {
     const int tid_ = tid_now();
-    constexpr int NU = NTN * MT, DU = (NU + DFF_NWAVES - 1) / DFF_NWAVES, LHS2 = (32 * KB32 + DFF_SPAD) / 2;
+    constexpr int NU = NTN * MT, DU = (NU + DFF_NWAVES - 1) / DFF_NWAVES, DRU = DU < 2 ? DU : 2, LHS2 = (32 * KB32 + DFF_SPAD) / 2;
     const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     const int kg = lane >> 4, mm = lane & 15;
     const gu32x4* wp = (const gu32x4*)Wp + lane;
-    u32x4 b[DU][KB32][3];
+    u32x4 b[DRU][KB32][3];
+    auto fill = [&](u32x4 (&slot)[KB32][3], int d) {
+        const int nt = min(wave + DFF_NWAVES * d, NU - 1) / MT;
 #pragma unroll
-    for (int d = 0; d < DU; ++d) {
-        const int u = wave + DFF_NWAVES * d;
-        if (u < NU) {
-            const int nt = u / MT;
+        for (int kb = 0; kb < KB32; ++kb)
 #pragma unroll
-            for (int kb = 0; kb < KB32; ++kb)
+            for (int p = 0; p < 3; ++p) slot[kb][p] = wp[(((size_t)(nt0 + nt) * KB32 + kb) * 3 + p) * 64];
+    };
 #pragma unroll
-                for (int p = 0; p < 3; ++p) b[d][kb][p] = wp[(((size_t)(nt0 + nt) * KB32 + kb) * 3 + p) * 64];
-        }
-    }
+    for (int d = 0; d < DRU; ++d) fill(b[d], d);
+    if constexpr (DU > DRU) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int d = 0; d < DU; ++d) {
         const int u = wave + DFF_NWAVES * d;
@@ -524,12 +525,15 @@ DEVI void gemm_wide_units_split(const lu32* as, int R, int rowsA, const unsigned
                 const u32x4 ah = *(const lu32x4*)(as + ro + 16 * kb);
                 const u32x4 am = *(const lu32x4*)(as + R * LHS2 + ro + 16 * kb);
                 const u32x4 al = *(const lu32x4*)(as + 2 * R * LHS2 + ro + 16 * kb);
-                cs = mfma_bf16(b[d][kb][0], al, cs);
-                cb = mfma_bf16(b[d][kb][0], am, cb);
-                cs2 = mfma_bf16(b[d][kb][2], ah, cs2);
-                cb2 = mfma_bf16(b[d][kb][1], ah, cb2);
-                cs = mfma_bf16(b[d][kb][1], am, cs);
-                cb = mfma_bf16(b[d][kb][0], ah, cb);
+                cs = mfma_bf16(b[d % DRU][kb][0], al, cs);
+                cb = mfma_bf16(b[d % DRU][kb][0], am, cb);
+                cs2 = mfma_bf16(b[d % DRU][kb][2], ah, cs2);
+                cb2 = mfma_bf16(b[d % DRU][kb][1], ah, cb2);
+                cs = mfma_bf16(b[d % DRU][kb][1], am, cs);
+                cb = mfma_bf16(b[d % DRU][kb][0], ah, cb);
+            }
+            if constexpr (DU > DRU) {
+                if (d + DRU < DU) { fill(b[d % DRU], d + DRU); __builtin_amdgcn_sched_barrier(0); }
             }
             epi(nt, mt, (cb + cb2) + (cs + cs2));
         }
@@ -1529,9 +1533,13 @@ DEVI void co_dot_rows(f32x4 (&acc)[MT], const lfloat* A, const lfloat* B, int ld
 // the matching T entries are exact zeros).
 // k-step (kt, s) covers k = 16 kt + 4 s .. + 3 (lane: + kk); T's rows and columns at or beyond the workgroup's real
 // `rows` are exact zeros (P, dS), so the k-steps that start there are skipped.
-template <int MT, bool TRANS>
+// PL_: leading dimension of T.  The default (16 MT + 4) tile arrays have 16 MT rows; a TIGHT one (LdsLayout, PL_ < 16 MT) has the
+// workgroup's RN allocated rows and no columns beyond PL_: operand reads are clamped to row RN - 1 (they feed output rows /
+// k-steps that are discarded / skipped), and a column index beyond PL_ wraps into the next row (finite, discarded likewise).
+template <int MT, bool TRANS, int PL_ = 16 * MT + 4>
 DEVI f32x4 co_mm(const lfloat* T, int mo, const lfloat* B, int ldb, int RN, int rows, int lane) {
-    constexpr int PL = 16 * MT + 4;
+    constexpr int PL = PL_;
+    constexpr bool TIGHT = PL_ < 16 * MT;
     const int kk = lane >> 4, mm = lane & 15;
     f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
     // (the operands of row tile kt + 1 are requested before the products of tile kt, as volatile reads: the compiler sinks
@@ -1542,7 +1550,8 @@ DEVI f32x4 co_mm(const lfloat* T, int mo, const lfloat* B, int ldb, int RN, int 
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int k = 16 * kt + 4 * s + kk;
-            an[s] = TRANS ? *(vlp)(T + k * PL + 16 * mo + mm) : *(vlp)(T + (16 * mo + mm) * PL + k);
+            an[s] = TRANS ? *(vlp)(T + (TIGHT ? min(k, RN - 1) : k) * PL + 16 * mo + mm)
+                          : *(vlp)(T + (TIGHT ? min(16 * mo + mm, RN - 1) : 16 * mo + mm) * PL + k);
             bn[s] = *(vlp)(B + min(k, RN - 1) * ldb + mm);
         }
     };
@@ -1567,9 +1576,10 @@ DEVI f32x4 co_mm(const lfloat* T, int mo, const lfloat* B, int ldb, int RN, int 
 // hook(step), step = 0 .. 4 MT - 1, runs once per k-step: a place to spread another phase's weight requests over this one's
 // MFMAs (a burst of them stalls the wave at issue while the CU's one texture-address unit takes 16 cycles per KiB).
 struct NoStepHook { DEVI void operator()(int) const {} };
-template <int MT, bool TRANS, class SH = NoStepHook>
+template <int MT, bool TRANS, int PL_ = 16 * MT + 4, class SH = NoStepHook>
 DEVI void co_mm5(f32x4 (&c)[5], const lfloat* T, int mo, const lfloat* B, int ldb, int RN, int rows, int lane, SH hook = SH()) {
-    constexpr int PL = 16 * MT + 4, NS = 4 * MT;
+    constexpr int PL = PL_, NS = 4 * MT;
+    constexpr bool TIGHT = PL_ < 16 * MT;   // (see co_mm)
     const int kk = lane >> 4, mm = lane & 15;
 #pragma unroll
     for (int nt = 0; nt < 5; ++nt) c[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1579,7 +1589,11 @@ DEVI void co_mm5(f32x4 (&c)[5], const lfloat* T, int mo, const lfloat* B, int ld
     // phases built on this ran at 40 % of their MFMA time).  Reads of skipped steps are harmless (clamped rows).
     // (volatile: a plain read that is only used inside the next step's branch gets sunk into it again)
     typedef const volatile lfloat* vlp;
-    auto a_of = [&](int st) { const int k = 4 * st + kk; return TRANS ? *(vlp)(T + k * PL + 16 * mo + mm) : *(vlp)(T + (16 * mo + mm) * PL + k); };
+    auto a_of = [&](int st) {
+        const int k = 4 * st + kk;
+        return TRANS ? *(vlp)(T + (TIGHT ? min(k, RN - 1) : k) * PL + 16 * mo + mm)
+                     : *(vlp)(T + (TIGHT ? min(16 * mo + mm, RN - 1) : 16 * mo + mm) * PL + k);
+    };
     auto b_of = [&](int st) { return (vlp)(B + min(4 * st + kk, RN - 1) * ldb + mm); };
     float a_n = a_of(0), b_n[5];
     {
@@ -1677,11 +1691,13 @@ DEVI void co_fix_g(const CoGeo& g, int hh, int it, int lane) {   // G_ext ext: [
 // extension tile: xrel_i = sum_j a_ij x_j - x_i
 // SPW: the 64 regular columns of o_ext are written as bf16 pieces ([piece][RN][64 HGS + 8], into R3 | R4, free in the
 // forward pass) for gemm_tall_split; the extension columns stay fp32 in R0.
-template <int MT, int HGS, bool GEN, bool SPW = false>
+template <int MT, int HGS, bool GEN, bool SPW = false, int PL_ = 16 * MT + 4>
 DEVI void co_softmax_pv(const CoGeo& g, gfloat* sP /* P block of head hg*HGS */, gfloat* sM /* m12 block of head hg*HGS (GEN) */,
                         lfloat* oxt = nullptr /* != null: the extension columns of o_ext go here (rows x 16 HGS) instead of R0 */) {
     const int tid_ = tid_now(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
-    constexpr int LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL, PS = 16 * MT;
+    constexpr int LQ = 80 * HGS + 4, PL = PL_, PT = 16 * MT * PL, PS = 16 * MT;
+    constexpr bool TIGHT = PL_ < 16 * MT;   // P tile array of RN rows x PL columns (LdsLayout): no pad rows, no columns >= PL
+    static_assert(!TIGHT || HGS == 1, "tight tile arrays: one head per group");
     const int quad = lane >> 4, col = lane & 15;
     int gj[MT];
 #pragma unroll
@@ -1716,13 +1732,13 @@ DEVI void co_softmax_pv(const CoGeo& g, gfloat* sP /* P block of head hg*HGS */,
 #pragma unroll
                 for (int jt = 0; jt < MT; ++jt) {
                     const float p = gi >= 0 ? e[jt] * rden : 0.f;
-                    pl[16 * jt] = p;
+                    if (!TIGHT || (i < g.RN && 16 * jt + col < PL)) pl[16 * jt] = p;
                     if (gi >= 0) st_ntg(ps + 16 * jt, p);
                 }
             }
         }
         f32x4 o[5];
-        co_mm5<MT, false>(o, g.Pbuf + hh * PT, it, g.Rg + 2 * g.RN * LQ + hh * 80, LQ, g.RN, g.rows, lane);
+        co_mm5<MT, false, PL>(o, g.Pbuf + hh * PT, it, g.Rg + 2 * g.RN * LQ + hh * 80, LQ, g.RN, g.rows, lane);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * it + 4 * quad + r;
@@ -1900,10 +1916,12 @@ DEVI float co_dx_ext(const CoGeo& g, int row, int col, float e) {
 // backward: da = G_ext V_ext^T ; ds = scale a (da - sum_j a da) -> dSbuf.
 // DQ: the same wave goes on with dQ_ext = dS K_ext for its row tile -> buffer 4 (no barrier needed: it
 // only reads the dS rows it has just written).
-template <int MT, int HGS, bool DQ, bool GEN>
+template <int MT, int HGS, bool DQ, bool GEN, int PL_ = 16 * MT + 4>
 DEVI void co_ds(const CoGeo& g) {
     const int tid_ = tid_now(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
-    constexpr int LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL;
+    constexpr int LQ = 80 * HGS + 4, PL = PL_, PT = 16 * MT * PL;
+    constexpr bool TIGHT = PL_ < 16 * MT;   // (see co_softmax_pv)
+    static_assert(!TIGHT || (HGS == 1 && !DQ), "tight tile arrays: one head per group, three-phase backward");
     const int quad = lane >> 4, col = lane & 15;
     for (int item = wave; item < HGS * MT; item += DFF_NWAVES) {
         const int hh = item / MT, it = item - hh * MT;
@@ -1914,17 +1932,18 @@ DEVI void co_ds(const CoGeo& g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = 16 * it + 4 * quad + r;
-                const lfloat* pl = g.Pbuf + hh * PT + i * PL + col;
+                const lfloat* pl = g.Pbuf + hh * PT + (TIGHT ? min(i, g.RN - 1) : i) * PL + col;
                 float p[MT], sm = 0.f;
 #pragma unroll
                 for (int jt = 0; jt < MT; ++jt) {
-                    p[jt] = pl[16 * jt];
+                    p[jt] = (!TIGHT || 16 * jt + col < PL) ? pl[16 * jt] : 0.f;
                     sm += p[jt] * acc[jt][r];
                 }
                 sm = row16_sum(sm);
                 lfloat* dl = g.dSbuf + hh * PT + i * PL + col;
 #pragma unroll
-                for (int jt = 0; jt < MT; ++jt) dl[16 * jt] = 0.125f * (p[jt] * (acc[jt][r] - sm));
+                for (int jt = 0; jt < MT; ++jt)
+                    if (!TIGHT || (i < g.RN && 16 * jt + col < PL)) dl[16 * jt] = 0.125f * (p[jt] * (acc[jt][r] - sm));
             }
         }
         if (DQ) {
@@ -1982,17 +2001,18 @@ struct QkvTRingHook {
         for (int st = 0; st < NS; ++st) (*this)(st);
     }
 };
-template <int MT, int HGS, bool EXT_ONLY, bool GEN, bool KVS = false, bool VSP = false, class SH = NoStepHook>
+template <int MT, int HGS, bool EXT_ONLY, bool GEN, bool KVS = false, bool VSP = false, class SH = NoStepHook, int PL_ = 16 * MT + 4>
 DEVI void co_dv_dk(const CoGeo& g, SH hook = SH()) {
     const int tid_ = tid_now(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
-    constexpr int LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL;
+    constexpr int LQ = 80 * HGS + 4, PL = PL_, PT = 16 * MT * PL;
+    static_assert(PL_ == 16 * MT + 4 || EXT_ONLY, "tight tile arrays: three-phase backward (co_dqkv), only the layer-0 form runs here");
     const int quad = lane >> 4, col = lane & 15;
     if (EXT_ONLY) {
         for (int item = wave; item < 2 * HGS * MT; item += DFF_NWAVES) {
             const int which = item / (HGS * MT), r0 = item - which * (HGS * MT);   // 0: dV, 1: dK
             const int hh = r0 / MT, mo = r0 - hh * MT;
             const lfloat* T = (which ? g.dSbuf : g.Pbuf) + hh * PT;
-            const f32x4 acc = co_mm<MT, true>(T, mo, g.Rg + (which ? 0 : 3) * g.RN * LQ + hh * 80 + 64, LQ, g.RN, g.rows, lane);
+            const f32x4 acc = co_mm<MT, true, PL>(T, mo, g.Rg + (which ? 0 : 3) * g.RN * LQ + hh * 80 + 64, LQ, g.RN, g.rows, lane);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * mo + 4 * quad + r;
@@ -2003,7 +2023,7 @@ DEVI void co_dv_dk(const CoGeo& g, SH hook = SH()) {
         if (GEN) {   // the logits' distance term reaches x_i through Q_ext as well: dE/dx_i += -2 s_i sum_j dS_ij x_j
             for (int item = wave; item < HGS * MT; item += DFF_NWAVES) {
                 const int hh = item / MT, it = item - hh * MT;
-                const f32x4 acc = co_mm<MT, false>(g.dSbuf + hh * PT, it, g.Rg + g.RN * LQ + hh * 80 + 64, LQ, g.RN, g.rows, lane);
+                const f32x4 acc = co_mm<MT, false, PL>(g.dSbuf + hh * PT, it, g.Rg + g.RN * LQ + hh * 80 + 64, LQ, g.RN, g.rows, lane);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) (void)co_dq_ext<HGS>(g, hh, 16 * it + 4 * quad + r, col, acc[r]);
             }
@@ -2055,10 +2075,10 @@ DEVI void co_dv_dk(const CoGeo& g, SH hook = SH()) {
 // WHICH 1: dQ_ext = dS K_ext       (reads dSbuf, R1) -> R3
 // WHICH 2: dK_ext = dS^T Q_ext     (reads dSbuf, R0) -> R1
 // the extension tiles of dV_ext / dK_ext are dE/dx_j and go to this wave's dxw instead.
-template <int MT, int HGS, int WHICH, bool GEN>
+template <int MT, int HGS, int WHICH, bool GEN, int PL_ = 16 * MT + 4>
 DEVI void co_dqkv(const CoGeo& g) {
     const int tid_ = tid_now(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
-    constexpr int LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL;
+    constexpr int LQ = 80 * HGS + 4, PL = PL_, PT = 16 * MT * PL;
     constexpr int SRC = WHICH == 0 ? 3 : WHICH == 1 ? 1 : 0;
     constexpr int DST = WHICH == 0 ? 2 : WHICH == 1 ? 3 : 1;
     const int quad = lane >> 4, col = lane & 15;
@@ -2066,7 +2086,7 @@ DEVI void co_dqkv(const CoGeo& g) {
     for (int item = wave; item < HGS * MT * 5; item += DFF_NWAVES) {
         const int hh = item / (MT * 5), rem = item - hh * (MT * 5);
         const int mo = rem / 5, nt = rem - mo * 5;
-        const f32x4 acc = co_mm<MT, WHICH != 1>(T + hh * PT, mo, g.Rg + SRC * g.RN * LQ + hh * 80 + 16 * nt, LQ, g.RN, g.rows, lane);
+        const f32x4 acc = co_mm<MT, WHICH != 1, PL>(T + hh * PT, mo, g.Rg + SRC * g.RN * LQ + hh * 80 + 16 * nt, LQ, g.RN, g.rows, lane);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * mo + 4 * quad + r;
@@ -2098,10 +2118,10 @@ struct CoReload {
 };
 // The item -> address maps depend on the thread and the workgroup's row count only: planned once per hg loop
 // (the divisions are the expensive part), then every issue / commit is an unpack and an add.
-template <int MT, int HGS>
+template <int MT, int HGS, int PL_ = 16 * MT + 4>
 DEVI void co_reload_plan(CoReload<MT, HGS>& rl, const CoGeo& g, bool need_p, int tid) {
     using RL = CoReload<MT, HGS>;
-    constexpr int PS = 16 * MT, LQ = 80 * HGS + 4, PL = 16 * MT + 4, PT = 16 * MT * PL;
+    constexpr int PS = 16 * MT, LQ = 80 * HGS + 4, PL = PL_, PT = 16 * MT * PL;
     const int nq = g.rows * RL::NQ, total = nq + (need_p ? g.rows * RL::NP : 0);
 #pragma unroll
     for (int u = 0; u < RL::U; ++u) {
@@ -2124,6 +2144,7 @@ DEVI void co_reload_plan(CoReload<MT, HGS>& rl, const CoGeo& g, bool need_p, int
             const unsigned src = (unsigned)((hh * g.RN + row) * (PS / 4) + c4);
             const unsigned dst = (unsigned)(hh * PT + row * PL + 4 * c4) >> 2;
             code = src | dst << 14;
+            if (PL_ < 16 * MT && 4 * c4 >= PL) { rl.code[u] = code; continue; }   // tight tile array: these columns do not exist (pad beads)
         }
         rl.code[u] = code | (it0 < total ? 1u << 29 : 0u);
     }
@@ -2187,6 +2208,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
     // protein G's 56 rows in one) was built and measured: 16 values per lane and array spill (412 B of scratch on villin's
     // variant), villin +5 %, protein G no better than the two 16-lane passes.
     constexpr int LPG = 16;
+    constexpr int PLT = LL::template pl<SPW>();   // leading dimension of the P / dS tile arrays (TIGHT: 16 MT - 4, see LdsLayout)
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     Ctx c;
@@ -2435,7 +2457,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             // meanwhile and park its tiles in registers; they write them (LDS + stash) next to the W_o GEMM of the
             // current group, once the barrier has retired its q | k | v.  o_ext's extension columns live in dSbuf
             // (idle in the forward pass) so that R0 is free by then.
-            constexpr bool PIPE = SPW && !GEN && HGS == 1 && MT < DFF_NWAVES;   // HGS = 2: the parked tiles (7 x MT) do not fit the register file
+            constexpr bool PIPE = SPW && !GEN && HGS == 1 && MT < 4;   // HGS = 2: the parked tiles (7 x MT) do not fit the register file; MT = 4: 16 parked tiles neither
             lfloat* const oxt = PIPE ? geo.dSbuf : nullptr;
             constexpr int DWO = 2 * HGS < 4 ? 2 * HGS : 4;
             auto wo_gemm = [&](int hg, auto pre, u32x4 (&bw)[DWO][NTW][3]) {
@@ -2520,7 +2542,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 if (cached) {
                     const int tid = tid_now();
                     CoReload<MT, HGS> rl;
-                    co_reload_plan<MT, HGS>(rl, geo, false, tid);
+                    co_reload_plan<MT, HGS, PLT>(rl, geo, false, tid);
                     co_reload_issue<MT, HGS>(rl, sqkv_r + (size_t)hg * HGS * RN * DFF_QKVW, sPl);
                     co_reload_commit<MT, HGS>(rl, geo);
                 }
@@ -2550,7 +2572,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 pf.tick(3);
                 l2_wo(lw, hg);
                 if constexpr (GEN || MT == 4)   // MT = 4 (protein G): measured 1.3 % slower transposed (16 probabilities per lane)
-                    co_softmax_pv<MT, HGS, GEN, SPW>(geo, sPl + (size_t)hg * HGS * RN * c.sl.PS,
+                    co_softmax_pv<MT, HGS, GEN, SPW, PLT>(geo, sPl + (size_t)hg * HGS * RN * c.sl.PS,
                                                      (gfloat*)sb + c.sl.m12 + (size_t)hg * HGS * RN * 4, oxt);
                 else
                     co_softmax_pv_t<MT, HGS, SPW>(geo, sPl + (size_t)hg * HGS * RN * c.sl.PS, oxt,
@@ -2687,7 +2709,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             const gfloat* const sqkv = (const gfloat*)(l == 0 ? c.l0 : sb) + c.sl.qkvx;
             const gfloat* const sPl = (const gfloat*)sb + c.sl.P;
             CoReload<MT, HGS> rl;
-            co_reload_plan<MT, HGS>(rl, geo, true, tid_now());
+            co_reload_plan<MT, HGS, PLT>(rl, geo, true, tid_now());
             co_reload_issue<MT, HGS>(rl, sqkv + (size_t)hg_lo * HGS * RN * DFF_QKVW, sPl + (size_t)hg_lo * HGS * RN * c.sl.PS);
             rowb_ln2_gate1<H, LPG, SPW>(c, lw, l, tbuf);
             wg_sync<SPILL>();
@@ -2820,17 +2842,17 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 pf.tick(16);
                 constexpr bool FIVE = LL::NREG == 5;
                 if (l > 0 || full0) {
-                    co_ds<MT, HGS, FIVE, GEN>(geo);
+                    co_ds<MT, HGS, FIVE, GEN, PLT>(geo);
                     wg_sync<SPILL>();
                     pf.tick(17);
                     if (FIVE) {
                         co_dv_dk<MT, HGS, false, GEN, SPW && LL::KVS, SPW && LL::VSP>(geo);
                     } else {
-                        co_dqkv<MT, HGS, 0, GEN>(geo);
+                        co_dqkv<MT, HGS, 0, GEN, PLT>(geo);
                         wg_sync<SPILL>();
-                        co_dqkv<MT, HGS, 1, GEN>(geo);
+                        co_dqkv<MT, HGS, 1, GEN, PLT>(geo);
                         wg_sync<SPILL>();
-                        co_dqkv<MT, HGS, 2, GEN>(geo);
+                        co_dqkv<MT, HGS, 2, GEN, PLT>(geo);
                     }
                     wg_sync<SPILL>();
                     pf.tick(18);
@@ -2857,10 +2879,10 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         },
                         geo.Rg, LQ, RN, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
                 } else {
-                    co_ds<MT, HGS, false, GEN>(geo);
+                    co_ds<MT, HGS, false, GEN, PLT>(geo);
                     wg_sync<SPILL>();
                     pf.tick(17);
-                    co_dv_dk<MT, HGS, true, GEN>(geo);
+                    co_dv_dk<MT, HGS, true, GEN, false, false, NoStepHook, PLT>(geo);
                 }
                 wg_sync<SPILL>();
                 pf.tick(19);
@@ -3035,6 +3057,12 @@ static unsigned lds_floats_of(int N, int G) { return LdsLayout<H, MT, HGS, SP>(N
       &lds_floats_of<H, MT, HGS, false, true>, "dff_fused_kernel<" #H "," #MT "," #HGS ",false,split_bf16>" },  \
     { H, MT, HGS, false, true, true, (const void*)&dff_fused_kernel<H, MT, HGS, false, true, true>,             \
       &lds_floats_of<H, MT, HGS, false, true>, "dff_fused_kernel<" #H "," #MT "," #HGS ",false,gen,split_bf16>" }
+#define VAR_SPW_SPILL(H, MT, HGS)                                                                               \
+    { H, MT, HGS, true, false, true, (const void*)&dff_fused_kernel<H, MT, HGS, true, false, true>,             \
+      &lds_floats_of<H, MT, HGS, true, true>, "dff_fused_kernel<" #H "," #MT "," #HGS ",true,split_bf16>" }
+#define VAR_PAIR_SPW_SPILL(H, MT, HGS)                                                                            \
+    { H, MT, HGS, true, false, true, (const void*)&dff_fused_kernel<H, MT, HGS, true, false, true, true>,         \
+      &lds_floats_of<H, MT, HGS, true, true>, "dff_fused_kernel<" #H "," #MT "," #HGS ",true,split_bf16,pair>", true }
 #define VAR_PAIR(H, MT, HGS, SP)                                                                                  \
     { H, MT, HGS, SP, false, false, (const void*)&dff_fused_kernel<H, MT, HGS, SP, false, false, true>,           \
       &lds_floats_of<H, MT, HGS, SP, false>, "dff_fused_kernel<" #H "," #MT "," #HGS "," #SP ",pair>", true }
@@ -3045,8 +3073,8 @@ static const Variant g_variants[] = {
 #ifndef DFF_FAST_BUILD
     VAR(64, 1, 4, false),  VAR(64, 2, 2, false),  VAR(96, 1, 4, false),  VAR(96, 2, 2, false),
     VAR(128, 1, 4, false), VAR(128, 2, 2, false), VAR(128, 3, 1, false), VAR(128, 4, 1, true),
-    VAR_SPW(96, 2, 2), VAR_SPW(128, 2, 2), VAR_SPW(128, 3, 1),
-    VAR_PAIR(128, 4, 1, true), VAR_PAIR_SPW(128, 3, 1), VAR_PAIR_SPW(128, 2, 2), VAR_PAIR_SPW(96, 2, 2),
+    VAR_SPW(96, 2, 2), VAR_SPW(128, 2, 2), VAR_SPW(128, 3, 1), VAR_SPW_SPILL(128, 4, 1),
+    VAR_PAIR(128, 4, 1, true), VAR_PAIR_SPW(128, 3, 1), VAR_PAIR_SPW(128, 2, 2), VAR_PAIR_SPW(96, 2, 2), VAR_PAIR_SPW_SPILL(128, 4, 1),
 #elif defined(DFF_ONLY)   // development builds: one named variant, e.g. -DDFF_ONLY="VAR_SPW(128,3,1)"
     DFF_ONLY,
 #else   // development builds: one variant, so that the <= 16-row kernel can be iterated on quickly
