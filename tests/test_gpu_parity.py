@@ -556,10 +556,10 @@ def test_ddpm_chain_variance_at_full_size(dff):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", ["chignolin", "trp_cage", "bba", "villin"])
+@pytest.mark.parametrize("cfg", ["chignolin", "trp_cage", "bba", "villin", "protein_g"])
 def test_split_bf16_weight_gemms_are_fp32_exact(dff, cfg, golden, monkeypatch):
-    """Default variants where they exist (chignolin: all eight weight GEMMs of the <= 16-row kernel; trp-cage, BBA, villin:
-    the K = H ones of the generic kernel): the weight GEMMs run on v_mfma_f32_16x16x32_bf16 with every fp32 operand split
+    """Default variants where they exist (chignolin: all eight weight GEMMs of the <= 16-row kernel; trp-cage, BBA, villin
+    and -- round 4 -- protein G: those of the generic kernel): the weight GEMMs run on v_mfma_f32_16x16x32_bf16 with every fp32 operand split
     exactly into three bf16 pieces (six products kept).  DFF_SPLIT_BF16=0 when the model is created selects the pure
     v_mfma_f32_16x16x4_f32 variants.  Both are held to the SAME tolerances against the reference's float64 forces, and a
     fused Langevin run of one is compared with the other."""

@@ -21,8 +21,12 @@ if [ "$cmd" = build ]; then
 elif [ "$cmd" = buildk ]; then   # the <= 64-row kernel TU instead (e.g. flags: -DDFF_FAST_BUILD -DDFF_ONLY="VAR_SPW(128,3,1)")
     name=$1; flags=$2
     d=build/exp/$name; mkdir -p $d
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-result $flags -c $SRC/dff_kernels.hip -o $d/dff_kernels.o
-    hipcc --offload-arch=gfx950 -shared -fPIC $d/dff_kernels.o build/obj/dff_small_m0.o build/obj/dff_small_m1.o build/obj/dff_small_m2.o build/obj/dff_host.o -o $d/libdff_amd.so
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-result $flags -c $SRC/dff_kernels.hip -o $d/dff_kernels.o &
+    host=build/obj/dff_host.o
+    case "$flags" in *DFF_PROF=1*)   # the host half refuses dff_debug_profile unless it was built with the stage ticks too
+        hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-result -DDFF_PROF=1 -c $SRC/dff_host.hip -o $d/dff_host.o; host=$d/dff_host.o;; esac
+    wait
+    hipcc --offload-arch=gfx950 -shared -fPIC $d/dff_kernels.o build/obj/dff_small_m0.o build/obj/dff_small_m1.o build/obj/dff_small_m2.o $host -o $d/libdff_amd.so
     echo "$flags" > $d/flags
     echo "built $d ($flags)"
 elif [ "$cmd" = run ]; then

@@ -783,6 +783,9 @@ DEVI void gemm_tall_split_st(f32x4 (&acc)[NTW][MT], int LS2, const lu32* as, int
 #ifndef DFF_L2W
 #define DFF_L2W 1
 #endif
+#ifndef DFF_GXT
+#define DFF_GXT 1
+#endif
 // L2 warm-up.  The weights of a phase are what all 32 workgroups of an XCD ask their L2 for at about the same time; they are
 // 15 MB per step (villin) against 4 MB of L2, so whoever is first pays the trip to memory and the others queue behind the
 // same lines: the convoy moves at the pace of a miss per phase.  Here each workgroup requests 1/32 of the NEXT phase's lines
@@ -2823,7 +2826,12 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                             }
                         };
                     if (l > 0 || full0) l2_wqkvT(lw, hg);
-                    if constexpr (SPW)
+                    if constexpr (SPW && MT == 4 && DFF_GXT)
+                        // four row tiles: a wave takes a whole TILE (all row tiles), so its 12 KB of weights come through the CU
+                        // once; as (tile, row-tile) units four waves each stream the same tile
+                        gemm_wide_split_st<MT, H / 32, HGS * 5, 1>(asplit, RN, RN, lw.WoxT_s, hg * HGS * 5, [](int, float (&)[1]) {},
+                            [&](int nt, int mt, const f32x4& acc, const float (&)[1], bool valid, int) { if (valid) gx_epi(nt, mt, acc); });
+                    else if constexpr (SPW)
                         gemm_wide_units_split<MT, H / 32, HGS * 5>(asplit, RN, RN, lw.WoxT_s, hg * HGS * 5, gx_epi);
                     else
                         gemm_wide_units<MT, NT_H, HGS * 5>(abufL, LH, RN, lw.WoxT_p, NT_H, 0, hg * HGS * 5, gx_epi, NoHook());
