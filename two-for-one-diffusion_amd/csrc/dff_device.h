@@ -99,7 +99,7 @@ struct LdsLayout {
     // fp32 row, dK's l pieces in the extension columns of the R1 / R2 rows, dV's in `lsplit` (LSV dwords per row) where the
     // LDS has room for it (DFF_KVSPLIT, VSP)
     static constexpr bool KVS = NREG == 5 && DFF_KVSPLIT;
-    static constexpr bool VSP = KVS && !(H == 96 && MT == 2);
+    static constexpr bool VSP = KVS;   // (round 4: also BBA's shape (96,2,2) -- the fp32 abuf the split engine no longer has paid for the area)
     static constexpr int LSV = 32 * HGS + 4;
     // P / dS tile arrays.  Default: 16 MT rows x (16 MT + 4) floats per head.  TIGHT (split engine at four row tiles, i.e.
     // protein G: 56 rows; round 4): the workgroup's ALLOCATED rows only, 16 MT - 4 = 60 floats each -- columns 60..63 do not
