@@ -152,7 +152,7 @@ struct LdsLayout {
         asplit = o;
         if (spw) o += 3u * R * LHS2;   // [h | m | l] bf16 pieces of abuf (R x H each, row stride H + 8)
         lsplit = o;
-        if (spw && VSP) o += R * LSV;
+        if (spw && VSP) o += 2 * R * LSV;   // l pieces of dV, then of dQ (co_ds; round 4)
         junk = o;  o += 64;                    // landing pad of the L2 warm-up loads (l2_touch)
         total = o;
     }

@@ -786,6 +786,9 @@ DEVI void gemm_tall_split_st(f32x4 (&acc)[NTW][MT], int LS2, const lu32* as, int
 #ifndef DFF_GXT
 #define DFF_GXT 1
 #endif
+#ifndef DFF_QSP
+#define DFF_QSP 1   // dQ leaves co_ds as bf16 pieces (0: fp32, split by every wave of the back-projection)
+#endif
 // L2 warm-up.  The weights of a phase are what all 32 workgroups of an XCD ask their L2 for at about the same time; they are
 // 15 MB per step (villin) against 4 MB of L2, so whoever is first pays the trip to memory and the others queue behind the
 // same lines: the convoy moves at the pace of a miss per phase.  Here each workgroup requests 1/32 of the NEXT phase's lines
@@ -834,9 +837,10 @@ DEVI void qkvT_ring_fill(u32x4 (&b)[4][NTW][3], const unsigned* __restrict__ Ws,
     }
     asm volatile("" ::: "memory");
 }
-template <int MT, int NTW, int HGS, bool KVS = false, bool VSP = false, int PRE = 0>
+// QSP (round 4): dQ arrives as pieces as well (co_ds: [h | m] in place of the fp32 row of buffer regQ, l in `lsq`).
+template <int MT, int NTW, int HGS, bool KVS = false, bool VSP = false, int PRE = 0, bool QSP = false>
 DEVI void gemm_tall_qkvT_split(f32x4 (&acc)[NTW][MT], const lfloat* Rg, int regQ, int RN, const unsigned* __restrict__ Ws,
-                               int head0, int ntiles, const lu32* lsp, u32x4 (&b)[4][NTW][3]) {
+                               int head0, int ntiles, const lu32* lsp, u32x4 (&b)[4][NTW][3], const lu32* lsq = nullptr) {
     constexpr int LQ = 80 * HGS + 4, NKB = 6 * HGS, D = 4, KBtot = 6 * DFF_HEADS;
     const int tid_ = tid_now();
     const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
@@ -869,10 +873,11 @@ DEVI void gemm_tall_qkvT_split(f32x4 (&acc)[NTW][MT], const lfloat* Rg, int regQ
         const int hh = kb / 6, part = (kb % 6) / 2, half = kb % 2;
         const int aoff = (part == 0 ? regQ : part) * RN * LQ + hh * 80 + 32 * half;
         u32x4 ah[MT], am[MT], al[MT];
-        if (KVS && (part == 1 || (VSP && part == 2))) {
+        if (KVS && (part == 1 || (VSP && part == 2) || (QSP && part == 0))) {
             constexpr int LSV = 32 * HGS + 4;
-            const lu32* const hb = (const lu32*)(Rg + part * RN * LQ + hh * 80) + 16 * half;
-            const lu32* const lb = part == 1 ? (const lu32*)(Rg + (1 + half) * RN * LQ + hh * 80 + 64) : lsp + hh * 32 + 16 * half;
+            const lu32* const hb = (const lu32*)(Rg + (part == 0 ? regQ : part) * RN * LQ + hh * 80) + 16 * half;
+            const lu32* const lb = part == 1 ? (const lu32*)(Rg + (1 + half) * RN * LQ + hh * 80 + 64)
+                                             : (part == 2 ? lsp : lsq) + hh * 32 + 16 * half;
             const int lmul = part == 1 ? LQ : LSV;
             // (l, h, m: the order the products consume them)
 #pragma unroll
@@ -1633,6 +1638,7 @@ DEVI void co_mm5(f32x4 (&c)[5], const lfloat* T, int mo, const lfloat* B, int ld
 struct CoGeo {
     lfloat *Rg, *Pbuf, *dSbuf, *xs, *dxw;   // dxw: this wave's partial dE/dx
     lu32* lsp;                              // l pieces of dV (LdsLayout::lsplit)
+    lu32* lsq;                              // l pieces of dQ (behind them)
     lfloat* m12;                            // GEN: [m1 | m2] rows of the head group (backward)
     const int __attribute__((address_space(3))) * prow;   // protein index of each row, -1 for pad rows
     int N, RN, rows;
@@ -1919,7 +1925,7 @@ DEVI float co_dx_ext(const CoGeo& g, int row, int col, float e) {
 // backward: da = G_ext V_ext^T ; ds = scale a (da - sum_j a da) -> dSbuf.
 // DQ: the same wave goes on with dQ_ext = dS K_ext for its row tile -> buffer 4 (no barrier needed: it
 // only reads the dS rows it has just written).
-template <int MT, int HGS, bool DQ, bool GEN, int PL_ = 16 * MT + 4>
+template <int MT, int HGS, bool DQ, bool GEN, int PL_ = 16 * MT + 4, bool QSP = false>
 DEVI void co_ds(const CoGeo& g) {
     const int tid_ = tid_now(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     constexpr int LQ = 80 * HGS + 4, PL = PL_, PT = 16 * MT * PL;
@@ -1958,8 +1964,29 @@ DEVI void co_ds(const CoGeo& g) {
                 if (GEN) dq[4][r] = co_dq_ext<HGS>(g, hh, row, col, dq[4][r]);
                 if (row < g.rows) {
                     lfloat* d = g.Rg + 4 * g.RN * LQ + row * LQ + hh * 80 + col;
+                    if constexpr (QSP) {
+                        // the 64 regular columns leave as the bf16 pieces the back-projection multiplies (see co_dv_dk): split once
+                        // here instead of by each of the eight waves that read them
+                        constexpr int LSV = 32 * HGS + 4;
+                        lu16* const hm = (lu16*)(g.Rg + 4 * g.RN * LQ + hh * 80) + col;
+                        lu16* const lb0 = (lu16*)(g.lsq + hh * 32) + col;
+                        lu16* const lb1 = (lu16*)(g.lsq + hh * 32 + 16) + col;
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) {
+                            const float v = dq[nt][r];
+                            const unsigned uh = __float_as_uint(v) & 0xffff0000u;
+                            const float r1 = v - __uint_as_float(uh);
+                            const unsigned um = __float_as_uint(r1) & 0xffff0000u;
+                            const float r2 = r1 - __uint_as_float(um);
+                            hm[row * 2 * LQ + 16 * nt] = (unsigned short)(uh >> 16);
+                            hm[row * 2 * LQ + 64 + 16 * nt] = (unsigned short)(um >> 16);
+                            (nt < 2 ? lb0 : lb1)[row * 2 * LSV + 16 * (nt & 1)] = (unsigned short)(__float_as_uint(r2) >> 16);
+                        }
+                        d[64] = dq[4][r];
+                    } else {
 #pragma unroll
                     for (int nt = 0; nt < 5; ++nt) d[16 * nt] = dq[nt][r];
+                    }
                 }
             }
         }
@@ -2342,6 +2369,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
         geo.dxw = sm + ll.dxw + wave_ * RN * 4;
         geo.m12 = sm + ll.m12;
         geo.lsp = (lu32*)(sm + ll.lsplit);
+        geo.lsq = geo.lsp + RN * LL::LSV;
         geo.prow = (const int __attribute__((address_space(3)))*)(sm + ll.prow);
         geo.N = N; geo.RN = RN; geo.rows = rows;
     }
@@ -2760,7 +2788,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     const bool more = hg + 1 < hg_hi;
                     f32x4 gheld[DU];
                     if (wave_ < NI) {
-                        if (deep) co_ds<MT, HGS, true, GEN>(geo);
+                        if (deep) co_ds<MT, HGS, true, GEN, PLT, LL::KVS && DFF_QSP>(geo);
                         else co_ds<MT, HGS, false, GEN>(geo);
                     } else if (more) {
                         gx_units_hold<MT, H / 32, NTG, NI, NWH>(asplit, RN, RN, lw.WoxT_s, (hg + 1) * NTG, gheld);
@@ -2783,7 +2811,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         co_dv_dk<MT, HGS, false, GEN, LL::KVS, LL::VSP>(geo);
                         wg_sync<SPILL>();
                         pf.tick(18);
-                        gemm_tall_qkvT_split<MT, NTW, HGS, LL::KVS, LL::VSP, QPRE>(acc_a, geo.Rg, 4, RN, lw.WqkvxT_s, hg * HGS, NT_H, geo.lsp, bq);
+                        gemm_tall_qkvT_split<MT, NTW, HGS, LL::KVS, LL::VSP, QPRE, LL::KVS && DFF_QSP>(acc_a, geo.Rg, 4, RN, lw.WqkvxT_s, hg * HGS, NT_H, geo.lsp, bq, geo.lsq);
                         gemm_tall_kb<MT, NTW, 13>(acc_a, HGS,
                             [=](int i, int& aoff, int& wkb) { aoff = 4 * RN * LQ + i * 80 + 64; wkb = (hg * HGS + i) * 13 + 4; },
                             geo.Rg, LQ, RN, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
@@ -2850,7 +2878,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 pf.tick(16);
                 constexpr bool FIVE = LL::NREG == 5;
                 if (l > 0 || full0) {
-                    co_ds<MT, HGS, FIVE, GEN, PLT>(geo);
+                    co_ds<MT, HGS, FIVE, GEN, PLT, SPW && LL::KVS && DFF_QSP>(geo);
                     wg_sync<SPILL>();
                     pf.tick(17);
                     if (FIVE) {
@@ -2869,7 +2897,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     else if (l > 0) l2_w2t(m.layer[l - 1], ch_lo);
                     if constexpr (SPW) {
                         u32x4 bq[4][NTW][3];
-                        gemm_tall_qkvT_split<MT, NTW, HGS, LL::KVS, LL::VSP>(acc_a, geo.Rg, FIVE ? 4 : 3, RN, lw.WqkvxT_s, hg * HGS, NT_H, geo.lsp, bq);
+                        gemm_tall_qkvT_split<MT, NTW, HGS, LL::KVS, LL::VSP, 0, LL::KVS && DFF_QSP>(acc_a, geo.Rg, FIVE ? 4 : 3, RN, lw.WqkvxT_s, hg * HGS, NT_H, geo.lsp, bq, geo.lsq);
                         gemm_tall_kb<MT, NTW, 13>(acc_a, HGS,
                             [=](int i, int& aoff, int& wkb) {
                                 aoff = (FIVE ? 4 : 3) * RN * LQ + i * 80 + 64;
