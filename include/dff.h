@@ -46,7 +46,7 @@ typedef struct dff_model dff_model; /* opaque */
  * other combinations run the general ("gen") variants of the <= 64-row kernel. */
 typedef struct {
     int32_t n_beads;              /* num_beads, 2..DFF_MAX_BEADS */
-    int32_t hidden;               /* hidden_features_gnn: 64, 96 or 128 */
+    int32_t hidden;               /* hidden_features_gnn: 64, 96, 128 (any n_beads <= 64 with 128, <= 32 otherwise) or 256 (<= 32 beads) */
     int32_t n_layers;             /* num_layers_gnn, 1..8 */
     int32_t timesteps;            /* diffusion_steps (GaussianDiffusion timesteps), e.g. 1000 */
     int32_t use_intrinsic_coords; /* 0 / 1 */

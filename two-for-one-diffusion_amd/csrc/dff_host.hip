@@ -267,9 +267,11 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
     if (!(is01(cfg->use_intrinsic_coords) && is01(cfg->use_distances) && is01(cfg->use_abs_coords) && is01(cfg->conservative)))
         return fail(DFF_EINVAL, "use_intrinsic_coords, use_distances, use_abs_coords and conservative must be 0 or 1");
     const int H = cfg->hidden, N = cfg->n_beads, L = cfg->n_layers, I = DFF_INNER, F = 4 * H;
-    if (!(H == 64 || H == 96 || H == 128)) return fail(DFF_EINVAL, "hidden must be 64, 96 or 128 (got %d)", H);
+    // hidden sizes with kernel variants: the shipped 64 / 96 / 128, and 256 (the reference's own smoke test,
+    // models/graph_transformer.py:332-359; fp32 engine, <= 32 beads)
+    if (!(H == 64 || H == 96 || H == 128 || H == 256)) return fail(DFF_EINVAL, "hidden must be 64, 96, 128 or 256 (got %d)", H);
     if (N < 2 || N > DFF_MAX_BEADS) return fail(DFF_EINVAL, "n_beads must be in [2,%d] (got %d)", DFF_MAX_BEADS, N);
-    if (H < 128 && N > 32) return fail(DFF_EINVAL, "n_beads > 32 needs hidden = 128 in this build");
+    if (H != 128 && N > 32) return fail(DFF_EINVAL, "n_beads > 32 needs hidden = 128 in this build");
     if (L < 1 || L > DFF_MAX_LAYERS) return fail(DFF_EINVAL, "n_layers must be in [1,%d]", DFF_MAX_LAYERS);
     if (cfg->timesteps < 1) return fail(DFF_EINVAL, "timesteps must be >= 1");
     if (n_weights != dff_weight_count(cfg))
@@ -820,7 +822,10 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
     const bool gen = !(m->cfg.use_intrinsic_coords == 1 && m->cfg.use_distances == 0 && m->cfg.use_abs_coords == 0);
     const bool want_tab = a.mode != DFF_MODE_SCORE && !m->l0_off && !m->cfg.use_abs_coords;
     a.l0_tab = nullptr;
-    if (G * N <= 16 && !m->force_generic) {
+    const void* sfn_; unsigned slds_; const char* snm_;
+    const bool have_small = dff_small_pick(DFF_MODE_SCORE, H, 4, gen, false, &sfn_, &slds_, &snm_) ||
+                            dff_small_pick(DFF_MODE_SCORE, H, 8, gen, false, &sfn_, &slds_, &snm_);   // (hidden = 256: generic kernel only)
+    if (G * N <= 16 && !m->force_generic && have_small) {
         if (want_tab) {
             int rc = ensure_l0_table(m, a.mode == DFF_MODE_DDPM ? 2 : 1, a.t_norm, G, nullptr, stream);
             if (rc) return rc;

@@ -3109,6 +3109,9 @@ static const Variant g_variants[] = {
 #ifndef DFF_FAST_BUILD
     VAR(64, 1, 4, false),  VAR(64, 2, 2, false),  VAR(96, 1, 4, false),  VAR(96, 2, 2, false),
     VAR(128, 1, 4, false), VAR(128, 2, 2, false), VAR(128, 3, 1, false), VAR(128, 4, 1, true),
+    // hidden = 256 (the reference's own smoke test, models/graph_transformer.py:332-359; no shipped checkpoint): fp32 engine,
+    // up to 32 bead rows (the second shape keeps the residual stream in the stash to fit the LDS)
+    VAR(256, 1, 4, false), VAR(256, 2, 1, true),
     VAR_SPW(96, 2, 2), VAR_SPW(128, 2, 2), VAR_SPW(128, 3, 1), VAR_SPW_SPILL(128, 4, 1),
     VAR_PAIR(128, 4, 1, true), VAR_PAIR_SPW(128, 3, 1), VAR_PAIR_SPW(128, 2, 2), VAR_PAIR_SPW(96, 2, 2), VAR_PAIR_SPW_SPILL(128, 4, 1),
 #elif defined(DFF_ONLY)   // development builds: one named variant, e.g. -DDFF_ONLY="VAR_SPW(128,3,1)"
