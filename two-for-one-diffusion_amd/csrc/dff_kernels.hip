@@ -786,6 +786,9 @@ DEVI void gemm_tall_split_st(f32x4 (&acc)[NTW][MT], int LS2, const lu32* as, int
 #ifndef DFF_GXT
 #define DFF_GXT 1
 #endif
+#ifndef DFF_EXTPRE
+#define DFF_EXTPRE 1   // extension-block weights of the tall GEMMs requested before the split GEMM (0: behind it, as until round 3)
+#endif
 #ifndef DFF_QSP
 #define DFF_QSP 1   // dQ leaves co_ds as bf16 pieces (0: fp32, split by every wave of the back-projection)
 #endif
@@ -1115,6 +1118,46 @@ DEVI void gemm_tall_kb_st(f32x4 (&acc)[NTW][MT], KF kf, const lfloat* A, int lda
             for (int i = 0; i < NTW; ++i) b[d][i] = wp[(tbase[i] + wkb2) * 64];
             __builtin_amdgcn_sched_barrier(0);
         }
+    }
+}
+
+// The extension k-steps that follow a split tall GEMM (one fp32 k-step per head of the group, weights = the s = 0 slots of the
+// fp32 image's extension blocks), in two halves: the weights are requested BEFORE the split GEMM and multiplied after it.
+// As one call behind the GEMM (gemm_tall_kb) their trip to the L2 was fully exposed, once per head and layer in the forward
+// output projection and again in the back-projection.
+template <int NTW, int NH>
+struct ExtW { float b[NH][NTW]; };
+template <int NTW, int NH, class WK>
+DEVI void ext_fetch(ExtW<NTW, NH>& e, WK wk, const float* __restrict__ Wp, int KBtot, int ntiles) {
+    const int tid_ = tid_now();
+    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+    const gf32x4* wp = (const gf32x4*)Wp + lane;
+#pragma unroll
+    for (int i = 0; i < NH; ++i)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int nt = wave + DFF_NWAVES * t;
+            e.b[i][t] = *(const gfloat*)(wp + ((size_t)(nt < ntiles ? nt : 0) * KBtot + wk(i)) * 64);
+        }
+    asm volatile("" ::: "memory");
+}
+template <int MT, int NTW, int NH, class AO>
+DEVI void ext_apply(f32x4 (&acc)[NTW][MT], const ExtW<NTW, NH>& e, AO aoff_of, const lfloat* A, int lda, int rowsA, int ntiles) {
+    const int tid_ = tid_now();
+    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+    const int kk = lane >> 4, mm = lane & 15;
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        float ax[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) ax[mt] = A[aoff_of(i) + min(mt * 16 + mm, rowsA - 1) * lda + kk];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+            if (t == 0 || wave + DFF_NWAVES * t < ntiles) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(e.b[i][t], ax[mt], acc[t][mt], 0, 0, 0);
+            }
     }
 }
 
@@ -2492,16 +2535,13 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             lfloat* const oxt = PIPE ? geo.dSbuf : nullptr;
             constexpr int DWO = 2 * HGS < 4 ? 2 * HGS : 4;
             auto wo_gemm = [&](int hg, auto pre, u32x4 (&bw)[DWO][NTW][3]) {
+                ExtW<NTW, HGS> ew;
+                if constexpr (DFF_EXTPRE) ext_fetch<NTW, HGS>(ew, [=](int i) { return (hg * HGS + i) * 5 + 4; }, lw.Wox_p, DFF_HEADS * 5, NT_H);
                 gemm_tall_split_st_b<MT, NTW, 2 * HGS, decltype(pre)::value>(acc_o, (64 * HGS + DFF_SPAD) / 2, (const lu32*)(geo.Rg + 3 * RN * LQ), RN, RN,
                                                      lw.Wox_s, 2 * DFF_HEADS, hg * HGS * 2, NT_H, bw);
-                if (oxt)
-                    gemm_tall_kb<MT, NTW, 5>(acc_o, HGS,
-                        [=](int i, int& aoff, int& wkb) { aoff = i * 16; wkb = (hg * HGS + i) * 5 + 4; },
-                        oxt, 16 * HGS, RN, lw.Wox_p, DFF_HEADS * 5, NT_H);
-                else
-                    gemm_tall_kb<MT, NTW, 5>(acc_o, HGS,
-                        [=](int i, int& aoff, int& wkb) { aoff = i * 80 + 64; wkb = (hg * HGS + i) * 5 + 4; },
-                        geo.Rg, LQ, RN, lw.Wox_p, DFF_HEADS * 5, NT_H);
+                if constexpr (!DFF_EXTPRE) ext_fetch<NTW, HGS>(ew, [=](int i) { return (hg * HGS + i) * 5 + 4; }, lw.Wox_p, DFF_HEADS * 5, NT_H);
+                if (oxt) ext_apply<MT, NTW, HGS>(acc_o, ew, [=](int i) { return i * 16; }, oxt, 16 * HGS, RN, NT_H);
+                else ext_apply<MT, NTW, HGS>(acc_o, ew, [=](int i) { return i * 80 + 64; }, geo.Rg, LQ, RN, NT_H);
             };
             if constexpr (PIPE) if (!cached) {
                 constexpr int NI = HGS * MT, NWH = DFF_NWAVES - NI, NTQ = HGS * 13, CNTH = (NTQ + NWH - 1) / NWH;
@@ -2811,10 +2851,11 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         co_dv_dk<MT, HGS, false, GEN, LL::KVS, LL::VSP>(geo);
                         wg_sync<SPILL>();
                         pf.tick(18);
+                        ExtW<NTW, HGS> ew;
+                        if constexpr (DFF_EXTPRE) ext_fetch<NTW, HGS>(ew, [=](int i) { return (hg * HGS + i) * 13 + 4; }, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
                         gemm_tall_qkvT_split<MT, NTW, HGS, LL::KVS, LL::VSP, QPRE, LL::KVS && DFF_QSP>(acc_a, geo.Rg, 4, RN, lw.WqkvxT_s, hg * HGS, NT_H, geo.lsp, bq, geo.lsq);
-                        gemm_tall_kb<MT, NTW, 13>(acc_a, HGS,
-                            [=](int i, int& aoff, int& wkb) { aoff = 4 * RN * LQ + i * 80 + 64; wkb = (hg * HGS + i) * 13 + 4; },
-                            geo.Rg, LQ, RN, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
+                        if constexpr (!DFF_EXTPRE) ext_fetch<NTW, HGS>(ew, [=](int i) { return (hg * HGS + i) * 13 + 4; }, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
+                        ext_apply<MT, NTW, HGS>(acc_a, ew, [=](int i) { return 4 * RN * LQ + i * 80 + 64; }, geo.Rg, LQ, RN, NT_H);
                     } else {
                         co_dv_dk<MT, HGS, true, GEN>(geo);
                     }
@@ -2897,13 +2938,11 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     else if (l > 0) l2_w2t(m.layer[l - 1], ch_lo);
                     if constexpr (SPW) {
                         u32x4 bq[4][NTW][3];
+                        ExtW<NTW, HGS> ew;
+                        if constexpr (DFF_EXTPRE) ext_fetch<NTW, HGS>(ew, [=](int i) { return (hg * HGS + i) * 13 + 4; }, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
                         gemm_tall_qkvT_split<MT, NTW, HGS, LL::KVS, LL::VSP, 0, LL::KVS && DFF_QSP>(acc_a, geo.Rg, FIVE ? 4 : 3, RN, lw.WqkvxT_s, hg * HGS, NT_H, geo.lsp, bq, geo.lsq);
-                        gemm_tall_kb<MT, NTW, 13>(acc_a, HGS,
-                            [=](int i, int& aoff, int& wkb) {
-                                aoff = (FIVE ? 4 : 3) * RN * LQ + i * 80 + 64;
-                                wkb = (hg * HGS + i) * 13 + 4;
-                            },
-                            geo.Rg, LQ, RN, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
+                        if constexpr (!DFF_EXTPRE) ext_fetch<NTW, HGS>(ew, [=](int i) { return (hg * HGS + i) * 13 + 4; }, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
+                        ext_apply<MT, NTW, HGS>(acc_a, ew, [=](int i) { return (FIVE ? 4 : 3) * RN * LQ + i * 80 + 64; }, geo.Rg, LQ, RN, NT_H);
                     } else
                     gemm_tall_kb_st<MT, NTW, 13, 13 * HGS>(acc_a,
                         [=](int i, int& aoff, int& wkb) {
