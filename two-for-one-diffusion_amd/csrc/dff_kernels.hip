@@ -492,6 +492,86 @@ DEVI void gemm_wide_split_st(const lu32* as, int R, int rowsA, const unsigned* _
     }
 }
 
+// The same GEMM with TWO output tiles per wave side by side (k-block-major): an A fragment read from LDS feeds both tiles'
+// products.  With three or four row tiles the A operand does not fit the register file (ARES), every tile re-reads all of
+// it, and three ds_read_b128 per six 16-cycle products make the LDS as busy as the matrix pipes (8 waves x 24 LDS cycles
+// against 2 waves x 96 pipe cycles per SIMD): the two limits add up instead of overlapping.  Pairs q = wave + 8 i cover
+// tiles 2 q and 2 q + 1 (a surplus tile repeats NTN - 1 with valid = false); ring of two k-blocks (both tiles' pieces).
+template <int MT, int KB32, int NTN, int NAUX, class Pre, class Epi>
+DEVI void gemm_wide_split_k2(const lu32* as, int R, int rowsA, const unsigned* __restrict__ Wp, int nt0, Pre pre, Epi epi) {
+    constexpr int LHS2 = (32 * KB32 + DFF_SPAD) / 2, NP = (NTN + 1) / 2, CNT = (NP + DFF_NWAVES - 1) / DFF_NWAVES, DR = 2;
+    static_assert(KB32 >= DR, "ring");
+    const int tid_ = tid_now();
+    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+    const int kg = lane >> 4, mm = lane & 15;
+    int rowoff[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) rowoff[mt] = min(mt * 16 + mm, rowsA - 1) * LHS2 + 4 * kg;
+    const gu32x4* wp = (const gu32x4*)Wp + lane;
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) {
+        const int q = wave + DFF_NWAVES * i;
+        const int t0 = min(2 * q, NTN - 1), t1 = min(2 * q + 1, NTN - 1);
+        const bool v0 = 2 * q < NTN, v1 = 2 * q + 1 < NTN;
+        u32x4 b[DR][2][3];
+        float aux[2][NAUX];
+        auto fill = [&](u32x4 (&slot)[2][3], int kb) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) slot[0][p] = wp[(((size_t)(nt0 + t0) * KB32 + kb) * 3 + p) * 64];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) slot[1][p] = wp[(((size_t)(nt0 + t1) * KB32 + kb) * 3 + p) * 64];
+        };
+#pragma unroll
+        for (int d = 0; d < DR; ++d) fill(b[d], d);
+        pre(t0, aux[0]);
+        pre(t1, aux[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 cs[2][MT], cb[2][MT];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) { cs[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; cb[t][mt] = cs[t][mt]; }
+        u32x4 apre[3];
+        apre[0] = *(const volatile lu32x4*)(as + rowoff[0]);
+        apre[1] = *(const volatile lu32x4*)(as + R * LHS2 + rowoff[0]);
+        apre[2] = *(const volatile lu32x4*)(as + 2 * R * LHS2 + rowoff[0]);
+        if (v0) {   // (wave-uniform; a wave without a pair skips the products)
+#pragma unroll
+            for (int kb = 0; kb < KB32; ++kb) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const u32x4 ah = apre[0], am = apre[1], al = apre[2];
+                    const int mtn = (mt + 1) % MT, kbn = (mt + 1 == MT) ? (kb + 1) % KB32 : kb;
+                    const int on = rowoff[mtn] + 16 * kbn;
+                    apre[0] = *(const volatile lu32x4*)(as + on);
+                    apre[1] = *(const volatile lu32x4*)(as + R * LHS2 + on);
+                    apre[2] = *(const volatile lu32x4*)(as + 2 * R * LHS2 + on);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        cs[t][mt] = mfma_bf16(b[kb % DR][t][0], al, cs[t][mt]);
+                        cb[t][mt] = mfma_bf16(b[kb % DR][t][0], am, cb[t][mt]);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        cs[t][mt] = mfma_bf16(b[kb % DR][t][2], ah, cs[t][mt]);
+                        cb[t][mt] = mfma_bf16(b[kb % DR][t][1], ah, cb[t][mt]);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        cs[t][mt] = mfma_bf16(b[kb % DR][t][1], am, cs[t][mt]);
+                        cb[t][mt] = mfma_bf16(b[kb % DR][t][0], ah, cb[t][mt]);
+                    }
+                }
+                if (kb + DR < KB32) { fill(b[kb % DR], kb + DR); __builtin_amdgcn_sched_barrier(0); }
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) epi(t0, mt, cb[0][mt] + cs[0][mt], aux[0], v0, i);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) epi(t1, mt, cb[1][mt] + cs[1][mt], aux[1], v1, i);
+    }
+}
+
 // gemm_wide_units on the split operands (few output tiles: (tile, row-tile) units round-robin over the waves, loop-free).
 // Up to two units per wave: all weights requested up front.  More (four row tiles: 5 tiles x 4 = 20 units, three per
 // wave): a ring of two units -- three units of K = 128 weights at once are 144 registers.
@@ -785,6 +865,9 @@ DEVI void gemm_tall_split_st(f32x4 (&acc)[NTW][MT], int LS2, const lu32* as, int
 #endif
 #ifndef DFF_GXT
 #define DFF_GXT 1
+#endif
+#ifndef DFF_K2
+#define DFF_K2 1   // wide split GEMMs at four row tiles: two output tiles per wave off one A read (gemm_wide_split_k2; three row tiles: measured 0.6 % slower, 204 B of scratch)
 #endif
 #ifndef DFF_EXTPRE
 #define DFF_EXTPRE 1   // extension-block weights of the tall GEMMs requested before the split GEMM (0: behind it, as until round 3)
@@ -2634,7 +2717,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                             st_ntg4(ok ? sq + (size_t)hh * RN * DFF_QKVW + (size_t)row * DFF_QKVW + 16 * tt + c4 : junk, v);
                         };
                     if constexpr (SPW)
-                        gemm_wide_split_st<MT, H / 32, HGS * 13, 4>(asplit, RN, RN, lw.Wqkvx_s, hg * HGS * 13, qkv_pre, qkv_epi);
+                        if constexpr (MT >= 4 && DFF_K2) gemm_wide_split_k2<MT, H / 32, HGS * 13, 4>(asplit, RN, RN, lw.Wqkvx_s, hg * HGS * 13, qkv_pre, qkv_epi);
+                        else gemm_wide_split_st<MT, H / 32, HGS * 13, 4>(asplit, RN, RN, lw.Wqkvx_s, hg * HGS * 13, qkv_pre, qkv_epi);
                     else
                         gemm_wide_st<MT, NT_H, HGS * 13, 4>(abufL, LH, RN, lw.Wqkvx_p, hg * HGS * 13, qkv_pre, qkv_epi);
                 }
@@ -2697,7 +2781,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         };
                     l2_w2(lw, ch);
                     if constexpr (SPW)
-                        gemm_wide_split_st<MT, H / 32, FC / 16, 4>(asplit, RN, RN, lw.W1_s, ch * (FC / 16), w1_pre, w1_epi);
+                        if constexpr (MT >= 4 && DFF_K2) gemm_wide_split_k2<MT, H / 32, FC / 16, 4>(asplit, RN, RN, lw.W1_s, ch * (FC / 16), w1_pre, w1_epi);
+                        else gemm_wide_split_st<MT, H / 32, FC / 16, 4>(asplit, RN, RN, lw.W1_s, ch * (FC / 16), w1_pre, w1_epi);
                     else
                         gemm_wide_st<MT, NT_H, FC / 16, 4>(abufL, LH, RN, lw.W1_p, ch * (FC / 16), w1_pre, w1_epi);
                 }
@@ -2754,7 +2839,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         };
                     l2_w1t(lw, ch);
                     if constexpr (SPW)
-                        gemm_wide_split_st<MT, H / 32, FC / 16, 4 * MT>(asplit, RN, RN, lw.W2T_s, ch * (FC / 16), w2t_pre, w2t_epi);
+                        if constexpr (MT >= 4 && DFF_K2) gemm_wide_split_k2<MT, H / 32, FC / 16, 4 * MT>(asplit, RN, RN, lw.W2T_s, ch * (FC / 16), w2t_pre, w2t_epi);
+                        else gemm_wide_split_st<MT, H / 32, FC / 16, 4 * MT>(asplit, RN, RN, lw.W2T_s, ch * (FC / 16), w2t_pre, w2t_epi);
                     else
                         gemm_wide_st<MT, NT_H, FC / 16, 4 * MT>(abufL, LH, RN, lw.W2T_p, ch * (FC / 16), w2t_pre, w2t_epi);
                 }
