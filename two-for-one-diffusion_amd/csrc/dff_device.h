@@ -189,19 +189,9 @@ DEVI float row16_max(float v) {
     v = fmaxf(v, dpp_mov<0x140>(v));
     return v;
 }
-DEVI float grp16_sum(float v) { return row16_sum(v); }
 DEVI float grp_sum(float v, int np) {
     for (int o = np >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
-}
-DEVI float grp_max(float v, int np) {
-    for (int o = np >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-DEVI float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-DEVI float gelu_grad_f(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) +
-           x * expf(-0.5f * x * x) * 0.39894228040143267794f;
 }
 // GELU(erf) value and derivative in one go: the forward FFN epilogue stashes gelu'(h_pre) so that the
 // backward epilogue is a single multiply (one erf + one exp per element per step instead of two + one)

@@ -197,181 +197,8 @@ DEVI void gemm_wide_st(const lfloat* A, int lda, int rowsA, const float* __restr
     }
 }
 
-// abuf (R x H fp32, leading dimension H + 4) -> as[piece][row][LHS2] (bf16 pairs): all threads, two columns each
-template <int H>
-DEVI void split_rows(const lfloat* abuf, lu32* as, int R) {
-    constexpr int LH = H + 4, LHS2 = (H + DFF_SPAD) / 2;
-    const int tid_ = tid_now();
-    for (int it = tid_; it < R * (H / 2); it += DFF_NTHREADS) {
-        const int row = it / (H / 2), c2 = it - row * (H / 2);
-        unsigned hh[2], mm[2], ll[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const float v = abuf[row * LH + 2 * c2 + q];
-            const unsigned uh = __float_as_uint(v) & 0xffff0000u;
-            const float r = v - __uint_as_float(uh);
-            const unsigned um = __float_as_uint(r) & 0xffff0000u;
-            const float r2 = r - __uint_as_float(um);
-            hh[q] = uh; mm[q] = um; ll[q] = __float_as_uint(r2);
-        }
-        as[(0 * R + row) * LHS2 + c2] = __builtin_amdgcn_perm(hh[1], hh[0], 0x07060302u);
-        as[(1 * R + row) * LHS2 + c2] = __builtin_amdgcn_perm(mm[1], mm[0], 0x07060302u);
-        as[(2 * R + row) * LHS2 + c2] = __builtin_amdgcn_perm(ll[1], ll[0], 0x07060302u);
-    }
-}
-// gemm_wide on the split operands: Wp = pack_b_split image ([tile][k32-block][piece][lane] x 8 bf16), as = split_rows
-// output.  Same tile -> wave assignment, ring and pre / epi contract as gemm_wide.
-template <int MT, int KB32, int NAUX, class Pre, class Epi>
-DEVI void gemm_wide_split(const lu32* as, int R, int rowsA, const unsigned* __restrict__ Wp, int nt0, int ntn, Pre pre, Epi epi) {
-    const int tid_ = tid_now();
-    constexpr int D = 2, LHS2 = (32 * KB32 + DFF_SPAD) / 2;
-    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
-    const int kg = lane >> 4, mm = lane & 15;
-    int rowoff[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) rowoff[mt] = min(mt * 16 + mm, rowsA - 1) * LHS2 + 4 * kg;
-    const gu32x4* wp = (const gu32x4*)Wp + lane;
-    const int cnt = wave < ntn ? (ntn - wave + DFF_NWAVES - 1) / DFF_NWAVES : 0;
-    u32x4 b[D][KB32][3];
-    float aux[D][NAUX];
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-        if (d < cnt) {
-#pragma unroll
-            for (int kb = 0; kb < KB32; ++kb)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) b[d][kb][p] = wp[(((size_t)(nt0 + wave + DFF_NWAVES * d) * KB32 + kb) * 3 + p) * 64];
-            pre(wave + DFF_NWAVES * d, aux[d]);
-        }
-    for (int i0 = 0; i0 < cnt; i0 += D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int i = i0 + d;
-            if (i < cnt) {
-                const int nt = wave + DFF_NWAVES * i;
-                f32x4 cs[MT], cb[MT];   // small terms / big terms
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) { cs[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; cb[mt] = cs[mt]; }
-#pragma unroll
-                for (int kb = 0; kb < KB32; ++kb) {
-                    u32x4 ah[MT], am[MT], al[MT];
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        ah[mt] = *(const lu32x4*)(as + rowoff[mt] + 16 * kb);
-                        am[mt] = *(const lu32x4*)(as + R * LHS2 + rowoff[mt] + 16 * kb);
-                        al[mt] = *(const lu32x4*)(as + 2 * R * LHS2 + rowoff[mt] + 16 * kb);
-                    }
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) cs[mt] = mfma_bf16(b[d][kb][0], al[mt], cs[mt]);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) cb[mt] = mfma_bf16(b[d][kb][0], am[mt], cb[mt]);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) cs[mt] = mfma_bf16(b[d][kb][2], ah[mt], cs[mt]);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) cb[mt] = mfma_bf16(b[d][kb][1], ah[mt], cb[mt]);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) cs[mt] = mfma_bf16(b[d][kb][1], am[mt], cs[mt]);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) cb[mt] = mfma_bf16(b[d][kb][0], ah[mt], cb[mt]);
-                }
-                float auxc[NAUX];
-#pragma unroll
-                for (int q = 0; q < NAUX; ++q) auxc[q] = aux[d][q];
-                if (i + D < cnt) {
-#pragma unroll
-                    for (int kb = 0; kb < KB32; ++kb)
-#pragma unroll
-                        for (int p = 0; p < 3; ++p) b[d][kb][p] = wp[(((size_t)(nt0 + nt + DFF_NWAVES * D) * KB32 + kb) * 3 + p) * 64];
-                    pre(nt + DFF_NWAVES * D, aux[d]);
-                }
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) epi(nt, mt, cb[mt] + cs[mt], auxc, true, 0);
-            }
-        }
-    }
-}
-
-// The same with a ring of three HALF tiles (k-blocks [0, KB32/2) and [KB32/2, KB32) of a tile are separate entries):
-// 1.5 tiles of lookahead in 18 instead of 24 operand registers per lane, which is what keeps the H = 128 variants
-// out of scratch.  Entries e = 2 i + half; six entries (three tiles) per trip so that slot, half and aux index are static.
-template <int MT, int KB32, int NAUX, class Pre, class Epi>
-DEVI void gemm_wide_split_h(const lu32* as, int R, int rowsA, const unsigned* __restrict__ Wp, int nt0, int ntn, Pre pre, Epi epi) {
-    static_assert(KB32 % 2 == 0, "even number of 32-row k-blocks");
-    const int tid_ = tid_now();
-    constexpr int HB = KB32 / 2, LHS2 = (32 * KB32 + DFF_SPAD) / 2;
-    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
-    const int kg = lane >> 4, mm = lane & 15;
-    int rowoff[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) rowoff[mt] = min(mt * 16 + mm, rowsA - 1) * LHS2 + 4 * kg;
-    const gu32x4* wp = (const gu32x4*)Wp + lane;
-    const int cnt = wave < ntn ? (ntn - wave + DFF_NWAVES - 1) / DFF_NWAVES : 0;
-    const int ne = 2 * cnt;
-    u32x4 b[3][HB][3];
-    float aux[3][NAUX];
-    auto fill = [&](u32x4 (&slot)[HB][3], int e) {
-        const size_t tile = (size_t)(nt0 + wave + DFF_NWAVES * (e >> 1));
-#pragma unroll
-        for (int kb = 0; kb < HB; ++kb)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) slot[kb][p] = wp[((tile * KB32 + (e & 1) * HB + kb) * 3 + p) * 64];
-    };
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-        if (j < ne) {
-            fill(b[j], j);
-            if ((j & 1) == 0) pre(wave + DFF_NWAVES * (j >> 1), aux[j >> 1]);
-        }
-    f32x4 cs[MT], cb[MT];
-    for (int e0 = 0; e0 < ne; e0 += 6) {
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int e = e0 + j;
-            if (e < ne) {
-                constexpr int dummy = 0; (void)dummy;
-                const int half = j & 1, slot = j % 3, it = j >> 1;
-                const int nt = wave + DFF_NWAVES * (e >> 1);
-                if (half == 0) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) { cs[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; cb[mt] = cs[mt]; }
-                }
-#pragma unroll
-                for (int kb = 0; kb < HB; ++kb) {
-                    // one row tile's pieces live at a time (3 registers x 4 instead of 9 x 4); its two accumulator chains alternate
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        const int o = rowoff[mt] + 16 * (half * HB + kb);
-                        const u32x4 ah = *(const lu32x4*)(as + o);
-                        const u32x4 am = *(const lu32x4*)(as + R * LHS2 + o);
-                        const u32x4 al = *(const lu32x4*)(as + 2 * R * LHS2 + o);
-                        cs[mt] = mfma_bf16(b[slot][kb][0], al, cs[mt]);
-                        cb[mt] = mfma_bf16(b[slot][kb][0], am, cb[mt]);
-                        cs[mt] = mfma_bf16(b[slot][kb][2], ah, cs[mt]);
-                        cb[mt] = mfma_bf16(b[slot][kb][1], ah, cb[mt]);
-                        cs[mt] = mfma_bf16(b[slot][kb][1], am, cs[mt]);
-                        cb[mt] = mfma_bf16(b[slot][kb][0], ah, cb[mt]);
-                    }
-                }
-                float auxc[NAUX];
-                if (half == 1) {
-#pragma unroll
-                    for (int q = 0; q < NAUX; ++q) auxc[q] = aux[it][q];
-                }
-                if (e + 3 < ne) {
-                    fill(b[slot], e + 3);
-                    // entry e + 3 opens tile (e + 3) >> 1 when it is a first half: its aux slot is ((j + 3) >> 1) % 3
-                    if (((j + 3) & 1) == 0) pre(wave + DFF_NWAVES * ((e + 3) >> 1), aux[((j + 3) >> 1) % 3]);
-                }
-                if (half == 1) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) epi(nt, mt, cb[mt] + cs[mt], auxc, true, 0);
-                }
-            }
-        }
-    }
-}
-
-// The same, loop-free: NTN is a compile-time tile count, every wave runs ceil(NTN / 8) tiles (a wave without a tile
+// gemm_wide on the split operands (Wp = pack_b_split image: [tile][k32-block][piece][lane] x 8 bf16; as = the piece arrays the
+// row stages write, rstore_a), loop-free: NTN is a compile-time tile count, every wave runs ceil(NTN / 8) tiles (a wave without a tile
 // of its own in the last round repeats tile NTN - 1 with valid = false: it would idle at the barrier anyway), and
 // pre / epi issue the SAME global loads and stores for every tile (epilogues redirect what must not be stored to the
 // stash's junk slot).  With no control flow around VMEM the compiler counts the operations in flight exactly;
@@ -690,78 +517,6 @@ DEVI void store_split4(lu32* as, int R, int LS2, int row, int col, const f32x4 v
     *(lu32x2*)(as + 1 * R * LS2 + o) = (u32x2){__builtin_amdgcn_perm(mm[1], mm[0], 0x07060302u), __builtin_amdgcn_perm(mm[3], mm[2], 0x07060302u)};
     *(lu32x2*)(as + 2 * R * LS2 + o) = (u32x2){__builtin_amdgcn_perm(ll[1], ll[0], 0x07060302u), __builtin_amdgcn_perm(ll[3], ll[2], 0x07060302u)};
 }
-// "tall" GEMM (Nout = H) on split operands: acc[i][mt] += A[:, 32 kb ..] W[kb0 + kb], kb < nkb; A pieces as written by
-// store_split with LS = 32 nkb + 8; W = pack_b_split image with KBtot k-blocks per tile.  Wave w owns tiles w + 8 i.
-// One accumulator per output tile, small terms first inside every k-block.
-template <int MT, int NTW>
-DEVI void gemm_tall_split(f32x4 (&acc)[NTW][MT], int nkb, int LS2 /* dwords per piece row */, const lu32* as, int R, int rowsA,
-                          const unsigned* __restrict__ Wp, int KBtot, int kb0, int ntiles) {
-    const int tid_ = tid_now();
-    constexpr int D = 3;
-    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
-    const int kg = lane >> 4, mm = lane & 15;
-    int rowoff[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) rowoff[mt] = min(mt * 16 + mm, rowsA - 1) * LS2 + 4 * kg;
-    const gu32x4* wp = (const gu32x4*)Wp + lane;
-    size_t tbase[NTW];
-    bool tok[NTW];
-#pragma unroll
-    for (int i = 0; i < NTW; ++i) {
-        const int nt = wave + DFF_NWAVES * i;
-        tok[i] = nt < ntiles;
-        tbase[i] = ((size_t)(tok[i] ? nt : 0) * KBtot + kb0) * 3;
-    }
-    if (!tok[0]) return;
-    u32x4 b[D][NTW][3];
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-        if (d < nkb) {
-#pragma unroll
-            for (int i = 0; i < NTW; ++i)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) b[d][i][p] = wp[(tbase[i] + 3 * d + p) * 64];
-        }
-    for (int k0 = 0; k0 < nkb; k0 += D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int kb = k0 + d;
-            if (kb < nkb) {
-                u32x4 ah[MT], am[MT], al[MT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const int o = rowoff[mt] + 16 * kb;
-                    ah[mt] = *(const lu32x4*)(as + o);
-                    am[mt] = *(const lu32x4*)(as + R * LS2 + o);
-                    al[mt] = *(const lu32x4*)(as + 2 * R * LS2 + o);
-                }
-#pragma unroll
-                for (int i = 0; i < NTW; ++i)
-                    if (tok[i]) {
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][0], al[mt], acc[i][mt]);
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][2], ah[mt], acc[i][mt]);
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][1], am[mt], acc[i][mt]);
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][0], am[mt], acc[i][mt]);
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][1], ah[mt], acc[i][mt]);
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][0], ah[mt], acc[i][mt]);
-                    }
-                if (kb + D < nkb) {
-#pragma unroll
-                    for (int i = 0; i < NTW; ++i)
-#pragma unroll
-                        for (int p = 0; p < 3; ++p) b[d][i][p] = wp[(tbase[i] + 3 * (kb + D) + p) * 64];
-                }
-            }
-        }
-    }
-}
-
 // The same with a compile-time k-block count: loop-free, so that the ring (D k-blocks ahead) is waited for exactly.
 // (PRE: the ring's first D k-blocks were requested by tall_ring_fill before the barrier in front of this GEMM)
 template <int NTW, int D>
@@ -857,9 +612,6 @@ DEVI void gemm_tall_split_st(f32x4 (&acc)[NTW][MT], int LS2, const lu32* as, int
 #ifndef DFF_WOPRE
 #define DFF_WOPRE 1
 #endif
-#ifndef DFF_QPRE
-#define DFF_QPRE 0   // (measured: even one k-block of the ring held across the barrier spills -- 571 -> 592 us on villin)
-#endif
 #ifndef DFF_L2W
 #define DFF_L2W 1
 #endif
@@ -898,31 +650,6 @@ DEVI void l2_touch(unsigned junk_byte, const void* base, int ntiles, size_t stri
     }
 }
 
-// d(LN1 out) += [dq | dk | dv] [W_q | W_k | W_v] of HGS heads on the split engine.  The operand rows live in LDS as fp32
-// (dQ_ext in head buffer regQ, dK in 1, dV in 2: there is no room for their bf16 pieces), so every wave splits the
-// fragments it reads in registers (split8): ~130 VALU next to 18 bf16 MFMAs per 32-column block, against the
-// 24 fp32 MFMAs (32 cycles each, vector port blocked) of the fp32 engine.  Ws = pack_b_split image of the 192 regular
-// rows per head; the extension rows (du) stay on the fp32 image (gemm_tall_kb, one k-step per head).
-// KVS / VSP: dK (and dV) are bf16 pieces already (co_dv_dk) -- their fragments are three 16-byte reads.
-// The first D k-blocks of a wave's tiles for gemm_tall_qkvT_split, requested a phase early (PRE): the ring then crosses
-// the barrier in registers and the GEMM starts on landed operands instead of on a trip to the L2.
-template <int NTW>
-DEVI void qkvT_ring_fill(u32x4 (&b)[4][NTW][3], const unsigned* __restrict__ Ws, int head0, int ntiles) {
-    constexpr int KBtot = 6 * DFF_HEADS;
-    const int tid_ = tid_now();
-    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
-    const gu32x4* wp = (const gu32x4*)Ws + lane;
-#pragma unroll
-    for (int i = 0; i < NTW; ++i) {
-        const int nt = wave + DFF_NWAVES * i;
-        const size_t tb = ((size_t)(nt < ntiles ? nt : 0) * KBtot + 6 * head0) * 3;
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) b[d][i][p] = wp[(tb + 3 * d + p) * 64];
-    }
-    asm volatile("" ::: "memory");
-}
 // QSP (round 4): dQ arrives as pieces as well (co_ds: [h | m] in place of the fp32 row of buffer regQ, l in `lsq`).
 template <int MT, int NTW, int HGS, bool KVS = false, bool VSP = false, int PRE = 0, bool QSP = false>
 DEVI void gemm_tall_qkvT_split(f32x4 (&acc)[NTW][MT], const lfloat* Rg, int regQ, int RN, const unsigned* __restrict__ Ws,
@@ -1006,12 +733,6 @@ DEVI void gemm_tall_qkvT_split(f32x4 (&acc)[NTW][MT], const lfloat* Rg, int regQ
     }
 }
 
-template <int MT, int KB32, int NAUX, class Pre, class Epi>
-DEVI void gemm_wide_split_sel(const lu32* as, int R, int rowsA, const unsigned* __restrict__ Wp, int nt0, int ntn, Pre pre, Epi epi) {
-    if constexpr (KB32 % 2 == 0 && KB32 >= 4) gemm_wide_split_h<MT, KB32, NAUX>(as, R, rowsA, Wp, nt0, ntn, pre, epi);
-    else gemm_wide_split<MT, KB32, NAUX>(as, R, rowsA, Wp, nt0, ntn, pre, epi);
-}
-
 // wide GEMM with few output tiles (NTN * MT (tile, row-tile) units <= a few per wave): the UNITS, not the tiles, go
 // round-robin over the waves, so that all four SIMDs carry the same MFMA load; loop-free, all weights loaded up
 // front, hook() as in gemm_wide.  epi(nt_local, mt, acc).
@@ -1051,84 +772,6 @@ DEVI void gemm_wide_units(const lfloat* A, int lda, int rowsA, const float* __re
                 }
             }
             epi(nt, mt, acc0 + acc1);
-        }
-    }
-}
-
-// "tall" GEMM over an explicit list of 16-wide k-blocks: kf(i, aoff, wkb) names the i-th block (its A
-// columns start at A + aoff, its weights are k-block wkb of the packed image).  Ring of D k-blocks.
-// XPER > 0: weight k-blocks with wkb % XPER == 4 are head extension blocks (rows 4..15 zero): one k-step over
-// columns 0..3 instead of four (packed with row lane >> 4 in k-step 0, dff_host.hip pack_b).
-template <int MT, int NTW, int XPER, class KF>
-DEVI void gemm_tall_kb(f32x4 (&acc)[NTW][MT], int nkb, KF kf, const lfloat* A, int lda, int rowsA,
-                       const float* __restrict__ Wp, int KBtot, int ntiles) {
-    const int tid_ = tid_now();
-    constexpr int D = 4;
-    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
-    const int kk = lane >> 4, mm = lane & 15;
-    int rowoff[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) rowoff[mt] = min(mt * 16 + mm, rowsA - 1) * lda + 4 * kk;
-    const gf32x4* wp = (const gf32x4*)Wp + lane;
-    size_t tbase[NTW];
-    bool tok[NTW];
-#pragma unroll
-    for (int i = 0; i < NTW; ++i) {
-        const int nt = wave + DFF_NWAVES * i;
-        tok[i] = nt < ntiles;
-        tbase[i] = (size_t)(tok[i] ? nt : 0) * KBtot;
-    }
-    if (!tok[0]) return;
-    f32x4 b[D][NTW];
-    int aoff[D];
-    bool ext[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-        if (d < nkb) {
-            int wkb;
-            kf(d, aoff[d], wkb);
-            ext[d] = XPER > 0 && wkb % (XPER > 0 ? XPER : 1) == 4;
-#pragma unroll
-            for (int i = 0; i < NTW; ++i) b[d][i] = wp[(tbase[i] + wkb) * 64];
-        }
-    for (int i0 = 0; i0 < nkb; i0 += D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int ib = i0 + d;
-            if (ib < nkb) {
-                if (XPER > 0 && ext[d]) {
-                    float ax[MT];
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) ax[mt] = A[aoff[d] + rowoff[mt] - 3 * kk];
-#pragma unroll
-                    for (int i = 0; i < NTW; ++i)
-                        if (tok[i]) {
-#pragma unroll
-                            for (int mt = 0; mt < MT; ++mt)
-                                acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[d][i][0], ax[mt], acc[i][mt], 0, 0, 0);
-                        }
-                } else {
-                    f32x4 a[MT];
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) a[mt] = *(const lf32x4*)(A + aoff[d] + rowoff[mt]);
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-                        for (int i = 0; i < NTW; ++i)
-                            if (tok[i]) {
-#pragma unroll
-                                for (int mt = 0; mt < MT; ++mt)
-                                    acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[d][i][s4], a[mt][s4], acc[i][mt], 0, 0, 0);
-                            }
-                }
-                if (ib + D < nkb) {
-                    int wkb;
-                    kf(ib + D, aoff[d], wkb);
-                    ext[d] = XPER > 0 && wkb % (XPER > 0 ? XPER : 1) == 4;
-#pragma unroll
-                    for (int i = 0; i < NTW; ++i) b[d][i] = wp[(tbase[i] + wkb) * 64];
-                }
-            }
         }
     }
 }
@@ -2119,44 +1762,6 @@ DEVI void co_ds(const CoGeo& g) {
     }
 }
 
-// backward, with the fifth buffer: dV_ext = P^T G_ext (-> R2) and dK_ext = dS^T Q_ext (-> R1) in ONE phase
-// (nothing reads R1 / R2 any more); their extension tiles are dE/dx_j -> this wave's dxw.
-// EXT_ONLY (layer 0: nothing upstream of q, k, v depends on x): only those extension tiles.
-// KVS (SPW variants): the 64 regular columns of a dK / dV row leave as the bf16 pieces the back-projection multiplies
-// (gemm_tall_qkvT_split): split ONCE here instead of by each of the eight waves that read them.  [h | m] take the place of
-// the fp32 row (2 x 128 B); the l pieces of dK go to the extension columns of the same head in the R1 row (columns 0..31)
-// and the R2 row (32..63) -- K_ext's / V_ext's x columns are dead by now and rewritten with the next head (co_fill_x) --
-// and those of dV to g.lsp (VSP; otherwise dV stays fp32).
-// requests of qkvT_ring_fill, 12 NTW of them, dealt out over NS steps
-template <int NTW, int NS, int PD = 4>
-struct QkvTRingHook {
-    u32x4 (&b)[4][NTW][3];
-    const gu32x4* wp;
-    size_t tb[NTW];
-    DEVI QkvTRingHook(u32x4 (&b_)[4][NTW][3], const unsigned* __restrict__ Ws, int head0, int ntiles) : b(b_) {
-        const int tid_ = tid_now();
-        const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
-        wp = (const gu32x4*)Ws + lane;
-#pragma unroll
-        for (int i = 0; i < NTW; ++i) {
-            const int nt = wave + DFF_NWAVES * i;
-            tb[i] = ((size_t)(nt < ntiles ? nt : 0) * (6 * DFF_HEADS) + 6 * head0) * 3;
-        }
-    }
-    DEVI void operator()(int step) const {
-        constexpr int NL = 3 * PD * NTW;
-#pragma unroll
-        for (int q = 0; q < NL; ++q)
-            if (q * NS / NL == step) {   // load q belongs to step floor(q NS / NL)
-                const int d = q / (3 * NTW), i = (q / 3) % NTW, p = q % 3;
-                b[d][i][p] = wp[(tb[i] + 3 * d + p) * 64];
-            }
-    }
-    DEVI void all() const {
-#pragma unroll
-        for (int st = 0; st < NS; ++st) (*this)(st);
-    }
-};
 template <int MT, int HGS, bool EXT_ONLY, bool GEN, bool KVS = false, bool VSP = false, class SH = NoStepHook, int PL_ = 16 * MT + 4>
 DEVI void co_dv_dk(const CoGeo& g, SH hook = SH()) {
     const int tid_ = tid_now(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
@@ -2926,20 +2531,12 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     pf.tick(17);
                     if (deep) {
                         u32x4 bq[4][NTW][3];
-                        constexpr int QPRE = DFF_QPRE;   // k-blocks of the ring requested a phase early
-                        if constexpr (QPRE > 0) {
-                            // (one item per wave at most: waves without one have nothing to hide the requests behind, and nothing to delay)
-                            static_assert(2 * HGS * MT <= DFF_NWAVES, "");
-                            QkvTRingHook<NTW, 4 * MT, QPRE> rh(bq, lw.WqkvxT_s, hg * HGS, NT_H);
-                            if (wave_ >= 2 * HGS * MT) rh.all();
-                            co_dv_dk<MT, HGS, false, GEN, LL::KVS, LL::VSP>(geo, rh);
-                        } else
                         co_dv_dk<MT, HGS, false, GEN, LL::KVS, LL::VSP>(geo);
                         wg_sync<SPILL>();
                         pf.tick(18);
                         ExtW<NTW, HGS> ew;
                         if constexpr (DFF_EXTPRE) ext_fetch<NTW, HGS>(ew, [=](int i) { return (hg * HGS + i) * 13 + 4; }, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
-                        gemm_tall_qkvT_split<MT, NTW, HGS, LL::KVS, LL::VSP, QPRE, LL::KVS && DFF_QSP>(acc_a, geo.Rg, 4, RN, lw.WqkvxT_s, hg * HGS, NT_H, geo.lsp, bq, geo.lsq);
+                        gemm_tall_qkvT_split<MT, NTW, HGS, LL::KVS, LL::VSP, 0, LL::KVS && DFF_QSP>(acc_a, geo.Rg, 4, RN, lw.WqkvxT_s, hg * HGS, NT_H, geo.lsp, bq, geo.lsq);
                         if constexpr (!DFF_EXTPRE) ext_fetch<NTW, HGS>(ew, [=](int i) { return (hg * HGS + i) * 13 + 4; }, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
                         ext_apply<MT, NTW, HGS>(acc_a, ew, [=](int i) { return 4 * RN * LQ + i * 80 + 64; }, geo.Rg, LQ, RN, NT_H);
                     } else {
