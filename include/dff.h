@@ -32,7 +32,8 @@ extern "C" {
 #define DFF_EHIP 2        /* a HIP runtime call failed (see dff_last_error) */
 #define DFF_ENOMEM 3
 
-#define DFF_MAX_BEADS 64
+#define DFF_MAX_BEADS 64      /* array bound of the ABI structs */
+#define DFF_MAX_BEADS_LDS 61  /* largest n_beads dff_model_create accepts: what the kernels' 160 KB of LDS hold (hidden 128) */
 
 typedef struct dff_model dff_model; /* opaque */
 
@@ -45,8 +46,8 @@ typedef struct dff_model dff_model; /* opaque */
  * (1, 0, 0, conservative 1) and run the specialised kernels; main_train.py's defaults (0, 1, 1) and the
  * other combinations run the general ("gen") variants of the <= 64-row kernel. */
 typedef struct {
-    int32_t n_beads;              /* num_beads, 2..DFF_MAX_BEADS */
-    int32_t hidden;               /* hidden_features_gnn: 64, 96, 128 (any n_beads <= 64 with 128, <= 32 otherwise) or 256 (<= 32 beads) */
+    int32_t n_beads;              /* num_beads, 2..DFF_MAX_BEADS_LDS */
+    int32_t hidden;               /* hidden_features_gnn: 64, 96, 128 (n_beads <= 61 with 128, <= 32 otherwise) or 256 (<= 32 beads) */
     int32_t n_layers;             /* num_layers_gnn, 1..8 */
     int32_t timesteps;            /* diffusion_steps (GaussianDiffusion timesteps), e.g. 1000 */
     int32_t use_intrinsic_coords; /* 0 / 1 */

@@ -796,6 +796,44 @@ def test_bench_two_ranks_on_one_gpu(dff):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N", [49, 53, 56, 57, 60, 61])
+def test_four_row_tiles_at_odd_bead_counts(dff, N, monkeypatch):
+    """The four-row-tile shape beyond protein G's 56 beads (round 4: its split-engine variant keeps P / dS tile arrays of the
+    real rows x 60 columns -- `LdsLayout`, TIGHT -- whose guards only matter when the row count is not a multiple of 4 or 16,
+    and it fits the LDS up to 56 rows: 57..64 beads must fall back to the fp32 engine of the same shape by themselves).
+    Forces against the oracle twin in float64, one workgroup and two workgroups per protein, split and fp32 engines."""
+    from dff_amd.score import GraphTransformer
+    H, L = 128, 2
+    if N == 61:
+        with pytest.raises(ValueError, match="does not fit the LDS"):
+            GraphTransformer(62, H, device="cuda:0", n_layers=L, use_intrinsic_coords=True, use_abs_coords=False,
+                             use_distances=False, conservative=True, state_dict=synth.synth_gnn_params(62, H, L))
+    params = synth.synth_gnn_params(N, H, L, seed=4000 + N)
+    x = synth.normal((3, N, 3), 40, N).astype(np.float32) * 1.5
+    t = np.array([0.01, 0.3, 0.7], np.float32)
+    ref64 = twin.score(twin.to_torch(params, torch.float64), torch.from_numpy(x).double(), torch.from_numpy(t).double(), L).numpy()
+    ref32 = twin.score(twin.to_torch(params), torch.from_numpy(x), torch.from_numpy(t), L).numpy()
+    r32 = rel(ref32, ref64)
+    for split in (True, False):
+        monkeypatch.setenv("DFF_SPLIT_BF16", "1" if split else "0")
+        model = GraphTransformer(N, H, device="cuda:0", n_layers=L, use_intrinsic_coords=True, use_abs_coords=False,
+                                 use_distances=False, conservative=True, state_dict=params)
+        try:
+            for pair in (True, False):
+                model.native.pair(pair)
+                f = model.native.score(torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()).cpu().numpy()
+                kname = model.native.last_launch()[0]
+                assert kname.startswith("dff_fused_kernel<128,4,1,true") and ("pair" in kname) == pair, kname
+                assert ("split_bf16" in kname) == (split and N <= 56), (N, kname)      # 57+ rows: the split A operand does not fit
+                r64 = rel(f, ref64)
+                print(f"N={N} {kname}: rel(hip,ref64)={r64:.3e} rel(ref32,ref64)={r32:.3e}")
+                assert r64 <= 1e-5 and r64 <= GUARD * r32, (N, kname, r64, r32)
+                assert model.native.status() == 0
+        finally:
+            model.native.pair(True)
+
+
+@pytest.mark.gpu
 def test_pair_failure_word_is_sticky_reported_once_and_never_syncs_the_launch_path(dff, golden):
     """The two-workgroups-per-protein variants' failure word (round 4): the launch path does not read it (stays
     asynchronous); a launch queued on top of a failure leaves at kernel entry (outputs untouched), the host's next status

@@ -52,7 +52,8 @@ def test_config_limits_are_reported():
     not silently mis-run (the reference itself accepts any hidden_nf)."""
     from dff_amd import binding
     lib = binding.load_library()
-    for n_beads, hidden, ok in ((10, 256, True), (32, 256, True), (33, 256, False), (10, 192, False), (56, 128, True)):
+    for n_beads, hidden, ok in ((10, 256, True), (32, 256, True), (33, 256, False), (10, 192, False), (56, 128, True), (61, 128, True),
+                                (62, 128, False)):
         cfg = binding.DffConfig(n_beads, hidden, 2, 1000, 1, 0, 0, 1)
         n = lib.dff_weight_count(cfg)
         w = np.zeros(n, np.float32)

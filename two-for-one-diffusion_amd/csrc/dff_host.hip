@@ -272,6 +272,9 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
     if (!(H == 64 || H == 96 || H == 128 || H == 256)) return fail(DFF_EINVAL, "hidden must be 64, 96, 128 or 256 (got %d)", H);
     if (N < 2 || N > DFF_MAX_BEADS) return fail(DFF_EINVAL, "n_beads must be in [2,%d] (got %d)", DFF_MAX_BEADS, N);
     if (H != 128 && N > 32) return fail(DFF_EINVAL, "n_beads > 32 needs hidden = 128 in this build");
+    // (four row tiles: 520 floats of LDS per bead row + 36 KB of tile arrays and bookkeeping -- 61 rows are what 160 KB hold;
+    // the largest shipped model, protein G, has 56)
+    if (N > DFF_MAX_BEADS_LDS) return fail(DFF_EINVAL, "n_beads > %d does not fit the LDS of this build's kernels (got %d)", DFF_MAX_BEADS_LDS, N);
     if (L < 1 || L > DFF_MAX_LAYERS) return fail(DFF_EINVAL, "n_layers must be in [1,%d]", DFF_MAX_LAYERS);
     if (cfg->timesteps < 1) return fail(DFF_EINVAL, "timesteps must be >= 1");
     if (n_weights != dff_weight_count(cfg))

@@ -1329,6 +1329,7 @@ DEVI f32x4 co_mm(const lfloat* T, int mo, const lfloat* B, int ldb, int RN, int 
             const int k = 16 * kt + 4 * s + kk;
             an[s] = TRANS ? *(vlp)(T + (TIGHT ? min(k, RN - 1) : k) * PL + 16 * mo + mm)
                           : *(vlp)(T + (TIGHT ? min(16 * mo + mm, RN - 1) : 16 * mo + mm) * PL + k);
+            if (TIGHT && TRANS && k >= RN) an[s] = 0.f;   // a row the tight array does not have: zero, as the wide array's pad rows
             bn[s] = *(vlp)(B + min(k, RN - 1) * ldb + mm);
         }
     };
@@ -1368,8 +1369,11 @@ DEVI void co_mm5(f32x4 (&c)[5], const lfloat* T, int mo, const lfloat* B, int ld
     typedef const volatile lfloat* vlp;
     auto a_of = [&](int st) {
         const int k = 4 * st + kk;
-        return TRANS ? *(vlp)(T + (TIGHT ? min(k, RN - 1) : k) * PL + 16 * mo + mm)
-                     : *(vlp)(T + (TIGHT ? min(16 * mo + mm, RN - 1) : 16 * mo + mm) * PL + k);
+        const float v = TRANS ? *(vlp)(T + (TIGHT ? min(k, RN - 1) : k) * PL + 16 * mo + mm)
+                              : *(vlp)(T + (TIGHT ? min(16 * mo + mm, RN - 1) : 16 * mo + mm) * PL + k);
+        // (TRANS: k is a ROW of the tile array; the tight one has no pad rows, and a k-step that straddles the last real row --
+        // row counts that are not a multiple of 4 -- must see zeros there, as it does in the wide array)
+        return (TIGHT && TRANS && k >= RN) ? 0.f : v;
     };
     auto b_of = [&](int st) { return (vlp)(B + min(4 * st + kk, RN - 1) * ldb + mm); };
     float a_n = a_of(0), b_n[5];
