@@ -834,6 +834,48 @@ def test_four_row_tiles_at_odd_bead_counts(dff, N, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("H,N", [(128, 17), (128, 23), (128, 32), (128, 33), (128, 41), (128, 45), (128, 48), (96, 17), (96, 26), (96, 32),
+                                 (64, 17), (64, 31)])
+def test_two_and_three_row_tiles_at_odd_bead_counts(dff, H, N, monkeypatch):
+    """Every shape of the <= 64-row kernel away from the shipped bead counts (row counts that are not multiples of 4 / 16, full
+    tiles): forces against the oracle twin in float64, split and fp32 engines, one and two workgroups per protein.  (Round 4
+    moved the split A operand, dQ and dV into bf16 pieces written by their producers; the edge-size test of the four-row-tile
+    shape found a pad-row bug that the shipped sizes could not show.)"""
+    from dff_amd.score import GraphTransformer
+    L = 2
+    params = synth.synth_gnn_params(N, H, L, seed=5000 + N + H)
+    x = synth.normal((3, N, 3), 41, N).astype(np.float32) * 1.5
+    t = np.array([0.01, 0.3, 0.7], np.float32)
+    ref64 = twin.score(twin.to_torch(params, torch.float64), torch.from_numpy(x).double(), torch.from_numpy(t).double(), L).numpy()
+    r32 = rel(twin.score(twin.to_torch(params), torch.from_numpy(x), torch.from_numpy(t), L).numpy(), ref64)
+    mt = (N + 15) // 16
+    seen = set()
+    for split in (True, False):
+        monkeypatch.setenv("DFF_SPLIT_BF16", "1" if split else "0")
+        model = GraphTransformer(N, H, device="cuda:0", n_layers=L, use_intrinsic_coords=True, use_abs_coords=False,
+                                 use_distances=False, conservative=True, state_dict=params)
+        try:
+            for pair in (True, False):
+                model.native.pair(pair)
+                f = model.native.score(torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()).cpu().numpy()
+                kname = model.native.last_launch()[0]
+                # (hidden 128 at 32 rows does not fit the LDS in two row tiles: the three-row-tile shape takes it)
+                assert kname.startswith(f"dff_fused_kernel<{H},{3 if (H, N) == (128, 32) else mt},"), kname
+                seen.add(kname)
+                r64 = rel(f, ref64)
+                print(f"H={H} N={N} {kname}: rel(hip,ref64)={r64:.3e} rel(ref32,ref64)={r32:.3e}")
+                assert r64 <= 1e-5 and r64 <= GUARD * r32, (N, kname, r64, r32)
+                assert model.native.status() == 0
+        finally:
+            model.native.pair(True)
+    # the split engine wherever its operands fit the LDS next to the head buffers (the smallest size of every shape does);
+    # beyond that the fp32 engine of the same shape takes over by itself
+    assert any("split_bf16" not in k for k in seen), seen
+    if (H, N) in ((128, 17), (128, 33), (96, 17)):
+        assert any("split_bf16" in k for k in seen), seen
+
+
+@pytest.mark.gpu
 def test_pair_failure_word_is_sticky_reported_once_and_never_syncs_the_launch_path(dff, golden):
     """The two-workgroups-per-protein variants' failure word (round 4): the launch path does not read it (stays
     asynchronous); a launch queued on top of a failure leaves at kernel entry (outputs untouched), the host's next status

@@ -59,11 +59,13 @@ struct StashLayout {
 // qkvx: per head an (R x 208) block, row = [q(64) | u(16) | k(64) | v(64)] (the "extended head" of
 // dff_internal.h); P: per head an (R x PS) block of softmax rows over ALL rows of the workgroup
 // (zeros outside the row's own protein).
-__host__ __device__ inline StashLayout dff_stash_layout(int N, int G, int H, int L) {
+// mt = row tiles of the kernel variant that runs (its compile-time MT): a stashed probability row is 16 MT floats, and a
+// shape may be larger than the rows need (hidden 128 at 32 rows runs the three-row-tile shape: two do not fit the LDS).
+__host__ __device__ inline StashLayout dff_stash_layout(int N, int G, int H, int L, int mt) {
     StashLayout s;
     const unsigned R = (unsigned)(G * N), F = 4u * H;
     unsigned o = 0;
-    s.PS = 16u * ((R + 15u) / 16u);
+    s.PS = 16u * (unsigned)mt;
     s.nodes_in = o; o += R * H;
     s.attn_out = o; o += R * H;
     s.ff = o;       o += R * H;

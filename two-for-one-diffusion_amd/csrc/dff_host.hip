@@ -159,6 +159,7 @@ struct dff_model {
     const char* last_kernel = "";
     int last_grid = 0, last_lds = 0, last_G = 0, last_B = 0;
     unsigned long long last_stride = 0;
+    int last_mt = 1;                           // row tiles of the <= 64-row variant that ran last (stash layout of the debug reads)
     // precomputed layer-0 tables (see ensure_l0_table), keyed independently: [0] one entry at tnorm (Langevin),
     // [1] one entry per noise level (DDPM) -- `sample.py --gen_mode langevin` uses both, alternately
     struct L0Table {
@@ -697,7 +698,7 @@ static int launch_generic(dff_model* m, DffRunArgs& a, int G, const Variant* v, 
     const int npairs = v->pair ? 8 * ((a.B + 7) / 8) : 0;
     const int grid_all = v->pair ? 2 * npairs : (a.B + G - 1) / G;
     const int grid_max = v->pair ? grid_all : (grid_all < m->max_wgs ? grid_all : m->max_wgs);
-    const StashLayout sl = dff_stash_layout(N, G, H, L);
+    const StashLayout sl = dff_stash_layout(N, G, H, L, v->MT);
     { int rc = ensure_stash(m, (size_t)grid_max * sl.total); if (rc) return rc; }
     a.xchg = nullptr; a.xflag = nullptr; a.xpairs = npairs;
     if (v->pair) {
@@ -722,6 +723,7 @@ static int launch_generic(dff_model* m, DffRunArgs& a, int G, const Variant* v, 
     }
     m->last_small = false;
     m->last_pair = v->pair;
+    m->last_mt = v->MT;
     a.G = G;
     a.prof = m->prof_on ? m->prof : nullptr;
     a.stash = m->stash;
@@ -756,7 +758,7 @@ static int ensure_l0_table(dff_model* m, int kind, float t_norm, int G, const Va
         return DFF_OK;
     const int nent = kind == 2 ? T : 1;
     size_t layer_stride, total;
-    if (v) { const StashLayout sl = dff_stash_layout(N, G, H, L); layer_stride = sl.layer_stride; total = sl.total; }
+    if (v) { const StashLayout sl = dff_stash_layout(N, G, H, L, v->MT); layer_stride = sl.layer_stride; total = sl.total; }
     else   { const SmallStash sl = dff_small_stash(N, G, H, L); layer_stride = sl.layer_stride; total = sl.total; }
     const size_t need = (size_t)nent * layer_stride;
     tb.valid = false;   // invalid until filled
@@ -843,10 +845,11 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
         const Variant* vs = dff_fused_variants(&nv);
         for (int q = 0; q < nv; ++q) {
             const Variant& c = vs[q];
-            // (a split-engine variant must also fit the 160 KB of LDS at this row count: the four-row-tile one does up to
-            // 56 rows -- protein G --, beyond that the fp32 engine of the same shape runs)
+            // (a variant must also fit the 160 KB of LDS at this row count: e.g. the four-row-tile split variant does up to
+            // 56 rows -- protein G --, beyond that the fp32 engine of the same shape runs; a shape that does not fit at all
+            // -- hidden 128 at 32 rows in two row tiles -- hands over to the next larger one below)
             if (c.H == H && c.MT == mt_ && c.gen == gen && !c.pair && (!c.spw || m->split) && (!r || c.spw) &&
-                (!c.spw || c.lds_floats(N, G) * sizeof(float) <= 160u * 1024u)) r = &c;
+                c.lds_floats(N, G) * sizeof(float) <= 160u * 1024u) r = &c;
         }
         return r;
     };
@@ -857,10 +860,15 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
             if (vs[q].pair && vs[q].H == H && vs[q].MT == mt_ && vs[q].spw == spw_) return &vs[q];
         return nullptr;
     };
-    v = pick(mt);
+    auto pick_up = [&](int mt0) -> const Variant* {   // the smallest shape from mt0 row tiles up that exists and fits
+        for (int mt_ = mt0; mt_ <= 4; ++mt_)
+            if (const Variant* r = pick(mt_)) { mt = mt_; return r; }
+        return nullptr;
+    };
+    v = pick_up(mt);
     if (!v) {  // fall back to one protein per workgroup
-        G = 1; mt = mt_min;
-        v = pick(mt);
+        G = 1;
+        v = pick_up(mt_min);
     }
     if (!v) return fail(DFF_EINVAL, "no kernel variant for hidden=%d rows=%d", H, G * N);
     if (want_tab) {
@@ -985,7 +993,7 @@ extern "C" int dff_debug_stash(dff_model* m, int b, int layer, int what, float* 
         R = G * N + 1;   // arrays carry one dummy row
         PS = 16;
     } else {
-        const StashLayout sl = dff_stash_layout(N, G, H, L);
+        const StashLayout sl = dff_stash_layout(N, G, H, L, m->last_mt);
         o_nodes = sl.nodes_in; o_attn = sl.attn_out; o_ff = sl.ff; o_hpre = sl.h_pre; o_qkv = sl.qkvx; o_P = sl.P;
         lstride = sl.layer_stride; total = sl.total;
         R = G * N;

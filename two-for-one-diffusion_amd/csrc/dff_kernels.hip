@@ -2021,7 +2021,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
     c.abuf = smem + ll.abuf;
     c.asp = asplit; c.RNa = c.G * c.N;
     c.Pbuf = smem + ll.Pbuf; c.dSbuf = smem + ll.dSbuf; c.Rg = smem + ll.Rg;
-    c.sl = dff_stash_layout(c.N, c.G, H, m.L);
+    c.sl = dff_stash_layout(c.N, c.G, H, m.L, MT);
     c.stash = a.stash + (size_t)blockIdx.x * a.stash_stride;
     c.resbuf = SPILL ? (c.stash + c.sl.dn_spill) : (smem + ll.resbuf);
     float* tbuf = c.Rg;  // GEMM outputs of width H alias the start of the head-group region
