@@ -876,6 +876,34 @@ def test_two_and_three_row_tiles_at_odd_bead_counts(dff, H, N, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("H,N,G", [(64, 2, 1), (64, 3, 5), (64, 7, 2), (64, 11, 1), (64, 13, 1), (64, 16, 1), (96, 2, 8), (96, 9, 1), (96, 16, 1),
+                                   (128, 4, 4), (128, 10, 1), (128, 15, 1), (256, 2, 1), (256, 16, 1), (256, 17, 1), (256, 32, 1)])
+def test_small_models_at_odd_sizes(dff, H, N, G, monkeypatch):
+    """Bead counts and hidden sizes between the shipped ones on the <= 16-row kernel (all its wave / engine variants: 8 waves up to
+    10 rows, 4 above; split and fp32; G proteins per workgroup, ragged batch) and at hidden 256's limits (<= 64-row kernel only:
+    16 | 17 rows = one | two row tiles, 32 = the largest it takes): forces against the oracle twin in float64."""
+    from dff_amd.score import GraphTransformer
+    L = 2
+    params = synth.synth_gnn_params(N, H, L, seed=6000 + N + H)
+    B = 7
+    x = synth.normal((B, N, 3), 42, N).astype(np.float32) * 1.5
+    t = np.linspace(0.001, 0.9, B).astype(np.float32)
+    ref64 = twin.score(twin.to_torch(params, torch.float64), torch.from_numpy(x).double(), torch.from_numpy(t).double(), L).numpy()
+    r32 = rel(twin.score(twin.to_torch(params), torch.from_numpy(x), torch.from_numpy(t), L).numpy(), ref64)
+    for split in (True, False):
+        monkeypatch.setenv("DFF_SPLIT_BF16", "1" if split else "0")
+        model = GraphTransformer(N, H, device="cuda:0", n_layers=L, use_intrinsic_coords=True, use_abs_coords=False,
+                                 use_distances=False, conservative=True, state_dict=params)
+        model.native.set_group(G)
+        f = model.native.score(torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()).cpu().numpy()
+        kname = model.native.last_launch()[0]
+        assert ("small" in kname) == (H != 256 and G * N <= 16), kname
+        r64 = rel(f, ref64)
+        print(f"H={H} N={N} G={G} {kname}: rel(hip,ref64)={r64:.3e} rel(ref32,ref64)={r32:.3e}")
+        assert r64 <= 1e-5 and r64 <= GUARD * max(r32, 4e-7), (H, N, G, kname, r64, r32)
+
+
+@pytest.mark.gpu
 def test_pair_failure_word_is_sticky_reported_once_and_never_syncs_the_launch_path(dff, golden):
     """The two-workgroups-per-protein variants' failure word (round 4): the launch path does not read it (stays
     asynchronous); a launch queued on top of a failure leaves at kernel entry (outputs untouched), the host's next status
