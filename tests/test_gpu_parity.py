@@ -689,6 +689,38 @@ def test_full_size_langevin_subset_vs_oracle(dff, cfg, P, wgs):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("H,N", [(128, 32), (128, 45), (128, 49), (96, 26), (256, 20)])
+def test_fused_langevin_at_odd_bead_counts(dff, H, N):
+    """The fused Langevin loop (layer-0 table, stash reloads, integrator) away from the shipped sizes: a hidden-128 model at 32
+    rows on the three-row-tile shape (stash rows sized by the shape, not the rows), 45 rows (fp32 engine: the split operands do
+    not fit), 49 rows on the tight four-row-tile split variant with two workgroups per protein, BBA's shape at 26, hidden 256:
+    6 steps on supplied noise against the oracle twin, all trajectories."""
+    from dff_amd.score import GraphTransformer
+    from dff_amd.ddpm import GaussianDiffusion
+    from dff_amd.langevin import LangevinDiffusion
+    L, K, P, norm, tlev, temp = 2, 6, 5, 3.0, 20, 340
+    params = synth.synth_gnn_params(N, H, L, seed=7000 + N + H, decoder_scale=1e-2)
+    model = GraphTransformer(N, H, device="cuda:0", n_layers=L, use_intrinsic_coords=True, use_abs_coords=False,
+                             use_distances=False, conservative=True, state_dict=params)
+    diff = GaussianDiffusion(model, num_atoms=N, timesteps=1000, norm_factor=norm)
+    x0 = synth.normal((P, N, 3), 43, N).astype(np.float32)
+    x0 = (x0 - x0.mean(1, keepdims=True)) * norm
+    noises = synth.normal((K, P, N, 3), 44, N).astype(np.float32)
+    masses = [12.0] * N
+    ld = LangevinDiffusion(diff, torch.from_numpy(x0), K, save_interval=2, t=tlev, diffusion_steps=1000, temp_data=temp,
+                           temp_sim=temp, dt=None, masses=masses, friction=1.0, kb="consistent", verbose=False)
+    traj = ld.sample(noises=torch.from_numpy(noises)).numpy().reshape(P, K // 2, N, 3)
+    kname = model.native.last_launch()[0]
+    c = twin.langevin_constants(norm, tlev, twin.make_schedule(), temp, temp, masses, 1.0, None)
+    fr, ke, xl, vl = twin.simulate(twin.to_torch(params), torch.from_numpy(x0) / norm, torch.from_numpy(noises), masses, c, L, 2)
+    ref = (fr * norm).numpy()
+    err = np.abs(traj - ref).max() / np.abs(ref).max()
+    print(f"H={H} N={N} {kname}: {K}-step Langevin rel err {err:.3e}")
+    assert err <= STEP_TOL * K, (H, N, kname, err)
+    assert model.native.status() == 0
+
+
+@pytest.mark.gpu
 def test_full_size_ddpm_subset_vs_oracle(dff):
     """BASELINE config 3's batch (4096 chignolin samples per launch call = two launches of 2048 workgroups) with the
     network live: 8 fused reverse steps t = 7 .. 0 on supplied noise vs the oracle's p_sample_loop on six samples."""
