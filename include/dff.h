@@ -158,7 +158,9 @@ int dff_debug_max_workgroups(dff_model* m, int n);
 /* Debugging: on == 0 makes the sampling loops recompute layer 0 every step instead of reading the
  * precomputed per-noise-level table of layer-0 inputs (results are bit-identical either way). */
 int dff_debug_l0_table(dff_model* m, int on);
-/* Debugging: on == 0 never splits a protein over two workgroups (the PAIR variants of the <= 64-row kernel, chosen
+/* Debugging: on == 2 = on, and the exchanges always run the agent-scope protocol of a pair whose blocks sit on different XCDs
+ * (never observed: blocks b and b + 8 share one; the kernel checks at run time and takes an L2-local path when they do).
+ * on == 0 never splits a protein over two workgroups (the PAIR variants of the <= 64-row kernel, chosen
  * automatically when one workgroup per protein would leave at least half the CUs idle, e.g. protein G at 128 per GPU). */
 int dff_debug_pair(dff_model* m, int on);
 /* dff_model_status for tests: *status = the sticky word, which is then CLEARED.  Synchronises the device. */

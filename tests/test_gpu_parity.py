@@ -1046,16 +1046,17 @@ def test_pair_variant_equals_one_workgroup_variant(dff, cfg, golden):
     x, t = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["t"]).cuda()
     out = {}
     try:
-        for on in (True, False):
+        for on in (True, 2, False):     # 2: the exchange protocol of a pair whose blocks sit on different XCDs
             model.native.pair(on)
             f = model.native.score(x, t).cpu().numpy()
-            assert ("pair" in model.native.last_launch()[0]) == on
+            assert ("pair" in model.native.last_launch()[0]) == bool(on)
             assert model.native.pair_status() == 0
             r64, r32 = rel(f, g["forces64"]), rel(g["forces32"], g["forces64"])
             print(f"{cfg}: pair={on} rel(hip,ref64)={r64:.3e} rel(ref32,ref64)={r32:.3e}")
             assert r64 <= 1e-5 and r64 <= GUARD * r32
             out[on] = f
         assert rel(out[True], out[False]) <= 5e-6
+        assert np.array_equal(out[True], out[2])     # same sums in the same order, whichever way the tiles travel
         model.native.pair(True)
         xb = torch.from_numpy(synth.normal((13, N, 3), 6, 6).astype(np.float32)).cuda()      # 13 proteins: 2 block groups
         tb = torch.full((13,), 0.02).cuda()

@@ -178,7 +178,8 @@ class Model:
     def max_workgroups(self, n: int = 2048):
         _check(self.lib, self.lib.dff_debug_max_workgroups(self.handle, int(n)), "dff_debug_max_workgroups")
 
-    def pair(self, on: bool = True):
+    def pair(self, on=True):
+        """True / False: allow / never use the two-workgroups-per-protein variants; 2: allow, and force their cross-XCD exchange protocol."""
         _check(self.lib, self.lib.dff_debug_pair(self.handle, int(on)), "dff_debug_pair")
 
     def pair_status(self) -> int:

@@ -183,6 +183,7 @@ struct dff_model {
     unsigned* xflag = nullptr;
     size_t xflag_n = 0;
     bool pair_off = false;                     // debugging: never use a PAIR variant
+    bool pair_slow = false;                    // tests: PAIR variants always run the cross-XCD (agent-scope) exchange protocol
     bool last_pair = false;
     unsigned sticky = 0;                       // the sticky error word as the host last read it (read_status): a non-zero one
                                                // refuses further PAIR launches WITHOUT touching the device
@@ -562,6 +563,7 @@ static int clear_status(dff_model* m);
 extern "C" int dff_debug_pair(dff_model* m, int on) {
     if (!m) return fail(DFF_EINVAL, "null model");
     m->pair_off = on == 0;
+    m->pair_slow = on == 2;
     // turning the PAIR variants off is how a caller recovers from a partner timeout: the one-workgroup kernels do not look
     // at the word, so it is cleared here (it would otherwise fail every later status check of a model that works again)
     if (m->pair_off && m->sticky) return clear_status(m);
@@ -700,9 +702,9 @@ static int launch_generic(dff_model* m, DffRunArgs& a, int G, const Variant* v, 
     const int grid_max = v->pair ? grid_all : (grid_all < m->max_wgs ? grid_all : m->max_wgs);
     const StashLayout sl = dff_stash_layout(N, G, H, L, v->MT);
     { int rc = ensure_stash(m, (size_t)grid_max * sl.total); if (rc) return rc; }
-    a.xchg = nullptr; a.xflag = nullptr; a.xpairs = npairs;
+    a.xchg = nullptr; a.xflag = nullptr; a.xpairs = npairs; a.xslow = m->pair_slow ? 1 : 0;
     if (v->pair) {
-        const size_t need = (size_t)npairs * 4 * (size_t)(G * N) * (H + 4), nflag = (size_t)2 * npairs + 1;
+        const size_t need = (size_t)npairs * 4 * (size_t)(G * N) * (H + 4), nflag = (size_t)4 * npairs + 1;   // error word, [pair][half] sequence flags, [pair][half] XCD ids
         if (need > m->xchg_floats) {
             if (m->xchg) HIPCHK(hipFree(m->xchg));
             m->xchg = nullptr; m->xchg_floats = 0;
@@ -711,7 +713,7 @@ static int launch_generic(dff_model* m, DffRunArgs& a, int G, const Variant* v, 
         }
         if (!m->xflag) {   // once per model, sized for the largest grid a PAIR launch can have (one block per CU): no
                            // re-allocation -- and so no synchronisation -- on the launch path afterwards
-            const size_t cap = (size_t)(m->n_cus > 512 ? m->n_cus : 512) + 1;
+            const size_t cap = 2 * (size_t)(m->n_cus > 256 ? m->n_cus : 256) + 1;   // 4 words per pair, at most n_cus / 2 pairs
             HIPCHK(hipMalloc((void**)&m->xflag, cap * sizeof(unsigned)));
             HIPCHK(hipMemsetAsync(m->xflag, 0, sizeof(unsigned), stream));
             m->xflag_n = cap;

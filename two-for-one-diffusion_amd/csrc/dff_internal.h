@@ -105,4 +105,5 @@ struct DffRunArgs {
     float* xchg;
     unsigned* xflag;
     int xpairs;
+    int xslow;       // tests: never take the same-XCD fast path of the exchanges (the agent-scope protocol a cross-XCD pair runs)
 };

@@ -615,6 +615,9 @@ DEVI void gemm_tall_split_st(f32x4 (&acc)[NTW][MT], int LS2, const lu32* as, int
 #ifndef DFF_L2W
 #define DFF_L2W 1
 #endif
+#ifndef DFF_XFAST
+#define DFF_XFAST 1   // PAIR: plain stores / L2-served loads when both blocks of a pair report the same XCD (0: always sc1)
+#endif
 #ifndef DFF_GXT
 #define DFF_GXT 1
 #endif
@@ -2032,6 +2035,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
     (void)HG0;
     // ---- PAIR: partial-tile exchange (see the comment above the kernel) ----
     unsigned xseq = 0;   // exchanges done so far in this launch (both blocks of a pair count alike)
+    bool xfast = false;   // both blocks of the pair run on one XCD (decided once per launch, below): the exchange stays in its L2
     auto pair_exchange = [&](float* tile /* LDS, rows x ncols floats, leading dimension ld */, int ncols, int ld) {
         if constexpr (PAIR) {
             const int tid_ = tid_now();
@@ -2050,12 +2054,14 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             for (int it = tid_; it < c.rows * n4; it += DFF_NTHREADS) {
                 const int row = it / n4, c4 = it - row * n4;
                 const f32x4 v = *(const f32x4*)(tile + row * ld + 4 * c4);
-                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(mine + (size_t)row * ncols + 4 * c4), "v"(v) : "memory");
+                if (xfast) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(mine + (size_t)row * ncols + 4 * c4), "v"(v) : "memory");
+                else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(mine + (size_t)row * ncols + 4 * c4), "v"(v) : "memory");
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid_ == 0) {
-                __hip_atomic_store(flags + hf, xseq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (xfast) asm volatile("global_store_dword %0, %1, off" ::"v"(flags + hf), "v"(xseq + 1) : "memory");   // (stays in the shared L2)
+                else __hip_atomic_store(flags + hf, xseq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // never hang the GPU: the spin is bounded (~1 s), and once any pair has given up (error word set) nobody spins
                 unsigned* const err = a.xflag;
                 unsigned spins = 0;
@@ -2121,6 +2127,33 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
         const unsigned failed = ((const unsigned*)smem)[ll.junk];
         __syncthreads();
         if (failed) return;
+    }
+    // PAIR, same-XCD fast path (round 4).  The two blocks of a pair exchange 13 partial tiles per step through agent-scope
+    // (sc1) stores and loads, which are written through to / served from memory because the XCDs' L2s are not coherent with
+    // each other.  Blocks b and b + 8 are observed to share an XCD -- NOT a guarantee -- so each block publishes the XCD it
+    // actually runs on (s_getreg_b32 HW_REG_XCC_ID) and reads its partner's, once per launch: when they agree, the one L2
+    // they share IS their coherence point, and the tiles and flags travel as plain stores (acknowledged by that L2:
+    // s_waitcnt vmcnt(0)) and L1-bypassing loads that hit it; otherwise the sc1 protocol runs as before.
+    if constexpr (PAIR && DFF_XFAST) {
+        unsigned* const xw = a.xflag + 1 + 2 * a.xpairs + 2 * unit;
+        if (tid == 0) {
+            const unsigned my_xcc = (__builtin_amdgcn_s_getreg(20 | ((4 - 1) << 11)) & 15u) + 1u;
+            __hip_atomic_store(xw + hf, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned* const err = a.xflag;
+            unsigned theirs = 0, spins = 0;
+            while ((theirs = __hip_atomic_load(xw + (1 - hf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+                __builtin_amdgcn_s_sleep(2);
+                if ((++spins & 1023u) == 0 &&
+                    (spins > (1u << 21) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                    atomicOr(err, 1u);
+                    break;
+                }
+            }
+            ((unsigned*)smem)[ll.junk] = (theirs == my_xcc && !a.xslow) ? 1u : 0u;
+        }
+        __syncthreads();
+        xfast = ((const unsigned*)smem)[ll.junk] != 0u;
+        __syncthreads();
     }
     if (tid < 64) ((int*)smem)[ll.prow + tid] = tid < rows ? tid / N : -1;
 
