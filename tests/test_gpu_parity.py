@@ -721,6 +721,31 @@ def test_fused_langevin_at_odd_bead_counts(dff, H, N):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("H,N", [(128, 32), (128, 49), (96, 26), (256, 20), (64, 13)])
+def test_fused_reverse_loop_at_odd_bead_counts(dff, H, N):
+    """The fused reverse-DDPM loop (one table entry per noise level, posterior update, clamp / centre flag) away from the shipped
+    sizes -- see test_fused_langevin_at_odd_bead_counts for the shapes: 6 reverse steps t = 5 .. 0 on supplied noise against the
+    oracle's p_sample_loop, all samples."""
+    from dff_amd.score import GraphTransformer
+    from dff_amd.ddpm import GaussianDiffusion
+    L, K, B = 2, 6, 5
+    params = synth.synth_gnn_params(N, H, L, seed=8000 + N + H)
+    model = GraphTransformer(N, H, device="cuda:0", n_layers=L, use_intrinsic_coords=True, use_abs_coords=False,
+                             use_distances=False, conservative=True, state_dict=params)
+    diff = GaussianDiffusion(model, num_atoms=N, timesteps=1000, norm_factor=3.0)
+    x = synth.normal((B, N, 3), 45, N).astype(np.float32)
+    x = (x - x.mean(1, keepdims=True)) * 0.6
+    noises = synth.normal((K, B, N, 3), 46, N).astype(np.float32)
+    y = diff.p_sample_loop_from(torch.from_numpy(x), K - 1, 0, noises=torch.from_numpy(noises)).cpu().numpy()
+    kname = model.native.last_launch()[0]
+    ref = twin.p_sample_loop(twin.to_torch(params), twin.make_schedule(), torch.from_numpy(x), torch.from_numpy(noises), K - 1, L).numpy()
+    err = np.abs(y - ref).max() / np.abs(ref).max()
+    print(f"H={H} N={N} {kname}: {K} reverse steps rel err {err:.3e}")
+    assert err <= STEP_TOL * K, (H, N, kname, err)
+    assert np.abs(y.mean(1)).max() < 1e-4 and model.native.status() == 0
+
+
+@pytest.mark.gpu
 def test_full_size_ddpm_subset_vs_oracle(dff):
     """BASELINE config 3's batch (4096 chignolin samples per launch call = two launches of 2048 workgroups) with the
     network live: 8 fused reverse steps t = 7 .. 0 on supplied noise vs the oracle's p_sample_loop on six samples."""
