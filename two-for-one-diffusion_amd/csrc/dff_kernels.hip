@@ -615,6 +615,9 @@ DEVI void gemm_tall_split_st(f32x4 (&acc)[NTW][MT], int LS2, const lu32* as, int
 #ifndef DFF_L2W
 #define DFF_L2W 1
 #endif
+#ifndef DFF_DQKV_ROWS
+#define DFF_DQKV_ROWS 1   // four row tiles: a wave owns a row tile's column tiles in the three-phase dV / dQ / dK products
+#endif
 #ifndef DFF_XFAST
 #define DFF_XFAST 1   // PAIR: plain stores / L2-served loads when both blocks of a pair report the same XCD (0: always sc1)
 #endif
@@ -1357,13 +1360,13 @@ DEVI f32x4 co_mm(const lfloat* T, int mo, const lfloat* B, int ldb, int RN, int 
 // hook(step), step = 0 .. 4 MT - 1, runs once per k-step: a place to spread another phase's weight requests over this one's
 // MFMAs (a burst of them stalls the wave at issue while the CU's one texture-address unit takes 16 cycles per KiB).
 struct NoStepHook { DEVI void operator()(int) const {} };
-template <int MT, bool TRANS, int PL_ = 16 * MT + 4, class SH = NoStepHook>
-DEVI void co_mm5(f32x4 (&c)[5], const lfloat* T, int mo, const lfloat* B, int ldb, int RN, int rows, int lane, SH hook = SH()) {
+template <int MT, bool TRANS, int NT, int PL_ = 16 * MT + 4, class SH = NoStepHook>
+DEVI void co_mmN(f32x4 (&c)[NT], const lfloat* T, int mo, const lfloat* B, int ldb, int RN, int rows, int lane, SH hook = SH()) {
     constexpr int PL = PL_, NS = 4 * MT;
     constexpr bool TIGHT = PL_ < 16 * MT;   // (see co_mm)
     const int kk = lane >> 4, mm = lane & 15;
 #pragma unroll
-    for (int nt = 0; nt < 5; ++nt) c[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NT; ++nt) c[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // k-step st contracts k = 4 st + kk.  The steps beyond the workgroup's rows are skipped by a (uniform) branch, and the
     // compiler will not lift an LDS read over a branch: the operands of step st + 1 are therefore requested BEFORE the
     // products of step st -- otherwise every product waits out the LDS latency of its own operands (3 of 5 did: the
@@ -1379,30 +1382,34 @@ DEVI void co_mm5(f32x4 (&c)[5], const lfloat* T, int mo, const lfloat* B, int ld
         return (TIGHT && TRANS && k >= RN) ? 0.f : v;
     };
     auto b_of = [&](int st) { return (vlp)(B + min(4 * st + kk, RN - 1) * ldb + mm); };
-    float a_n = a_of(0), b_n[5];
+    float a_n = a_of(0), b_n[NT];
     {
         vlp bp = b_of(0);
 #pragma unroll
-        for (int nt = 0; nt < 5; ++nt) b_n[nt] = bp[16 * nt];
+        for (int nt = 0; nt < NT; ++nt) b_n[nt] = bp[16 * nt];
     }
 #pragma unroll
     for (int st = 0; st < NS; ++st) {
         const float a_c = a_n;
-        float b_c[5];
+        float b_c[NT];
 #pragma unroll
-        for (int nt = 0; nt < 5; ++nt) b_c[nt] = b_n[nt];
+        for (int nt = 0; nt < NT; ++nt) b_c[nt] = b_n[nt];
         if (st + 1 < NS) {
             a_n = a_of(st + 1);
             vlp bp = b_of(st + 1);
 #pragma unroll
-            for (int nt = 0; nt < 5; ++nt) b_n[nt] = bp[16 * nt];
+            for (int nt = 0; nt < NT; ++nt) b_n[nt] = bp[16 * nt];
         }
         if (st % 4 == 0 || 4 * st < rows) {
 #pragma unroll
-            for (int nt = 0; nt < 5; ++nt) c[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_c, b_c[nt], c[nt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) c[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_c, b_c[nt], c[nt], 0, 0, 0);
         }
         hook(st);
     }
+}
+template <int MT, bool TRANS, int PL_ = 16 * MT + 4, class SH = NoStepHook>
+DEVI void co_mm5(f32x4 (&c)[5], const lfloat* T, int mo, const lfloat* B, int ldb, int RN, int rows, int lane, SH hook = SH()) {
+    co_mmN<MT, TRANS, 5, PL_, SH>(c, T, mo, B, ldb, RN, rows, lane, hook);
 }
 
 
@@ -1868,6 +1875,40 @@ DEVI void co_dqkv(const CoGeo& g) {
                 }
             }
         }
+    }
+}
+
+// The same three phases for exactly four row tiles on eight waves, shipped input branch (protein G, round 4): instead of 20
+// single-tile items over 8 waves (three rounds of LDS-latency-bound 16 x 16 products: 24 scalar reads for 14 k-steps), wave w
+// takes row tile w & 3 and runs its column tiles {0, 1, 2} (w < 4) or {3, 4} (w >= 4) side by side off ONE read of the
+// tile-array operand: the two waves of a SIMD share a row tile's five products.
+template <int MT, int WHICH, int PL_>
+DEVI void co_dqkv_rows(const CoGeo& g) {
+    static_assert(MT == 4 && DFF_NWAVES == 8, "two waves per row tile");
+    constexpr int LQ = 84;
+    constexpr int SRC = WHICH == 0 ? 3 : WHICH == 1 ? 1 : 0;
+    constexpr int DST = WHICH == 0 ? 2 : WHICH == 1 ? 3 : 1;
+    const int tid_ = tid_now(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+    const int quad = lane >> 4, col = lane & 15, mo = wave & (MT - 1);
+    const lfloat* const T = WHICH == 0 ? g.Pbuf : g.dSbuf;
+    auto put = [&](int nt, const f32x4& acc) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * mo + 4 * quad + r;
+            if (row < g.rows) {
+                if (WHICH != 1 && nt == 4) { if (col < 3) g.dxw[row * 4 + col] += acc[r]; }
+                else g.Rg[DST * g.RN * LQ + row * LQ + 16 * nt + col] = acc[r];
+            }
+        }
+    };
+    if (wave < MT) {
+        f32x4 c[3];
+        co_mmN<MT, WHICH != 1, 3, PL_>(c, T, mo, g.Rg + SRC * g.RN * LQ, LQ, g.RN, g.rows, lane);
+        put(0, c[0]); put(1, c[1]); put(2, c[2]);
+    } else {
+        f32x4 c[2];
+        co_mmN<MT, WHICH != 1, 2, PL_>(c, T, mo, g.Rg + SRC * g.RN * LQ + 48, LQ, g.RN, g.rows, lane);
+        put(3, c[0]); put(4, c[1]);
     }
 }
 
@@ -2645,11 +2686,19 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     if (FIVE) {
                         co_dv_dk<MT, HGS, false, GEN, SPW && LL::KVS, SPW && LL::VSP>(geo);
                     } else {
+                        if constexpr (MT == 4 && HGS == 1 && !GEN && DFF_DQKV_ROWS) {
+                            co_dqkv_rows<MT, 0, PLT>(geo);
+                            wg_sync<SPILL>();
+                            co_dqkv_rows<MT, 1, PLT>(geo);
+                            wg_sync<SPILL>();
+                            co_dqkv_rows<MT, 2, PLT>(geo);
+                        } else {
                         co_dqkv<MT, HGS, 0, GEN, PLT>(geo);
                         wg_sync<SPILL>();
                         co_dqkv<MT, HGS, 1, GEN, PLT>(geo);
                         wg_sync<SPILL>();
                         co_dqkv<MT, HGS, 2, GEN, PLT>(geo);
+                        }
                     }
                     wg_sync<SPILL>();
                     pf.tick(18);
