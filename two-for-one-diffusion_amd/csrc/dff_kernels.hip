@@ -615,6 +615,9 @@ DEVI void gemm_tall_split_st(f32x4 (&acc)[NTW][MT], int LS2, const lu32* as, int
 #ifndef DFF_L2W
 #define DFF_L2W 1
 #endif
+#ifndef DFF_PSPLIT
+#define DFF_PSPLIT 1   // co_dqkv_rows: dQ / dK as bf16 pieces
+#endif
 #ifndef DFF_DQKV_ROWS
 #define DFF_DQKV_ROWS 1   // four row tiles: a wave owns a row tile's column tiles in the three-phase dV / dQ / dK products
 #endif
@@ -1882,7 +1885,10 @@ DEVI void co_dqkv(const CoGeo& g) {
 // single-tile items over 8 waves (three rounds of LDS-latency-bound 16 x 16 products: 24 scalar reads for 14 k-steps), wave w
 // takes row tile w & 3 and runs its column tiles {0, 1, 2} (w < 4) or {3, 4} (w >= 4) side by side off ONE read of the
 // tile-array operand: the two waves of a SIMD share a row tile's five products.
-template <int MT, int WHICH, int PL_>
+// PSPLIT (split engine): dQ and dK leave as the bf16 pieces the back-projection multiplies ([h | m] in place of the fp32 row; dQ's
+// l pieces in g.lsq = the P tile array, dead after the dV phase; dK's in the extension columns of the R1 / R2 rows, as co_dv_dk
+// does); dV, whose phase has no dead buffer to put l pieces in, stays fp32 and is split by the back-projection's waves.
+template <int MT, int WHICH, int PL_, bool PSPLIT = false>
 DEVI void co_dqkv_rows(const CoGeo& g) {
     static_assert(MT == 4 && DFF_NWAVES == 8, "two waves per row tile");
     constexpr int LQ = 84;
@@ -1891,13 +1897,26 @@ DEVI void co_dqkv_rows(const CoGeo& g) {
     const int tid_ = tid_now(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     const int quad = lane >> 4, col = lane & 15, mo = wave & (MT - 1);
     const lfloat* const T = WHICH == 0 ? g.Pbuf : g.dSbuf;
+    constexpr int LSV = 36;   // dwords per row of dQ's l pieces (LdsLayout::LSV at one head per group)
     auto put = [&](int nt, const f32x4& acc) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * mo + 4 * quad + r;
             if (row < g.rows) {
                 if (WHICH != 1 && nt == 4) { if (col < 3) g.dxw[row * 4 + col] += acc[r]; }
-                else g.Rg[DST * g.RN * LQ + row * LQ + 16 * nt + col] = acc[r];
+                else if (PSPLIT && WHICH != 0 && nt < 4) {
+                    lu16* const hm = (lu16*)(g.Rg + DST * g.RN * LQ) + col;
+                    lu16* const lb = (WHICH == 1 ? (lu16*)(g.lsq + (nt < 2 ? 0 : 16)) : (lu16*)(g.Rg + (nt < 2 ? 1 : 2) * g.RN * LQ + 64)) + col;
+                    const int ls = WHICH == 1 ? 2 * LSV : 2 * LQ;
+                    const float v = acc[r];
+                    const unsigned uh = __float_as_uint(v) & 0xffff0000u;
+                    const float r1 = v - __uint_as_float(uh);
+                    const unsigned um = __float_as_uint(r1) & 0xffff0000u;
+                    const float r2 = r1 - __uint_as_float(um);
+                    hm[row * 2 * LQ + 16 * nt] = (unsigned short)(uh >> 16);
+                    hm[row * 2 * LQ + 64 + 16 * nt] = (unsigned short)(um >> 16);
+                    lb[row * ls + 16 * (nt & 1)] = (unsigned short)(__float_as_uint(r2) >> 16);
+                } else g.Rg[DST * g.RN * LQ + row * LQ + 16 * nt + col] = acc[r];
             }
         }
     };
@@ -2152,6 +2171,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
         geo.m12 = sm + ll.m12;
         geo.lsp = (lu32*)(sm + ll.lsplit);
         geo.lsq = geo.lsp + RN * LL::LSV;
+        if constexpr (LL::TIGHT_OK && SPW) geo.lsq = (lu32*)(sm + ll.Pbuf);   // (tight layout: the P tile array, dead after the dV phase)
         geo.prow = (const int __attribute__((address_space(3)))*)(sm + ll.prow);
         geo.N = N; geo.RN = RN; geo.rows = rows;
     }
@@ -2689,9 +2709,9 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         if constexpr (MT == 4 && HGS == 1 && !GEN && DFF_DQKV_ROWS) {
                             co_dqkv_rows<MT, 0, PLT>(geo);
                             wg_sync<SPILL>();
-                            co_dqkv_rows<MT, 1, PLT>(geo);
+                            co_dqkv_rows<MT, 1, PLT, SPW && DFF_PSPLIT>(geo);
                             wg_sync<SPILL>();
-                            co_dqkv_rows<MT, 2, PLT>(geo);
+                            co_dqkv_rows<MT, 2, PLT, SPW && DFF_PSPLIT>(geo);
                         } else {
                         co_dqkv<MT, HGS, 0, GEN, PLT>(geo);
                         wg_sync<SPILL>();
@@ -2709,7 +2729,10 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         u32x4 bq[4][NTW][3];
                         ExtW<NTW, HGS> ew;
                         if constexpr (DFF_EXTPRE) ext_fetch<NTW, HGS>(ew, [=](int i) { return (hg * HGS + i) * 13 + 4; }, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
-                        gemm_tall_qkvT_split<MT, NTW, HGS, LL::KVS, LL::VSP, 0, LL::KVS && DFF_QSP>(acc_a, geo.Rg, FIVE ? 4 : 3, RN, lw.WqkvxT_s, hg * HGS, NT_H, geo.lsp, bq, geo.lsq);
+                        {
+                            constexpr bool RP = MT == 4 && HGS == 1 && !GEN && DFF_DQKV_ROWS && DFF_PSPLIT;   // co_dqkv_rows<..., PSPLIT>
+                            gemm_tall_qkvT_split<MT, NTW, HGS, LL::KVS || RP, LL::VSP, 0, (LL::KVS && DFF_QSP) || RP>(acc_a, geo.Rg, FIVE ? 4 : 3, RN, lw.WqkvxT_s, hg * HGS, NT_H, geo.lsp, bq, geo.lsq);
+                        }
                         if constexpr (!DFF_EXTPRE) ext_fetch<NTW, HGS>(ew, [=](int i) { return (hg * HGS + i) * 13 + 4; }, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
                         ext_apply<MT, NTW, HGS>(acc_a, ew, [=](int i) { return (FIVE ? 4 : 3) * RN * LQ + i * 80 + 64; }, geo.Rg, LQ, RN, NT_H);
                     } else
