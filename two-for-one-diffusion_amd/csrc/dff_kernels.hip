@@ -621,6 +621,9 @@ DEVI void gemm_tall_split_st(f32x4 (&acc)[NTW][MT], int LS2, const lu32* as, int
 #ifndef DFF_DQKV_ROWS
 #define DFF_DQKV_ROWS 1   // four row tiles: a wave owns a row tile's column tiles in the three-phase dV / dQ / dK products
 #endif
+#ifndef DFF_GXTILE
+#define DFF_GXTILE 1   // backward head pipeline: a spare wave parks a whole G_ext tile (all row tiles) where tiles == spare waves
+#endif
 #ifndef DFF_XFAST
 #define DFF_XFAST 1   // PAIR: plain stores / L2-served loads when both blocks of a pair report the same XCD (0: always sc1)
 #endif
@@ -2615,11 +2618,19 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 const bool deep = l > 0 || full0;
                 for (int hg = hg_lo; hg < hg_hi; ++hg) {
                     const bool more = hg + 1 < hg_hi;
-                    f32x4 gheld[DU];
+                    // (GXTILE: as many spare waves as G_ext has tiles -- villin's shape -- : a wave takes a whole TILE, all row tiles,
+                    // so its 12 KB of weights cross the CU once; as (tile, row-tile) units three waves stream each tile)
+                    constexpr bool GXTILE = (NTG == NWH || DFF_GXTILE > 1) && DFF_GXTILE;
+                    constexpr int CNTG = (NTG + NWH - 1) / NWH;   // tiles per spare wave (GXTILE)
+                    f32x4 gheld[GXTILE ? CNTG * MT : DU];
                     if (wave_ < NI) {
                         if (deep) co_ds<MT, HGS, true, GEN, PLT, LL::KVS && DFF_QSP>(geo);
                         else co_ds<MT, HGS, false, GEN>(geo);
                     } else if (more) {
+                        if constexpr (GXTILE)
+                            gemm_wide_split_st<MT, H / 32, NTG, 1, NI, NWH, 2>(asplit, RN, RN, lw.WoxT_s, (hg + 1) * NTG, [](int, float (&)[1]) {},
+                                [&](int, int mt, const f32x4& acc, const float (&)[1], bool, int i) { gheld[i * MT + mt] = acc; });
+                        else
                         gx_units_hold<MT, H / 32, NTG, NI, NWH>(asplit, RN, RN, lw.WoxT_s, (hg + 1) * NTG, gheld);
                     }
                     if (deep) l2_wqkvT(lw, hg);
@@ -2645,9 +2656,14 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     if (more) {
                         if (wave_ >= NI) {
 #pragma unroll
-                            for (int d = 0; d < DU; ++d) {
-                                const int u = wave_ - NI + NWH * d;
-                                gx_epi(u / MT, u - (u / MT) * MT, gheld[d]);
+                            for (int d = 0; d < (GXTILE ? CNTG * MT : DU); ++d) {
+                                if constexpr (GXTILE) {
+                                    const int nt = wave_ - NI + NWH * (d / MT);
+                                    if (nt < NTG) gx_epi(nt, d % MT, gheld[d]);
+                                } else {
+                                    const int u = wave_ - NI + NWH * d;
+                                    gx_epi(u / MT, u - (u / MT) * MT, gheld[d]);
+                                }
                             }
                         }
                         commit_issue(hg + 1);
