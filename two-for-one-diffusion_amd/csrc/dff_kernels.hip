@@ -621,6 +621,9 @@ DEVI void gemm_tall_split_st(f32x4 (&acc)[NTW][MT], int LS2, const lu32* as, int
 #ifndef DFF_DQKV_ROWS
 #define DFF_DQKV_ROWS 1   // four row tiles: a wave owns a row tile's column tiles in the three-phase dV / dQ / dK products
 #endif
+#ifndef DFF_GXTILE0
+#define DFF_GXTILE0 1
+#endif
 #ifndef DFF_GXTILE
 #define DFF_GXTILE 1   // backward head pipeline: a spare wave parks a whole G_ext tile (all row tiles) where tiles == spare waves
 #endif
@@ -2611,6 +2614,10 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                                                  sPl + (size_t)(hg + 1) * HGS * RN * c.sl.PS);
                     co_fill_x<HGS, GEN>(geo);
                 };
+                if constexpr (NTG == NWH && DFF_GXTILE0)   // (the first head's G_ext, all waves: whole tiles as well)
+                    gemm_wide_split_st<MT, H / 32, NTG, 1>(asplit, RN, RN, lw.WoxT_s, hg_lo * NTG, [](int, float (&)[1]) {},
+                        [&](int nt, int mt, const f32x4& acc, const float (&)[1], bool valid, int) { if (valid) gx_epi(nt, mt, acc); });
+                else
                 gemm_wide_units_split<MT, H / 32, NTG>(asplit, RN, RN, lw.WoxT_s, hg_lo * NTG, gx_epi);
                 commit_issue(hg_lo);
                 wg_sync<SPILL>();
