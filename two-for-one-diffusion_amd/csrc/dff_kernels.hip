@@ -29,6 +29,9 @@
 #ifndef DFF_APRE
 #define DFF_APRE 1
 #endif
+#ifndef DFF_QTPRE
+#define DFF_QTPRE 1
+#endif
 #ifndef DFF_TPRE_MT
 #define DFF_TPRE_MT 3   // tall split GEMMs: A fragments one k-block ahead, up to this many row tiles (four: measured neutral)
 #endif
@@ -717,13 +720,36 @@ DEVI void gemm_tall_qkvT_split(f32x4 (&acc)[NTW][MT], const lfloat* Rg, int regQ
                 for (int p = 0; p < 3; ++p) b[d][i][p] = wp[(tbase[i] + 3 * d + p) * 64];
     }
     __builtin_amdgcn_sched_barrier(0);
+    // QTPRE: every operand arrives as pieces (dQ, dK and dV all split by their producers) and the shape has up to three row
+    // tiles: the fragments of k-block kb + 1 are requested before the products of kb (as in gemm_tall_split_st_b)
+    constexpr bool QTPRE = KVS && VSP && QSP && MT <= DFF_TPRE_MT && DFF_QTPRE;
+    u32x4 nh[QTPRE ? MT : 1], nm[QTPRE ? MT : 1], nl[QTPRE ? MT : 1];
+    auto p_load = [&](u32x4 (&xl)[QTPRE ? MT : 1], u32x4 (&xh)[QTPRE ? MT : 1], u32x4 (&xm)[QTPRE ? MT : 1], int kb) {
+        constexpr int LSV = 32 * HGS + 4;
+        const int hh = kb / 6, part = (kb % 6) / 2, half = kb % 2;
+        const lu32* const hb = (const lu32*)(Rg + (part == 0 ? regQ : part) * RN * LQ + hh * 80) + 16 * half;
+        const lu32* const lb = part == 1 ? (const lu32*)(Rg + (1 + half) * RN * LQ + hh * 80 + 64)
+                                         : (part == 2 ? lsp : lsq) + hh * 32 + 16 * half;
+        const int lmul = part == 1 ? LQ : LSV;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xl[mt] = *(const volatile lu32x4*)(lb + min(mt * 16 + mm, RN - 1) * lmul + 4 * kg);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xh[mt] = *(const volatile lu32x4*)(hb + rowoff[mt] - 4 * kg);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xm[mt] = *(const volatile lu32x4*)(hb + 32 + rowoff[mt] - 4 * kg);
+    };
+    if constexpr (QTPRE) p_load(nl, nh, nm, 0);
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
         const int d = kb % D;
         const int hh = kb / 6, part = (kb % 6) / 2, half = kb % 2;
         const int aoff = (part == 0 ? regQ : part) * RN * LQ + hh * 80 + 32 * half;
         u32x4 ah[MT], am[MT], al[MT];
-        if (KVS && (part == 1 || (VSP && part == 2) || (QSP && part == 0))) {
+        if constexpr (QTPRE) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) { al[mt] = nl[mt]; ah[mt] = nh[mt]; am[mt] = nm[mt]; }
+            if (kb + 1 < NKB) p_load(nl, nh, nm, kb + 1);
+        } else if (KVS && (part == 1 || (VSP && part == 2) || (QSP && part == 0))) {
             constexpr int LSV = 32 * HGS + 4;
             const lu32* const hb = (const lu32*)(Rg + (part == 0 ? regQ : part) * RN * LQ + hh * 80) + 16 * half;
             const lu32* const lb = part == 1 ? (const lu32*)(Rg + (1 + half) * RN * LQ + hh * 80 + 64)
