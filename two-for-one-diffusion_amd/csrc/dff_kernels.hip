@@ -29,6 +29,9 @@
 #ifndef DFF_APRE
 #define DFF_APRE 1
 #endif
+#ifndef DFF_PIPEB_128_2
+#define DFF_PIPEB_128_2 1   // trp-cage's shape in the backward head pipeline (half-unit ring entries)
+#endif
 #ifndef DFF_QTPRE
 #define DFF_QTPRE 1
 #endif
@@ -459,41 +462,47 @@ template <int MT, int KB32, int NT, int W0, int NWV>
 DEVI void gx_units_hold(const lu32* as, int R, int rowsA, const unsigned* __restrict__ Wp, int nt0,
                         f32x4 (&held)[(NT * MT + NWV - 1) / NWV]) {
     constexpr int NU = NT * MT, DU = (NU + NWV - 1) / NWV, LHS2 = (32 * KB32 + DFF_SPAD) / 2;
+    // ring of two entries; at K = 128 an entry is HALF a unit (two k-blocks, 24 registers): whole units -- 96 registers in
+    // flight -- were what made trp-cage's shape spill with this pipeline
+    constexpr int NHALF = (KB32 % 2 == 0 && KB32 >= 4) ? 2 : 1, KH = KB32 / NHALF, NE = DU * NHALF;
     const int tid_ = tid_now();
     const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6) - W0;
     const int kg = lane >> 4, mm = lane & 15;
     const gu32x4* wp = (const gu32x4*)Wp + lane;
-    u32x4 b[2][KB32][3];
-    auto fill = [&](u32x4 (&slot)[KB32][3], int d) {
-        const int nt = min(wave + NWV * d, NU - 1) / MT;
+    u32x4 b[2][KH][3];
+    auto fill = [&](u32x4 (&slot)[KH][3], int e) {
+        const int nt = min(wave + NWV * (e / NHALF), NU - 1) / MT;
 #pragma unroll
-        for (int kb = 0; kb < KB32; ++kb)
+        for (int kb = 0; kb < KH; ++kb)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) slot[kb][p] = wp[(((size_t)(nt0 + nt) * KB32 + kb) * 3 + p) * 64];
+            for (int p = 0; p < 3; ++p) slot[kb][p] = wp[(((size_t)(nt0 + nt) * KB32 + (e % NHALF) * KH + kb) * 3 + p) * 64];
     };
     fill(b[0], 0);
-    if (DU > 1) fill(b[1], 1);
+    if (NE > 1) fill(b[1], 1);
     __builtin_amdgcn_sched_barrier(0);
+    f32x4 cs, cb, cs2, cb2;
 #pragma unroll
-    for (int d = 0; d < DU; ++d) {
+    for (int e = 0; e < NE; ++e) {
+        const int d = e / NHALF, h = e % NHALF;
         const int u = min(wave + NWV * d, NU - 1);
         const int mt = u - (u / MT) * MT;
         const int ro = min(mt * 16 + mm, rowsA - 1) * LHS2 + 4 * kg;
-        f32x4 cs = {0.f, 0.f, 0.f, 0.f}, cb = {0.f, 0.f, 0.f, 0.f}, cs2 = cs, cb2 = cs;
+        if (h == 0) { cs = (f32x4){0.f, 0.f, 0.f, 0.f}; cb = cs; cs2 = cs; cb2 = cs; }
 #pragma unroll
-        for (int kb = 0; kb < KB32; ++kb) {
-            const u32x4 ah = *(const lu32x4*)(as + ro + 16 * kb);
-            const u32x4 am = *(const lu32x4*)(as + R * LHS2 + ro + 16 * kb);
-            const u32x4 al = *(const lu32x4*)(as + 2 * R * LHS2 + ro + 16 * kb);
-            cs = mfma_bf16(b[d % 2][kb][0], al, cs);
-            cb = mfma_bf16(b[d % 2][kb][0], am, cb);
-            cs2 = mfma_bf16(b[d % 2][kb][2], ah, cs2);
-            cb2 = mfma_bf16(b[d % 2][kb][1], ah, cb2);
-            cs = mfma_bf16(b[d % 2][kb][1], am, cs);
-            cb = mfma_bf16(b[d % 2][kb][0], ah, cb);
+        for (int kb = 0; kb < KH; ++kb) {
+            const int ka = h * KH + kb;
+            const u32x4 ah = *(const lu32x4*)(as + ro + 16 * ka);
+            const u32x4 am = *(const lu32x4*)(as + R * LHS2 + ro + 16 * ka);
+            const u32x4 al = *(const lu32x4*)(as + 2 * R * LHS2 + ro + 16 * ka);
+            cs = mfma_bf16(b[e % 2][kb][0], al, cs);
+            cb = mfma_bf16(b[e % 2][kb][0], am, cb);
+            cs2 = mfma_bf16(b[e % 2][kb][2], ah, cs2);
+            cb2 = mfma_bf16(b[e % 2][kb][1], ah, cb2);
+            cs = mfma_bf16(b[e % 2][kb][1], am, cs);
+            cb = mfma_bf16(b[e % 2][kb][0], ah, cb);
         }
-        if (d + 2 < DU) { fill(b[d % 2], d + 2); __builtin_amdgcn_sched_barrier(0); }
-        held[d] = (cb + cb2) + (cs + cs2);
+        if (e + 2 < NE) { fill(b[e % 2], e + 2); __builtin_amdgcn_sched_barrier(0); }
+        if (h == NHALF - 1) held[d] = (cb + cb2) + (cs + cs2);
     }
 }
 
@@ -2637,7 +2646,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             // Measured per shape: (128,3,1) villin 631 -> 586 us, (96,2,2) BBA 338 -> 329; (128,2,2) trp-cage 363 -> 391 (the 20 parked
             // units + two K = 128 weight tiles in flight spill: 248 B of scratch), so that shape keeps the serial loop.
             constexpr bool PIPEB = SPW && !GEN && MT < 4 && HGS * MT < DFF_NWAVES && (5 * HGS * MT) % (DFF_NWAVES - HGS * MT) == 0 &&
-                                   !(H == 128 && HGS == 2);
+                                   (DFF_PIPEB_128_2 || !(H == 128 && HGS == 2));
             if constexpr (PIPEB) {
                 constexpr int NI = HGS * MT, NWH = DFF_NWAVES - NI, NTG = 5 * HGS, DU = NTG * MT / NWH;
                 const int tid = tid_now();
