@@ -26,6 +26,9 @@
 // softmax / LayerNorm / GELU / gates / the N x N contractions run on the VALU out of LDS.
 #include "dff_device.h"
 #include <type_traits>
+#ifndef DFF_AUXLATE
+#define DFF_AUXLATE 1   // wide split GEMMs: the tiles' auxiliary rows are requested behind the ring's first entries (protein G -1.1 %, trp-cage -0.5 %, villin / BBA -0.2 %)
+#endif
 #ifndef DFF_APRE
 #define DFF_APRE 1
 #endif
@@ -244,10 +247,18 @@ DEVI void gemm_wide_split_st(const lu32* as, int R, int rowsA, const unsigned* _
 #pragma unroll
             for (int p = 0; p < 3; ++p) slot[kb][p] = wp[((tile * KB32 + (e % NHALF) * HB + kb) * 3 + p) * 64];
     };
+    // DFF_AUXLATE: the ring's first entries are requested BEFORE the tiles' auxiliary rows.  Loads return in order, and an
+    // auxiliary row may come from HBM (the backward's gelu' rows out of the stash): requested in between, every ring entry
+    // behind it waits a memory latency the first entries' products could have covered.
 #pragma unroll
     for (int j = 0; j < DR; ++j) {
         fill(b[j], j);
-        if (j % NHALF == 0) pre(tile_of(j / NHALF), aux[(j / NHALF) % NA]);
+        if constexpr (!DFF_AUXLATE) if (j % NHALF == 0) pre(tile_of(j / NHALF), aux[(j / NHALF) % NA]);
+    }
+    if constexpr (DFF_AUXLATE) {
+#pragma unroll
+        for (int j = 0; j < DR; ++j)
+            if (j % NHALF == 0) pre(tile_of(j / NHALF), aux[(j / NHALF) % NA]);
     }
     // the loads above are issued HERE: left alone, the scheduler sinks each next to its first use (one L2 latency
     // per k-block instead of one per GEMM)
@@ -359,8 +370,10 @@ DEVI void gemm_wide_split_k2(const lu32* as, int R, int rowsA, const unsigned* _
         };
 #pragma unroll
         for (int d = 0; d < DR; ++d) fill(b[d], d);
-        pre(t0, aux[0]);
-        pre(t1, aux[1]);
+        if constexpr (!(DFF_AUXLATE && KB32 > DR)) {
+            pre(t0, aux[0]);
+            pre(t1, aux[1]);
+        }
         __builtin_amdgcn_sched_barrier(0);
         f32x4 cs[2][MT], cb[2][MT];
 #pragma unroll
@@ -398,8 +411,15 @@ DEVI void gemm_wide_split_k2(const lu32* as, int R, int rowsA, const unsigned* _
                         cb[t][mt] = mfma_bf16(b[kb % DR][t][0], ah, cb[t][mt]);
                     }
                 }
-                if (kb + DR < KB32) { fill(b[kb % DR], kb + DR); __builtin_amdgcn_sched_barrier(0); }
+                if (kb + DR < KB32) {
+                    fill(b[kb % DR], kb + DR);
+                    if constexpr (DFF_AUXLATE) if (kb == 0) { pre(t0, aux[0]); pre(t1, aux[1]); }   // (behind three k-blocks, see gemm_wide_split_st)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
+        } else if constexpr (DFF_AUXLATE && KB32 > DR) {
+            pre(t0, aux[0]);
+            pre(t1, aux[1]);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) epi(t0, mt, cb[0][mt] + cs[0][mt], aux[0], v0, i);
