@@ -26,6 +26,11 @@
 // in the sampling loops: no stash traffic (SmallLds<..., FOLD>, KEEPROWS).
 #include "dff_device.h"
 
+#ifdef DFF_MARKS   // development: stage markers ("; ##MARK <tick id>") in the ISA listing, to bin spills / waits by stage
+#define DFF_MARK(n) asm volatile("; ##MARK " #n)
+#else
+#define DFF_MARK(n) ((void)0)
+#endif
 #ifndef DFF_SDR
 #define DFF_SDR 4   // split-ring depth in units (SPW variants)
 #endif
@@ -1220,7 +1225,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         } }
         if (step == 0) centre();
         if (step == 0 || !cached0) __syncthreads();   // (later steps: the barrier that ended the previous update stage)
-        pf.tick(0);
+        pf.tick(0); DFF_MARK(0);
 
         // =============================== forward ===============================
         if (!cached0) {
@@ -1302,7 +1307,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 }
                 __syncthreads();
             }
-            pf.tick(1);
+            pf.tick(1); DFF_MARK(1);
             // ---- attention block: wave w owns heads w and w+4 (ring holds the first entries) ----
             {
                 DFF_LANE_CONSTS
@@ -1383,12 +1388,12 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                             head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
                             head_commit(hr, Qx, Kx, Vx, pb, true, false, lane, RLA, XLD);
                         }
-                        pf.tick(12);
+                        pf.tick(12); DFF_MARK(12);
                         head_math(wave);
-                        pf.tick(13);
+                        pf.tick(13); DFF_MARK(13);
                         const SSeq<U_WOX, 0, MW, KO, KO, 0, 0, E> sq{ss_wox(lw, wave), ss_wox(lw, wave), sn0, sn1};
                         stall_run<0, 2, E, true>(sring, acc_o, wox_fa32, sq, lane, wox_xa, wox_ext(lw, wave, lane), DFF_HEADS * 5 * 256);
-                        pf.tick(14);
+                        pf.tick(14); DFF_MARK(14);
                     } else {
                         u32x4 ah[KB32], am[KB32], al[KB32];
                         a_load(ah, am, al, lane);
@@ -1398,7 +1403,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         lfloat* const wq = wr + col;
                         float bq[2][1];
                         bq[0][0] = bh[0]; bq[1][0] = bh[16];
-                        pf.tick(1);
+                        pf.tick(1); DFF_MARK(1);
                         const SSeq<U_QKV, U_WOX, MW, KQ, KO, 0, 0, E, 4 * KB32> sq{ss_qkv(lw, wave), ss_wox(lw, wave), sn0, sn1};   // tile 4 of 13: [u | s]
                         swide_run<0, NQT, KB32, 1>(sring, bq, ah, am, al, sq, lane,
                             [=](int t, float (&ax)[1]) { ax[0] = bh[t * 16]; },
@@ -1410,12 +1415,12 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                                 dl[l0] = v0; dl[l1] = v1; dl[l2] = v2; dl[l3] = v3;
                             });
                         if (st_qkv) head_store<FOLD>(Qx, Kx, Vx, sb + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, RA, lane, RLA, XLD);
-                        pf.tick(12);
+                        pf.tick(12); DFF_MARK(12);
                         head_math(wave);
                         if constexpr (KEEP2) { if (keep2) keep2_copy(Qx, Qsave, true, lane, pcij); }
-                        pf.tick(13);
+                        pf.tick(13); DFF_MARK(13);
                         stall_run<U_QKV, 2, E, true>(sring, acc_o, wox_fa32, sq, lane, wox_xa, wox_ext(lw, wave, lane), DFF_HEADS * 5 * 256);
-                        pf.tick(14);
+                        pf.tick(14); DFF_MARK(14);
                     }
                 } else if (cached) {
                     // layer-0 q_ext / k / v are x-independent and t is fixed: re-read, no GEMM
@@ -1467,28 +1472,28 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     };
                     float bq[DR][1];
                     qkv_bias(std::integral_constant<int, 0>{}, wave, bq);
-                    pf.tick(1);
+                    pf.tick(1); DFF_MARK(1);
                     if constexpr (HPW == 2) {
                         qkv(std::integral_constant<int, 0>{}, wave, bq, s_wox(lw, wave));
-                        pf.tick(12);
+                        pf.tick(12); DFF_MARK(12);
                         qkv_bias(std::integral_constant<int, 2>{}, wave + 4, bq);
                         head_math(wave);
-                        pf.tick(13);
+                        pf.tick(13); DFF_MARK(13);
                         tall_run<1, 5, E, 4>(ring, acc_o, wox_fa, s_wox(lw, wave), s_qkv(lw, wave + 4), lane);
-                        pf.tick(14);
+                        pf.tick(14); DFF_MARK(14);
                         qkv(std::integral_constant<int, 2>{}, wave + 4, bq, s_wox(lw, wave + 4));
-                        pf.tick(12);
+                        pf.tick(12); DFF_MARK(12);
                         head_math(wave + 4);
-                        pf.tick(13);
+                        pf.tick(13); DFF_MARK(13);
                         tall_run<3, 5, E, 4>(ring, acc_o, wox_fa, s_wox(lw, wave + 4), after, lane);   // ends at phase 0
-                        pf.tick(14);
+                        pf.tick(14); DFF_MARK(14);
                     } else {
                         qkv(std::integral_constant<int, 0>{}, wave, bq, s_wox(lw, wave));
-                        pf.tick(12);
+                        pf.tick(12); DFF_MARK(12);
                         head_math(wave);
-                        pf.tick(13);
+                        pf.tick(13); DFF_MARK(13);
                         tall_run<13 % DR, 5, E, 4>(ring, acc_o, wox_fa, s_wox(lw, wave), after, lane);       // 18 entries: phase 0
-                        pf.tick(14);
+                        pf.tick(14); DFF_MARK(14);
                         static_assert(18 % DR == 0, "ring phase");
                     }
                 }
@@ -1496,7 +1501,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 for (int nt = 0; nt < E; ++nt) c_store_offs(mypart, mro, 16 * nt, acc_o[nt], lane);
             }
             __syncthreads();
-            pf.tick(2);
+            pf.tick(2); DFF_MARK(2);
             // ---- row stage B: attn_out = sum_w part + bo ; gate1 ; LN2 -> abuf ----
             { DFF_ROW_CONSTS
             if (ract) {
@@ -1527,7 +1532,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 if (l + 1 < m.L) { ro_load(4, m.layer[l + 1].ln1_g, sub); ro_load(5, m.layer[l + 1].ln1_b, sub); }
             } }
             __syncthreads();
-            pf.tick(3);
+            pf.tick(3); DFF_MARK(3);
             // ---- FFN: wave w owns hidden columns [w H, (w+1) H) ----
             {
                 DFF_LANE_CONSTS
@@ -1569,10 +1574,10 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     if constexpr (SPW) {
                         u32x4 ah[KB32], am[KB32], al[KB32];
                         a_load(ah, am, al, lane);
-                        pf.tick(19);
+                        pf.tick(19); DFF_MARK(19);
                         if (lastl) swide_run<0, NTS, KB32, 1>(sring, b1r, ah, am, al, sqf_last, lane, w1_pre, w1_epi);
                         else swide_run<0, NTS, KB32, 1>(sring, b1r, ah, am, al, sqf_next, lane, w1_pre, w1_epi);
-                        pf.tick(20);
+                        pf.tick(20); DFF_MARK(20);
                     } else
                     wide_run<0, NTS, E, 1>(ring, b1r, afr, s_w1(lw), s_w2(lw), lane, w1_pre, w1_epi);
                 }
@@ -1586,7 +1591,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         else stall_run<U_W1, FS / 32, E, false>(sring, acc_f, [=](int kb) { return ha + 32 * kb; }, sqf_next, lane);
                     }
                     else tall_run<NTS % DR, NTS, E, -1>(ring, acc_f, [=](int kb) { return ha + 16 * kb; }, s_w2(lw), after, lane);
-                    pf.tick(21);
+                    pf.tick(21); DFF_MARK(21);
                     // gelu'(h_pre) rows of this wave's hidden slice: LDS tile -> stash, 16 bytes per lane (rows beyond the real
                     // ones go to the dummy stash row); before the partial sums below reuse the tile
                     if (!gp_lds) {
@@ -1604,7 +1609,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 for (int nt = 0; nt < E; ++nt) c_store_offs(mypart, mro, 16 * nt, acc_f[nt], lane);
             }
             __syncthreads();
-            pf.tick(4);
+            pf.tick(4); DFF_MARK(4);
             // ---- row stage C: ff = sum_w part + b2 ; gate2 ; next layer's LN1 or the energy head ----
             { DFF_ROW_CONSTS
             if (ract) {
@@ -1674,7 +1679,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             // the stash written in the forward pass is re-read below by other lanes / waves
             if (l == m.L - 1) __threadfence_block();
             __syncthreads();
-            pf.tick(5);
+            pf.tick(5); DFF_MARK(5);
         }
 
         // =============================== backward ===============================
@@ -1741,7 +1746,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             }
             __syncthreads();
             }
-            pf.tick(6);
+            pf.tick(6); DFF_MARK(6);
             // ---- FFN backward slice: dh = dff W2[:, slice] ; * gelu'(h_pre) ; partial df = dh_pre W1[slice, :] ----
             {
                 DFF_LANE_CONSTS
@@ -1806,7 +1811,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 for (int nt = 0; nt < E; ++nt) c_store_offs(mypart, mro, 16 * nt, acc_f[nt], lane);
             }
             __syncthreads();
-            pf.tick(7);
+            pf.tick(7); DFF_MARK(7);
             // first head of this layer's attention backward: start the stash read (hidden by row stage E)
             if constexpr (HDMA) {
                 if (!(KEEP_LAST && l == m.L - 1 && l > 0) && !(KEEP2 && l == m.L - 2 && l > 0 && MODE != DFF_MODE_SCORE))
@@ -1825,11 +1830,11 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 float n1[HC], d1[HC], dyg[HC], xh[HC], ps[HC], ao[HC], ni[HC];
                 rows_of(l, ao, ni, nullptr, 0);
                 psum_all(ps, rrow * LH + sub);
-                pf.tick(22);
+                pf.tick(22); DFF_MARK(22);
                 float g1;
                 if constexpr (KEEPROWS) g1 = gate_get(l, std::integral_constant<int, 0>{});
                 else g1 = ro_gate(ao, ni, 3);
-                pf.tick(23);
+                pf.tick(23); DFF_MARK(23);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) n1[i] = ao[i] * g1 + ni[i] * (1.0f - g1);
                 float mean, rstd;
@@ -1882,7 +1887,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 if constexpr (KEEPROWS) { if (l > 0) ro_load3(6, m.layer[l - 1].g2, sub); }
             } }
             __syncthreads();
-            pf.tick(8);
+            pf.tick(8); DFF_MARK(8);
             // ---- attention backward: wave w owns heads w and w+4 ----
             {
                 DFF_LANE_CONSTS
@@ -2019,27 +2024,27 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA, XLD);
                         committed();
                         head_fetch(hr, sbq + sl.qkv + (size_t)h1 * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)h1 * 256, RA, true, lane, m12p(h1));
-                        pf.tick(8);
+                        pf.tick(8); DFF_MARK(8);
                         gext(std::integral_constant<int, 0>{}, wave, s_qkvt(lw, wave));
                         gfix();
-                        pf.tick(15);
+                        pf.tick(15); DFF_MARK(15);
                         ds_math();
-                        pf.tick(16);
+                        pf.tick(16); DFF_MARK(16);
                         dqkv();
-                        pf.tick(17);
+                        pf.tick(17); DFF_MARK(17);
                         tall_run<1, 13, E, 4>(ring, acc_a, qkvt_fa, s_qkvt(lw, wave), s_woxt(lw, h1), lane);
-                        pf.tick(18);
+                        pf.tick(18); DFF_MARK(18);
                         head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA, XLD);
                         committed();
                         gext(std::integral_constant<int, 2>{}, h1, s_qkvt(lw, h1));
                         gfix();
-                        pf.tick(15);
+                        pf.tick(15); DFF_MARK(15);
                         ds_math();
-                        pf.tick(16);
+                        pf.tick(16); DFF_MARK(16);
                         dqkv();
-                        pf.tick(17);
+                        pf.tick(17); DFF_MARK(17);
                         tall_run<3, 13, E, 4>(ring, acc_a, qkvt_fa, s_qkvt(lw, h1), after, lane);   // ends at phase 0
-                        pf.tick(18);
+                        pf.tick(18); DFF_MARK(18);
                     } else {
                         if constexpr (HDMA) {
                             head_dma_wait();   // (requested before row stage E; nothing for the last layer)
@@ -2050,18 +2055,18 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                             head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA, XLD);
                         }
                         committed();
-                        pf.tick(8);
+                        pf.tick(8); DFF_MARK(8);
                         if constexpr (SPW) sgext(sqa);
                         else gext(std::integral_constant<int, 0>{}, wave, s_qkvt(lw, wave));
                         gfix();
-                        pf.tick(15);
+                        pf.tick(15); DFF_MARK(15);
                         ds_math();
-                        pf.tick(16);
+                        pf.tick(16); DFF_MARK(16);
                         dqkv();
-                        pf.tick(17);
+                        pf.tick(17); DFF_MARK(17);
                         if constexpr (SPW) stall_run<U_GX, NKT, E, true>(sring, acc_a, qkvt_fa32, sqa, lane, qkvt_xa, qkvt_ext(lw, wave, lane), DFF_HEADS * 13 * 256);
                         else tall_run<5 % DR, 13, E, 4>(ring, acc_a, qkvt_fa, s_qkvt(lw, wave), after, lane);   // 18 entries: phase 0
-                        pf.tick(18);
+                        pf.tick(18); DFF_MARK(18);
                     }
 #pragma unroll
                     for (int nt = 0; nt < E; ++nt) c_store_offs(mypart, mro, 16 * nt, acc_a[nt], lane);
@@ -2118,7 +2123,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 }
             }
             __syncthreads();
-            pf.tick(9);
+            pf.tick(9); DFF_MARK(9);
             // ---- row stage F: dn = dn_in partial + LN1 backward(sum_w part)  (l > 0) ----
             // operands: ro[1] nodes_in, ro[2] ln1 gamma
             if (l > 0 || full0) {
@@ -2164,7 +2169,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 }
                 __syncthreads();
             }
-            pf.tick(10);
+            pf.tick(10); DFF_MARK(10);
         }
         { const int tq = tid_id();   // (opaque: the per-lane addresses below are re-derived every step, not hoisted and spilled)
         // dxs = sum of the waves' partial x-gradients (the force head wrote dxs itself); supplied / not yet drawn noise -> xib
@@ -2319,7 +2324,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             __syncthreads();
             if (tid < gcnt * 4 && (tid & 3) < 3 && !(fabsf(cm[tid]) < 1e-3f)) atomicOr(a.clamp_flag, 2);
         }
-        pf.tick(11);
+        pf.tick(11); DFF_MARK(11);
     }
     if (pf.on)
         for (int i = 0; i < DFF_NPROF; ++i) a.prof[i] = pf.acc[i];
