@@ -53,12 +53,28 @@ MIN_LAUNCHES = 8
 FORCE_DIST = os.environ.get("DFF_FORCE_DIST") == "1"
 
 
-def profile_figures(kname, cfg, P, chunk):
+def library_src_sha():
+    """Hash of the sources the loaded libdff_amd.so was built from (dff_version(); build.sh)."""
+    try:
+        from dff_amd import srcsha
+        return srcsha.library_sha()
+    except Exception:   # noqa: BLE001
+        return "unknown"
+
+
+CHECK_PROFILE_SHA = True   # (tests of the kernel-name matching against older rounds' profiles switch it off)
+
+
+def profile_figures(kname, cfg, P, chunk, lib_sha=None):
     """rocprofv3 figures for this exact kernel + workload from profiles/<round>/**/traffic.json (latest round wins;
     written by tools_profile_report.py from separate --pmc passes): HBM bytes per launch (FETCH_SIZE x 2 on gfx950 +
     WRITE_SIZE), HBM TB/s, MFMA pipe busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GUI cycles)), L2 hit rate.
-    Older traffic.json files carry the bytes only: the rest is derived from the summary.json next to them."""
+    Older traffic.json files carry the bytes only: the rest is derived from the summary.json next to them.
+    A traffic.json is tied to the sources it profiled (`src_sha`, stamped by tools_profile_report.py): when that is not the
+    hash of the running library the counters are NOT reported (all None) and `profile_stale` is True -- a kernel changed
+    after its last profile must not carry the old counters next to fresh timings."""
     best = None
+    lib_sha = lib_sha or (library_src_sha() if CHECK_PROFILE_SHA else None)
 
     def norm(n):   # rocprofv3 prints the full template argument list, the library its own short name
         n = n.replace(" ", "").replace("void", "")
@@ -80,11 +96,15 @@ def profile_figures(kname, cfg, P, chunk):
         if norm(t.get("kernel", "")) == norm(kname) and t.get("workload") == f"{cfg} P={P} chunk={chunk}":
             best = (t, os.path.dirname(f))
     if best is None:
-        return {"traffic": None, "hbm_tbps": None, "mfma_busy": None, "l2_hit": None, "profile": None}
+        return {"traffic": None, "hbm_tbps": None, "mfma_busy": None, "l2_hit": None, "profile": None, "profile_stale": None}
     t, d = best
+    if CHECK_PROFILE_SHA and (t.get("src_sha") != lib_sha or lib_sha == "unknown"):
+        return {"traffic": None, "hbm_tbps": None, "mfma_busy": None, "l2_hit": None, "profile": os.path.relpath(d, ROOT),
+                "profile_stale": True}
     out = {"traffic": float(t["hbm_bytes_per_launch"]),
            "hbm_tbps": t.get("hbm_tbps", float(t["hbm_bytes_per_launch"]) / (float(t["avg_launch_ms"]) * 1e-3) / 1e12),
-           "mfma_busy": t.get("mfma_busy"), "l2_hit": t.get("l2_hit"), "profile": os.path.relpath(d, ROOT)}
+           "mfma_busy": t.get("mfma_busy"), "l2_hit": t.get("l2_hit"), "profile": os.path.relpath(d, ROOT),
+           "profile_stale": False}
     if out["mfma_busy"] is None or out["l2_hit"] is None:
         try:
             c = {k: v["mean_per_launch"] for k, v in json.load(open(os.path.join(d, "summary.json")))["counters"].items()}
@@ -108,7 +128,8 @@ NOTES = {
     "roofline": "bound = fp32 compute (SURVEY 8d): frac = algorithmic TFLOP/s (official factorised FLOP count x proteins x steps / "
                 "HIP-event launch time) / 157.3.  split_peak_frac: against the split GEMMs' own roof, dense bf16 / 6 = 416.7.  "
                 "traffic = HBM bytes per launch, hbm_tbps, mfma_busy, l2_hit: rocprofv3 PMC passes of the same workload under "
-                "`profile` (FETCH_SIZE x2 + WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GUI cycles))",
+                "`profile` (FETCH_SIZE x2 + WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GUI cycles)); they are None and "
+                "profile_stale is true when that profile was taken on other sources than the running library's (src_sha)",
     "fold_kv": "hidden == head dim: k / v projections folded into q / out (exact); ~26 % fewer MFMAs issued than the FLOP count used",
     "timing": "persistent launches of `chunk` fused steps; --steps / --warmup are rounded up to whole launches, >= 8 timed launches",
     "cpu": "oracle/reference_twin.py (torch CPU port of the reference, materialised formulation), thread count picked by a probe",
@@ -130,12 +151,14 @@ def roofline(cfg, P, steps_per_launch, launch_ms, kname, brief=False):
          "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": pf["traffic"], "hbm_tbps": pf["hbm_tbps"],
          "mfma_busy": pf["mfma_busy"], "l2_hit": pf["l2_hit"], "kernel": kname, "avg_launch_ms": round(avg, 4),
          "min_launch_ms": round(float(np.min(launch_ms)), 4), "launches": len(launch_ms)}
+    r["profile"] = pf["profile"]
+    if pf["profile_stale"]:
+        r["profile_stale"] = True
     if brief:   # `also` entries: bound / peak / unit are the headline's
         for k in ("bound", "peak", "unit", "min_launch_ms", "launches"):
             del r[k]
     else:
         r["algorithmic_flops_per_launch"] = flops
-        r["profile"] = pf["profile"]
     if "split_bf16" in kname:
         r["split_peak_frac"] = round(ach / (PEAK_BF16_DENSE_TFLOPS / 6.0), 4)
     return r

@@ -133,14 +133,17 @@ int dff_ddpm_run(dff_model* m, int batch, float* x_dev, const float* noise_dev, 
  * partitioned below the CU count the driver reports; the results of that launch are invalid.  The samplers call this at
  * their host synchronisation points (end of LangevinDiffusion.simulate, GaussianDiffusion.check_clamp, the CLI) and raise;
  * once the host has seen the word, the next such launch on the same model refuses with DFF_EHIP; one queued before that
- * leaves at kernel entry (the word is read on the device), so nothing runs on top of invalid results.  The entry points
+ * leaves at kernel entry (the word is read on the device) with its OUTPUTS set to NaN (forces / energies, frames / kinetic
+ * energies, samples; the Langevin state x, v is left alone), so nothing runs on top of invalid results and a caller that
+ * never checks cannot mistake an unwritten buffer for forces.  The entry points
  * themselves never read it: they only enqueue on the caller's stream (round 4; they used to synchronise the device before
  * every two-workgroups launch).  The reference has no counterpart (one process, one kernel per op).  NOTE: which variant runs depends on the per-call batch (<= n_CUs / 2 proteins), and the two variants sum
  * in different orders: trajectories are bit-reproducible for a fixed per-rank batch, not across batch splits that cross
  * that threshold. */
 int dff_model_status(dff_model* m, unsigned* status);
 /* Clear the sticky word (synchronises the device): re-arms the two-workgroups variants after the caller has dealt with a
- * reported failure (e.g. the co-tenant that held the CUs is gone).  dff_debug_pair(m, 0) clears it as well. */
+ * reported failure (e.g. the co-tenant that held the CUs is gone).  dff_debug_pair(m, 0) clears it as well (whether or not
+ * the host has read it yet). */
 int dff_model_status_clear(dff_model* m);
 
 /* ---- introspection / debugging (used by tests and bench.py, not by samplers) ---- */
@@ -160,6 +163,8 @@ int dff_debug_max_workgroups(dff_model* m, int n);
 int dff_debug_l0_table(dff_model* m, int on);
 /* Debugging: on == 2 = on, and the exchanges always run the agent-scope protocol of a pair whose blocks sit on different XCDs
  * (never observed: blocks b and b + 8 share one; the kernel checks at run time and takes an L2-local path when they do).
+ * on == 3 = on, with partners placed on ADJACENT blocks (b, b + 1): under the hardware's round-robin placement they sit on
+ * different XCDs, so the run-time check itself selects the agent-scope protocol on pairs that really span two L2s.
  * on == 0 never splits a protein over two workgroups (the PAIR variants of the <= 64-row kernel, chosen
  * automatically when one workgroup per protein would leave at least half the CUs idle, e.g. protein G at 128 per GPU). */
 int dff_debug_pair(dff_model* m, int on);

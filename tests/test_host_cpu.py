@@ -187,6 +187,7 @@ def test_bench_finds_the_profiled_traffic_for_the_shipped_kernels():
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
+    bench.CHECK_PROFILE_SHA = False   # name / workload matching against every round's profiles; the hash check is the next test
     tr = lambda *a: bench.profile_figures(*a)["traffic"]   # noqa: E731
     t = tr("dff_small_kernel<64,8>", "chignolin", 256, 250)
     assert t is not None and 1e9 < t < 1e12
@@ -208,6 +209,7 @@ def test_bench_finds_the_profiled_traffic_for_the_shipped_kernels():
     assert 0.05 < h["mfma_busy"] < 1.0 and 0.0 < h["hbm_tbps"] < 8.0 and h["l2_hit"] > 0.5 and h["profile"].startswith("profiles/r")
     v = bench.roofline("villin", 256, 250, [131.0] * 8, "dff_fused_kernel<128,3,1,false,split_bf16>", brief=True)
     assert 0.05 < v["mfma_busy"] < 1.0 and v["hbm_tbps"] > 0.1 and "peak" not in v
+    assert v["profile"].startswith("profiles/r")   # (the brief entries name their profile directory too)
     # ... and the line must fit the driver's stdout tail: every `also` entry <= 700 bytes, what they share said once
     import json
     entry = {"workload": "villin (35 beads, H=128, L=3) Langevin, 256/GPU", "value": 1897.33, "unit": "MD-steps/s (batch 256, whole job)",
@@ -217,3 +219,40 @@ def test_bench_finds_the_profiled_traffic_for_the_shipped_kernels():
     assert bench.kernel_dtype("dff_small_kernel<64,8,split_bf16>") == "f32" and "3-way bf16 split" in bench.NOTES["dtype"]
     # algorithmic FLOPs per launch of the headline config: 22.00 MFLOP x 256 x 250
     assert abs(bench.MFLOP_PER_CALL["chignolin"] * 1e6 * 256 * 250 - 1.408e12) < 1e6
+
+
+def test_bench_drops_profile_counters_taken_on_other_sources(tmp_path):
+    """a traffic.json is tied to the sources it profiled (src_sha = sha256 over csrc/* + include/dff.h,
+    compiled into the library by build.sh, stamped by tools_profile_report.py).  bench.py reports the rocprofv3 counters
+    only next to a library built from the same sources; otherwise they are None and roofline.profile_stale is true."""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from dff_amd import srcsha
+    from dff_amd.binding import load_library
+    # the library carries the hash of the tree it was built from (build.sh) -- and the tree has not changed since
+    lib_sha = srcsha.library_sha(load_library())
+    assert len(lib_sha) == 16 and lib_sha == srcsha.tree_sha(), "libdff_amd.so is older than its sources: run ./build.sh"
+    assert bench.library_src_sha() == lib_sha
+    d = tmp_path / "profiles" / "r99" / "x"
+    d.mkdir(parents=True)
+    t = {"workload": "chignolin P=256 chunk=250", "kernel": "dff_small_kernel<64, 8, false, true, true, 1>",
+         "hbm_bytes_per_launch": 1.3e8, "avg_launch_ms": 13.2, "hbm_tbps": 0.0098, "mfma_busy": 0.33, "l2_hit": 0.999,
+         "src_sha": lib_sha}
+    json.dump(t, open(d / "traffic.json", "w"))
+    bench.ROOT = str(tmp_path)
+    kn = "dff_small_kernel<64,8,split_bf16,fold_kv>"
+    ok = bench.roofline("chignolin", 256, 250, [13.2] * 8, kn)
+    assert ok["traffic"] == 1.3e8 and ok["mfma_busy"] == 0.33 and "profile_stale" not in ok and ok["profile"] == "profiles/r99/x"
+    t["src_sha"] = "0123456789abcdef"   # the kernel changed after this profile was taken
+    json.dump(t, open(d / "traffic.json", "w"))
+    stale = bench.roofline("chignolin", 256, 250, [13.2] * 8, kn)
+    assert stale["profile_stale"] is True and stale["traffic"] is None and stale["mfma_busy"] is None and stale["hbm_tbps"] is None
+    assert stale["frac"] == ok["frac"]   # the timing figures do not depend on the profile
+    del t["src_sha"]                     # a profile from before round 5 (no hash): stale as well
+    json.dump(t, open(d / "traffic.json", "w"))
+    assert bench.roofline("chignolin", 256, 250, [13.2] * 8, kn, brief=True)["profile_stale"] is True

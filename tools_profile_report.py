@@ -105,6 +105,17 @@ def main():
         traffic["mfma_busy"] = mfma_util
     if "TCC_HIT_sum" in C:
         traffic["l2_hit"] = C["TCC_HIT_sum"] / (C["TCC_HIT_sum"] + C["TCC_MISS_sum"])
+    # the sources the profiled library was built from (tools_rocprof.sh asked the library itself); bench.py reports these
+    # counters only next to a library with the same hash
+    try:
+        traffic["src_sha"] = open(os.path.join(src, "src_sha.txt")).read().strip() or "unknown"
+    except OSError:
+        import sys
+        sys.path.insert(0, ROOT)
+        import dff_amd  # noqa: F401
+        from dff_amd import srcsha
+        traffic["src_sha"] = srcsha.tree_sha()
+        print(f"warning: no src_sha.txt in {src}; stamped the working tree's hash {traffic['src_sha']}")
     json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"))
     wc = C.get("SQ_WAVE_CYCLES", 1.0)
     lines = []

@@ -9,6 +9,8 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 BENCH="python $ROOT/bench.py --steps 1000 --warmup 250 --no-cpu --no-extras $*"
+# which sources the profiled library was built from (dff_version(); tools_profile_report.py stamps it into traffic.json)
+(cd $ROOT && python -c "import dff_amd; from dff_amd import srcsha; print(srcsha.library_sha())") > $OUT/src_sha.txt 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 i=0
 if [ "${DFF_PMC_SETS:-all}" = "traffic" ]; then   # HBM bytes only: FETCH_SIZE and WRITE_SIZE, each in its own pass

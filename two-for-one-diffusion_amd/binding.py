@@ -179,7 +179,8 @@ class Model:
         _check(self.lib, self.lib.dff_debug_max_workgroups(self.handle, int(n)), "dff_debug_max_workgroups")
 
     def pair(self, on=True):
-        """True / False: allow / never use the two-workgroups-per-protein variants; 2: allow, and force their cross-XCD exchange protocol."""
+        """True / False: allow / never use the two-workgroups-per-protein variants; 2: allow, and force their cross-XCD exchange protocol;
+        3: allow, with the two workgroups of a protein on adjacent blocks (different XCDs: the protocol is chosen by the kernel's own check)."""
         _check(self.lib, self.lib.dff_debug_pair(self.handle, int(on)), "dff_debug_pair")
 
     def pair_status(self) -> int:

@@ -23,6 +23,50 @@ typedef __attribute__((address_space(3))) float lfloat;
 typedef __attribute__((address_space(1))) float gfloat;
 typedef f32x4 __attribute__((address_space(3))) lf32x4;
 typedef f32x4 __attribute__((address_space(1))) gf32x4;
+// A weight image as a BUFFER: wp[i] with a wave-uniform index i is one buffer_load_dwordx4 -- resource descriptor (base) and
+// byte offset in SGPRs, computed on the scalar unit, ONE VGPR for the lane offset, shared by every stream of the kernel --
+// instead of a 64-bit per-lane pointer per stream (a VGPR pair each, v_mad_u64_u32 / v_lshl_add_u64 / quarter-rate
+// v_mul_lo_u32 per load, 64-bit VALU adds wherever consecutive loads are further apart than the 4 KB immediate reaches;
+// 303 of the 311 wide loads of villin's kernel, 21 % of its dynamic VALU was INT32).  Writing the address as
+// (uniform base + uniform index)[32-bit lane] is not enough (DFF_SADDR=1): the compiler merges base, index and lane into one
+// vector pointer and offsets that.  DFF_SADDR=0: the per-lane pointers of rounds 1-4.
+#ifndef DFF_SADDR
+#define DFF_SADDR 2
+#endif
+template <class T> struct WVal;
+template <> struct WVal<f32x4 __attribute__((address_space(1)))> { typedef f32x4 type; };
+typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+template <> struct WVal<u32x4_ __attribute__((address_space(1)))> { typedef u32x4_ type; };
+// MODE: 2 buffer, 1 saddr-shaped pointer arithmetic, 0 per-lane pointer.  DFF_WMODE(MT): what a GEMM core with MT row tiles uses
+// -- measured (round 5, us / step, buffer vs per-lane pointers): BBA's shape (96,2,2) 281 vs 291.5, trp-cage's (128,2,2) 300.5
+// vs 304.8, villin's (128,3,1) 487-495 vs 487-490, protein G's (128,4,1) 469-472 vs 465-467: the shapes with three and four
+// row tiles keep the per-lane pointers (their cores hold more streams' worth of SGPR offsets than they have SGPRs for).
+#define DFF_WMODE(MT) (DFF_SADDR == 2 ? ((MT) <= 2 ? 2 : 0) : DFF_SADDR)
+template <class GT, int MODE = DFF_SADDR>
+struct WPtr;
+template <class GT>
+struct WPtr<GT, 2> {
+    typedef typename WVal<GT>::type V;
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned lob;     // this lane's byte offset
+    DEVI WPtr(const GT* base, unsigned lane) : rs(__builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000)), lob(lane * 16u) {}
+    DEVI V operator[](size_t i) const {   // i: wave-uniform, in 16-byte elements
+        return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rs, lob, (unsigned)i * 16u, 0));
+    }
+    DEVI float first_float(size_t i) const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lob, (unsigned)i * 16u, 0)); }
+};
+template <class GT, int MODE>
+struct WPtr {
+    typedef typename WVal<GT>::type V;
+    const GT* base;   // wave-uniform
+    unsigned lo;      // this lane's element offset (< 64: cannot wrap)
+    DEVI WPtr(const GT* b, unsigned lane) : base(b), lo(lane) {}
+    DEVI V operator[](size_t i) const {
+        if constexpr (MODE == 1) return (base + i)[lo];
+        else return (base + lo)[i];
+    }
+    DEVI float first_float(size_t i) const { return *(const gfloat*)(base + i + lo); }
+};
 #ifndef DFF_STASH_NT
 #define DFF_STASH_NT 0   // 1: non-temporal stash traffic. Measured: default policy is 3% faster (stash stays in L2/MALL)
 #endif

@@ -183,7 +183,8 @@ struct dff_model {
     unsigned* xflag = nullptr;
     size_t xflag_n = 0;
     bool pair_off = false;                     // debugging: never use a PAIR variant
-    bool pair_slow = false;                    // tests: PAIR variants always run the cross-XCD (agent-scope) exchange protocol
+    int pair_slow = 0;                         // tests: 1 = PAIR variants always run the cross-XCD (agent-scope) exchange protocol; 2 = partners are
+                                               // ADJACENT blocks (different XCDs under round-robin placement), protocol chosen by the handshake
     bool last_pair = false;
     unsigned sticky = 0;                       // the sticky error word as the host last read it (read_status): a non-zero one
                                                // refuses further PAIR launches WITHOUT touching the device
@@ -563,10 +564,12 @@ static int clear_status(dff_model* m);
 extern "C" int dff_debug_pair(dff_model* m, int on) {
     if (!m) return fail(DFF_EINVAL, "null model");
     m->pair_off = on == 0;
-    m->pair_slow = on == 2;
+    m->pair_slow = on == 2 ? 1 : on == 3 ? 2 : 0;
     // turning the PAIR variants off is how a caller recovers from a partner timeout: the one-workgroup kernels do not look
     // at the word, so it is cleared here (it would otherwise fail every later status check of a model that works again)
-    if (m->pair_off && m->sticky) return clear_status(m);
+    // (unconditionally -- ADVICE r04: the DEVICE word may be set before the host has looked at it; clear_status synchronises,
+    // which a debug / recovery call may do)
+    if (m->pair_off && m->xflag) return clear_status(m);
     return DFF_OK;
 }
 
@@ -702,7 +705,7 @@ static int launch_generic(dff_model* m, DffRunArgs& a, int G, const Variant* v, 
     const int grid_max = v->pair ? grid_all : (grid_all < m->max_wgs ? grid_all : m->max_wgs);
     const StashLayout sl = dff_stash_layout(N, G, H, L, v->MT);
     { int rc = ensure_stash(m, (size_t)grid_max * sl.total); if (rc) return rc; }
-    a.xchg = nullptr; a.xflag = nullptr; a.xpairs = npairs; a.xslow = m->pair_slow ? 1 : 0;
+    a.xchg = nullptr; a.xflag = nullptr; a.xpairs = npairs; a.xslow = m->pair_slow;
     if (v->pair) {
         const size_t need = (size_t)npairs * 4 * (size_t)(G * N) * (H + 4), nflag = (size_t)4 * npairs + 1;   // error word, [pair][half] sequence flags, [pair][half] XCD ids
         if (need > m->xchg_floats) {
@@ -1163,4 +1166,10 @@ extern "C" int dff_pwd_hist(int device, const float* x, long long n, int N, int 
 }
 
 extern "C" const char* dff_last_error(void) { return g_err.c_str(); }
-extern "C" const char* dff_version(void) { return "dff-amd 0.1 (gfx950, mfma_f32_16x16x4f32)"; }
+// DFF_SRC_SHA (build.sh): sha256 over csrc/* + include/dff.h, 16 hex digits -- ties rocprof evidence to the code it profiled
+#ifndef DFF_SRC_SHA
+#define DFF_SRC_SHA unknown
+#endif
+#define DFF_STR2(x) #x
+#define DFF_STR(x) DFF_STR2(x)
+extern "C" const char* dff_version(void) { return "dff-amd 0.1 (gfx950, mfma_f32_16x16x4f32) src=" DFF_STR(DFF_SRC_SHA); }

@@ -95,7 +95,7 @@ DEVI void gemm_wide(const lfloat* A, int lda, int rowsA, const float* __restrict
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) ah[HOLD ? mt : 0][HOLD ? kb : 0] = *(const lf32x4*)(A + rowoff[mt] + 16 * kb);
     }
-    const gf32x4* wp = (const gf32x4*)Wp + lane + (size_t)kb0 * 64;
+    const WPtr<gf32x4, DFF_WMODE(MT)> wp((const gf32x4*)Wp + (size_t)kb0 * 64, (unsigned)lane & 63u);
     const int cnt = wave < ntn ? (ntn - wave + DFF_NWAVES - 1) / DFF_NWAVES : 0;
     f32x4 b[D][KB];
     float aux[D][NAUX];
@@ -160,7 +160,7 @@ DEVI void gemm_wide_st(const lfloat* A, int lda, int rowsA, const float* __restr
     int rowoff[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) rowoff[mt] = min(mt * 16 + mm, rowsA - 1) * lda + 4 * kk;
-    const gf32x4* wp = (const gf32x4*)Wp + lane;
+    const WPtr<gf32x4, DFF_WMODE(MT)> wp((const gf32x4*)Wp, (unsigned)lane & 63u);
     f32x4 b[DR][HB];
     float aux[NA][NAUX];
     auto tile_of = [&](int i) { return min(wave + DFF_NWAVES * i, NTN - 1); };
@@ -236,7 +236,7 @@ DEVI void gemm_wide_split_st(const lu32* as, int R, int rowsA, const unsigned* _
     int rowoff[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) rowoff[mt] = min(mt * 16 + mm, rowsA - 1) * LHS2 + 4 * kg;
-    const gu32x4* wp = (const gu32x4*)Wp + lane;
+    const WPtr<gu32x4, DFF_WMODE(MT)> wp((const gu32x4*)Wp, (unsigned)lane & 63u);
     u32x4 b[DR][HB][3];
     float aux[NA][NAUX];
     auto tile_of = [&](int i) { return min(wave + NWV * i, NTN - 1); };
@@ -354,7 +354,7 @@ DEVI void gemm_wide_split_k2(const lu32* as, int R, int rowsA, const unsigned* _
     int rowoff[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) rowoff[mt] = min(mt * 16 + mm, rowsA - 1) * LHS2 + 4 * kg;
-    const gu32x4* wp = (const gu32x4*)Wp + lane;
+    const WPtr<gu32x4, DFF_WMODE(MT)> wp((const gu32x4*)Wp, (unsigned)lane & 63u);
 #pragma unroll
     for (int i = 0; i < CNT; ++i) {
         const int q = wave + DFF_NWAVES * i;
@@ -437,7 +437,7 @@ DEVI void gemm_wide_units_split(const lu32* as, int R, int rowsA, const unsigned
     constexpr int NU = NTN * MT, DU = (NU + DFF_NWAVES - 1) / DFF_NWAVES, DRU = DU < 2 ? DU : 2, LHS2 = (32 * KB32 + DFF_SPAD) / 2;
     const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     const int kg = lane >> 4, mm = lane & 15;
-    const gu32x4* wp = (const gu32x4*)Wp + lane;
+    const WPtr<gu32x4, DFF_WMODE(MT)> wp((const gu32x4*)Wp, (unsigned)lane & 63u);
     u32x4 b[DRU][KB32][3];
     auto fill = [&](u32x4 (&slot)[KB32][3], int d) {
         const int nt = min(wave + DFF_NWAVES * d, NU - 1) / MT;
@@ -488,7 +488,7 @@ DEVI void gx_units_hold(const lu32* as, int R, int rowsA, const unsigned* __rest
     const int tid_ = tid_now();
     const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6) - W0;
     const int kg = lane >> 4, mm = lane & 15;
-    const gu32x4* wp = (const gu32x4*)Wp + lane;
+    const WPtr<gu32x4, DFF_WMODE(MT)> wp((const gu32x4*)Wp, (unsigned)lane & 63u);
     u32x4 b[2][KH][3];
     auto fill = [&](u32x4 (&slot)[KH][3], int e) {
         const int nt = min(wave + NWV * (e / NHALF), NU - 1) / MT;
@@ -554,11 +554,11 @@ DEVI void store_split4(lu32* as, int R, int LS2, int row, int col, const f32x4 v
 }
 // The same with a compile-time k-block count: loop-free, so that the ring (D k-blocks ahead) is waited for exactly.
 // (PRE: the ring's first D k-blocks were requested by tall_ring_fill before the barrier in front of this GEMM)
-template <int NTW, int D>
+template <int NTW, int D, int MT = 1>
 DEVI void tall_ring_fill(u32x4 (&b)[D][NTW][3], const unsigned* __restrict__ Wp, int KBtot, int kb0, int ntiles) {
     const int tid_ = tid_now();
     const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
-    const gu32x4* wp = (const gu32x4*)Wp + lane;
+    const WPtr<gu32x4, DFF_WMODE(MT)> wp((const gu32x4*)Wp, (unsigned)lane & 63u);
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
         const int nt = wave + DFF_NWAVES * i;
@@ -580,7 +580,7 @@ DEVI void gemm_tall_split_st_b(f32x4 (&acc)[NTW][MT], int LS2 /* dwords per piec
     int rowoff[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) rowoff[mt] = min(mt * 16 + mm, rowsA - 1) * LS2 + 4 * kg;
-    const gu32x4* wp = (const gu32x4*)Wp + lane;
+    const WPtr<gu32x4, DFF_WMODE(MT)> wp((const gu32x4*)Wp, (unsigned)lane & 63u);
     size_t tbase[NTW];
     bool tok[NTW];
 #pragma unroll
@@ -835,7 +835,7 @@ DEVI void gemm_wide_units(const lfloat* A, int lda, int rowsA, const float* __re
     constexpr int NU = NTN * MT, DU = (NU + DFF_NWAVES - 1) / DFF_NWAVES;
     const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     const int kk = lane >> 4, mm = lane & 15;
-    const gf32x4* wp = (const gf32x4*)Wp + lane + (size_t)kb0 * 64;
+    const WPtr<gf32x4, DFF_WMODE(MT)> wp((const gf32x4*)Wp + (size_t)kb0 * 64, (unsigned)lane & 63u);
     f32x4 b[DU][KB];
 #pragma unroll
     for (int d = 0; d < DU; ++d) {
@@ -879,7 +879,7 @@ DEVI void gemm_tall_kb_st(f32x4 (&acc)[NTW][MT], KF kf, const lfloat* A, int lda
     int rowoff[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) rowoff[mt] = min(mt * 16 + mm, rowsA - 1) * lda + 4 * kk;
-    const gf32x4* wp = (const gf32x4*)Wp + lane;
+    const WPtr<gf32x4, DFF_WMODE(MT)> wp((const gf32x4*)Wp, (unsigned)lane & 63u);
     size_t tbase[NTW];
     bool tok[NTW];
 #pragma unroll
@@ -945,17 +945,17 @@ DEVI void gemm_tall_kb_st(f32x4 (&acc)[NTW][MT], KF kf, const lfloat* A, int lda
 // output projection and again in the back-projection.
 template <int NTW, int NH>
 struct ExtW { float b[NH][NTW]; };
-template <int NTW, int NH, class WK>
+template <int NTW, int NH, int MT = 1, class WK>
 DEVI void ext_fetch(ExtW<NTW, NH>& e, WK wk, const float* __restrict__ Wp, int KBtot, int ntiles) {
     const int tid_ = tid_now();
     const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
-    const gf32x4* wp = (const gf32x4*)Wp + lane;
+    const WPtr<gf32x4, DFF_WMODE(MT)> wp((const gf32x4*)Wp, (unsigned)lane & 63u);
 #pragma unroll
     for (int i = 0; i < NH; ++i)
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
             const int nt = wave + DFF_NWAVES * t;
-            e.b[i][t] = *(const gfloat*)(wp + ((size_t)(nt < ntiles ? nt : 0) * KBtot + wk(i)) * 64);
+            e.b[i][t] = wp.first_float(((size_t)(nt < ntiles ? nt : 0) * KBtot + wk(i)) * 64);
         }
     asm volatile("" ::: "memory");
 }
@@ -2125,8 +2125,11 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
     Ctx c;
     c.N = m.N; c.G = a.G; c.L = m.L;
     // PAIR: blocks b and b + 8 form pair (b & 7) + 8 (b >> 4); hf = which half of the heads / FFN chunks this block owns
-    const int hf = PAIR ? (int)((blockIdx.x >> 3) & 1) : 0;
-    const int unit = PAIR ? (int)((blockIdx.x & 7) + 8 * (blockIdx.x >> 4)) : (int)blockIdx.x;
+    // (tests, a.xslow == 2: partners are blocks b and b + 1 instead -- under the round-robin placement they sit on DIFFERENT XCDs,
+    // the XCC-ID handshake below finds that out by itself and the exchanges run the agent-scope protocol where it is needed)
+    const bool adj = PAIR && a.xslow == 2;
+    const int hf = PAIR ? (int)(adj ? (blockIdx.x & 1) : ((blockIdx.x >> 3) & 1)) : 0;
+    const int unit = PAIR ? (int)(adj ? (blockIdx.x >> 1) : ((blockIdx.x & 7) + 8 * (blockIdx.x >> 4))) : (int)blockIdx.x;
     c.b0 = a.b_base + unit * a.G;
     c.gcnt = min(a.G, a.B - c.b0);
     if (c.gcnt <= 0) return;   // (both blocks of a pair leave together)
@@ -2270,7 +2273,29 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
         __syncthreads();
         const unsigned failed = ((const unsigned*)smem)[ll.junk];
         __syncthreads();
-        if (failed) return;
+        if (failed) {
+            // ... but not silently: a caller that never reaches a status check (Model.score() hands out a
+            // torch.empty buffer) must not read uninitialised memory as forces -- this launch's OUTPUTS become NaN: forces
+            // (+ energies), or the frames and kinetic energies of a Langevin launch, or the samples of a reverse chain.
+            // The Langevin state (x, v) is left as it was: after the host's status check has reported and cleared the
+            // word the caller can run the same steps again.
+            const float qnan = __builtin_nanf("");
+            const int nr3 = c.rows * 3;
+            const size_t o3 = (size_t)c.b0 * c.N * 3;
+            if (a.mode == DFF_MODE_SCORE) {
+                for (int i = tid; i < nr3; i += DFF_NTHREADS) a.force_out[o3 + i] = qnan;
+                if (a.energy_out) for (int i = tid; i < c.rows; i += DFF_NTHREADS) a.energy_out[(size_t)c.b0 * c.N + i] = qnan;
+            } else if (a.mode == DFF_MODE_LANGEVIN) {
+                const int nf = a.n_steps / (a.save_interval > 0 ? a.save_interval : 1);
+                for (int f = 0; f < nf; ++f) {
+                    if (a.frames) for (int i = tid; i < nr3; i += DFF_NTHREADS) a.frames[(size_t)f * a.B * c.N * 3 + o3 + i] = qnan;
+                    if (a.ke && tid < c.gcnt) a.ke[(size_t)f * a.B + c.b0 + tid] = qnan;
+                }
+            } else {
+                for (int i = tid; i < nr3; i += DFF_NTHREADS) a.x_io[o3 + i] = qnan;
+            }
+            return;
+        }
     }
     // PAIR, same-XCD fast path (round 4).  The two blocks of a pair exchange 13 partial tiles per step through agent-scope
     // (sc1) stores and loads, which are written through to / served from memory because the XCDs' L2s are not coherent with
@@ -2293,7 +2318,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     break;
                 }
             }
-            ((unsigned*)smem)[ll.junk] = (theirs == my_xcc && !a.xslow) ? 1u : 0u;
+            ((unsigned*)smem)[ll.junk] = (theirs == my_xcc && a.xslow != 1) ? 1u : 0u;
         }
         __syncthreads();
         xfast = ((const unsigned*)smem)[ll.junk] != 0u;
@@ -2405,10 +2430,10 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             constexpr int DWO = 2 * HGS < 4 ? 2 * HGS : 4;
             auto wo_gemm = [&](int hg, auto pre, u32x4 (&bw)[DWO][NTW][3]) {
                 ExtW<NTW, HGS> ew;
-                if constexpr (DFF_EXTPRE) ext_fetch<NTW, HGS>(ew, [=](int i) { return (hg * HGS + i) * 5 + 4; }, lw.Wox_p, DFF_HEADS * 5, NT_H);
+                if constexpr (DFF_EXTPRE) ext_fetch<NTW, HGS, MT>(ew, [=](int i) { return (hg * HGS + i) * 5 + 4; }, lw.Wox_p, DFF_HEADS * 5, NT_H);
                 gemm_tall_split_st_b<MT, NTW, 2 * HGS, decltype(pre)::value>(acc_o, (64 * HGS + DFF_SPAD) / 2, (const lu32*)(geo.Rg + 3 * RN * LQ), RN, RN,
                                                      lw.Wox_s, 2 * DFF_HEADS, hg * HGS * 2, NT_H, bw);
-                if constexpr (!DFF_EXTPRE) ext_fetch<NTW, HGS>(ew, [=](int i) { return (hg * HGS + i) * 5 + 4; }, lw.Wox_p, DFF_HEADS * 5, NT_H);
+                if constexpr (!DFF_EXTPRE) ext_fetch<NTW, HGS, MT>(ew, [=](int i) { return (hg * HGS + i) * 5 + 4; }, lw.Wox_p, DFF_HEADS * 5, NT_H);
                 if (oxt) ext_apply<MT, NTW, HGS>(acc_o, ew, [=](int i) { return i * 16; }, oxt, 16 * HGS, RN, NT_H);
                 else ext_apply<MT, NTW, HGS>(acc_o, ew, [=](int i) { return i * 80 + 64; }, geo.Rg, LQ, RN, NT_H);
             };
@@ -2454,7 +2479,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     else if (!more) l2_w1(lw, ch_lo);
                     u32x4 bw[DWO][NTW][3];
                     constexpr bool WOPRE = DFF_WOPRE;   // W_o's operands cross the barrier in registers
-                    if constexpr (WOPRE) tall_ring_fill<NTW, DWO>(bw, lw.Wox_s, 2 * DFF_HEADS, hg * HGS * 2, NT_H);
+                    if constexpr (WOPRE) tall_ring_fill<NTW, DWO, MT>(bw, lw.Wox_s, 2 * DFF_HEADS, hg * HGS * 2, NT_H);
                     wg_sync<SPILL>();
                     pf.tick(4);
                     float bias4[CNTH][4];
@@ -2728,9 +2753,9 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         wg_sync<SPILL>();
                         pf.tick(18);
                         ExtW<NTW, HGS> ew;
-                        if constexpr (DFF_EXTPRE) ext_fetch<NTW, HGS>(ew, [=](int i) { return (hg * HGS + i) * 13 + 4; }, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
+                        if constexpr (DFF_EXTPRE) ext_fetch<NTW, HGS, MT>(ew, [=](int i) { return (hg * HGS + i) * 13 + 4; }, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
                         gemm_tall_qkvT_split<MT, NTW, HGS, LL::KVS, LL::VSP, 0, LL::KVS && DFF_QSP>(acc_a, geo.Rg, 4, RN, lw.WqkvxT_s, hg * HGS, NT_H, geo.lsp, bq, geo.lsq);
-                        if constexpr (!DFF_EXTPRE) ext_fetch<NTW, HGS>(ew, [=](int i) { return (hg * HGS + i) * 13 + 4; }, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
+                        if constexpr (!DFF_EXTPRE) ext_fetch<NTW, HGS, MT>(ew, [=](int i) { return (hg * HGS + i) * 13 + 4; }, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
                         ext_apply<MT, NTW, HGS>(acc_a, ew, [=](int i) { return 4 * RN * LQ + i * 80 + 64; }, geo.Rg, LQ, RN, NT_H);
                     } else {
                         co_dv_dk<MT, HGS, true, GEN>(geo);
@@ -2828,12 +2853,12 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     if constexpr (SPW) {
                         u32x4 bq[4][NTW][3];
                         ExtW<NTW, HGS> ew;
-                        if constexpr (DFF_EXTPRE) ext_fetch<NTW, HGS>(ew, [=](int i) { return (hg * HGS + i) * 13 + 4; }, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
+                        if constexpr (DFF_EXTPRE) ext_fetch<NTW, HGS, MT>(ew, [=](int i) { return (hg * HGS + i) * 13 + 4; }, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
                         {
                             constexpr bool RP = MT == 4 && HGS == 1 && !GEN && DFF_DQKV_ROWS && DFF_PSPLIT;   // co_dqkv_rows<..., PSPLIT>
                             gemm_tall_qkvT_split<MT, NTW, HGS, LL::KVS || RP, LL::VSP, 0, (LL::KVS && DFF_QSP) || RP>(acc_a, geo.Rg, FIVE ? 4 : 3, RN, lw.WqkvxT_s, hg * HGS, NT_H, geo.lsp, bq, geo.lsq);
                         }
-                        if constexpr (!DFF_EXTPRE) ext_fetch<NTW, HGS>(ew, [=](int i) { return (hg * HGS + i) * 13 + 4; }, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
+                        if constexpr (!DFF_EXTPRE) ext_fetch<NTW, HGS, MT>(ew, [=](int i) { return (hg * HGS + i) * 13 + 4; }, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
                         ext_apply<MT, NTW, HGS>(acc_a, ew, [=](int i) { return (FIVE ? 4 : 3) * RN * LQ + i * 80 + 64; }, geo.Rg, LQ, RN, NT_H);
                     } else
                     gemm_tall_kb_st<MT, NTW, 13, 13 * HGS>(acc_a,
@@ -3013,7 +3038,14 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_debug_gemm_kernel(const floa
 // variant table handed to the host dispatcher (dff_host.hip); taking the kernels' addresses instantiates them
 // ------------------------------------------------------------------------------------------
 template <int H, int MT, int HGS, bool SP, bool SPW>
-static unsigned lds_floats_of(int N, int G) { return LdsLayout<H, MT, HGS, SP>(N, G, SPW).total; }
+static unsigned lds_floats_of(int N, int G) {
+    // The TIGHT tile arrays (LdsLayout: 16 MT - 4 = 60 columns, no pad rows) are correct for at most 16 MT - 4 bead rows:
+    // the k-step over columns 60..63 is skipped because it would only hold pad beads.  Today the LDS budget already turns
+    // away 57+ rows; say so explicitly instead of relying on it: "does not fit", the dispatcher moves on.
+    using LL = LdsLayout<H, MT, HGS, SP>;
+    if (SPW && LL::TIGHT_OK && G * N > LL::PL_TIGHT) return 0x3fffffffu;   // (x 4 bytes still fits 32 bits)
+    return LL(N, G, SPW).total;
+}
 #define VAR(H, MT, HGS, SP)                                                                                     \
     { H, MT, HGS, SP, false, false, (const void*)&dff_fused_kernel<H, MT, HGS, SP, false, false>,               \
       &lds_floats_of<H, MT, HGS, SP, false>, "dff_fused_kernel<" #H "," #MT "," #HGS "," #SP ">" },             \
