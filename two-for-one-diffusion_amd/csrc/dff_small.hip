@@ -520,6 +520,12 @@ DEVI f32x4 wv_dot_rows(const lfloat* A, const lfloat* B, int lane) {
 template <int NT0, int NT1, bool TRANS, int XLD = DFF_XLD, class Epi>
 DEVI void wv_mm(const lfloat* T, const lfloat* B, int lane, int ks, Epi epi) {
     const int kk = lane >> 4, mm = lane & 15;
+    // (DFF_TIMING_NOCONF: timing-only builds for the bank-conflict question -- the column reads of B and the transposed reads of T
+    // use a row stride of 16 mod 64 dwords, which is conflict-free for them (and reads the wrong data): bit 0 = B, bit 1 = T)
+#ifndef DFF_TIMING_NOCONF
+#define DFF_TIMING_NOCONF 0
+#endif
+    constexpr int XB = (DFF_TIMING_NOCONF & 1) ? 80 : XLD, TP = (DFF_TIMING_NOCONF & 2) ? 16 : DFF_PLD;
     // k-step s covers k = 4 s .. 4 s + 3 (lane: k = 4 s + kk), so trailing all-zero k-steps can be dropped
     // (volatile: the operands of k-steps 1..3 are only used inside the row-count branches below, and the compiler sinks a
     // plain LDS read into the branch that uses it -- every product then waits out the latency of its own operands)
@@ -530,12 +536,12 @@ DEVI void wv_mm(const lfloat* T, const lfloat* B, int lane, int ks, Epi epi) {
 #endif
     float as[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) as[s] = TRANS ? *(vlp)(T + (4 * s + kk) * DFF_PLD + mm) : *(vlp)(T + mm * DFF_PLD + 4 * s + kk);
+    for (int s = 0; s < 4; ++s) as[s] = TRANS ? *(vlp)(T + (4 * s + kk) * TP + mm) : *(vlp)(T + mm * DFF_PLD + 4 * s + kk);
     float bv[NT1 - NT0][4];
 #pragma unroll
     for (int nt = NT0; nt < NT1; ++nt)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) bv[nt - NT0][s] = *(vlp)(B + (4 * s + kk) * XLD + 16 * nt + mm);
+        for (int s = 0; s < 4; ++s) bv[nt - NT0][s] = *(vlp)(B + (4 * s + kk) * XB + 16 * nt + mm);
     f32x4 acc[NT1 - NT0];
 #pragma unroll
     for (int nt = 0; nt < NT1 - NT0; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -725,7 +731,12 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             const int kb = cl >> 5, kk = cl & 31, kg = (kk & 15) >> 2, j = ((kk >> 4) << 2) | (kk & 3);
             lu16* const q = asp16 + ((((kb * 4 + kg) * 16 + row) * 4 + (j >> 1)) * 2 + (j & 1));
             constexpr int PS = (H / 32) * 256 * 2;   // halfwords per piece
+#if DFF_TIMING_NOCONF & 4   // timing-only: the three 16-bit stores of a lane land in its own bank (wrong layout)
+            lu16* const q2 = asp16 + ((threadIdx.x & 63) * 2 + ((cl >> 5) & 1) * 128) % (3 * PS - 2 * 128);
+            q2[0] = (unsigned short)(b >> 16); q2[256] = (unsigned short)(c >> 16); q2[512] = (unsigned short)(__float_as_uint(s2) >> 16);
+#else
             q[0] = (unsigned short)(b >> 16); q[PS] = (unsigned short)(c >> 16); q[2 * PS] = (unsigned short)(__float_as_uint(s2) >> 16);
+#endif
         } else {
             abuf[row * LH + cl] = v;
         }
