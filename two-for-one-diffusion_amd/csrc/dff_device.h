@@ -67,23 +67,41 @@ struct WPtr {
     }
     DEVI float first_float(size_t i) const { return *(const gfloat*)(base + i + lo); }
 };
+// Cache policy of the stash traffic that is written once and read once (per head: q_ext | k | v rows, P, gelu'(h_pre) out; the
+// backward's head reload and its gelu' rows in).  POL bit 0: non-temporal LOADS, bit 1: non-temporal STORES.  Round 5, us / step
+// (sites: 1 head reload, 2 q|k|v out, 4 P out, 8 gelu' out, 16 gelu' in; DFF_STASH_SITES forces a site mask):
+//   villin (three row tiles, 1.3 MB of stash per protein and step)   none 493-504 | 1: 478 | 1+16: 477.6 | 1+2 / 1+4 / 1+8: 480-481 | all stores too: 488.5
+//   protein G, two workgroups per protein (four row tiles)           none 482-488 | 1: 473-475 | 1+16: 426-430 | 1+2: 428.5 | 1+4: 428-433 | 1+2+4+8: 432 | all: 434
+//   protein G at 256 per GPU (one workgroup per protein)             none 818-825 | 1+2+4+8: 745 | all: 748
+//   trp-cage / BBA (two row tiles), loads | stores non-temporal: +1 % | +2-3.5 %  -> default policy
+// A stash line that is read exactly once should not stay in the XCD's 4 MB L2 next to the weight images every workgroup
+// streams: with three / four row tiles the resident workgroups' stash outgrows it (L2 hit rate 0.87 / 0.76 in profiles/r04).
+// Both load sites go non-temporal there, the stores keep the default policy (they are what the loads then find in the MALL).
+// DFF_STASH_NT >= 0 forces one policy everywhere (0 = default, 1 = loads, 2 = stores, 3 = both).  The <= 16-row kernels keep
+// the default (round 2: -3 % with both non-temporal; the headline variant has no stash traffic in the sampling loops at all).
 #ifndef DFF_STASH_NT
-#define DFF_STASH_NT 0   // 1: non-temporal stash traffic. Measured: default policy is 3% faster (stash stays in L2/MALL)
+#define DFF_STASH_NT -1
 #endif
-#if DFF_STASH_NT
-DEVI void st_ntg(gfloat* p, float v) { __builtin_nontemporal_store(v, p); }
-DEVI float ld_ntg(const gfloat* p) { return __builtin_nontemporal_load(p); }
-DEVI f32x4 ld_ntg4(const gfloat* p) { return __builtin_nontemporal_load((const gf32x4*)p); }
-DEVI void st_ntg4(gfloat* p, const f32x4 v) { __builtin_nontemporal_store(v, (gf32x4*)p); }
-#else
-DEVI void st_ntg(gfloat* p, float v) { *p = v; }
-DEVI float ld_ntg(const gfloat* p) { return *p; }
-DEVI f32x4 ld_ntg4(const gfloat* p) { return *(const gf32x4*)p; }
-DEVI void st_ntg4(gfloat* p, const f32x4 v) { *(gf32x4*)p = v; }
+#define DFF_STASH_POL(MT) (DFF_STASH_NT >= 0 ? DFF_STASH_NT : ((MT) >= 3 ? 1 : 0))
+// per-site form for experiments: DFF_STASH_SITES = bit mask of the sites that go non-temporal (whatever MT) --
+//   1 head reload (q_ext | k | v | P in), 2 q_ext | k | v out, 4 P out, 8 gelu' out, 16 gelu' in;  < 0: DFF_STASH_POL(MT) at every site
+#ifndef DFF_STASH_SITES
+#define DFF_STASH_SITES -1
 #endif
+#define DFF_SITE_LD(MT, bit) (DFF_STASH_SITES >= 0 ? ((DFF_STASH_SITES & (bit)) ? 1 : 0) : (DFF_STASH_POL(MT) & 1))
+#define DFF_SITE_ST(MT, bit) (DFF_STASH_SITES >= 0 ? ((DFF_STASH_SITES & (bit)) ? 2 : 0) : (DFF_STASH_POL(MT) & 2))
+template <int POL = 0> DEVI void st_ntg(gfloat* p, float v) { if constexpr (POL & 2) __builtin_nontemporal_store(v, p); else *p = v; }
+template <int POL = 0> DEVI float ld_ntg(const gfloat* p) { if constexpr (POL & 1) return __builtin_nontemporal_load(p); else return *p; }
+template <int POL = 0> DEVI f32x4 ld_ntg4(const gfloat* p) {
+    if constexpr (POL & 1) return __builtin_nontemporal_load((const gf32x4*)p); else return *(const gf32x4*)p;
+}
+template <int POL = 0> DEVI void st_ntg4(gfloat* p, const f32x4 v) {
+    if constexpr (POL & 2) __builtin_nontemporal_store(v, (gf32x4*)p); else *(gf32x4*)p = v;
+}
 // four consecutive floats (16-byte aligned) into a scalar aux array of an epilogue
+template <int POL = 0>
 DEVI void ld4_aux(float* aux, const gfloat* p) {
-    const f32x4 v = *(const gf32x4*)p;
+    const f32x4 v = ld_ntg4<POL>(p);
     aux[0] = v[0]; aux[1] = v[1]; aux[2] = v[2]; aux[3] = v[3];
 }
 

@@ -1611,7 +1611,7 @@ DEVI void co_softmax_pv(const CoGeo& g, gfloat* sP /* P block of head hg*HGS */,
                 for (int jt = 0; jt < MT; ++jt) {
                     const float p = gi >= 0 ? e[jt] * rden : 0.f;
                     if (!TIGHT || (i < g.RN && 16 * jt + col < PL)) pl[16 * jt] = p;
-                    if (gi >= 0) st_ntg(ps + 16 * jt, p);
+                    if (gi >= 0) st_ntg<DFF_SITE_ST(MT, 4)>(ps + 16 * jt, p);
                 }
             }
         }
@@ -1643,7 +1643,7 @@ DEVI void co_softmax_pv(const CoGeo& g, gfloat* sP /* P block of head hg*HGS */,
                 const float D = quad_sum(tq);
                 if (row < g.rows) {
                     g.Rg[row * LQ + hh * 80 + 64 + col] = col < 3 ? e - xr : col == 3 ? D : 0.f;
-                    if (col < 4) st_ntg(sM + ((size_t)hh * g.RN + row) * 4 + col, e);
+                    if (col < 4) st_ntg<DFF_SITE_ST(MT, 4)>(sM + ((size_t)hh * g.RN + row) * 4 + col, e);
                 }
             }
         }
@@ -1726,7 +1726,7 @@ DEVI void co_softmax_pv_t(const CoGeo& g, gfloat* sP /* P block of head hg*HGS *
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 p[jt][r] *= rden;
-                st_ntg(gi >= 0 ? ps + 16 * jt + 4 * r : junk, p[jt][r]);
+                st_ntg<DFF_SITE_ST(MT, 4)>(gi >= 0 ? ps + 16 * jt + 4 * r : junk, p[jt][r]);
             }
         // o^T = (P V_ext)^T: first operand = V_ext (k = bead, column n), second = P from the registers
         f32x4 o[5];
@@ -2068,7 +2068,7 @@ DEVI void co_reload_issue(CoReload<MT, HGS>& rl, const gfloat* sqkv /* head hg*H
     for (int u = 0; u < RL::U; ++u) {
         const unsigned code = rl.code[u];
         const gfloat* const base = (code >> 28 & 1u) ? sqkv : sP;
-        rl.t[u] = ld_ntg4(base + 4 * (code & 0x3fffu));
+        rl.t[u] = ld_ntg4<DFF_SITE_LD(MT, 1)>(base + 4 * (code & 0x3fffu));
     }
     // without this the compiler sinks the loads down to their use in co_reload_commit (no global store in between)
     asm volatile("" ::: "memory");
@@ -2455,7 +2455,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         const bool ok = valid && row < rows;
                         const f32x4 v = acc + (f32x4){aux[0], aux[1], aux[2], aux[3]};
                         if (ok) *(lf32x4*)(Rl + reg * RN * LQ + row * LQ + hh * 80 + 16 * (tt - 5 * reg + (reg >> 1)) + c4) = v;
-                        st_ntg4(ok ? sq + (size_t)hh * RN * DFF_QKVW + (size_t)row * DFF_QKVW + 16 * tt + c4 : junk, v);
+                        st_ntg4<DFF_SITE_ST(MT, 2)>(ok ? sq + (size_t)hh * RN * DFF_QKVW + (size_t)row * DFF_QKVW + 16 * tt + c4 : junk, v);
                     };
                 };
                 gemm_wide_split_st<MT, H / 32, NTQ, 4>(asplit, RN, RN, lw.Wqkvx_s, hg_lo * NTQ, mk_pre(hg_lo), mk_epi(hg_lo));
@@ -2525,7 +2525,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                             const bool ok = valid && row < rows;
                             const f32x4 v = acc + (f32x4){aux[0], aux[1], aux[2], aux[3]};
                             if (ok) *(lf32x4*)(Rl + reg * RN * LQ + row * LQ + hh * 80 + 16 * (tt - 5 * reg + (reg >> 1)) + c4) = v;
-                            st_ntg4(ok ? sq + (size_t)hh * RN * DFF_QKVW + (size_t)row * DFF_QKVW + 16 * tt + c4 : junk, v);
+                            st_ntg4<DFF_SITE_ST(MT, 2)>(ok ? sq + (size_t)hh * RN * DFF_QKVW + (size_t)row * DFF_QKVW + 16 * tt + c4 : junk, v);
                         };
                     if constexpr (SPW)
                         if constexpr (MT >= 4 && DFF_K2) gemm_wide_split_k2<MT, H / 32, HGS * 13, 4>(asplit, RN, RN, lw.Wqkvx_s, hg * HGS * 13, qkv_pre, qkv_epi);
@@ -2584,7 +2584,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                             f32x4 gv, gp;
 #pragma unroll
                             for (int r = 0; r < 4; ++r) { float v_, p_; gelu_both(acc[r] + aux[r], v_, p_); gv[r] = v_; gp[r] = p_; }
-                            st_ntg4(ok ? shp + (size_t)row * F + cl : junk, gp);   // the slot "h_pre" holds gelu'(h_pre)
+                            st_ntg4<DFF_SITE_ST(MT, 8)>(ok ? shp + (size_t)row * F + cl : junk, gp);   // the slot "h_pre" holds gelu'(h_pre)
                             if (ok) {
                                 if constexpr (SPW) store_split4((lu32*)hl, RN, (FC + DFF_SPAD) / 2, row, cl, gv);
                                 else *(lf32x4*)(hl + row * LF + cl) = gv;
@@ -2638,7 +2638,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                             const int lane = tid & 63, cl = 16 * nt + 4 * (lane >> 4);
 #pragma unroll
                             for (int mt = 0; mt < MT; ++mt)
-                                ld4_aux(aux + 4 * mt, shp + (size_t)min(mt * 16 + (lane & 15), rows - 1) * F + cl);
+                                ld4_aux<DFF_SITE_LD(MT, 16)>(aux + 4 * mt, shp + (size_t)min(mt * 16 + (lane & 15), rows - 1) * F + cl);
                         };
                     auto w2t_epi = [=](int nt, int mt, const f32x4& acc, const float (&aux)[4 * MT], bool valid, int) {
                             const int lane = tid & 63, cl = 16 * nt + 4 * (lane >> 4), row = mt * 16 + (lane & 15);
@@ -2814,7 +2814,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     if (GEN) {   // [m1 | m2] rows of this head group (contiguous in the stash and in LDS); before the
                                  // next group's rows are requested: a load issued after them would wait for them
                         const gfloat* const sM = (const gfloat*)sb + c.sl.m12 + (size_t)hg * HGS * RN * 4;
-                        for (int i2 = tid; i2 < HGS * RN * 4; i2 += DFF_NTHREADS) geo.m12[i2] = ld_ntg(sM + i2);
+                        for (int i2 = tid; i2 < HGS * RN * 4; i2 += DFF_NTHREADS) geo.m12[i2] = ld_ntg<DFF_SITE_LD(MT, 1)>(sM + i2);
                     }
                     if (hg + 1 < hg_hi)
                         co_reload_issue<MT, HGS>(rl, sqkv + (size_t)(hg + 1) * HGS * RN * DFF_QKVW,

@@ -31,6 +31,27 @@
 #else
 #define DFF_MARK(n) ((void)0)
 #endif
+// DFF_PRIO (experiments): s_setprio by phase and SIMD sibling.  The two waves of a SIMD (w, w + 4) share its issue ports and
+// matrix pipe; the hardware favours the older one, the block between two barriers ends with the slower one.
+//   1 / 2: waves >= 4 / < 4 raised inside the wave-private blocks;  3 / 4: raised in the GEMM phases for waves >= 4 / < 4 and
+//   in the attention-math phases for the other half (skews the siblings against each other: GEMM of one under attention of the other)
+#ifndef DFF_PRIO
+#define DFF_PRIO 0
+#endif
+template <int N>
+DEVI void phase_prio(int wave) {
+    if constexpr (DFF_PRIO != 0) {
+        constexpr bool att = N == 12 || N == 15;
+        constexpr bool gemm = N == 1 || N == 13 || N == 17 || N == 8 || N == 3 || N == 6 || N == 19;
+        constexpr bool row = N == 2 || N == 4 || N == 7 || N == 9 || N == 5 || N == 10;
+        const bool hiw = (wave >= 4) == (DFF_PRIO == 1 || DFF_PRIO == 3);
+        if (row) __builtin_amdgcn_s_setprio(0);
+        else if (att || gemm) {
+            const bool up = (DFF_PRIO <= 2) ? hiw : (gemm ? hiw : !hiw);
+            if (up) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+        }
+    }
+}
 #ifndef DFF_SDR
 #define DFF_SDR 4   // split-ring depth in units (SPW variants)
 #endif
@@ -554,6 +575,19 @@ DEVI void wv_mm(const lfloat* T, const lfloat* B, int lane, int ks, Epi epi) {
         }
 #pragma unroll
     for (int nt = NT0; nt < NT1; ++nt) epi(nt, acc[nt - NT0]);
+}
+
+// all five tiles of a head product; SPLIT: as {0, 1, 2} | {3, 4} -- 28 instead of 44 operand + accumulator registers live at once
+// (the hidden-96 kernels sit at the 256-VGPR limit of two waves per SIMD in exactly these phases: DFF_MM_SPLIT)
+#ifndef DFF_MM_SPLIT
+#define DFF_MM_SPLIT 1
+#endif
+template <bool SPLIT, bool TRANS, int XLD = DFF_XLD, class Epi>
+DEVI void wv_mm5(const lfloat* T, const lfloat* B, int lane, int ks, Epi epi) {
+    if constexpr (SPLIT) {
+        wv_mm<0, 3, TRANS, XLD>(T, B, lane, ks, epi);
+        wv_mm<3, 5, TRANS, XLD>(T, B, lane, ks, epi);
+    } else wv_mm<0, 5, TRANS, XLD>(T, B, lane, ks, epi);
 }
 
 // q_ext / k / v / P of one (layer, head) travelling stash -> registers -> LDS (16 rows each;
@@ -1236,7 +1270,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         } }
         if (step == 0) centre();
         if (step == 0 || !cached0) __syncthreads();   // (later steps: the barrier that ended the previous update stage)
-        pf.tick(0); DFF_MARK(0);
+        pf.tick(0); DFF_MARK(0); phase_prio<0>(wave);
 
         // =============================== forward ===============================
         if (!cached0) {
@@ -1318,7 +1352,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 }
                 __syncthreads();
             }
-            pf.tick(1); DFF_MARK(1);
+            pf.tick(1); DFF_MARK(1); phase_prio<1>(wave);
             // ---- attention block: wave w owns heads w and w+4 (ring holds the first entries) ----
             {
                 DFF_LANE_CONSTS
@@ -1367,7 +1401,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     if (p0keep) p0_copy(true, pcij);
                     else if (st_qkv) *(gf32x4*)(sb + sl.P + (size_t)h * 256 + 4 * lane) = *(const lf32x4*)(pb + (lane >> 2) * DFF_PLD + 4 * (lane & 3));
                     // O_ext = P V_ext (5 tiles) -> Q region; extension columns become xrel = xbar - x_i
-                    wv_mm<0, 5, false, XLD>(pb, Vx, lane, ks4, [&](int nt, const f32x4& acc) {
+                    wv_mm5<(DFF_MM_SPLIT && H > 64), false, XLD>(pb, Vx, lane, ks4, [&](int nt, const f32x4& acc) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             float v = acc[r];
@@ -1399,12 +1433,12 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                             head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
                             head_commit(hr, Qx, Kx, Vx, pb, true, false, lane, RLA, XLD);
                         }
-                        pf.tick(12); DFF_MARK(12);
+                        pf.tick(12); DFF_MARK(12); phase_prio<12>(wave);
                         head_math(wave);
-                        pf.tick(13); DFF_MARK(13);
+                        pf.tick(13); DFF_MARK(13); phase_prio<13>(wave);
                         const SSeq<U_WOX, 0, MW, KO, KO, 0, 0, E> sq{ss_wox(lw, wave), ss_wox(lw, wave), sn0, sn1};
                         stall_run<0, 2, E, true>(sring, acc_o, wox_fa32, sq, lane, wox_xa, wox_ext(lw, wave, lane), DFF_HEADS * 5 * 256);
-                        pf.tick(14); DFF_MARK(14);
+                        pf.tick(14); DFF_MARK(14); phase_prio<14>(wave);
                     } else {
                         u32x4 ah[KB32], am[KB32], al[KB32];
                         a_load(ah, am, al, lane);
@@ -1414,7 +1448,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         lfloat* const wq = wr + col;
                         float bq[2][1];
                         bq[0][0] = bh[0]; bq[1][0] = bh[16];
-                        pf.tick(1); DFF_MARK(1);
+                        pf.tick(1); DFF_MARK(1); phase_prio<1>(wave);
                         const SSeq<U_QKV, U_WOX, MW, KQ, KO, 0, 0, E, 4 * KB32> sq{ss_qkv(lw, wave), ss_wox(lw, wave), sn0, sn1};   // tile 4 of 13: [u | s]
                         swide_run<0, NQT, KB32, 1>(sring, bq, ah, am, al, sq, lane,
                             [=](int t, float (&ax)[1]) { ax[0] = bh[t * 16]; },
@@ -1426,12 +1460,12 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                                 dl[l0] = v0; dl[l1] = v1; dl[l2] = v2; dl[l3] = v3;
                             });
                         if (st_qkv) head_store<FOLD>(Qx, Kx, Vx, sb + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, RA, lane, RLA, XLD);
-                        pf.tick(12); DFF_MARK(12);
+                        pf.tick(12); DFF_MARK(12); phase_prio<12>(wave);
                         head_math(wave);
                         if constexpr (KEEP2) { if (keep2) keep2_copy(Qx, Qsave, true, lane, pcij); }
-                        pf.tick(13); DFF_MARK(13);
+                        pf.tick(13); DFF_MARK(13); phase_prio<13>(wave);
                         stall_run<U_QKV, 2, E, true>(sring, acc_o, wox_fa32, sq, lane, wox_xa, wox_ext(lw, wave, lane), DFF_HEADS * 5 * 256);
-                        pf.tick(14); DFF_MARK(14);
+                        pf.tick(14); DFF_MARK(14); phase_prio<14>(wave);
                     }
                 } else if (cached) {
                     // layer-0 q_ext / k / v are x-independent and t is fixed: re-read, no GEMM
@@ -1483,28 +1517,28 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     };
                     float bq[DR][1];
                     qkv_bias(std::integral_constant<int, 0>{}, wave, bq);
-                    pf.tick(1); DFF_MARK(1);
+                    pf.tick(1); DFF_MARK(1); phase_prio<1>(wave);
                     if constexpr (HPW == 2) {
                         qkv(std::integral_constant<int, 0>{}, wave, bq, s_wox(lw, wave));
-                        pf.tick(12); DFF_MARK(12);
+                        pf.tick(12); DFF_MARK(12); phase_prio<12>(wave);
                         qkv_bias(std::integral_constant<int, 2>{}, wave + 4, bq);
                         head_math(wave);
-                        pf.tick(13); DFF_MARK(13);
+                        pf.tick(13); DFF_MARK(13); phase_prio<13>(wave);
                         tall_run<1, 5, E, 4>(ring, acc_o, wox_fa, s_wox(lw, wave), s_qkv(lw, wave + 4), lane);
-                        pf.tick(14); DFF_MARK(14);
+                        pf.tick(14); DFF_MARK(14); phase_prio<14>(wave);
                         qkv(std::integral_constant<int, 2>{}, wave + 4, bq, s_wox(lw, wave + 4));
-                        pf.tick(12); DFF_MARK(12);
+                        pf.tick(12); DFF_MARK(12); phase_prio<12>(wave);
                         head_math(wave + 4);
-                        pf.tick(13); DFF_MARK(13);
+                        pf.tick(13); DFF_MARK(13); phase_prio<13>(wave);
                         tall_run<3, 5, E, 4>(ring, acc_o, wox_fa, s_wox(lw, wave + 4), after, lane);   // ends at phase 0
-                        pf.tick(14); DFF_MARK(14);
+                        pf.tick(14); DFF_MARK(14); phase_prio<14>(wave);
                     } else {
                         qkv(std::integral_constant<int, 0>{}, wave, bq, s_wox(lw, wave));
-                        pf.tick(12); DFF_MARK(12);
+                        pf.tick(12); DFF_MARK(12); phase_prio<12>(wave);
                         head_math(wave);
-                        pf.tick(13); DFF_MARK(13);
+                        pf.tick(13); DFF_MARK(13); phase_prio<13>(wave);
                         tall_run<13 % DR, 5, E, 4>(ring, acc_o, wox_fa, s_wox(lw, wave), after, lane);       // 18 entries: phase 0
-                        pf.tick(14); DFF_MARK(14);
+                        pf.tick(14); DFF_MARK(14); phase_prio<14>(wave);
                         static_assert(18 % DR == 0, "ring phase");
                     }
                 }
@@ -1512,7 +1546,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 for (int nt = 0; nt < E; ++nt) c_store_offs(mypart, mro, 16 * nt, acc_o[nt], lane);
             }
             __syncthreads();
-            pf.tick(2); DFF_MARK(2);
+            pf.tick(2); DFF_MARK(2); phase_prio<2>(wave);
             // ---- row stage B: attn_out = sum_w part + bo ; gate1 ; LN2 -> abuf ----
             { DFF_ROW_CONSTS
             if (ract) {
@@ -1543,7 +1577,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 if (l + 1 < m.L) { ro_load(4, m.layer[l + 1].ln1_g, sub); ro_load(5, m.layer[l + 1].ln1_b, sub); }
             } }
             __syncthreads();
-            pf.tick(3); DFF_MARK(3);
+            pf.tick(3); DFF_MARK(3); phase_prio<3>(wave);
             // ---- FFN: wave w owns hidden columns [w H, (w+1) H) ----
             {
                 DFF_LANE_CONSTS
@@ -1585,10 +1619,10 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     if constexpr (SPW) {
                         u32x4 ah[KB32], am[KB32], al[KB32];
                         a_load(ah, am, al, lane);
-                        pf.tick(19); DFF_MARK(19);
+                        pf.tick(19); DFF_MARK(19); phase_prio<19>(wave);
                         if (lastl) swide_run<0, NTS, KB32, 1>(sring, b1r, ah, am, al, sqf_last, lane, w1_pre, w1_epi);
                         else swide_run<0, NTS, KB32, 1>(sring, b1r, ah, am, al, sqf_next, lane, w1_pre, w1_epi);
-                        pf.tick(20); DFF_MARK(20);
+                        pf.tick(20); DFF_MARK(20); phase_prio<20>(wave);
                     } else
                     wide_run<0, NTS, E, 1>(ring, b1r, afr, s_w1(lw), s_w2(lw), lane, w1_pre, w1_epi);
                 }
@@ -1602,7 +1636,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         else stall_run<U_W1, FS / 32, E, false>(sring, acc_f, [=](int kb) { return ha + 32 * kb; }, sqf_next, lane);
                     }
                     else tall_run<NTS % DR, NTS, E, -1>(ring, acc_f, [=](int kb) { return ha + 16 * kb; }, s_w2(lw), after, lane);
-                    pf.tick(21); DFF_MARK(21);
+                    pf.tick(21); DFF_MARK(21); phase_prio<21>(wave);
                     // gelu'(h_pre) rows of this wave's hidden slice: LDS tile -> stash, 16 bytes per lane (rows beyond the real
                     // ones go to the dummy stash row); before the partial sums below reuse the tile
                     if (!gp_lds) {
@@ -1620,7 +1654,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 for (int nt = 0; nt < E; ++nt) c_store_offs(mypart, mro, 16 * nt, acc_f[nt], lane);
             }
             __syncthreads();
-            pf.tick(4); DFF_MARK(4);
+            pf.tick(4); DFF_MARK(4); phase_prio<4>(wave);
             // ---- row stage C: ff = sum_w part + b2 ; gate2 ; next layer's LN1 or the energy head ----
             { DFF_ROW_CONSTS
             if (ract) {
@@ -1690,7 +1724,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             // the stash written in the forward pass is re-read below by other lanes / waves
             if (l == m.L - 1) __threadfence_block();
             __syncthreads();
-            pf.tick(5); DFF_MARK(5);
+            pf.tick(5); DFF_MARK(5); phase_prio<5>(wave);
         }
 
         // =============================== backward ===============================
@@ -1757,7 +1791,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             }
             __syncthreads();
             }
-            pf.tick(6); DFF_MARK(6);
+            pf.tick(6); DFF_MARK(6); phase_prio<6>(wave);
             // ---- FFN backward slice: dh = dff W2[:, slice] ; * gelu'(h_pre) ; partial df = dh_pre W1[slice, :] ----
             {
                 DFF_LANE_CONSTS
@@ -1822,7 +1856,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 for (int nt = 0; nt < E; ++nt) c_store_offs(mypart, mro, 16 * nt, acc_f[nt], lane);
             }
             __syncthreads();
-            pf.tick(7); DFF_MARK(7);
+            pf.tick(7); DFF_MARK(7); phase_prio<7>(wave);
             // first head of this layer's attention backward: start the stash read (hidden by row stage E)
             if constexpr (HDMA) {
                 if (!(KEEP_LAST && l == m.L - 1 && l > 0) && !(KEEP2 && l == m.L - 2 && l > 0 && MODE != DFF_MODE_SCORE))
@@ -1841,11 +1875,11 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 float n1[HC], d1[HC], dyg[HC], xh[HC], ps[HC], ao[HC], ni[HC];
                 rows_of(l, ao, ni, nullptr, 0);
                 psum_all(ps, rrow * LH + sub);
-                pf.tick(22); DFF_MARK(22);
+                pf.tick(22); DFF_MARK(22); phase_prio<22>(wave);
                 float g1;
                 if constexpr (KEEPROWS) g1 = gate_get(l, std::integral_constant<int, 0>{});
                 else g1 = ro_gate(ao, ni, 3);
-                pf.tick(23); DFF_MARK(23);
+                pf.tick(23); DFF_MARK(23); phase_prio<23>(wave);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) n1[i] = ao[i] * g1 + ni[i] * (1.0f - g1);
                 float mean, rstd;
@@ -1898,7 +1932,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 if constexpr (KEEPROWS) { if (l > 0) ro_load3(6, m.layer[l - 1].g2, sub); }
             } }
             __syncthreads();
-            pf.tick(8); DFF_MARK(8);
+            pf.tick(8); DFF_MARK(8); phase_prio<8>(wave);
             // ---- attention backward: wave w owns heads w and w+4 ----
             {
                 DFF_LANE_CONSTS
@@ -1977,7 +2011,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 const lfloat* const qkvt_xa = Gx + col * XLD + 64 + quad;
                 auto dqkv = [&]() {
                     // dV_ext = P^T G_ext -> V region (ext columns: dx term sum_i a_ij r_i)
-                    wv_mm<0, 5, true, XLD>(pb, Gx, lane, ks4, [&](int nt, const f32x4& acc) {
+                    constexpr bool MMS = DFF_MM_SPLIT && H > 64;
+                    wv_mm5<MMS, true, XLD>(pb, Gx, lane, ks4, [&](int nt, const f32x4& acc) {
                         if constexpr (FOLD) { if (nt < 4) acc_a[nt < 4 ? nt : 0] += acc; }   // v = n: dV IS a term of d(LayerNorm output)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -1986,7 +2021,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         }
                     });
                     // dQ_ext = dS K_ext -> G region (ext columns: du, and ds in the GEN variants)
-                    wv_mm<0, 5, false, XLD>(dsb, Kx, lane, ks4, [&](int nt, const f32x4& acc) {
+                    wv_mm5<MMS, false, XLD>(dsb, Kx, lane, ks4, [&](int nt, const f32x4& acc) {
                         f32x4 v = acc;
                         if constexpr (GEN) {
                             if (nt == 4) {
@@ -1997,7 +2032,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         c_store_offs(Gx, lro, 16 * nt, v, lane);
                     });
                     // dK_ext = dS^T Q_ext -> K region (ext columns: dx term sum_i dS_ij u_i)
-                    wv_mm<0, 5, true, XLD>(dsb, Qx, lane, ks4, [&](int nt, const f32x4& acc) {
+                    wv_mm5<MMS, true, XLD>(dsb, Qx, lane, ks4, [&](int nt, const f32x4& acc) {
                         if constexpr (FOLD) { if (nt < 4) acc_a[nt < 4 ? nt : 0] += acc; }   // k = n: so is dK
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -2035,27 +2070,27 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA, XLD);
                         committed();
                         head_fetch(hr, sbq + sl.qkv + (size_t)h1 * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)h1 * 256, RA, true, lane, m12p(h1));
-                        pf.tick(8); DFF_MARK(8);
+                        pf.tick(8); DFF_MARK(8); phase_prio<8>(wave);
                         gext(std::integral_constant<int, 0>{}, wave, s_qkvt(lw, wave));
                         gfix();
-                        pf.tick(15); DFF_MARK(15);
+                        pf.tick(15); DFF_MARK(15); phase_prio<15>(wave);
                         ds_math();
-                        pf.tick(16); DFF_MARK(16);
+                        pf.tick(16); DFF_MARK(16); phase_prio<16>(wave);
                         dqkv();
-                        pf.tick(17); DFF_MARK(17);
+                        pf.tick(17); DFF_MARK(17); phase_prio<17>(wave);
                         tall_run<1, 13, E, 4>(ring, acc_a, qkvt_fa, s_qkvt(lw, wave), s_woxt(lw, h1), lane);
-                        pf.tick(18); DFF_MARK(18);
+                        pf.tick(18); DFF_MARK(18); phase_prio<18>(wave);
                         head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA, XLD);
                         committed();
                         gext(std::integral_constant<int, 2>{}, h1, s_qkvt(lw, h1));
                         gfix();
-                        pf.tick(15); DFF_MARK(15);
+                        pf.tick(15); DFF_MARK(15); phase_prio<15>(wave);
                         ds_math();
-                        pf.tick(16); DFF_MARK(16);
+                        pf.tick(16); DFF_MARK(16); phase_prio<16>(wave);
                         dqkv();
-                        pf.tick(17); DFF_MARK(17);
+                        pf.tick(17); DFF_MARK(17); phase_prio<17>(wave);
                         tall_run<3, 13, E, 4>(ring, acc_a, qkvt_fa, s_qkvt(lw, h1), after, lane);   // ends at phase 0
-                        pf.tick(18); DFF_MARK(18);
+                        pf.tick(18); DFF_MARK(18); phase_prio<18>(wave);
                     } else {
                         if constexpr (HDMA) {
                             head_dma_wait();   // (requested before row stage E; nothing for the last layer)
@@ -2066,18 +2101,18 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                             head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA, XLD);
                         }
                         committed();
-                        pf.tick(8); DFF_MARK(8);
+                        pf.tick(8); DFF_MARK(8); phase_prio<8>(wave);
                         if constexpr (SPW) sgext(sqa);
                         else gext(std::integral_constant<int, 0>{}, wave, s_qkvt(lw, wave));
                         gfix();
-                        pf.tick(15); DFF_MARK(15);
+                        pf.tick(15); DFF_MARK(15); phase_prio<15>(wave);
                         ds_math();
-                        pf.tick(16); DFF_MARK(16);
+                        pf.tick(16); DFF_MARK(16); phase_prio<16>(wave);
                         dqkv();
-                        pf.tick(17); DFF_MARK(17);
+                        pf.tick(17); DFF_MARK(17); phase_prio<17>(wave);
                         if constexpr (SPW) stall_run<U_GX, NKT, E, true>(sring, acc_a, qkvt_fa32, sqa, lane, qkvt_xa, qkvt_ext(lw, wave, lane), DFF_HEADS * 13 * 256);
                         else tall_run<5 % DR, 13, E, 4>(ring, acc_a, qkvt_fa, s_qkvt(lw, wave), after, lane);   // 18 entries: phase 0
-                        pf.tick(18); DFF_MARK(18);
+                        pf.tick(18); DFF_MARK(18); phase_prio<18>(wave);
                     }
 #pragma unroll
                     for (int nt = 0; nt < E; ++nt) c_store_offs(mypart, mro, 16 * nt, acc_a[nt], lane);
@@ -2134,7 +2169,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 }
             }
             __syncthreads();
-            pf.tick(9); DFF_MARK(9);
+            pf.tick(9); DFF_MARK(9); phase_prio<9>(wave);
             // ---- row stage F: dn = dn_in partial + LN1 backward(sum_w part)  (l > 0) ----
             // operands: ro[1] nodes_in, ro[2] ln1 gamma
             if (l > 0 || full0) {
@@ -2180,7 +2215,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 }
                 __syncthreads();
             }
-            pf.tick(10); DFF_MARK(10);
+            pf.tick(10); DFF_MARK(10); phase_prio<10>(wave);
         }
         { const int tq = tid_id();   // (opaque: the per-lane addresses below are re-derived every step, not hoisted and spilled)
         // dxs = sum of the waves' partial x-gradients (the force head wrote dxs itself); supplied / not yet drawn noise -> xib
@@ -2335,7 +2370,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             __syncthreads();
             if (tid < gcnt * 4 && (tid & 3) < 3 && !(fabsf(cm[tid]) < 1e-3f)) atomicOr(a.clamp_flag, 2);
         }
-        pf.tick(11); DFF_MARK(11);
+        pf.tick(11); DFF_MARK(11); phase_prio<11>(wave);
     }
     if (pf.on)
         for (int i = 0; i < DFF_NPROF; ++i) a.prof[i] = pf.acc[i];
