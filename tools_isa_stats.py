@@ -25,7 +25,7 @@ def main():
             name, body = parts[i], parts[i + 1]
             if name not in meta:
                 continue
-            lines = body.split('s_endpgm')[0].split('\n')
+            lines = body.split('.Lfunc_end')[0].split('\n')
             mf = [k for k, l in enumerate(lines) if 'v_mfma' in l]
             inner = lines[mf[0]:mf[-1] + 1] if mf else []
             c = lambda pat, ls=lines: sum(1 for l in ls if re.search(pat, l))   # noqa: E731
