@@ -90,12 +90,22 @@ struct WPtr {
 #endif
 #define DFF_SITE_LD(MT, bit) (DFF_STASH_SITES >= 0 ? ((DFF_STASH_SITES & (bit)) ? 1 : 0) : (DFF_STASH_POL(MT) & 1))
 #define DFF_SITE_ST(MT, bit) (DFF_STASH_SITES >= 0 ? ((DFF_STASH_SITES & (bit)) ? 2 : 0) : (DFF_STASH_POL(MT) & 2))
-template <int POL = 0> DEVI void st_ntg(gfloat* p, float v) { if constexpr (POL & 2) __builtin_nontemporal_store(v, p); else *p = v; }
+// (DFF_TIMING_NOSTASH: timing-only builds -- bit 0 drops the policy-site stores, bit 1 the policy-site loads: upper bounds of what
+// the stash traffic costs)
+#ifndef DFF_TIMING_NOSTASH
+#define DFF_TIMING_NOSTASH 0
+#endif
+template <int POL = 0> DEVI void st_ntg(gfloat* p, float v) {
+    if constexpr (DFF_TIMING_NOSTASH & 1) { asm volatile("" ::"v"(p), "v"(v)); return; }
+    if constexpr (POL & 2) __builtin_nontemporal_store(v, p); else *p = v;
+}
 template <int POL = 0> DEVI float ld_ntg(const gfloat* p) { if constexpr (POL & 1) return __builtin_nontemporal_load(p); else return *p; }
 template <int POL = 0> DEVI f32x4 ld_ntg4(const gfloat* p) {
+    if constexpr (DFF_TIMING_NOSTASH & 2) { f32x4 z = {1.f, 0.5f, 0.25f, 0.125f}; asm volatile("" : "+v"(z) : "v"(p)); return z; }
     if constexpr (POL & 1) return __builtin_nontemporal_load((const gf32x4*)p); else return *(const gf32x4*)p;
 }
 template <int POL = 0> DEVI void st_ntg4(gfloat* p, const f32x4 v) {
+    if constexpr (DFF_TIMING_NOSTASH & 1) { asm volatile("" ::"v"(p), "v"(v)); return; }
     if constexpr (POL & 2) __builtin_nontemporal_store(v, (gf32x4*)p); else *(gf32x4*)p = v;
 }
 // four consecutive floats (16-byte aligned) into a scalar aux array of an epilogue
