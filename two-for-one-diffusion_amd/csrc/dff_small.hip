@@ -52,6 +52,11 @@ DEVI void phase_prio(int wave) {
         }
     }
 }
+// DFF_TIMING_F16 (timing-only, wrong numerics): what a two-piece weight format with three products per unit would run like --
+// two of a unit's three pieces are loaded, three of its six MFMAs issued, two of the three A pieces written / read
+#ifndef DFF_TIMING_F16
+#define DFF_TIMING_F16 0
+#endif
 #ifndef DFF_SDR
 #define DFF_SDR 4   // split-ring depth in units (SPW variants)
 #endif
@@ -272,7 +277,7 @@ DEVI SStream sstream(const unsigned* Wp, int unit0) { return SStream{(const gu32
 DEVI void sfill(u32x4 (&slot)[3], const gu32x4* p, int lane) {
     const unsigned lo = (unsigned)lane & 63u;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) slot[q] = (p + 64 * q)[lo];
+    for (int q = 0; q < (DFF_TIMING_F16 ? 2 : 3); ++q) slot[q] = (p + 64 * q)[lo];
 }
 // The weights a wave needs between two workgroup barriers form ONE sequence of units: N0 units of stream s0 followed by
 // N1 units of s1 (e.g. QKV_ext then [W_o;W_oc]; W1 then W2), and after them the first DR units of the NEXT block (M0
@@ -308,7 +313,7 @@ DEVI void sfill_k(u32x4 (&slot)[3], const gu32x4* p, int lane) {
     const unsigned lo = (unsigned)lane & 63u;
     slot[0] = p[lo];
     slot[1] = (p + 64)[lo];
-    if constexpr (KIND == 0) slot[2] = (p + 128)[lo];
+    if constexpr (KIND == 0 && !DFF_TIMING_F16) slot[2] = (p + 128)[lo];
 }
 // a unit of a head's EXTENSION output tile ([u | s | 0 ...], [r | g_D | 0 ...]): only output columns 0..3 have weights, i.e.
 // only lanes with (lane & 15) < 4 hold anything but zeros -- they alone load (256 B instead of 1 KiB per piece: these
@@ -317,7 +322,7 @@ DEVI void sfill_ext(u32x4 (&slot)[3], const gu32x4* p, int lane) {
     const unsigned lo = (unsigned)lane & 63u;
     const bool has = (lane & 15) < 4;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < (DFF_TIMING_F16 ? 2 : 3); ++q) {
         u32x4 v = {0u, 0u, 0u, 0u};
         if (has) v = (p + 64 * q)[lo];
         slot[q] = v;
@@ -326,7 +331,7 @@ DEVI void sfill_ext(u32x4 (&slot)[3], const gu32x4* p, int lane) {
 // the three piece operands of the unit held by a slot
 template <int KIND>
 DEVI void unit_pieces(const u32x4 (&slot)[3], u32x4& bh, u32x4& bm, u32x4& bl) {
-    if constexpr (KIND == 0) { bh = slot[0]; bm = slot[1]; bl = slot[2]; }
+    if constexpr (KIND == 0) { bh = slot[0]; bm = slot[1]; bl = DFF_TIMING_F16 ? slot[1] : slot[2]; }
     else split8(__builtin_bit_cast(f32x4, slot[0]), __builtin_bit_cast(f32x4, slot[1]), bh, bm, bl);
 }
 template <int N0_, int N1_, int M0_, int K0_, int K1_, int KN0_, int KN1_, int E_, int XU_ = -1>
@@ -380,12 +385,18 @@ DEVI void swide_from(SRing<DR>& ring, float (&aux)[2][NAUX], const u32x4 (&ah)[K
                 if (kb == 0) seq_refill<DR, I0 + T * KB32 + 0>(ring, q, lane);
                 if (kb == 1) seq_refill<DR, I0 + T * KB32 + (KB32 > 1 ? 1 : 0)>(ring, q, lane);
             }
+#if DFF_TIMING_F16
+            cs = mfma_bf16(am[kb], bh, cs);
+            cs = mfma_bf16(ah[kb], bm, cs);
+            cb = mfma_bf16(ah[kb], bh, cb);
+#else
             cs = mfma_bf16(al[kb], bh, cs);
             cb = mfma_bf16(am[kb], bh, cb);
             cs = mfma_bf16(ah[kb], bl, cs);
             cb = mfma_bf16(ah[kb], bm, cb);
             cs = mfma_bf16(am[kb], bm, cs);
             cb = mfma_bf16(ah[kb], bh, cb);
+#endif
         }
         if constexpr (Q::kind(I0 + T * KB32) == 0) {
             if constexpr (KB32 >= 1) seq_refill<DR, I0 + T * KB32 + 0>(ring, q, lane);
@@ -421,11 +432,11 @@ DEVI void stall_from(SRing<DR>& ring, f32x4 (&acc)[E], f32x4& x0, f32x4& x1, con
         }
         if constexpr (Q::kind(I0 + KB * E) == 0) {
 #pragma unroll
-            for (int nt = 0; nt < E; ++nt) acc[nt] = mfma_bf16(al, ring.b[(I0 + KB * E + nt) % DR][0], acc[nt]);
+            for (int nt = 0; nt < E; ++nt) if (!DFF_TIMING_F16) acc[nt] = mfma_bf16(al, ring.b[(I0 + KB * E + nt) % DR][0], acc[nt]);
 #pragma unroll
-            for (int nt = 0; nt < E; ++nt) acc[nt] = mfma_bf16(ah, ring.b[(I0 + KB * E + nt) % DR][2], acc[nt]);
+            for (int nt = 0; nt < E; ++nt) if (!DFF_TIMING_F16) acc[nt] = mfma_bf16(ah, ring.b[(I0 + KB * E + nt) % DR][2], acc[nt]);
 #pragma unroll
-            for (int nt = 0; nt < E; ++nt) acc[nt] = mfma_bf16(am, ring.b[(I0 + KB * E + nt) % DR][1], acc[nt]);
+            for (int nt = 0; nt < E; ++nt) if (!DFF_TIMING_F16) acc[nt] = mfma_bf16(am, ring.b[(I0 + KB * E + nt) % DR][1], acc[nt]);
 #pragma unroll
             for (int nt = 0; nt < E; ++nt) acc[nt] = mfma_bf16(am, ring.b[(I0 + KB * E + nt) % DR][0], acc[nt]);
 #pragma unroll
@@ -769,7 +780,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             lu16* const q2 = asp16 + ((threadIdx.x & 63) * 2 + ((cl >> 5) & 1) * 128) % (3 * PS - 2 * 128);
             q2[0] = (unsigned short)(b >> 16); q2[256] = (unsigned short)(c >> 16); q2[512] = (unsigned short)(__float_as_uint(s2) >> 16);
 #else
-            q[0] = (unsigned short)(b >> 16); q[PS] = (unsigned short)(c >> 16); q[2 * PS] = (unsigned short)(__float_as_uint(s2) >> 16);
+            q[0] = (unsigned short)(b >> 16); q[PS] = (unsigned short)(c >> 16);
+            if (!DFF_TIMING_F16) q[2 * PS] = (unsigned short)(__float_as_uint(s2) >> 16);
 #endif
         } else {
             abuf[row * LH + cl] = v;
@@ -783,7 +795,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         for (int kb = 0; kb < H / 32; ++kb) {
             ah[kb] = *(const lu32x4*)(q + kb * 256);
             am[kb] = *(const lu32x4*)(q + PS + kb * 256);
-            al[kb] = *(const lu32x4*)(q + 2 * PS + kb * 256);
+            al[kb] = DFF_TIMING_F16 ? am[kb] : *(const lu32x4*)(q + 2 * PS + kb * 256);
         }
     };
     lfloat* const dxw = sm + LL::dxw + wave * 128;
@@ -958,8 +970,26 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #ifndef DFF_XI_PRE
 #define DFF_XI_PRE 1
 #endif
+#ifndef DFF_XI_STAGE
+#define DFF_XI_STAGE 0
+#endif
     const bool xi_pre = DFF_XI_PRE && MODE != DFF_MODE_SCORE && !a.noise && rows * LPR <= (NW - 1) * 64;
     static_assert(H % LPR == 0, "row layout");
+    // (DFF_XI_STAGE: the row stage of layer 0 in whose shadow the idle wave draws -- 0: A, 1: B, 2: C)
+    auto draw_xi = [&](int t_int_, int step_) {
+        if (xi_pre && wave == NW - 1) {
+            const int ln = lane_id();
+            if (ln < rows * 4 && (ln & 3) < 3) {
+                const int row = ln >> 2, g = row / N;
+#ifdef DFF_TIMING_NONOISE
+                xib[ln] = 0.5f;
+#else
+                xib[ln] = philox_normal(a.seed, a.item_offset + (size_t)b0 + g,
+                                        MODE == DFF_MODE_DDPM ? (uint64_t)t_int_ : a.step_offset + step_, row - g * N, ln & 3);
+#endif
+            }
+        }
+    };
     auto rsum = [](float v) {   // all-reduce over the LPR lanes of a row
         if constexpr (LPR == 32) {
             // lanes l and l^16 first (gfx950 v_permlane16_swap: [0] + [1] = v[l] + v[l^16]), then the 16-lane rows
@@ -1342,14 +1372,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     if constexpr (KEEPROWS) { keep_put(0, KN{}, x); keep_put(0, KL{}, nva); }
                 }
                 if (ract) pre_B(lw, sub);
-                if (xi_pre && wave == NW - 1) {
-                    const int ln = lane_id();
-                    if (ln < rows * 4 && (ln & 3) < 3) {
-                        const int row = ln >> 2, g = row / N;
-                        xib[ln] = philox_normal(a.seed, a.item_offset + (size_t)b0 + g,
-                                                MODE == DFF_MODE_DDPM ? (uint64_t)t_int : a.step_offset + step, row - g * N, ln & 3);
-                    }
-                }
+                if constexpr (DFF_XI_STAGE == 0) draw_xi(t_int, step);
                 __syncthreads();
             }
             pf.tick(1); DFF_MARK(1); phase_prio<1>(wave);
@@ -1576,6 +1599,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 ro_load(0, lw.b2, sub); ro_load3(1, lw.g2, sub);
                 if (l + 1 < m.L) { ro_load(4, m.layer[l + 1].ln1_g, sub); ro_load(5, m.layer[l + 1].ln1_b, sub); }
             } }
+            if constexpr (DFF_XI_STAGE == 1) { if (l == 0) draw_xi(t_int, step); }
             __syncthreads();
             pf.tick(3); DFF_MARK(3); phase_prio<3>(wave);
             // ---- FFN: wave w owns hidden columns [w H, (w+1) H) ----
@@ -1721,6 +1745,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     pre_B(m.layer[l + 1], sub);
                 }
             } }
+            if constexpr (DFF_XI_STAGE == 2) { if (l == 0) draw_xi(t_int, step); }
             // the stash written in the forward pass is re-read below by other lanes / waves
             if (l == m.L - 1) __threadfence_block();
             __syncthreads();
