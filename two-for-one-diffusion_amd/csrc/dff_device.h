@@ -415,6 +415,51 @@ DEVI f32x4 mfma_bf16(const u32x4 a, const u32x4 b, const f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// ---- two-piece fp16 split (round 5, the <= 16-row FOLD kernel): x = h + l' / 2048 with h = RTZ_f16(x), l' = RTZ_f16((x - h) 2048):
+// 22 significant bits, and  a.b ~ ah.bh + (ah.bl' + al'.bh) / 2048  -- THREE v_mfma_f32_16x16x32_f16 instead of six bf16 ones
+// and 4 instead of 6 bytes per weight.  Dropped: al.bl (2^-22) and the pieces' truncation (2^-22 each); measured against
+// float64 the products are as accurate as an fp32 FMA chain (tools: profiles/r05/f16_engine).  fp16 has 5 exponent bits:
+// the hardware keeps subnormals in v_cvt_pkrtz_f16_f32 and in the MFMA inputs (tools_ubench/f16_denorm.hip), so a piece
+// resolves 2^-24 / 2048 = 3e-11 ABSOLUTE whatever the element's size -- negligible next to O(1) forward activations and
+// O(0.1) weights; the backward's operands (gradients, any magnitude) are scaled row-wise by a power of two first.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+DEVI f32x4 mfma_f16(const u32x4 a, const u32x4 b, const f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+#define DFF_F16_LSCALE 2048.0f
+#define DFF_F16_LINV (1.0f / 2048.0f)
+// one pair of values -> (h pair, l' pair), element 0 in the low half
+DEVI void split2h(float e0, float e1, unsigned& h, unsigned& l) {
+    const auto ph = __builtin_amdgcn_cvt_pkrtz(e0, e1);
+    const float r0 = e0 - (float)ph[0], r1 = e1 - (float)ph[1];
+    h = __builtin_bit_cast(unsigned, ph);
+    l = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0 * DFF_F16_LSCALE, r1 * DFF_F16_LSCALE));
+}
+// eight consecutive fp32 -> the two fp16 operands (the layout of split8 below)
+DEVI void split8h(const f32x4& x0, const f32x4& x1, u32x4& h, u32x4& l) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float e0 = q < 2 ? x0[2 * q] : x1[2 * q - 4], e1 = q < 2 ? x0[2 * q + 1] : x1[2 * q - 3];
+        unsigned hh, ll;
+        split2h(e0, e1, hh, ll);
+        h[q] = hh; l[q] = ll;
+    }
+}
+// one value -> its two 16-bit pieces (row stages)
+DEVI void split1h(float v, unsigned short& h, unsigned short& l) {
+    unsigned hh, ll;
+    split2h(v, 0.f, hh, ll);
+    h = (unsigned short)hh; l = (unsigned short)ll;
+}
+// power-of-two scale that brings a row maximum `mx` (>= 0) to [16, 32): s = 2^(4 - floor(log2 mx)), and its inverse; exact.
+// (the exponent is clamped: a zero / denormal row gets 2^67, whose products with the row are still zero / tiny)
+DEVI void pow2_scale(float mx, float& s, float& inv) {
+    int ex = (int)((__float_as_uint(mx) >> 23) & 255u);
+    ex = ex < 64 ? 64 : (ex > 250 ? 250 : ex);
+    s = __uint_as_float((unsigned)(258 - ex) << 23);     // 2^(127 + 4 - (ex - 127) - 127) -> biased 258 - ex
+    inv = __uint_as_float((unsigned)(ex - 4) << 23);     // 2^((ex - 127) - 4)            -> biased ex - 4
+}
+
 // eight consecutive fp32 (x0 = k 0..3, x1 = k 4..7) -> the three bf16-pair operands of v_mfma_f32_16x16x32_bf16 (~44 VALU)
 DEVI void split8(const f32x4& x0, const f32x4& x1, u32x4& h, u32x4& m, u32x4& l) {
 #pragma unroll

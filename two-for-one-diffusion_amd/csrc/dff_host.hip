@@ -124,6 +124,45 @@ static std::vector<uint32_t> pack_units(const std::vector<std::pair<int, int>>& 
     }
     return out;
 }
+// fp16 (binary16) with round-toward-zero, subnormals kept: what v_cvt_pkrtz_f16_f32 does on the device
+static uint16_t f32_to_f16_rtz(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u, a = u & 0x7fffffffu;
+    if (a >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | ((a > 0x7f800000u) ? 0x200u : 0u));   // inf / nan
+    const int e = (int)(a >> 23) - 127;
+    if (e > 15) return (uint16_t)(sign | 0x7bffu);                      // beyond fp16: the largest finite value (toward zero)
+    if (e >= -14) return (uint16_t)(sign | (uint32_t)(e + 15) << 10 | ((a >> 13) & 0x3ffu));
+    if (e < -25) return (uint16_t)sign;
+    const uint32_t mant = (a & 0x7fffffu) | 0x800000u;                    // subnormal: value = mant 2^(e - 23) = m16 2^-24
+    return (uint16_t)(sign | (mant >> (-e - 1)));                         // mant >> (23 - (e + 24)) = mant >> (-e - 1)
+}
+static float f16_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, mnt = h & 0x3ffu;
+    float f;
+    if (e == 0) { f = (float)mnt * 5.9604644775390625e-08f; uint32_t u; memcpy(&u, &f, 4); u |= sign; memcpy(&f, &u, 4); return f; }
+    const uint32_t u = sign | ((e == 31 ? 255u : e + 112u) << 23) | (mnt << 13);
+    memcpy(&f, &u, 4);
+    return f;
+}
+// The same unit sequence as TWO fp16 pieces per weight for the <= 16-row FOLD kernel's fp16 engine (dff_small.hip, stream kind
+// -1): [piece h | l'][lane][8 fp16], h = RTZ_f16(w), l' = RTZ_f16((w - h) 2048): w = h + l' / 2048 to 22 bits (3e-11 absolute).
+static std::vector<uint32_t> pack_units_f16(const std::vector<std::pair<int, int>>& units, int Nout,
+                                            const std::function<double(int, int)>& w) {
+    std::vector<uint32_t> out(units.size() * 2 * 64 * 4, 0u);
+    for (size_t u = 0; u < units.size(); ++u) {
+        const int nt = units[u].first, c0 = units[u].second;
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+                const int c = c0 + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3), n = 16 * nt + (lane & 15);
+                const float v = n < Nout ? (float)w(c, n) : 0.f;
+                const uint16_t h = f32_to_f16_rtz(v);
+                const uint16_t l = f32_to_f16_rtz((v - f16_to_f32(h)) * 2048.0f);
+                out[((u * 2 + 0) * 64 + lane) * 4 + (j >> 1)] |= (uint32_t)h << (16 * (j & 1));
+                out[((u * 2 + 1) * 64 + lane) * 4 + (j >> 1)] |= (uint32_t)l << (16 * (j & 1));
+            }
+    }
+    return out;
+}
 static std::vector<std::pair<int, int>> units_wide(int K, int Nout) {   // [tile][k-block]
     std::vector<std::pair<int, int>> u;
     for (int nt = 0; nt < (Nout + 15) / 16; ++nt)
@@ -490,21 +529,26 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
             // fold_kv on the shipped input branch: the <= 16-row kernel's FOLD variant streams [q' | u] (5 tiles per head) and
             // back-projects dQ only (2 k-blocks per head); k = v = LayerNorm output never goes through a GEMM there
             const bool sfold = m->fold_kv && intr && !dist && !ab;
+            // the FOLD variant's engine decides the image format: two fp16 pieces (round 5) or three bf16 pieces
+            const bool f16img = sfold && dff_small_fold_f16();
+            auto PU = [&](const std::vector<std::pair<int, int>>& un, int nout, const std::function<double(int, int)>& wf) {
+                return f16img ? pack_units_f16(un, nout, wf) : pack_units(un, nout, wf);
+            };
             if (sfold) {
-                if ((rc_ = upload_u32(m, pack_units(units_wide(H, 8 * 80), 8 * 80, [&](int k, int n) { return wqkvx((n / 80) * 208 + n % 80, k); }), &d.Wqkvx_w))) return rc_;
+                if ((rc_ = upload_u32(m, PU(units_wide(H, 8 * 80), 8 * 80, [&](int k, int n) { return wqkvx((n / 80) * 208 + n % 80, k); }), &d.Wqkvx_w))) return rc_;
             } else
-            if ((rc_ = upload_u32(m, pack_units(units_wide(H, 8 * 208), 8 * 208, [&](int k, int n) { return wqkvx(n, k); }), &d.Wqkvx_w))) return rc_;
-            if ((rc_ = upload_u32(m, pack_units(units_wide(H, F), F, [&](int k, int n) { return (double)W1[(size_t)n * H + k]; }), &d.W1_w))) return rc_;
-            if ((rc_ = upload_u32(m, pack_units(units_wide(H, F), F, [&](int k, int n) { return (double)W2[(size_t)k * F + n]; }), &d.W2T_w))) return rc_;
-            if ((rc_ = upload_u32(m, pack_units(units_wide(H, 8 * 80), 8 * 80, [&](int k, int n) { return wox(n, k); }), &d.WoxT_w))) return rc_;
+            if ((rc_ = upload_u32(m, PU(units_wide(H, 8 * 208), 8 * 208, [&](int k, int n) { return wqkvx(n, k); }), &d.Wqkvx_w))) return rc_;
+            if ((rc_ = upload_u32(m, PU(units_wide(H, F), F, [&](int k, int n) { return (double)W1[(size_t)n * H + k]; }), &d.W1_w))) return rc_;
+            if ((rc_ = upload_u32(m, PU(units_wide(H, F), F, [&](int k, int n) { return (double)W2[(size_t)k * F + n]; }), &d.W2T_w))) return rc_;
+            if ((rc_ = upload_u32(m, PU(units_wide(H, 8 * 80), 8 * 80, [&](int k, int n) { return wox(n, k); }), &d.WoxT_w))) return rc_;
             // Nout = H: the 64 regular rows of every head of [W_o ; W_oc] / [q | k | v] (extension rows: fp32 k-step off the fp32 images)
-            if ((rc_ = upload_u32(m, pack_units(units_tall(8 * 64, H), H, [&](int c, int n) { return wox((c / 64) * 80 + c % 64, n); }), &d.Wox_t))) return rc_;
-            if ((rc_ = upload_u32(m, pack_units(units_tall(F, H), H, [&](int k, int n) { return (double)W2[(size_t)n * F + k]; }), &d.W2_t))) return rc_;
-            if ((rc_ = upload_u32(m, pack_units(units_tall(F, H), H, [&](int k, int n) { return (double)W1[(size_t)k * H + n]; }), &d.W1T_t))) return rc_;
+            if ((rc_ = upload_u32(m, PU(units_tall(8 * 64, H), H, [&](int c, int n) { return wox((c / 64) * 80 + c % 64, n); }), &d.Wox_t))) return rc_;
+            if ((rc_ = upload_u32(m, PU(units_tall(F, H), H, [&](int k, int n) { return (double)W2[(size_t)n * F + k]; }), &d.W2_t))) return rc_;
+            if ((rc_ = upload_u32(m, PU(units_tall(F, H), H, [&](int k, int n) { return (double)W1[(size_t)k * H + n]; }), &d.W1T_t))) return rc_;
             if (sfold) {
-                if ((rc_ = upload_u32(m, pack_units(units_tall(8 * 64, H), H, [&](int c, int n) { return wqkvx((c / 64) * 208 + c % 64, n); }), &d.WqkvxT_t))) return rc_;
+                if ((rc_ = upload_u32(m, PU(units_tall(8 * 64, H), H, [&](int c, int n) { return wqkvx((c / 64) * 208 + c % 64, n); }), &d.WqkvxT_t))) return rc_;
             } else
-            if ((rc_ = upload_u32(m, pack_units(units_tall(8 * 192, H), H, [&](int c, int n) {
+            if ((rc_ = upload_u32(m, PU(units_tall(8 * 192, H), H, [&](int c, int n) {
                      const int h = c / 192, cc = c % 192;
                      return wqkvx(h * 208 + (cc < 64 ? cc : cc + 16), n); }), &d.WqkvxT_t))) return rc_;
         }

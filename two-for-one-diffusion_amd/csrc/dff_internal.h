@@ -107,3 +107,7 @@ struct DffRunArgs {
     int xpairs;
     int xslow;       // tests: never take the same-XCD fast path of the exchanges (the agent-scope protocol a cross-XCD pair runs)
 };
+
+// true when the <= 16-row FOLD kernels were compiled with the two-piece fp16 engine (dff_small.hip DFF_F16): the host packs
+// that variant's weight images accordingly (dff_host.hip pack_units_f16)
+bool dff_small_fold_f16();

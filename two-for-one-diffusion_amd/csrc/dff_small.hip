@@ -52,10 +52,10 @@ DEVI void phase_prio(int wave) {
         }
     }
 }
-// DFF_TIMING_F16 (timing-only, wrong numerics): what a two-piece weight format with three products per unit would run like --
-// two of a unit's three pieces are loaded, three of its six MFMAs issued, two of the three A pieces written / read
-#ifndef DFF_TIMING_F16
-#define DFF_TIMING_F16 0
+// DFF_F16 (round 5): the FOLD variant (chignolin: the headline) runs its weight GEMMs on the TWO-piece fp16 split (dff_device.h
+// split8h): stream kind -1 = host-split fp16 image, 4 B per weight, 2 KB units, three v_mfma_f32_16x16x32_f16 per unit.
+#ifndef DFF_F16
+#define DFF_F16 1
 #endif
 #ifndef DFF_SDR
 #define DFF_SDR 4   // split-ring depth in units (SPW variants)
@@ -273,11 +273,11 @@ struct SRing {
 struct SStream {
     const gu32x4* base;   // wave-uniform; unit j at base + 192 j, piece p at + 64 p, lane at + lane
 };
-DEVI SStream sstream(const unsigned* Wp, int unit0) { return SStream{(const gu32x4*)Wp + (size_t)unit0 * 192}; }
+DEVI SStream sstream(const unsigned* Wp, int unit0, int ust = 192) { return SStream{(const gu32x4*)Wp + (size_t)unit0 * ust}; }
 DEVI void sfill(u32x4 (&slot)[3], const gu32x4* p, int lane) {
     const unsigned lo = (unsigned)lane & 63u;
 #pragma unroll
-    for (int q = 0; q < (DFF_TIMING_F16 ? 2 : 3); ++q) slot[q] = (p + 64 * q)[lo];
+    for (int q = 0; q < 3; ++q) slot[q] = (p + 64 * q)[lo];
 }
 // The weights a wave needs between two workgroup barriers form ONE sequence of units: N0 units of stream s0 followed by
 // N1 units of s1 (e.g. QKV_ext then [W_o;W_oc]; W1 then W2), and after them the first DR units of the NEXT block (M0
@@ -302,7 +302,7 @@ DEVI void split_afrag(const f32x4 (&a)[2 * KB32], u32x4 (&ah)[KB32], u32x4 (&am)
 template <int KIND, int E>
 DEVI const gu32x4* unit_addr(const SStream& w, int j) {
     if constexpr (KIND == 0) return w.base + (size_t)j * 192;
-    else if constexpr (KIND == 1) return w.base + (size_t)j * 128;
+    else if constexpr (KIND == 1 || KIND == -1) return w.base + (size_t)j * 128;   // (-1: fp16 image, two pieces per unit)
     else {
         const int kb = j / E, nt = j - kb * E;
         return w.base + (size_t)nt * KIND * 64 + (size_t)(2 * kb + (KIND == DFF_HEADS * 13 && kb >= 2 ? 1 : 0)) * 64;
@@ -313,16 +313,17 @@ DEVI void sfill_k(u32x4 (&slot)[3], const gu32x4* p, int lane) {
     const unsigned lo = (unsigned)lane & 63u;
     slot[0] = p[lo];
     slot[1] = (p + 64)[lo];
-    if constexpr (KIND == 0 && !DFF_TIMING_F16) slot[2] = (p + 128)[lo];
+    if constexpr (KIND == 0) slot[2] = (p + 128)[lo];
 }
 // a unit of a head's EXTENSION output tile ([u | s | 0 ...], [r | g_D | 0 ...]): only output columns 0..3 have weights, i.e.
 // only lanes with (lane & 15) < 4 hold anything but zeros -- they alone load (256 B instead of 1 KiB per piece: these
 // tiles are 1/13 of the QKV_ext stream and 1/5 of the [W_o;W_oc]^T stream)
+template <int KIND = 0>
 DEVI void sfill_ext(u32x4 (&slot)[3], const gu32x4* p, int lane) {
     const unsigned lo = (unsigned)lane & 63u;
     const bool has = (lane & 15) < 4;
 #pragma unroll
-    for (int q = 0; q < (DFF_TIMING_F16 ? 2 : 3); ++q) {
+    for (int q = 0; q < (KIND < 0 ? 2 : 3); ++q) {
         u32x4 v = {0u, 0u, 0u, 0u};
         if (has) v = (p + 64 * q)[lo];
         slot[q] = v;
@@ -331,7 +332,8 @@ DEVI void sfill_ext(u32x4 (&slot)[3], const gu32x4* p, int lane) {
 // the three piece operands of the unit held by a slot
 template <int KIND>
 DEVI void unit_pieces(const u32x4 (&slot)[3], u32x4& bh, u32x4& bm, u32x4& bl) {
-    if constexpr (KIND == 0) { bh = slot[0]; bm = slot[1]; bl = DFF_TIMING_F16 ? slot[1] : slot[2]; }
+    if constexpr (KIND < 0) { bh = slot[0]; bm = slot[1]; bl = slot[1]; }   // (fp16: h | l', no third piece)
+    else if constexpr (KIND == 0) { bh = slot[0]; bm = slot[1]; bl = slot[2]; }
     else split8(__builtin_bit_cast(f32x4, slot[0]), __builtin_bit_cast(f32x4, slot[1]), bh, bm, bl);
 }
 template <int N0_, int N1_, int M0_, int K0_, int K1_, int KN0_, int KN1_, int E_, int XU_ = -1>
@@ -355,7 +357,7 @@ struct SSeq {
 template <int DR, int I, class Q>
 DEVI void seq_refill(SRing<DR>& ring, const Q& q, int lane) {   // slot of unit I <- unit I + DR (or the next block's)
     constexpr int slot = I % DR, J = I + DR;
-    if constexpr (J < Q::N0 && Q::K0 == 0 && Q::XU >= 0 && (J == Q::XU || J == Q::XU + 1)) sfill_ext(ring.b[slot], unit_addr<0, Q::E>(q.s0, J), lane);
+    if constexpr (J < Q::N0 && Q::K0 <= 0 && Q::XU >= 0 && (J == Q::XU || J == Q::XU + 1)) sfill_ext<Q::K0>(ring.b[slot], unit_addr<Q::K0, Q::E>(q.s0, J), lane);
     else if constexpr (J < Q::N0) sfill_k<Q::K0>(ring.b[slot], unit_addr<Q::K0, Q::E>(q.s0, J), lane);
     else if constexpr (J < Q::N0 + Q::N1) sfill_k<Q::K1>(ring.b[slot], unit_addr<Q::K1, Q::E>(q.s1, J - Q::N0), lane);
     else if constexpr (slot < Q::M0) sfill_k<Q::KN0>(ring.b[slot], unit_addr<Q::KN0, Q::E>(q.n0, slot), lane);
@@ -381,24 +383,24 @@ DEVI void swide_from(SRing<DR>& ring, float (&aux)[2][NAUX], const u32x4 (&ah)[K
             u32x4 bh, bm, bl;
             unit_pieces<Q::kind(I0 + T * KB32)>(ring.b[(I0 + T * KB32 + kb) % DR], bh, bm, bl);
             // a slot whose weights were split into temporaries is refilled before its MFMAs are issued
-            if constexpr (Q::kind(I0 + T * KB32) != 0) {
+            if constexpr (Q::kind(I0 + T * KB32) > 0) {
                 if (kb == 0) seq_refill<DR, I0 + T * KB32 + 0>(ring, q, lane);
                 if (kb == 1) seq_refill<DR, I0 + T * KB32 + (KB32 > 1 ? 1 : 0)>(ring, q, lane);
             }
-#if DFF_TIMING_F16
-            cs = mfma_bf16(am[kb], bh, cs);
-            cs = mfma_bf16(ah[kb], bm, cs);
-            cb = mfma_bf16(ah[kb], bh, cb);
-#else
+            if constexpr (Q::kind(I0 + T * KB32) < 0) {   // fp16: am / bm hold the l' pieces; cs collects the 2^11-scaled cross terms
+                cs = mfma_f16(am[kb], bh, cs);
+                cs = mfma_f16(ah[kb], bm, cs);
+                cb = mfma_f16(ah[kb], bh, cb);
+            } else {
             cs = mfma_bf16(al[kb], bh, cs);
             cb = mfma_bf16(am[kb], bh, cb);
             cs = mfma_bf16(ah[kb], bl, cs);
             cb = mfma_bf16(ah[kb], bm, cb);
             cs = mfma_bf16(am[kb], bm, cs);
             cb = mfma_bf16(ah[kb], bh, cb);
-#endif
+            }
         }
-        if constexpr (Q::kind(I0 + T * KB32) == 0) {
+        if constexpr (Q::kind(I0 + T * KB32) <= 0) {
             if constexpr (KB32 >= 1) seq_refill<DR, I0 + T * KB32 + 0>(ring, q, lane);
             if constexpr (KB32 >= 2) seq_refill<DR, I0 + T * KB32 + 1>(ring, q, lane);
         }
@@ -406,7 +408,8 @@ DEVI void swide_from(SRing<DR>& ring, float (&aux)[2][NAUX], const u32x4 (&ah)[K
 #pragma unroll
         for (int i = 0; i < NAUX; ++i) auxc[i] = aux[T % 2][i];
         if constexpr (T + 2 < N) pre(T + 2, aux[T % 2]);
-        epi(T, cb + cs, auxc);
+        if constexpr (Q::kind(I0 + T * KB32) < 0) epi(T, cb + cs * DFF_F16_LINV, auxc);
+        else epi(T, cb + cs, auxc);
         swide_from<I0, T + 1, N, KB32, NAUX>(ring, aux, ah, am, al, q, lane, pre, epi);
     }
 }
@@ -422,21 +425,37 @@ DEVI void swide_run(SRing<DR>& ring, float (&aux)[2][NAUX], const u32x4 (&ah)[KB
 // EXT: one fp32 k-step on top for a head's extension columns (of which only 0..3 carry data): A element *ext_a, weights
 // ext_w[nt * ext_ts] (the s = 0 slots of the fp32 image's extension block, dff_host.hip pack_b), requested first, used last.
 template <int I0, int KB, int NKB, int E, int DR, class Q, class FA>
-DEVI void stall_from(SRing<DR>& ring, f32x4 (&acc)[E], f32x4& x0, f32x4& x1, const FA& fa, const Q& q, int lane) {
+DEVI void stall_from(SRing<DR>& ring, f32x4 (&acc)[E], f32x4 (&acc2)[E], f32x4& x0, f32x4& x1, const FA& fa, const Q& q, int lane, float sa) {
     if constexpr (KB < NKB) {
+        constexpr int KD = Q::kind(I0 + KB * E);
         u32x4 ah, am, al;
-        split8(x0, x1, ah, am, al);
+        if constexpr (KD < 0) { split8h(x0, x1, ah, am); al = am; }   // fp16: (h, l')
+        else split8(x0, x1, ah, am, al);
         if constexpr (KB + 1 < NKB) {
             const lfloat* pn = fa(KB + 1);
             x0 = *(const lf32x4*)pn; x1 = *(const lf32x4*)(pn + 16);
+            if constexpr (KD < 0) { x0 *= sa; x1 *= sa; }
         }
-        if constexpr (Q::kind(I0 + KB * E) == 0) {
+        if constexpr (KD < 0) {
+            // acc: h.h ; acc2: the two cross terms, 2^11 too large (stall_run folds them in at the end)
 #pragma unroll
-            for (int nt = 0; nt < E; ++nt) if (!DFF_TIMING_F16) acc[nt] = mfma_bf16(al, ring.b[(I0 + KB * E + nt) % DR][0], acc[nt]);
+            for (int nt = 0; nt < E; ++nt) acc2[nt] = mfma_f16(am, ring.b[(I0 + KB * E + nt) % DR][0], acc2[nt]);
 #pragma unroll
-            for (int nt = 0; nt < E; ++nt) if (!DFF_TIMING_F16) acc[nt] = mfma_bf16(ah, ring.b[(I0 + KB * E + nt) % DR][2], acc[nt]);
+            for (int nt = 0; nt < E; ++nt) acc2[nt] = mfma_f16(ah, ring.b[(I0 + KB * E + nt) % DR][1], acc2[nt]);
 #pragma unroll
-            for (int nt = 0; nt < E; ++nt) if (!DFF_TIMING_F16) acc[nt] = mfma_bf16(am, ring.b[(I0 + KB * E + nt) % DR][1], acc[nt]);
+            for (int nt = 0; nt < E; ++nt) acc[nt] = mfma_f16(ah, ring.b[(I0 + KB * E + nt) % DR][0], acc[nt]);
+            static_assert(E == 4, "refill list");
+            seq_refill<DR, I0 + KB * E + 0>(ring, q, lane);
+            seq_refill<DR, I0 + KB * E + 1>(ring, q, lane);
+            seq_refill<DR, I0 + KB * E + 2>(ring, q, lane);
+            seq_refill<DR, I0 + KB * E + 3>(ring, q, lane);
+        } else if constexpr (KD == 0) {
+#pragma unroll
+            for (int nt = 0; nt < E; ++nt) acc[nt] = mfma_bf16(al, ring.b[(I0 + KB * E + nt) % DR][0], acc[nt]);
+#pragma unroll
+            for (int nt = 0; nt < E; ++nt) acc[nt] = mfma_bf16(ah, ring.b[(I0 + KB * E + nt) % DR][2], acc[nt]);
+#pragma unroll
+            for (int nt = 0; nt < E; ++nt) acc[nt] = mfma_bf16(am, ring.b[(I0 + KB * E + nt) % DR][1], acc[nt]);
 #pragma unroll
             for (int nt = 0; nt < E; ++nt) acc[nt] = mfma_bf16(am, ring.b[(I0 + KB * E + nt) % DR][0], acc[nt]);
 #pragma unroll
@@ -467,24 +486,49 @@ DEVI void stall_from(SRing<DR>& ring, f32x4 (&acc)[E], f32x4& x0, f32x4& x1, con
             one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{});
             one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
         }
-        stall_from<I0, KB + 1, NKB, E>(ring, acc, x0, x1, fa, q, lane);
+        stall_from<I0, KB + 1, NKB, E>(ring, acc, acc2, x0, x1, fa, q, lane, sa);
     }
 }
+// rsc (fp16 engine, backward): per-row power-of-two scales of this GEMM's A operand, rsc[row] = s, rsc[16 + row] = 1 / s (LDS,
+// written by the row stage that scaled the chain's input): the A fragments (and the extension element) are multiplied by
+// s[row] before they are split, `acc` -- which may already hold true-unit terms -- enters and leaves in true units.
 template <int I0, int NKB, int E, bool EXT, int DR, class Q, class FA>
 DEVI void stall_run(SRing<DR>& ring, f32x4 (&acc)[E], const FA fa, const Q& q, int lane,
-                    const lfloat* ext_a = nullptr, const gfloat* ext_w = nullptr, int ext_ts = 0) {
+                    const lfloat* ext_a = nullptr, const gfloat* ext_w = nullptr, int ext_ts = 0, const lfloat* rsc = nullptr) {
+    constexpr bool F16 = Q::kind(I0) < 0;
     float bx[E];
     if constexpr (EXT) {
 #pragma unroll
         for (int nt = 0; nt < E; ++nt) bx[nt] = ext_w[(size_t)nt * ext_ts];
     }
+    float sa = 1.0f;
+    f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, si4 = {1.f, 1.f, 1.f, 1.f};
+    if (F16 && rsc) {
+        sa = rsc[lane & 15];
+        const int q4 = (lane >> 4) * 4;
+        sc4 = *(const lf32x4*)(rsc + q4); si4 = *(const lf32x4*)(rsc + 16 + q4);
+#pragma unroll
+        for (int nt = 0; nt < E; ++nt) acc[nt] *= sc4;
+    }
+    f32x4 acc2[E];
+#pragma unroll
+    for (int nt = 0; nt < E; ++nt) acc2[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const lfloat* p0 = fa(0);
     f32x4 x0 = *(const lf32x4*)p0, x1 = *(const lf32x4*)(p0 + 16);
-    stall_from<I0, 0, NKB, E>(ring, acc, x0, x1, fa, q, lane);
+    if constexpr (F16) { x0 *= sa; x1 *= sa; }
+    stall_from<I0, 0, NKB, E>(ring, acc, acc2, x0, x1, fa, q, lane, sa);
+    if constexpr (F16) {
+#pragma unroll
+        for (int nt = 0; nt < E; ++nt) acc[nt] += acc2[nt] * DFF_F16_LINV;
+    }
     if constexpr (EXT) {
-        const float ax = *ext_a;
+        const float ax = *ext_a * sa;
 #pragma unroll
         for (int nt = 0; nt < E; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, bx[nt], acc[nt], 0, 0, 0);
+    }
+    if (F16 && rsc) {
+#pragma unroll
+        for (int nt = 0; nt < E; ++nt) acc[nt] *= si4;
     }
 }
 
@@ -769,19 +813,24 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     // the consuming waves' A fragments expect (element j of lane (row, kg) of k-block kb: column 32 kb + 16 (j >> 2) + 4 kg + (j & 3))
     auto a_store = [=](int row, int cl, float v) {
         if constexpr (SPW) {
+            const int kb = cl >> 5, kk = cl & 31, kg = (kk & 15) >> 2, j = ((kk >> 4) << 2) | (kk & 3);
+            lu16* const q = asp16 + ((((kb * 4 + kg) * 16 + row) * 4 + (j >> 1)) * 2 + (j & 1));
+            constexpr int PS = (H / 32) * 256 * 2;   // halfwords per piece
+            if constexpr (FOLD && DFF_F16) {   // fp16 engine: (h, l') -- callers scale the backward's rows first
+                unsigned short hh, ll;
+                split1h(v, hh, ll);
+                q[0] = hh; q[PS] = ll;
+                return;
+            }
             const unsigned b = __float_as_uint(v);
             const float r = v - __uint_as_float(b & 0xffff0000u);
             const unsigned c = __float_as_uint(r);
             const float s2 = r - __uint_as_float(c & 0xffff0000u);
-            const int kb = cl >> 5, kk = cl & 31, kg = (kk & 15) >> 2, j = ((kk >> 4) << 2) | (kk & 3);
-            lu16* const q = asp16 + ((((kb * 4 + kg) * 16 + row) * 4 + (j >> 1)) * 2 + (j & 1));
-            constexpr int PS = (H / 32) * 256 * 2;   // halfwords per piece
 #if DFF_TIMING_NOCONF & 4   // timing-only: the three 16-bit stores of a lane land in its own bank (wrong layout)
             lu16* const q2 = asp16 + ((threadIdx.x & 63) * 2 + ((cl >> 5) & 1) * 128) % (3 * PS - 2 * 128);
             q2[0] = (unsigned short)(b >> 16); q2[256] = (unsigned short)(c >> 16); q2[512] = (unsigned short)(__float_as_uint(s2) >> 16);
 #else
-            q[0] = (unsigned short)(b >> 16); q[PS] = (unsigned short)(c >> 16);
-            if (!DFF_TIMING_F16) q[2 * PS] = (unsigned short)(__float_as_uint(s2) >> 16);
+            q[0] = (unsigned short)(b >> 16); q[PS] = (unsigned short)(c >> 16); q[2 * PS] = (unsigned short)(__float_as_uint(s2) >> 16);
 #endif
         } else {
             abuf[row * LH + cl] = v;
@@ -795,7 +844,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         for (int kb = 0; kb < H / 32; ++kb) {
             ah[kb] = *(const lu32x4*)(q + kb * 256);
             am[kb] = *(const lu32x4*)(q + PS + kb * 256);
-            al[kb] = DFF_TIMING_F16 ? am[kb] : *(const lu32x4*)(q + 2 * PS + kb * 256);
+            if constexpr (FOLD && DFF_F16) al[kb] = am[kb];   // (two pieces: h, l')
+            else al[kb] = *(const lu32x4*)(q + 2 * PS + kb * 256);
         }
     };
     lfloat* const dxw = sm + LL::dxw + wave * 128;
@@ -998,6 +1048,33 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         }
         return row16_sum(v);
     };
+    auto rmaxf = [](float v) {   // all-reduce (max) over the LPR lanes of a row
+        if constexpr (LPR == 32) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+            v = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        return row16_max(v);
+    };
+    // fp16 engine, backward: a row stage's K = H GEMM input is a gradient of any magnitude -> each row is scaled by a power of two
+    // that brings its maximum to [16, 32) before it is split (exact), the wave-private chain behind it runs in scaled units
+    // (everything between two row stages is linear per row) and whoever leaves the chain multiplies by the inverse: `inv` for
+    // the thread's own row (the FFN backward's partial sums come back to the same thread), rs[row] / rs[16 + row] in LDS for
+    // the waves of the attention backward block.  Without the fp16 engine: plain stores, inv = 1.
+    lfloat* const rsc = sm + LL::asp + 2 * (H / 32) * 256;   // (the third piece's area of `asp`: the fp16 engine has two)
+    auto a_store_row = [&](int rrow, int sub, const float (&v)[HC], float& inv, bool publish) {
+        float sc = 1.0f;
+        inv = 1.0f;
+        if constexpr (FOLD && DFF_F16) {
+            float mx = 0.f;
+#pragma unroll
+            for (int i = 0; i < HC; ++i) mx = fmaxf(mx, fabsf(v[i]));
+            pow2_scale(rmaxf(mx), sc, inv);
+            if (publish && sub == 0) { rsc[rrow] = sc; rsc[16 + rrow] = inv; }
+        }
+#pragma unroll
+        for (int i = 0; i < HC; ++i) a_store(rrow, sub + LPR * i, v[i] * sc);
+    };
+    float invD = 1.0f;   // inverse row scale of the FFN backward chain in flight (stage D -> stage E of the same layer)
     auto ln_stats_row = [&](const float (&x)[HC], float& mean, float& rstd) {   // LayerNorm statistics of one row
         float t = 0.f;
 #pragma unroll
@@ -1104,12 +1181,14 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         }
         dg = rsum(dg);
         const float dz = dg * g2 * (1.0f - g2);
+        float dffv[HC];
 #pragma unroll
         for (int i = 0; i < HC; ++i) {
             const int cl = sub + LPR * i;
-            a_store(rrow, cl, dn[i] * g2 + dz * (ro[W][i] + ro[W + 2][i]));
+            dffv[i] = dn[i] * g2 + dz * (ro[W][i] + ro[W + 2][i]);
             resbuf[rrow * LH + cl] = dn[i] * (1.0f - g2) + dz * (ro[W + 1][i] - ro[W + 2][i]);
         }
+        a_store_row(rrow, sub, dffv, invD, false);
     };
     // The empty asm READS every row-stage operand register: the compiler takes whatever s_waitcnt their loads still need
     // here.  Called at the START of each wave-private block -- the operands were requested by the row stage before it and
@@ -1145,15 +1224,18 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #define DFF_KO 0
 #define DFF_KT 0
 #endif
-    constexpr int KQ = DFF_KQ ? 1 : 0, KO = DFF_KO ? DFF_HEADS * 5 : 0, KT = DFF_KT ? DFF_HEADS * 13 : 0;
-    auto ss_qkv = [&](const DffLayerDev& lw, int h) { return KQ ? SStream{(const gu32x4*)lw.Wqkvx_p + (size_t)h * 13 * E * 64} : sstream(lw.Wqkvx_w, h * U_QKV); };
-    auto ss_wox = [&](const DffLayerDev& lw, int h) { return KO ? SStream{(const gu32x4*)lw.Wox_p + (size_t)h * 5 * 64} : sstream(lw.Wox_t, h * 2 * E); };
-    auto ss_w1 = [&](const DffLayerDev& lw) { return sstream(lw.W1_w, wave * NTS * KB32); };
-    auto ss_w2 = [&](const DffLayerDev& lw) { return sstream(lw.W2_t, wave * (FS / 32) * E); };
-    auto ss_w2t = [&](const DffLayerDev& lw) { return sstream(lw.W2T_w, wave * NTS * KB32); };
-    auto ss_w1t = [&](const DffLayerDev& lw) { return sstream(lw.W1T_t, wave * (FS / 32) * E); };
-    auto ss_woxt = [&](const DffLayerDev& lw, int h) { return sstream(lw.WoxT_w, h * 5 * KB32); };
-    auto ss_qkvt = [&](const DffLayerDev& lw, int h) { return KT ? SStream{(const gu32x4*)lw.WqkvxT_p + (size_t)h * 13 * 64} : sstream(lw.WqkvxT_t, h * U_QKVT); };
+    constexpr bool F16E = FOLD && DFF_F16;   // fp16 two-piece engine (kind -1 streams)
+    constexpr int KS = F16E ? -1 : 0;        // kind of the host-split images
+    constexpr int KQ = F16E ? -1 : DFF_KQ ? 1 : 0, KO = F16E ? -1 : DFF_KO ? DFF_HEADS * 5 : 0, KT = F16E ? -1 : DFF_KT ? DFF_HEADS * 13 : 0;
+    constexpr int UST = F16E ? 128 : 192;    // 16-byte slots per unit of a host-split image
+    auto ss_qkv = [&](const DffLayerDev& lw, int h) { return KQ > 0 ? SStream{(const gu32x4*)lw.Wqkvx_p + (size_t)h * 13 * E * 64} : sstream(lw.Wqkvx_w, h * U_QKV, UST); };
+    auto ss_wox = [&](const DffLayerDev& lw, int h) { return KO > 0 ? SStream{(const gu32x4*)lw.Wox_p + (size_t)h * 5 * 64} : sstream(lw.Wox_t, h * 2 * E, UST); };
+    auto ss_w1 = [&](const DffLayerDev& lw) { return sstream(lw.W1_w, wave * NTS * KB32, UST); };
+    auto ss_w2 = [&](const DffLayerDev& lw) { return sstream(lw.W2_t, wave * (FS / 32) * E, UST); };
+    auto ss_w2t = [&](const DffLayerDev& lw) { return sstream(lw.W2T_w, wave * NTS * KB32, UST); };
+    auto ss_w1t = [&](const DffLayerDev& lw) { return sstream(lw.W1T_t, wave * (FS / 32) * E, UST); };
+    auto ss_woxt = [&](const DffLayerDev& lw, int h) { return sstream(lw.WoxT_w, h * 5 * KB32, UST); };
+    auto ss_qkvt = [&](const DffLayerDev& lw, int h) { return KT > 0 ? SStream{(const gu32x4*)lw.WqkvxT_p + (size_t)h * 13 * 64} : sstream(lw.WqkvxT_t, h * U_QKVT, UST); };
     // extension-block weights of the tall GEMMs for the fp32 k-step (s = 0 slots of the fp32 images)
     auto wox_ext = [&](const DffLayerDev& lw, int h, int lane) { return (const gfloat*)lw.Wox_p + ((size_t)(5 * h + 4) * 64 + lane) * 4; };
     auto qkvt_ext = [&](const DffLayerDev& lw, int h, int lane) { return (const gfloat*)lw.WqkvxT_p + ((size_t)(13 * h + 4) * 64 + lane) * 4; };
@@ -1459,7 +1541,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         pf.tick(12); DFF_MARK(12); phase_prio<12>(wave);
                         head_math(wave);
                         pf.tick(13); DFF_MARK(13); phase_prio<13>(wave);
-                        const SSeq<U_WOX, 0, MW, KO, KO, 0, 0, E> sq{ss_wox(lw, wave), ss_wox(lw, wave), sn0, sn1};
+                        const SSeq<U_WOX, 0, MW, KO, KO, KS, KS, E> sq{ss_wox(lw, wave), ss_wox(lw, wave), sn0, sn1};
                         stall_run<0, 2, E, true>(sring, acc_o, wox_fa32, sq, lane, wox_xa, wox_ext(lw, wave, lane), DFF_HEADS * 5 * 256);
                         pf.tick(14); DFF_MARK(14); phase_prio<14>(wave);
                     } else {
@@ -1472,7 +1554,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         float bq[2][1];
                         bq[0][0] = bh[0]; bq[1][0] = bh[16];
                         pf.tick(1); DFF_MARK(1); phase_prio<1>(wave);
-                        const SSeq<U_QKV, U_WOX, MW, KQ, KO, 0, 0, E, 4 * KB32> sq{ss_qkv(lw, wave), ss_wox(lw, wave), sn0, sn1};   // tile 4 of 13: [u | s]
+                        const SSeq<U_QKV, U_WOX, MW, KQ, KO, KS, KS, E, 4 * KB32> sq{ss_qkv(lw, wave), ss_wox(lw, wave), sn0, sn1};   // tile 4 of 13: [u | s]
                         swide_run<0, NQT, KB32, 1>(sring, bq, ah, am, al, sq, lane,
                             [=](int t, float (&ax)[1]) { ax[0] = bh[t * 16]; },
                             [=](int t, const f32x4& acc, const float (&ax)[1]) {
@@ -1610,8 +1692,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 const WStream after = lastl ? s_w2t(lw) : s_qkv(m.layer[lastl ? l : l + 1], wave);
                 // what follows: the last layer's FFN backward (W2^T, W1^T) or the next layer's QKV_ext (whose units MW.. are "n1")
                 const SStream qn = ss_qkv(m.layer[lastl ? l : l + 1], wave);
-                const SSeq<U_W1, U_W2, MW, 0, 0, 0, 0, E> sqf_last{ss_w1(lw), ss_w2(lw), ss_w2t(lw), ss_w1t(lw)};
-                const SSeq<U_W1, U_W2, SDR, 0, 0, KQ, KQ, E> sqf_next{ss_w1(lw), ss_w2(lw), qn, qn};
+                const SSeq<U_W1, U_W2, MW, KS, KS, KS, KS, E> sqf_last{ss_w1(lw), ss_w2(lw), ss_w2t(lw), ss_w1t(lw)};
+                const SSeq<U_W1, U_W2, SDR, KS, KS, KQ, KQ, E> sqf_next{ss_w1(lw), ss_w2(lw), qn, qn};
                 f32x4 afr[E];
                 if constexpr (!SPW) load_afrag<E>(afr, abuf, LH, lane);
                 float b1r[DR][1];
@@ -1805,12 +1887,14 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 for (int i = 0; i < HC; ++i) dg += dn[i] * (fv[i] - n1[i]);
                 dg = rsum(dg);
                 const float dz = dg * g2 * (1.0f - g2);
+                float dffv[HC];
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
                     const int cl = sub + LPR * i;
-                    a_store(rrow, cl, dn[i] * g2 + dz * (ro[6][i] + ro[8][i]));
+                    dffv[i] = dn[i] * g2 + dz * (ro[6][i] + ro[8][i]);
                     resbuf[rrow * LH + cl] = dn[i] * (1.0f - g2) + dz * (ro[7][i] - ro[8][i]);
                 }
+                a_store_row(rrow, sub, dffv, invD, false);
                 // stage E operands: attn_out, nodes_in, g1 stay; LN2 gamma -> ro[2]
                 ro_load(2, lw.ln2_g, sub);
             }
@@ -1823,7 +1907,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 ro_touch();
                 const WStream after = s_woxt(lw, wave);
                 const SStream gn = ss_woxt(lw, wave);   // this layer's attention backward follows (G_ext GEMM: U_GX >= SDR units)
-                const SSeq<U_W1, U_W2, SDR, 0, 0, 0, 0, E> sqb{ss_w2t(lw), ss_w1t(lw), gn, gn};
+                const SSeq<U_W1, U_W2, SDR, KS, KS, KS, KS, E> sqb{ss_w2t(lw), ss_w1t(lw), gn, gn};
                 f32x4 afr[E];
                 if constexpr (!SPW) load_afrag<E>(afr, abuf, LH, lane);
                 float hp[DR][4];
@@ -1900,6 +1984,10 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 float n1[HC], d1[HC], dyg[HC], xh[HC], ps[HC], ao[HC], ni[HC];
                 rows_of(l, ao, ni, nullptr, 0);
                 psum_all(ps, rrow * LH + sub);
+                if constexpr (FOLD && DFF_F16) {   // the FFN backward chain ran in this row's scaled units
+#pragma unroll
+                    for (int i = 0; i < HC; ++i) ps[i] *= invD;
+                }
                 pf.tick(22); DFF_MARK(22); phase_prio<22>(wave);
                 float g1;
                 if constexpr (KEEPROWS) g1 = gate_get(l, std::integral_constant<int, 0>{});
@@ -1928,12 +2016,15 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 }
                 dg = rsum(dg);
                 const float dz = dg * g1 * (1.0f - g1);
+                float dav[HC], invE;
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
                     const int cl = sub + LPR * i;
-                    a_store(rrow, cl, d1[i] * g1 + dz * (ro[3][i] + ro[5][i]));
+                    dav[i] = d1[i] * g1 + dz * (ro[3][i] + ro[5][i]);
                     resbuf[rrow * LH + cl] = d1[i] * (1.0f - g1) + dz * (ro[4][i] - ro[5][i]);
                 }
+                a_store_row(rrow, sub, dav, invE, true);   // (scale and inverse -> rsc: the attention backward block's waves)
+                (void)invE;
                 if constexpr (KEEPROWS) {
                     // this layer's LayerNorm rows (the keys / values of its attention block) back into the shared buffer: kept in
                     // registers since the forward stage made them; the last layer's are still there
@@ -1974,8 +2065,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 (void)more;
                 // what follows: FFN backward of layer l - 1 (W2^T, W1^T); after layer 0 the next step re-stages its own first units
                 const DffLayerDev& lwp = m.layer[l > 0 ? l - 1 : 0];
-                const SSeq<U_GX, U_QKVT, MW, 0, KT, 0, 0, E, 4 * KB32> sqa{ss_woxt(lw, wave), ss_qkvt(lw, wave), ss_w2t(lwp), ss_w1t(lwp)};   // tile 4 of 5: [r | g_D]
-                const SSeq<U_GX, 0, MW, 0, 0, 0, 0, E, 4 * KB32> sqa0{ss_woxt(lw, wave), ss_woxt(lw, wave), ss_w2t(lwp), ss_w1t(lwp)};
+                const SSeq<U_GX, U_QKVT, MW, KS, KT, KS, KS, E, 4 * KB32> sqa{ss_woxt(lw, wave), ss_qkvt(lw, wave), ss_w2t(lwp), ss_w1t(lwp)};   // tile 4 of 5: [r | g_D]
+                const SSeq<U_GX, 0, MW, KS, KS, KS, KS, E, 4 * KB32> sqa0{ss_woxt(lw, wave), ss_woxt(lw, wave), ss_w2t(lwp), ss_w1t(lwp)};
                 u32x4 dah[KB32], dam[KB32], dal[KB32];   // SPW: dattn as bf16 pieces
                 if constexpr (SPW) a_load(dah, dam, dal, lane);
                 // this lane's share of the head's dE/dx terms (extension tiles of G_ext, dV_ext, dK_ext: rows quad * 4 + r,
@@ -2003,9 +2094,13 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     lfloat* const gb = Gx + col;
                     const int l0 = lro[0], l1 = lro[1], l2 = lro[2], l3 = lro[3];
                     f32x4* const dxrp = &dxr;
+                    // fp16 engine: dattn came in row-scaled (stage E): G_ext leaves the GEMM in true units again
+                    f32x4 gi4 = {1.f, 1.f, 1.f, 1.f};
+                    if constexpr (F16E) gi4 = *(const lf32x4*)(rsc + 16 + 4 * quad);
                     swide_run<0, 5, KB32, 1>(sring, none, dah, dam, dal, sq, lane,
                         [=](int, float (&)[1]) {},
-                        [=](int t, const f32x4& acc, const float (&)[1]) {
+                        [=](int t, const f32x4& acc0, const float (&)[1]) {
+                            const f32x4 acc = F16E ? acc0 * gi4 : acc0;
                             gb[l0 + 16 * t] = acc[0]; gb[l1 + 16 * t] = acc[1];
                             gb[l2 + 16 * t] = acc[2]; gb[l3 + 16 * t] = acc[3];
                             if (t == 4) *dxrp -= acc;
@@ -2135,7 +2230,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         pf.tick(16); DFF_MARK(16); phase_prio<16>(wave);
                         dqkv();
                         pf.tick(17); DFF_MARK(17); phase_prio<17>(wave);
-                        if constexpr (SPW) stall_run<U_GX, NKT, E, true>(sring, acc_a, qkvt_fa32, sqa, lane, qkvt_xa, qkvt_ext(lw, wave, lane), DFF_HEADS * 13 * 256);
+                        if constexpr (SPW) stall_run<U_GX, NKT, E, true>(sring, acc_a, qkvt_fa32, sqa, lane, qkvt_xa, qkvt_ext(lw, wave, lane), DFF_HEADS * 13 * 256,
+                                                                         F16E ? rsc : nullptr);   // (dQ' rows re-scaled by their dattn row's scale)
                         else tall_run<5 % DR, 13, E, 4>(ring, acc_a, qkvt_fa, s_qkvt(lw, wave), after, lane);   // 18 entries: phase 0
                         pf.tick(18); DFF_MARK(18); phase_prio<18>(wave);
                     }
@@ -2410,6 +2506,9 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 // per sampler mode: this one exports dff_small_pick_m<DFF_SMALL_MODE>.
 #ifndef DFF_SMALL_MODE
 #error "compile dff_small.hip with -DDFF_SMALL_MODE=0|1|2 (DFF_MODE_SCORE / LANGEVIN / DDPM): build.sh builds all three"
+#endif
+#if DFF_SMALL_MODE == 0
+bool dff_small_fold_f16() { return DFF_F16 != 0; }
 #endif
 #define DFF_CAT2(a, b) a##b
 #define DFF_CAT(a, b) DFF_CAT2(a, b)
