@@ -45,7 +45,7 @@ NORM_STD = {"chignolin": 3.113133430480957, "villin": 6.082900047302246, "protei
             "ala2": 0.9449278712272644, "trp_cage": 5.08211088180542, "bba": 6.294918537139893}
 TEMP = {"chignolin": 340, "villin": 360, "protein_g": 350, "ala2": 300, "trp_cage": 290, "bba": 325}
 PEAK_FP32_TFLOPS = 157.3            # MI355X_MICROARCH.md: f32 vector = f32 MFMA peak
-PEAK_BF16_DENSE_TFLOPS = 2500.0     # dense bf16 MFMA peak; an exact fp32 product costs six bf16 products
+PEAK_BF16_DENSE_TFLOPS = 2500.0     # dense bf16 / fp16 MFMA peak; an fp32-exact product costs six bf16 products or three fp16 ones
 MIN_LAUNCHES = 8
 # DFF_FORCE_DIST=1: run the N > 1 code (process group over RCCL, barriers, max-over-ranks all_reduce, the frame all_gather)
 # at ANY world size -- with one rank under torchrun this loads RCCL and executes every collective of the job on the one GPU
@@ -77,7 +77,7 @@ def profile_figures(kname, cfg, P, chunk, lib_sha=None):
     lib_sha = lib_sha or (library_src_sha() if CHECK_PROFILE_SHA else None)
 
     def norm(n):   # rocprofv3 prints the full template argument list, the library its own short name
-        n = n.replace(" ", "").replace("void", "")
+        n = n.replace(" ", "").replace("void", "").replace("split_f16", "split_bf16")   # (one template flag: the split engine, whichever pieces)
         if "<" not in n:
             return n
         base, args = n.split("<", 1)
@@ -122,16 +122,16 @@ def profile_figures(kname, cfg, P, chunk, lib_sha=None):
 
 # Said ONCE per line (`notes`), not once per entry: the driver keeps only the tail of stdout.
 NOTES = {
-    "dtype": "f32 everywhere.  Kernels named split_bf16 run the weight GEMMs as an exact 3-way bf16 split of every fp32 operand "
-             "(six v_mfma_f32_16x16x32_bf16 per fp32 product, fp32 accumulate; held to the fp32 reference's own error); attention "
-             "products and the other kernels: v_mfma_f32_16x16x4_f32 / fp32 VALU",
-    "roofline": "bound = fp32 compute (SURVEY 8d): frac = algorithmic TFLOP/s (official factorised FLOP count x proteins x steps / "
-                "HIP-event launch time) / 157.3.  split_peak_frac: against the split GEMMs' own roof, dense bf16 / 6 = 416.7.  "
-                "traffic = HBM bytes per launch, hbm_tbps, mfma_busy, l2_hit: rocprofv3 PMC passes of the same workload under "
-                "`profile` (FETCH_SIZE x2 + WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GUI cycles)); they are None and "
-                "profile_stale is true when that profile was taken on other sources than the running library's (src_sha)",
+    "dtype": "f32 everywhere.  Weight GEMMs of split_bf16 kernels: exact 3-way bf16 split of every fp32 operand (six "
+             "v_mfma_f32_16x16x32_bf16 per product); split_f16: 2-way fp16 split (22 bits per operand, three v_mfma_f32_16x16x32_f16, "
+             "gradients row-scaled by powers of two); fp32 accumulate, held to the fp32 reference's own error.  Attention products, "
+             "other kernels: v_mfma_f32_16x16x4_f32 / fp32 VALU",
+    "roofline": "bound = fp32 compute (SURVEY 8d): frac = algorithmic TFLOP/s (factorised FLOP count x proteins x steps / HIP-event "
+                "launch time) / 157.3.  split_peak_frac: vs the split GEMMs' own roof (dense bf16 / 6 = 416.7, fp16 / 3 = 833).  traffic "
+                "(HBM bytes per launch), hbm_tbps, mfma_busy, l2_hit: rocprofv3 PMC passes of the same workload under `profile`; None "
+                "+ profile_stale when that profile's sources (src_sha) are not the running library's",
     "fold_kv": "hidden == head dim: k / v projections folded into q / out (exact); ~26 % fewer MFMAs issued than the FLOP count used",
-    "timing": "persistent launches of `chunk` fused steps; --steps / --warmup are rounded up to whole launches, >= 8 timed launches",
+    "timing": "persistent launches of `chunk` fused steps; --steps / --warmup rounded up to whole launches, >= 8 timed launches",
     "cpu": "oracle/reference_twin.py (torch CPU port of the reference, materialised formulation), thread count picked by a probe",
     "also": "roofline objects there omit bound / peak / unit (= the headline's: mfma, 157.3, TFLOP/s)",
 }
@@ -161,6 +161,8 @@ def roofline(cfg, P, steps_per_launch, launch_ms, kname, brief=False):
         r["algorithmic_flops_per_launch"] = flops
     if "split_bf16" in kname:
         r["split_peak_frac"] = round(ach / (PEAK_BF16_DENSE_TFLOPS / 6.0), 4)
+    elif "split_f16" in kname:
+        r["split_peak_frac"] = round(ach / (PEAK_BF16_DENSE_TFLOPS / 3.0), 4)
     return r
 
 

@@ -556,6 +556,40 @@ def test_ddpm_chain_variance_at_full_size(dff):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dec,xs", [(1e-6, 1.0), (1e-2, 0.05), (1.0, 3.0), (1e2, 1.0), (1e4, 10.0)])
+def test_fp16_engine_over_gradient_magnitudes(dff, dec, xs, monkeypatch):
+    """Round 5: the headline kernel (chignolin: dff_small_kernel<64,8,split_f16,fold_kv>) runs its weight GEMMs on a TWO-piece
+    fp16 split (22 bits per operand, three MFMAs per product).  fp16 has five exponent bits, so the backward's GEMM inputs --
+    gradients, whose size follows the energy head's weights -- are scaled row-wise by powers of two before they are split
+    (dff_small.hip a_store_row).  Energy-head scales from 1e-6 to 1e4 (forces from 1e-7 to 1e3) and coordinates from 0.05 to
+    10 sigma: forces against the reference twin's float64 run stay within the usual bar -- 2.5 x the distance of the twin's
+    own float32 run on the same inputs -- and within 5e-6, the SAME relative error at every magnitude (a missing or wrong
+    row scale shows up as 1e-3 .. 1e-2 at the small end, profiles/r05/f16_engine); the fp32-MFMA engine (DFF_SPLIT_BF16=0)
+    runs next to it."""
+    from dff_amd.score import GraphTransformer
+    _, N, H, L = synth.SHIPPED_CONFIGS["chignolin"]
+    params = synth.synth_gnn_params(N, H, L, seed=4321, decoder_scale=dec)
+    x = (synth.normal((7, N, 3), 17, 5) * xs).astype(np.float32)
+    t = np.array([0.005, 0.02, 0.1, 0.5, 0.9, 0.999, 0.0], np.float32)
+    f32ref, f64 = twin_refs(params, x, t, L)
+    r32 = rel(f32ref, f64)
+    out = {}
+    for split in (True, False):
+        monkeypatch.setenv("DFF_SPLIT_BF16", "1" if split else "0")
+        model = GraphTransformer(N, H, device="cuda:0", n_layers=L, use_intrinsic_coords=True, use_abs_coords=False,
+                                 use_distances=False, conservative=True, state_dict=params)
+        f = model.native.score(torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()).cpu().numpy()
+        kname = model.native.last_launch()[0]
+        assert ("split_f16" in kname) == split, kname
+        assert np.isfinite(f).all()
+        out[split] = rel(f, f64)
+    print(f"decoder x{dec:g}, x x{xs:g}: rel(fp16 engine, f64)={out[True]:.3e} rel(fp32 engine, f64)={out[False]:.3e} "
+          f"rel(ref32, ref64)={r32:.3e} |F|max={np.abs(f64).max():.3e}")
+    assert out[True] <= 5e-6 and out[True] <= GUARD * max(r32, 4e-7)
+    assert out[False] <= 5e-6 and out[False] <= GUARD * max(r32, 4e-7)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg", ["chignolin", "trp_cage", "bba", "villin", "protein_g"])
 def test_split_bf16_weight_gemms_are_fp32_exact(dff, cfg, golden, monkeypatch):
     """Default variants where they exist (chignolin: all eight weight GEMMs of the <= 16-row kernel; trp-cage, BBA, villin
@@ -578,7 +612,7 @@ def test_split_bf16_weight_gemms_are_fp32_exact(dff, cfg, golden, monkeypatch):
     for split in (True, False):
         model = make(split, 1.0)
         f, e = model.native.score(torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["t"]).cuda(), return_energy=True)
-        assert ("split_bf16" in model.native.last_launch()[0]) == split, model.native.last_launch()
+        assert ("split_" in model.native.last_launch()[0]) == split, model.native.last_launch()   # split_bf16, or split_f16 (chignolin, round 5)
         f, e = f.cpu().numpy(), e.cpu().numpy()
         r64, r32 = rel(f, g["forces64"]), rel(g["forces32"], g["forces64"])
         print(f"{cfg}: split={split} rel(hip,ref64)={r64:.3e} rel(ref32,ref64)={r32:.3e}")
@@ -595,7 +629,7 @@ def test_split_bf16_weight_gemms_are_fp32_exact(dff, cfg, golden, monkeypatch):
         ld = LangevinDiffusion(diff, init, n_timesteps=20, save_interval=5, t=20, temp_data=340, temp_sim=340, dt=None,
                                masses=[12.0] * N, friction=1.0, verbose=False)
         out.append(ld.simulate(noises=noises))
-        assert ("split_bf16" in mdl.native.last_launch()[0]) == split
+        assert ("split_" in mdl.native.last_launch()[0]) == split
     assert rel(out[1], out[0]) <= 2e-5
 
 
@@ -929,9 +963,9 @@ def test_two_and_three_row_tiles_at_odd_bead_counts(dff, H, N, monkeypatch):
             model.native.pair(True)
     # the split engine wherever its operands fit the LDS next to the head buffers (the smallest size of every shape does);
     # beyond that the fp32 engine of the same shape takes over by itself
-    assert any("split_bf16" not in k for k in seen), seen
+    assert any("split_" not in k for k in seen), seen
     if (H, N) in ((128, 17), (128, 33), (96, 17)):
-        assert any("split_bf16" in k for k in seen), seen
+        assert any("split_" in k for k in seen), seen
 
 
 @pytest.mark.gpu

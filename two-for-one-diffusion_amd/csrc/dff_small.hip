@@ -2517,7 +2517,7 @@ bool DFF_CAT(dff_small_pick_m, DFF_SMALL_MODE)(int H, int NW, bool gen, bool spw
     if (H == 64 && NW == 8 && spw && fold && !gen) {
         *fn = (const void*)&dff_small_kernel<64, 8, false, true, true, MD>;
         *lds_floats = SmallLds<64, 8, true>::total;
-        *name = "dff_small_kernel<64,8,split_bf16,fold_kv>";
+        *name = DFF_F16 ? "dff_small_kernel<64,8,split_f16,fold_kv>" : "dff_small_kernel<64,8,split_bf16,fold_kv>";
         return true;
     }
     if (H == 64 && NW == 8 && spw) {
