@@ -103,6 +103,25 @@ static std::vector<uint32_t> pack_b_split(int K, int Nout, const std::function<d
 // 16-column output tile nt x 32 A-columns starting at c0, stored [piece h | m | l][lane][8 bf16].  Element j of lane
 // (n = lane & 15, kg = lane >> 4) is W(c0 + 16 (j >> 2) + 4 kg + (j & 3), 16 nt + n): the k order in which that kernel's A
 // fragments hold a 32-column block (two ds_read_b128, at columns 4 kg and 16 + 4 kg).  w = h + m + l exactly.
+static uint16_t f32_to_f16_rtz(float f);
+static float f16_to_f32(uint16_t h);
+// pack_b_split in the two-piece fp16 format of the round-5 engine: per (tile, 32-row k-block, piece h | l', lane) eight fp16
+static std::vector<uint32_t> pack_b_split_f16(int K, int Nout, const std::function<double(int, int)>& w) {
+    const int KB = K / 32, NT = (Nout + 15) / 16;
+    std::vector<uint32_t> out((size_t)NT * KB * 2 * 64 * 4, 0u);
+    for (int nt = 0; nt < NT; ++nt)
+        for (int kb = 0; kb < KB; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 32 * kb + 8 * (lane >> 4) + j, n = 16 * nt + (lane & 15);
+                    const float v = n < Nout ? (float)w(k, n) : 0.f;
+                    const uint16_t h = f32_to_f16_rtz(v);
+                    const uint16_t l = f32_to_f16_rtz((v - f16_to_f32(h)) * 2048.0f);
+                    out[((((size_t)nt * KB + kb) * 2 + 0) * 64 + lane) * 4 + (j >> 1)] |= (uint32_t)h << (16 * (j & 1));
+                    out[((((size_t)nt * KB + kb) * 2 + 1) * 64 + lane) * 4 + (j >> 1)] |= (uint32_t)l << (16 * (j & 1));
+                }
+    return out;
+}
 static std::vector<uint32_t> pack_units(const std::vector<std::pair<int, int>>& units, int Nout,
                                         const std::function<double(int, int)>& w) {
     std::vector<uint32_t> out(units.size() * 3 * 64 * 4, 0u);
@@ -510,14 +529,19 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
         d.Wqkvx_s = d.W1_s = d.W2T_s = d.WoxT_s = d.W2_s = d.W1T_s = d.Wox_s = d.WqkvxT_s = nullptr;
         if (m->split) {
             int rc_;
-            if ((rc_ = upload_u32(m, pack_b_split(H, 8 * 208, [&](int k, int n) { return wqkvx(n, k); }), &d.Wqkvx_s))) return rc_;
-            if ((rc_ = upload_u32(m, pack_b_split(H, F, [&](int k, int n) { return (double)W1[(size_t)n * H + k]; }), &d.W1_s))) return rc_;
-            if ((rc_ = upload_u32(m, pack_b_split(H, F, [&](int k, int n) { return (double)W2[(size_t)k * F + n]; }), &d.W2T_s))) return rc_;
-            if ((rc_ = upload_u32(m, pack_b_split(H, 8 * 80, [&](int k, int n) { return wox(n, k); }), &d.WoxT_s))) return rc_;
-            if ((rc_ = upload_u32(m, pack_b_split(F, H, [&](int k, int n) { return (double)W2[(size_t)n * F + k]; }), &d.W2_s))) return rc_;
-            if ((rc_ = upload_u32(m, pack_b_split(F, H, [&](int k, int n) { return (double)W1[(size_t)k * H + n]; }), &d.W1T_s))) return rc_;
+            // image format per GEMM group: two fp16 pieces where the kernels' engine takes them (dff_fused_f16_mask)
+            const int f16m = dff_fused_f16_mask();
+            auto PB = [&](int bit, int K_, int Nout_, const std::function<double(int, int)>& wf) {
+                return (f16m & bit) ? pack_b_split_f16(K_, Nout_, wf) : pack_b_split(K_, Nout_, wf);
+            };
+            if ((rc_ = upload_u32(m, PB(1, H, 8 * 208, [&](int k, int n) { return wqkvx(n, k); }), &d.Wqkvx_s))) return rc_;
+            if ((rc_ = upload_u32(m, PB(1, H, F, [&](int k, int n) { return (double)W1[(size_t)n * H + k]; }), &d.W1_s))) return rc_;
+            if ((rc_ = upload_u32(m, PB(2, H, F, [&](int k, int n) { return (double)W2[(size_t)k * F + n]; }), &d.W2T_s))) return rc_;
+            if ((rc_ = upload_u32(m, PB(4, H, 8 * 80, [&](int k, int n) { return wox(n, k); }), &d.WoxT_s))) return rc_;
+            if ((rc_ = upload_u32(m, PB(1, F, H, [&](int k, int n) { return (double)W2[(size_t)n * F + k]; }), &d.W2_s))) return rc_;
+            if ((rc_ = upload_u32(m, PB(2, F, H, [&](int k, int n) { return (double)W1[(size_t)k * H + n]; }), &d.W1T_s))) return rc_;
             // the 64 regular rows of every head of [W_o ; W_oc] (the extension rows stay on the fp32 image)
-            if ((rc_ = upload_u32(m, pack_b_split(8 * 64, H, [&](int k, int n) { return wox((k / 64) * 80 + k % 64, n); }), &d.Wox_s))) return rc_;
+            if ((rc_ = upload_u32(m, PB(1, 8 * 64, H, [&](int k, int n) { return wox((k / 64) * 80 + k % 64, n); }), &d.Wox_s))) return rc_;
             // ... and the 192 regular rows [q | k | v] of every head of QKV_ext^T
             if ((rc_ = upload_u32(m, pack_b_split(8 * 192, H, [&](int c, int n) {
                      const int h = c / 192, cc = c % 192;

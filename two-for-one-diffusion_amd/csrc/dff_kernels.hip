@@ -25,6 +25,12 @@
 // their transposes for the VJP) run on v_mfma_f32_16x16x4_f32 (exact fp32 == fmaf chain);
 // softmax / LayerNorm / GELU / gates / the N x N contractions run on the VALU out of LDS.
 #include "dff_device.h"
+// DFF_F16G (round 5): which weight GEMMs of the split variants run on the two-piece fp16 format (4 B per weight, three MFMAs per
+// unit and row tile; dff_device.h split8h) instead of the three-piece bf16 one: bit 0 = the forward images (Wqkvx, Wox, W1, W2;
+// their A operands are O(1) activations: no scaling), bit 1 = the FFN backward (W2T, W1T; row-scaled), bit 2 = G_ext (WoxT).
+#ifndef DFF_F16G
+#define DFF_F16G 1
+#endif
 #include <type_traits>
 #ifndef DFF_AUXLATE
 #define DFF_AUXLATE 1   // wide split GEMMs: the tiles' auxiliary rows are requested behind the ring's first entries (protein G -1.1 %, trp-cage -0.5 %, villin / BBA -0.2 %)
@@ -218,8 +224,11 @@ DEVI void gemm_wide_st(const lfloat* A, int lda, int rowsA, const float* __restr
 // (s_waitcnt vmcnt(0) in front of every MFMA block).  epi(nt, mt, acc, aux, valid).
 // Waves W0 .. W0 + NWV - 1 share the tiles (the others must not call); epi also gets the round index i (compile time
 // after unrolling: an epilogue may park the tile in registers, see the head loop of the forward pass).
-template <int MT, int KB32, int NTN, int NAUX, int W0 = 0, int NWV = DFF_NWAVES, int DRMAX = 3, class Pre, class Epi>
+// F16 (round 5): the two-piece fp16 format (dff_device.h split8h) -- image [tile][k-block][h | l'][lane], A pieces as[0] = h, as[1] = l',
+// three v_mfma_f32_16x16x32_f16 per (unit, row tile): cb = h.h, cs = the two 2^11-scaled cross terms, result cb + cs / 2048.
+template <int MT, int KB32, int NTN, int NAUX, int W0 = 0, int NWV = DFF_NWAVES, int DRMAX = 3, bool F16 = false, class Pre, class Epi>
 DEVI void gemm_wide_split_st(const lu32* as, int R, int rowsA, const unsigned* __restrict__ Wp, int nt0, Pre pre, Epi epi) {
+    constexpr int NP = F16 ? 2 : 3;
     constexpr bool HALVES = KB32 % 2 == 0 && KB32 >= 4;
     constexpr int NHALF = HALVES ? 2 : 1, HB = KB32 / NHALF, LHS2 = (32 * KB32 + DFF_SPAD) / 2;
     constexpr int CNT = (NTN + NWV - 1) / NWV, NE = CNT * NHALF;
@@ -245,7 +254,7 @@ DEVI void gemm_wide_split_st(const lu32* as, int R, int rowsA, const unsigned* _
 #pragma unroll
         for (int kb = 0; kb < HB; ++kb)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) slot[kb][p] = wp[((tile * KB32 + (e % NHALF) * HB + kb) * 3 + p) * 64];
+            for (int p = 0; p < NP; ++p) slot[kb][p] = wp[((tile * KB32 + (e % NHALF) * HB + kb) * NP + p) * 64];
     };
     // DFF_AUXLATE: the ring's first entries are requested BEFORE the tiles' auxiliary rows.  Loads return in order, and an
     // auxiliary row may come from HBM (the backward's gelu' rows out of the stash): requested in between, every ring entry
@@ -272,7 +281,7 @@ DEVI void gemm_wide_split_st(const lu32* as, int R, int rowsA, const unsigned* _
                 const int o = rowoff[mt] + 16 * kb;
                 ares[mt][kb][0] = *(const lu32x4*)(as + o);
                 ares[mt][kb][1] = *(const lu32x4*)(as + R * LHS2 + o);
-                ares[mt][kb][2] = *(const lu32x4*)(as + 2 * R * LHS2 + o);
+                if constexpr (!F16) ares[mt][kb][2] = *(const lu32x4*)(as + 2 * R * LHS2 + o);
             }
     }
     constexpr bool APRE = !ARES && DFF_APRE;
@@ -280,7 +289,7 @@ DEVI void gemm_wide_split_st(const lu32* as, int R, int rowsA, const unsigned* _
     if constexpr (APRE) {
         apre[0] = *(const volatile lu32x4*)(as + rowoff[0]);
         apre[1] = *(const volatile lu32x4*)(as + R * LHS2 + rowoff[0]);
-        apre[2] = *(const volatile lu32x4*)(as + 2 * R * LHS2 + rowoff[0]);
+        if constexpr (!F16) apre[2] = *(const volatile lu32x4*)(as + 2 * R * LHS2 + rowoff[0]);
     }
     f32x4 cs[MT], cb[MT];
 #pragma unroll
@@ -300,29 +309,35 @@ DEVI void gemm_wide_split_st(const lu32* as, int R, int rowsA, const unsigned* _
                     const int o = rowoff[mt] + 16 * (half * HB + kb);
                     u32x4 ah, am, al;
                     if constexpr (ARES) {
-                        ah = ares[mt][half * HB + kb][0]; am = ares[mt][half * HB + kb][1]; al = ares[mt][half * HB + kb][2];
+                        ah = ares[mt][half * HB + kb][0]; am = ares[mt][half * HB + kb][1]; al = ares[mt][half * HB + kb][F16 ? 1 : 2];
                     } else if constexpr (APRE) {
                         // this unit's fragments were requested a unit ago; request the next unit's (the first of the next
                         // entry after the last of this one: A is the same for every tile) before this unit's products
-                        ah = apre[0]; am = apre[1]; al = apre[2];
+                        ah = apre[0]; am = apre[1]; al = apre[F16 ? 1 : 2];
                         constexpr int dummy = 0; (void)dummy;
                         const int mtn = (mt + 1) % MT, kbn = (mt + 1 == MT) ? kb + 1 : kb;
                         const int kabs = (kbn == HB) ? ((half + 1) % NHALF) * HB : half * HB + kbn;
                         const int on = rowoff[mtn] + 16 * kabs;
                         apre[0] = *(const volatile lu32x4*)(as + on);
                         apre[1] = *(const volatile lu32x4*)(as + R * LHS2 + on);
-                        apre[2] = *(const volatile lu32x4*)(as + 2 * R * LHS2 + on);
+                        if constexpr (!F16) apre[2] = *(const volatile lu32x4*)(as + 2 * R * LHS2 + on);
                     } else {
                         ah = *(const lu32x4*)(as + o);
                         am = *(const lu32x4*)(as + R * LHS2 + o);
-                        al = *(const lu32x4*)(as + 2 * R * LHS2 + o);
+                        if constexpr (!F16) al = *(const lu32x4*)(as + 2 * R * LHS2 + o);
                     }
+                    if constexpr (F16) {
+                        cs[mt] = mfma_f16(b[slot][kb][0], am, cs[mt]);
+                        cs[mt] = mfma_f16(b[slot][kb][1], ah, cs[mt]);
+                        cb[mt] = mfma_f16(b[slot][kb][0], ah, cb[mt]);
+                    } else {
                     cs[mt] = mfma_bf16(b[slot][kb][0], al, cs[mt]);
                     cb[mt] = mfma_bf16(b[slot][kb][0], am, cb[mt]);
                     cs[mt] = mfma_bf16(b[slot][kb][2], ah, cs[mt]);
                     cb[mt] = mfma_bf16(b[slot][kb][1], ah, cb[mt]);
                     cs[mt] = mfma_bf16(b[slot][kb][1], am, cs[mt]);
                     cb[mt] = mfma_bf16(b[slot][kb][0], ah, cb[mt]);
+                    }
                 }
             }
         }
@@ -334,7 +349,7 @@ DEVI void gemm_wide_split_st(const lu32* as, int R, int rowsA, const unsigned* _
         if (half == NHALF - 1) {
             const bool valid = wave + NWV * i < NTN;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) epi(tile_of(i), mt, cb[mt] + cs[mt], aux[i % NA], valid, i);
+            for (int mt = 0; mt < MT; ++mt) epi(tile_of(i), mt, F16 ? cb[mt] + cs[mt] * DFF_F16_LINV : cb[mt] + cs[mt], aux[i % NA], valid, i);
         }
     }
 }
@@ -344,8 +359,9 @@ DEVI void gemm_wide_split_st(const lu32* as, int R, int rowsA, const unsigned* _
 // it, and three ds_read_b128 per six 16-cycle products make the LDS as busy as the matrix pipes (8 waves x 24 LDS cycles
 // against 2 waves x 96 pipe cycles per SIMD): the two limits add up instead of overlapping.  Pairs q = wave + 8 i cover
 // tiles 2 q and 2 q + 1 (a surplus tile repeats NTN - 1 with valid = false); ring of two k-blocks (both tiles' pieces).
-template <int MT, int KB32, int NTN, int NAUX, class Pre, class Epi>
+template <int MT, int KB32, int NTN, int NAUX, bool F16 = false, class Pre, class Epi>
 DEVI void gemm_wide_split_k2(const lu32* as, int R, int rowsA, const unsigned* __restrict__ Wp, int nt0, Pre pre, Epi epi) {
+    constexpr int NPC = F16 ? 2 : 3;   // pieces per weight
     constexpr int LHS2 = (32 * KB32 + DFF_SPAD) / 2, NP = (NTN + 1) / 2, CNT = (NP + DFF_NWAVES - 1) / DFF_NWAVES, DR = 2;
     static_assert(KB32 >= DR, "ring");
     const int tid_ = tid_now();
@@ -364,9 +380,9 @@ DEVI void gemm_wide_split_k2(const lu32* as, int R, int rowsA, const unsigned* _
         float aux[2][NAUX];
         auto fill = [&](u32x4 (&slot)[2][3], int kb) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) slot[0][p] = wp[(((size_t)(nt0 + t0) * KB32 + kb) * 3 + p) * 64];
+            for (int p = 0; p < NPC; ++p) slot[0][p] = wp[(((size_t)(nt0 + t0) * KB32 + kb) * NPC + p) * 64];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) slot[1][p] = wp[(((size_t)(nt0 + t1) * KB32 + kb) * 3 + p) * 64];
+            for (int p = 0; p < NPC; ++p) slot[1][p] = wp[(((size_t)(nt0 + t1) * KB32 + kb) * NPC + p) * 64];
         };
 #pragma unroll
         for (int d = 0; d < DR; ++d) fill(b[d], d);
@@ -383,18 +399,26 @@ DEVI void gemm_wide_split_k2(const lu32* as, int R, int rowsA, const unsigned* _
         u32x4 apre[3];
         apre[0] = *(const volatile lu32x4*)(as + rowoff[0]);
         apre[1] = *(const volatile lu32x4*)(as + R * LHS2 + rowoff[0]);
-        apre[2] = *(const volatile lu32x4*)(as + 2 * R * LHS2 + rowoff[0]);
+        if constexpr (!F16) apre[2] = *(const volatile lu32x4*)(as + 2 * R * LHS2 + rowoff[0]);
         if (v0) {   // (wave-uniform; a wave without a pair skips the products)
 #pragma unroll
             for (int kb = 0; kb < KB32; ++kb) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    const u32x4 ah = apre[0], am = apre[1], al = apre[2];
+                    const u32x4 ah = apre[0], am = apre[1], al = apre[F16 ? 1 : 2];
                     const int mtn = (mt + 1) % MT, kbn = (mt + 1 == MT) ? (kb + 1) % KB32 : kb;
                     const int on = rowoff[mtn] + 16 * kbn;
                     apre[0] = *(const volatile lu32x4*)(as + on);
                     apre[1] = *(const volatile lu32x4*)(as + R * LHS2 + on);
-                    apre[2] = *(const volatile lu32x4*)(as + 2 * R * LHS2 + on);
+                    if constexpr (!F16) apre[2] = *(const volatile lu32x4*)(as + 2 * R * LHS2 + on);
+                    if constexpr (F16) {
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) cs[t][mt] = mfma_f16(b[kb % DR][t][0], am, cs[t][mt]);
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) cs[t][mt] = mfma_f16(b[kb % DR][t][1], ah, cs[t][mt]);
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) cb[t][mt] = mfma_f16(b[kb % DR][t][0], ah, cb[t][mt]);
+                    } else {
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         cs[t][mt] = mfma_bf16(b[kb % DR][t][0], al, cs[t][mt]);
@@ -410,6 +434,7 @@ DEVI void gemm_wide_split_k2(const lu32* as, int R, int rowsA, const unsigned* _
                         cs[t][mt] = mfma_bf16(b[kb % DR][t][1], am, cs[t][mt]);
                         cb[t][mt] = mfma_bf16(b[kb % DR][t][0], ah, cb[t][mt]);
                     }
+                    }
                 }
                 if (kb + DR < KB32) {
                     fill(b[kb % DR], kb + DR);
@@ -422,9 +447,9 @@ DEVI void gemm_wide_split_k2(const lu32* as, int R, int rowsA, const unsigned* _
             pre(t1, aux[1]);
         }
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) epi(t0, mt, cb[0][mt] + cs[0][mt], aux[0], v0, i);
+        for (int mt = 0; mt < MT; ++mt) epi(t0, mt, F16 ? cb[0][mt] + cs[0][mt] * DFF_F16_LINV : cb[0][mt] + cs[0][mt], aux[0], v0, i);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) epi(t1, mt, cb[1][mt] + cs[1][mt], aux[1], v1, i);
+        for (int mt = 0; mt < MT; ++mt) epi(t1, mt, F16 ? cb[1][mt] + cs[1][mt] * DFF_F16_LINV : cb[1][mt] + cs[1][mt], aux[1], v1, i);
     }
 }
 
@@ -527,7 +552,15 @@ DEVI void gx_units_hold(const lu32* as, int R, int rowsA, const unsigned* __rest
 }
 
 // One element of a split A operand: three 16-bit stores (row-major bf16 pieces [piece][R][LS], LS in bf16 units).
+template <bool F16 = false>
 DEVI void store_split(lu16* as16, int R, int LS, int row, int col, float v) {
+    if constexpr (F16) {   // two fp16 pieces (h, l'): dff_device.h split1h
+        unsigned short hh, ll;
+        split1h(v, hh, ll);
+        as16[(0 * R + row) * LS + col] = hh;
+        as16[(1 * R + row) * LS + col] = ll;
+        return;
+    }
     const unsigned uh = __float_as_uint(v) & 0xffff0000u;
     const float r = v - __uint_as_float(uh);
     const unsigned um = __float_as_uint(r) & 0xffff0000u;
@@ -537,7 +570,17 @@ DEVI void store_split(lu16* as16, int R, int LS, int row, int col, float v) {
     as16[(2 * R + row) * LS + col] = (unsigned short)(__float_as_uint(r2) >> 16);
 }
 // Four consecutive columns (col % 4 == 0) of one row: one 8-byte store per piece (LS2 = dwords per piece row, even).
+template <bool F16 = false>
 DEVI void store_split4(lu32* as, int R, int LS2, int row, int col, const f32x4 v) {
+    if constexpr (F16) {
+        unsigned h0, l0, h1, l1;
+        split2h(v[0], v[1], h0, l0);
+        split2h(v[2], v[3], h1, l1);
+        const int o = row * LS2 + (col >> 1);
+        *(lu32x2*)(as + 0 * R * LS2 + o) = (u32x2){h0, h1};
+        *(lu32x2*)(as + 1 * R * LS2 + o) = (u32x2){l0, l1};
+        return;
+    }
     unsigned hh[4], mm[4], ll[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -554,25 +597,29 @@ DEVI void store_split4(lu32* as, int R, int LS2, int row, int col, const f32x4 v
 }
 // The same with a compile-time k-block count: loop-free, so that the ring (D k-blocks ahead) is waited for exactly.
 // (PRE: the ring's first D k-blocks were requested by tall_ring_fill before the barrier in front of this GEMM)
-template <int NTW, int D, int MT = 1>
+template <int NTW, int D, int MT = 1, bool F16 = false>
 DEVI void tall_ring_fill(u32x4 (&b)[D][NTW][3], const unsigned* __restrict__ Wp, int KBtot, int kb0, int ntiles) {
+    constexpr int NP = F16 ? 2 : 3;
     const int tid_ = tid_now();
     const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     const WPtr<gu32x4, DFF_WMODE(MT)> wp((const gu32x4*)Wp, (unsigned)lane & 63u);
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
         const int nt = wave + DFF_NWAVES * i;
-        const size_t tb = ((size_t)(nt < ntiles ? nt : 0) * KBtot + kb0) * 3;
+        const size_t tb = ((size_t)(nt < ntiles ? nt : 0) * KBtot + kb0) * NP;
 #pragma unroll
         for (int d = 0; d < D; ++d)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) b[d][i][p] = wp[(tb + 3 * d + p) * 64];
+            for (int p = 0; p < NP; ++p) b[d][i][p] = wp[(tb + NP * d + p) * 64];
     }
     asm volatile("" ::: "memory");
 }
-template <int MT, int NTW, int NKB, bool PRE = false>
+// F16: two-piece fp16 operands (see gemm_wide_split_st); the 2^11-scaled cross terms collect in a second accumulator set that is
+// folded into `acc` before the function returns (acc lives across head groups / FFN chunks in the callers).
+template <int MT, int NTW, int NKB, bool PRE = false, bool F16 = false>
 DEVI void gemm_tall_split_st_b(f32x4 (&acc)[NTW][MT], int LS2 /* dwords per piece row */, const lu32* as, int R, int rowsA,
                              const unsigned* __restrict__ Wp, int KBtot, int kb0, int ntiles, u32x4 (&b)[NKB < 4 ? NKB : 4][NTW][3]) {
+    constexpr int NP = F16 ? 2 : 3;
     const int tid_ = tid_now();
     constexpr int D = NKB < 4 ? NKB : 4;
     const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
@@ -587,7 +634,7 @@ DEVI void gemm_tall_split_st_b(f32x4 (&acc)[NTW][MT], int LS2 /* dwords per piec
     for (int i = 0; i < NTW; ++i) {
         const int nt = wave + DFF_NWAVES * i;
         tok[i] = nt < ntiles;
-        tbase[i] = ((size_t)(tok[i] ? nt : 0) * KBtot + kb0) * 3;
+        tbase[i] = ((size_t)(tok[i] ? nt : 0) * KBtot + kb0) * NP;
     }
     if (!tok[0]) return;
     if (!PRE) {
@@ -596,7 +643,14 @@ DEVI void gemm_tall_split_st_b(f32x4 (&acc)[NTW][MT], int LS2 /* dwords per piec
 #pragma unroll
             for (int i = 0; i < NTW; ++i)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) b[d][i][p] = wp[(tbase[i] + 3 * d + p) * 64];
+                for (int p = 0; p < NP; ++p) b[d][i][p] = wp[(tbase[i] + NP * d + p) * 64];
+    }
+    f32x4 acc2[F16 ? NTW : 1][F16 ? MT : 1];
+    if constexpr (F16) {
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc2[i][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     __builtin_amdgcn_sched_barrier(0);   // issue the ring's loads here (see gemm_wide_split_st)
     // TPRE (up to three row tiles: 24 .. 36 more registers; trp-cage -1.3 %, villin -0.8 %, BBA and protein G neutral): the A fragments of k-block kb + 1 are requested before the products of
@@ -605,7 +659,7 @@ DEVI void gemm_tall_split_st_b(f32x4 (&acc)[NTW][MT], int LS2 /* dwords per piec
     u32x4 nh[TPRE ? MT : 1], nm[TPRE ? MT : 1], nl[TPRE ? MT : 1];
     auto a_load = [&](u32x4 (&xl)[TPRE ? MT : 1], u32x4 (&xh)[TPRE ? MT : 1], u32x4 (&xm)[TPRE ? MT : 1], int kb) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) xl[mt] = *(const volatile lu32x4*)(as + 2 * R * LS2 + rowoff[mt] + 16 * kb);
+        for (int mt = 0; mt < MT; ++mt) if constexpr (!F16) xl[mt] = *(const volatile lu32x4*)(as + 2 * R * LS2 + rowoff[mt] + 16 * kb);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) xh[mt] = *(const volatile lu32x4*)(as + rowoff[mt] + 16 * kb);
 #pragma unroll
@@ -624,7 +678,7 @@ DEVI void gemm_tall_split_st_b(f32x4 (&acc)[NTW][MT], int LS2 /* dwords per piec
             if (kb + 1 < NKB) a_load(nl, nh, nm, kb + 1);
         } else {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) al[mt] = *(const volatile lu32x4*)(as + 2 * R * LS2 + rowoff[mt] + 16 * kb);
+        for (int mt = 0; mt < MT; ++mt) if constexpr (!F16) al[mt] = *(const volatile lu32x4*)(as + 2 * R * LS2 + rowoff[mt] + 16 * kb);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) ah[mt] = *(const volatile lu32x4*)(as + rowoff[mt] + 16 * kb);
 #pragma unroll
@@ -633,6 +687,14 @@ DEVI void gemm_tall_split_st_b(f32x4 (&acc)[NTW][MT], int LS2 /* dwords per piec
 #pragma unroll
         for (int i = 0; i < NTW; ++i)
             if (i == 0 || tok[i]) {
+                if constexpr (F16) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc2[i][mt] = mfma_f16(b[d][i][0], am[mt], acc2[i][mt]);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc2[i][mt] = mfma_f16(b[d][i][1], ah[mt], acc2[i][mt]);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_f16(b[d][i][0], ah[mt], acc[i][mt]);
+                } else {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][0], al[mt], acc[i][mt]);
 #pragma unroll
@@ -645,22 +707,29 @@ DEVI void gemm_tall_split_st_b(f32x4 (&acc)[NTW][MT], int LS2 /* dwords per piec
                 for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][1], ah[mt], acc[i][mt]);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][0], ah[mt], acc[i][mt]);
+                }
             }
         if (kb + D < NKB) {
 #pragma unroll
             for (int i = 0; i < NTW; ++i)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) b[d][i][p] = wp[(tbase[i] + 3 * (kb + D) + p) * 64];
+                for (int p = 0; p < NP; ++p) b[d][i][p] = wp[(tbase[i] + NP * (kb + D) + p) * 64];
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    if constexpr (F16) {
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[i][mt] += acc2[i][mt] * DFF_F16_LINV;
+    }
 }
 
-template <int MT, int NTW, int NKB>
+template <int MT, int NTW, int NKB, bool F16 = false>
 DEVI void gemm_tall_split_st(f32x4 (&acc)[NTW][MT], int LS2, const lu32* as, int R, int rowsA,
                              const unsigned* __restrict__ Wp, int KBtot, int kb0, int ntiles) {
     u32x4 b[NKB < 4 ? NKB : 4][NTW][3];
-    gemm_tall_split_st_b<MT, NTW, NKB>(acc, LS2, as, R, rowsA, Wp, KBtot, kb0, ntiles, b);
+    gemm_tall_split_st_b<MT, NTW, NKB, false, F16>(acc, LS2, as, R, rowsA, Wp, KBtot, kb0, ntiles, b);
 }
 
 #ifndef DFF_WOPRE
@@ -1061,7 +1130,7 @@ DEVI void rstore(float* p, const float (&x)[H / LP], int sub) {
 // A row stage's K = H GEMM input.  fp32 engine: the fp32 row into abuf.  Split engine (round 4): the three bf16 pieces
 // straight into the split A operand (as[piece][row][LHS2], what split_rows used to make of abuf in a pass -- and a workgroup
 // barrier -- of its own, four times per layer); abuf does not exist in those variants.
-template <int H, int LP, bool SPW>
+template <int H, int LP, bool SPW, bool F16 = false>
 DEVI void rstore_a(const Ctx& c, int row, const float (&x)[H / LP], int sub) {
     using M = RowMap<H, LP>;
     if constexpr (!SPW) {
@@ -1072,7 +1141,13 @@ DEVI void rstore_a(const Ctx& c, int row, const float (&x)[H / LP], int sub) {
         for (int j = 0; j < M::NV; ++j) {
             const int col = M::VW * sub + M::VW * LP * j;
             if constexpr (M::VW == 4) {
-                store_split4(c.asp, c.RNa, LHS2, row, col, (f32x4){x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3]});
+                store_split4<F16>(c.asp, c.RNa, LHS2, row, col, (f32x4){x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3]});
+            } else if constexpr (F16) {
+                unsigned h, l;
+                split2h(x[2 * j], x[2 * j + 1], h, l);
+                const int o = row * LHS2 + (col >> 1);
+                c.asp[0 * c.RNa * LHS2 + o] = h;
+                c.asp[1 * c.RNa * LHS2 + o] = l;
             } else {
                 unsigned hh[2], mm[2], ll[2];
 #pragma unroll
@@ -1149,8 +1224,8 @@ DEVI void gate_weights(float (&w)[3][H / LP], const float* g, int sub) {
 }
 
 // R0: nodes (resbuf) -> stash nodes_in ; LN1 -> abuf
-template <int H, int LP, bool SPW>
-DEVI void row_ln1(const Ctx& c, const DffLayerDev& lw, int l) {
+template <int H, int LP, bool SPW, bool F16 = false>
+DEVI void row_ln1(const Ctx& c, const DffLayerDev& lw, int l) {   // (F16: the GEMM behind it takes two-piece fp16 operands)
     const int tid_ = tid_now();
     constexpr int HC = H / LP, LH = H + 4;
     const int grp = tid_ / LP, sub = tid_ % LP;
@@ -1164,12 +1239,12 @@ DEVI void row_ln1(const Ctx& c, const DffLayerDev& lw, int l) {
         ln_stats<H, LP>(x, mean, rstd);
 #pragma unroll
         for (int i = 0; i < HC; ++i) x[i] = (x[i] - mean) * rstd * gam[i] + bet[i];
-        rstore_a<H, LP, SPW>(c, row, x, sub);
+        rstore_a<H, LP, SPW, F16>(c, row, x, sub);
     }
 }
 
 // R1: tbuf = attn_out, resbuf = nodes -> nodes1 (resbuf), stash attn_out, LN2 -> abuf
-template <int H, int LP, bool SPW>
+template <int H, int LP, bool SPW, bool F16 = false>
 DEVI void row_gate1_ln2(const Ctx& c, const DffLayerDev& lw, int l, const float* tbuf) {
     const int tid_ = tid_now();
     constexpr int HC = H / LP, LH = H + 4;
@@ -1190,7 +1265,7 @@ DEVI void row_gate1_ln2(const Ctx& c, const DffLayerDev& lw, int l, const float*
         ln_stats<H, LP>(n1, mean, rstd);
 #pragma unroll
         for (int i = 0; i < HC; ++i) n1[i] = (n1[i] - mean) * rstd * gam[i] + bet[i];
-        rstore_a<H, LP, SPW>(c, row, n1, sub);
+        rstore_a<H, LP, SPW, F16>(c, row, n1, sub);
     }
 }
 
@@ -1624,7 +1699,7 @@ DEVI void co_softmax_pv(const CoGeo& g, gfloat* sP /* P block of head hg*HGS */,
                 lfloat* d = g.Rg + row * LQ + hh * 80 + col;
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
-                    if constexpr (SPW) store_split((lu16*)(g.Rg + 3 * g.RN * LQ), g.RN, 64 * HGS + DFF_SPAD, row, hh * 64 + 16 * nt + col, o[nt][r]);
+                    if constexpr (SPW) store_split<(DFF_F16G & 1) != 0>((lu16*)(g.Rg + 3 * g.RN * LQ), g.RN, 64 * HGS + DFF_SPAD, row, hh * 64 + 16 * nt + col, o[nt][r]);
                     else d[16 * nt] = o[nt][r];
                 }
                 if (!GEN) {
@@ -1759,7 +1834,7 @@ DEVI void co_softmax_pv_t(const CoGeo& g, gfloat* sP /* P block of head hg*HGS *
         if (i < g.rows) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                if constexpr (SPW) store_split4((lu32*)(g.Rg + 3 * g.RN * LQ), g.RN, (64 * HGS + DFF_SPAD) / 2, i, hh * 64 + 16 * nt + 4 * quad, o[nt]);
+                if constexpr (SPW) store_split4<(DFF_F16G & 1) != 0>((lu32*)(g.Rg + 3 * g.RN * LQ), g.RN, (64 * HGS + DFF_SPAD) / 2, i, hh * 64 + 16 * nt + 4 * quad, o[nt]);
                 else *(lf32x4*)(g.Rg + i * LQ + hh * 80 + 16 * nt + 4 * quad) = o[nt];
             }
             // extension tile: xrel_i = sum_j a_ij x_j - x_i (columns 0..2; the others as the C-layout version leaves them)
@@ -2144,6 +2219,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
     // for the (missing) warm-up lines -- in the pipelined attention phases it asks after its own work, in the slack the
     // row-tile waves leave it before the barrier.
     constexpr size_t UB = SPW ? 3072 : 1024;          // bytes of one (tile, k-block) unit
+    constexpr bool FWD16 = SPW && (DFF_F16G & 1);     // forward weight GEMMs on the two-piece fp16 format
+    constexpr size_t UBF = FWD16 ? 2048 : UB;         // ... whose images have 2 KB units
     constexpr int KQ = SPW ? 32 : 16;                 // rows of a k-block
     const int wave_l2 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     auto l2w = [&](const void* base, size_t off, int ntiles, size_t stride, size_t bytes) {
@@ -2151,19 +2228,20 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             if (wave_l2 == DFF_NWAVES - 1) l2_touch(junk_b, (const char*)base + off, ntiles, stride, (int)(bytes >> 7));
     };
     auto l2w_flat = [&](const void* base, size_t off, size_t bytes) { l2w(base, off, 8, bytes / 8, bytes / 8); };
-    constexpr size_t QKV_HG = (size_t)HGS * 13 * (H / KQ) * UB;     // Wqkvx: a head group's 13 HGS tiles, contiguous
+    constexpr size_t QKV_HG = (size_t)HGS * 13 * (H / KQ) * UBF;    // Wqkvx: a head group's 13 HGS tiles, contiguous
     constexpr size_t GX_HG = (size_t)HGS * 5 * (H / KQ) * UB;       // WoxT: its 5 HGS tiles
-    constexpr size_t FFW_CH = (size_t)(LL::FC / 16) * (H / KQ) * UB;   // W1 / W2T: a chunk's tiles
+    constexpr size_t FFW_CH = (size_t)(LL::FC / 16) * (H / KQ) * UB;   // W2T: a chunk's tiles
+    constexpr size_t FFW1_CH = (size_t)(LL::FC / 16) * (H / KQ) * UBF;  // W1: likewise
     auto l2_wqkv = [&](const DffLayerDev& w, int hg) { l2w_flat(SPW ? (const void*)w.Wqkvx_s : (const void*)w.Wqkvx_p, hg * QKV_HG, QKV_HG); };
     auto l2_wgx = [&](const DffLayerDev& w, int hg) { l2w_flat(SPW ? (const void*)w.WoxT_s : (const void*)w.WoxT_p, hg * GX_HG, GX_HG); };
-    auto l2_w1 = [&](const DffLayerDev& w, int ch) { l2w_flat(SPW ? (const void*)w.W1_s : (const void*)w.W1_p, ch * FFW_CH, FFW_CH); };
+    auto l2_w1 = [&](const DffLayerDev& w, int ch) { l2w_flat(SPW ? (const void*)w.W1_s : (const void*)w.W1_p, ch * FFW1_CH, FFW1_CH); };
     auto l2_w2t = [&](const DffLayerDev& w, int ch) { l2w_flat(SPW ? (const void*)w.W2T_s : (const void*)w.W2T_p, ch * FFW_CH, FFW_CH); };
     // "tall" images (Nout = H): a few k-blocks of every one of the H / 16 tiles
-    auto l2_tall = [&](const void* base, int kb0, int nkb, int kbtot) { l2w(base, (size_t)kb0 * UB, H / 16, (size_t)kbtot * UB, (size_t)nkb * UB); };
-    auto l2_w2 = [&](const DffLayerDev& w, int ch) { l2_tall(SPW ? (const void*)w.W2_s : (const void*)w.W2_p, ch * (LL::FC / KQ), LL::FC / KQ, LL::F / KQ); };
+    auto l2_tall = [&](const void* base, int kb0, int nkb, int kbtot, size_t ub = (SPW ? 3072 : 1024)) { l2w(base, (size_t)kb0 * ub, H / 16, (size_t)kbtot * ub, (size_t)nkb * ub); };
+    auto l2_w2 = [&](const DffLayerDev& w, int ch) { l2_tall(SPW ? (const void*)w.W2_s : (const void*)w.W2_p, ch * (LL::FC / KQ), LL::FC / KQ, LL::F / KQ, UBF); };
     auto l2_w1t = [&](const DffLayerDev& w, int ch) { l2_tall(SPW ? (const void*)w.W1T_s : (const void*)w.W1T_p, ch * (LL::FC / KQ), LL::FC / KQ, LL::F / KQ); };
     constexpr int WO_KB = SPW ? 2 : 5, WQT_KB = SPW ? 6 : 13;       // k-blocks per head (split: the 64 regular rows only)
-    auto l2_wo = [&](const DffLayerDev& w, int hg) { l2_tall(SPW ? (const void*)w.Wox_s : (const void*)w.Wox_p, hg * HGS * WO_KB, HGS * WO_KB, DFF_HEADS * WO_KB); };
+    auto l2_wo = [&](const DffLayerDev& w, int hg) { l2_tall(SPW ? (const void*)w.Wox_s : (const void*)w.Wox_p, hg * HGS * WO_KB, HGS * WO_KB, DFF_HEADS * WO_KB, UBF); };
     auto l2_wqkvT = [&](const DffLayerDev& w, int hg) { l2_tall(SPW ? (const void*)w.WqkvxT_s : (const void*)w.WqkvxT_p, hg * HGS * WQT_KB, HGS * WQT_KB, DFF_HEADS * WQT_KB); };
     c.xst = smem + ll.xst; c.xs = smem + ll.xs; c.dxs = smem + ll.dxs; c.vst = smem + ll.vst;
     c.cm = smem + ll.cm; c.tn = smem + ll.tn;
@@ -2414,7 +2492,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 }
             } else {
                 l2_wqkv(lw, hg_lo);
-                row_ln1<H, LPG, SPW>(c, lw, l);
+                row_ln1<H, LPG, SPW, FWD16>(c, lw, l);
                 wg_sync<SPILL>();
             }
             pf.tick(1);
@@ -2431,7 +2509,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             auto wo_gemm = [&](int hg, auto pre, u32x4 (&bw)[DWO][NTW][3]) {
                 ExtW<NTW, HGS> ew;
                 if constexpr (DFF_EXTPRE) ext_fetch<NTW, HGS, MT>(ew, [=](int i) { return (hg * HGS + i) * 5 + 4; }, lw.Wox_p, DFF_HEADS * 5, NT_H);
-                gemm_tall_split_st_b<MT, NTW, 2 * HGS, decltype(pre)::value>(acc_o, (64 * HGS + DFF_SPAD) / 2, (const lu32*)(geo.Rg + 3 * RN * LQ), RN, RN,
+                gemm_tall_split_st_b<MT, NTW, 2 * HGS, decltype(pre)::value, FWD16>(acc_o, (64 * HGS + DFF_SPAD) / 2, (const lu32*)(geo.Rg + 3 * RN * LQ), RN, RN,
                                                      lw.Wox_s, 2 * DFF_HEADS, hg * HGS * 2, NT_H, bw);
                 if constexpr (!DFF_EXTPRE) ext_fetch<NTW, HGS, MT>(ew, [=](int i) { return (hg * HGS + i) * 5 + 4; }, lw.Wox_p, DFF_HEADS * 5, NT_H);
                 if (oxt) ext_apply<MT, NTW, HGS>(acc_o, ew, [=](int i) { return i * 16; }, oxt, 16 * HGS, RN, NT_H);
@@ -2458,7 +2536,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         st_ntg4<DFF_SITE_ST(MT, 2)>(ok ? sq + (size_t)hh * RN * DFF_QKVW + (size_t)row * DFF_QKVW + 16 * tt + c4 : junk, v);
                     };
                 };
-                gemm_wide_split_st<MT, H / 32, NTQ, 4>(asplit, RN, RN, lw.Wqkvx_s, hg_lo * NTQ, mk_pre(hg_lo), mk_epi(hg_lo));
+                gemm_wide_split_st<MT, H / 32, NTQ, 4, 0, DFF_NWAVES, 3, FWD16>(asplit, RN, RN, lw.Wqkvx_s, hg_lo * NTQ, mk_pre(hg_lo), mk_epi(hg_lo));
                 co_fill_x<HGS, GEN>(geo);   // once per layer: the forward pass never overwrites the K_ext / V_ext extension columns
                 wg_sync<SPILL>();
                 pf.tick(3);
@@ -2468,7 +2546,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     if (wave_ < NI) {
                         co_softmax_pv_t<MT, HGS, SPW>(geo, sPl + (size_t)hg * HGS * RN * c.sl.PS, oxt, junk);
                     } else if (more) {
-                        gemm_wide_split_st<MT, H / 32, NTQ, 1, NI, NWH, 2>(asplit, RN, RN, lw.Wqkvx_s, (hg + 1) * NTQ,
+                        gemm_wide_split_st<MT, H / 32, NTQ, 1, NI, NWH, 2, FWD16>(asplit, RN, RN, lw.Wqkvx_s, (hg + 1) * NTQ,
                             [](int, float (&)[1]) {},
                             [&](int, int mt, const f32x4& acc, const float (&)[1], bool, int i) { held[i][mt] = acc; });
                     }
@@ -2479,7 +2557,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     else if (!more) l2_w1(lw, ch_lo);
                     u32x4 bw[DWO][NTW][3];
                     constexpr bool WOPRE = DFF_WOPRE;   // W_o's operands cross the barrier in registers
-                    if constexpr (WOPRE) tall_ring_fill<NTW, DWO, MT>(bw, lw.Wox_s, 2 * DFF_HEADS, hg * HGS * 2, NT_H);
+                    if constexpr (WOPRE) tall_ring_fill<NTW, DWO, MT, FWD16>(bw, lw.Wox_s, 2 * DFF_HEADS, hg * HGS * 2, NT_H);
                     wg_sync<SPILL>();
                     pf.tick(4);
                     float bias4[CNTH][4];
@@ -2528,8 +2606,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                             st_ntg4<DFF_SITE_ST(MT, 2)>(ok ? sq + (size_t)hh * RN * DFF_QKVW + (size_t)row * DFF_QKVW + 16 * tt + c4 : junk, v);
                         };
                     if constexpr (SPW)
-                        if constexpr (MT >= 4 && DFF_K2) gemm_wide_split_k2<MT, H / 32, HGS * 13, 4>(asplit, RN, RN, lw.Wqkvx_s, hg * HGS * 13, qkv_pre, qkv_epi);
-                        else gemm_wide_split_st<MT, H / 32, HGS * 13, 4>(asplit, RN, RN, lw.Wqkvx_s, hg * HGS * 13, qkv_pre, qkv_epi);
+                        if constexpr (MT >= 4 && DFF_K2) gemm_wide_split_k2<MT, H / 32, HGS * 13, 4, FWD16>(asplit, RN, RN, lw.Wqkvx_s, hg * HGS * 13, qkv_pre, qkv_epi);
+                        else gemm_wide_split_st<MT, H / 32, HGS * 13, 4, 0, DFF_NWAVES, 3, FWD16>(asplit, RN, RN, lw.Wqkvx_s, hg * HGS * 13, qkv_pre, qkv_epi);
                     else
                         gemm_wide_st<MT, NT_H, HGS * 13, 4>(abufL, LH, RN, lw.Wqkvx_p, hg * HGS * 13, qkv_pre, qkv_epi);
                 }
@@ -2564,7 +2642,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             store_tall<MT, NTW>(acc_o, tbuf, LH, rows, NT_H, hf == 0 ? lw.bo : nullptr);
             pair_exchange(tbuf, H, LH);
             wg_sync<SPILL>();
-            row_gate1_ln2<H, LPG, SPW>(c, lw, l, tbuf);
+            row_gate1_ln2<H, LPG, SPW, FWD16>(c, lw, l, tbuf);
             wg_sync<SPILL>();
             pf.tick(7);
             // FFN: Linear(H,4H) -> GELU(erf) -> Linear(4H,H)   (graph_transformer.py:264-267)
@@ -2586,14 +2664,14 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                             for (int r = 0; r < 4; ++r) { float v_, p_; gelu_both(acc[r] + aux[r], v_, p_); gv[r] = v_; gp[r] = p_; }
                             st_ntg4<DFF_SITE_ST(MT, 8)>(ok ? shp + (size_t)row * F + cl : junk, gp);   // the slot "h_pre" holds gelu'(h_pre)
                             if (ok) {
-                                if constexpr (SPW) store_split4((lu32*)hl, RN, (FC + DFF_SPAD) / 2, row, cl, gv);
+                                if constexpr (SPW) store_split4<FWD16>((lu32*)hl, RN, (FC + DFF_SPAD) / 2, row, cl, gv);
                                 else *(lf32x4*)(hl + row * LF + cl) = gv;
                             }
                         };
                     l2_w2(lw, ch);
                     if constexpr (SPW)
-                        if constexpr (MT >= 4 && DFF_K2) gemm_wide_split_k2<MT, H / 32, FC / 16, 4>(asplit, RN, RN, lw.W1_s, ch * (FC / 16), w1_pre, w1_epi);
-                        else gemm_wide_split_st<MT, H / 32, FC / 16, 4>(asplit, RN, RN, lw.W1_s, ch * (FC / 16), w1_pre, w1_epi);
+                        if constexpr (MT >= 4 && DFF_K2) gemm_wide_split_k2<MT, H / 32, FC / 16, 4, FWD16>(asplit, RN, RN, lw.W1_s, ch * (FC / 16), w1_pre, w1_epi);
+                        else gemm_wide_split_st<MT, H / 32, FC / 16, 4, 0, DFF_NWAVES, 3, FWD16>(asplit, RN, RN, lw.W1_s, ch * (FC / 16), w1_pre, w1_epi);
                     else
                         gemm_wide_st<MT, NT_H, FC / 16, 4>(abufL, LH, RN, lw.W1_p, ch * (FC / 16), w1_pre, w1_epi);
                 }
@@ -2602,7 +2680,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 if (ch + 1 < ch_hi) l2_w1(lw, ch + 1);
                 else if (l == m.L - 1 && m.conservative) l2_w2t(lw, ch_lo);
                 if constexpr (SPW)
-                    gemm_tall_split_st<MT, NTW, FC / 32>(acc_f, (FC + DFF_SPAD) / 2, (const lu32*)geo.Rg, RN, RN, lw.W2_s, F / 32, ch * (FC / 32), NT_H);
+                    gemm_tall_split_st<MT, NTW, FC / 32, FWD16>(acc_f, (FC + DFF_SPAD) / 2, (const lu32*)geo.Rg, RN, RN, lw.W2_s, F / 32, ch * (FC / 32), NT_H);
                 else
                 gemm_tall_kb_st<MT, NTW, 0, FC / 16>(acc_f,
                     [=](int i, int& aoff, int& wkb) { aoff = 16 * i; wkb = ch * (FC / 16) + i; },
@@ -3083,6 +3161,7 @@ static const Variant g_variants[] = {
     VAR(64, 1, 4, false),
 #endif
 };
+int dff_fused_f16_mask() { return DFF_F16G; }
 const Variant* dff_fused_variants(int* count) {
     *count = (int)(sizeof(g_variants) / sizeof(g_variants[0]));
     return g_variants;
