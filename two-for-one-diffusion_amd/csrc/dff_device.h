@@ -186,7 +186,7 @@ struct LdsLayout {
     static constexpr bool TIGHT_OK = MT == 4 && HGS == 1;
     static constexpr int PL_WIDE = 16 * MT + 4, PL_TIGHT = 16 * MT - 4;
     template <bool SPW> static constexpr int pl() { return (SPW && TIGHT_OK) ? PL_TIGHT : PL_WIDE; }
-    unsigned xst, xs, dxs, vst, cm, tn, prof, prow, dxw, m12, abuf, resbuf, Pbuf, dSbuf, Rg, asplit, lsplit, junk, total;
+    unsigned xst, xs, dxs, vst, cm, tn, prof, prow, rsc, dxw, m12, abuf, resbuf, Pbuf, dSbuf, Rg, asplit, lsplit, junk, total;
     unsigned PT;   // floats of one head's P (or dS) tile array
     __host__ __device__ LdsLayout(int N, int G, bool spw = false) {
         const unsigned R = (unsigned)(G * N);
@@ -201,6 +201,7 @@ struct LdsLayout {
         tn = o;    o += 16;
         prof = o;  o += 2 * DFF_NPROF;
         prow = o;  o += 64;                    // protein index of each row (-1: pad row)
+        rsc = o;   if (spw) o += 64;           // fp16 engine: inverse row scales of the backward chain in flight (round 5)
         dxw = o;   o += DFF_NWAVES * R * 4;   // per-wave partial dE/dx (summed once per step)
         m12 = o;   if (!tight) o += HGS * R * 4;   // GEN: reloaded [m1 | m2] of the head group (backward); no GEN variant is TIGHT
         abuf = o;  if (!spw) o += R * LH;   // (split engine: the row stages write the bf16 pieces themselves, no fp32 copy)
@@ -509,6 +510,7 @@ struct Ctx {
     int N, G, gcnt, rows, NP, L;
     int b0;
     float *xst, *xs, *dxs, *vst, *cm, *tn, *abuf, *resbuf, *Pbuf, *dSbuf, *Rg;
+    float* rsc;    // fp16 engine (LdsLayout::rsc): rsc[row] = 1 / (power-of-two scale of the row's backward GEMM input)
     lu32* asp;     // split engine: the bf16 pieces of the K = H GEMM input (LdsLayout::asplit), RNa allocated rows
     int RNa;
     float* stash;  // this workgroup's slot

@@ -29,7 +29,7 @@
 // unit and row tile; dff_device.h split8h) instead of the three-piece bf16 one: bit 0 = the forward images (Wqkvx, Wox, W1, W2;
 // their A operands are O(1) activations: no scaling), bit 1 = the FFN backward (W2T, W1T; row-scaled), bit 2 = G_ext (WoxT).
 #ifndef DFF_F16G
-#define DFF_F16G 1
+#define DFF_F16G 3
 #endif
 #include <type_traits>
 #ifndef DFF_AUXLATE
@@ -1167,6 +1167,28 @@ DEVI void rstore_a(const Ctx& c, int row, const float (&x)[H / LP], int sub) {
     }
 }
 template <int LP>
+DEVI float grp_max_lp(float v) {   // all-reduce (max) over the LP lanes of a row
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    if constexpr (LP == 16) v = fmaxf(v, dpp_mov<0x140>(v));
+    return v;
+}
+// fp16 engine, backward: scale a row-stage output row (a gradient: any magnitude) by the power of two that brings its maximum to
+// [16, 32) before it is split into fp16 pieces; the inverse goes to c.rsc[row] for whoever takes the chain's result back
+// (everything between two row stages is linear per row).  Exact.
+template <int H, int LP>
+DEVI void row_pow2_scale(const Ctx& c, int row, float (&x)[H / LP], int sub) {
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < H / LP; ++i) mx = fmaxf(mx, fabsf(x[i]));
+    float sc, inv;
+    pow2_scale(grp_max_lp<LP>(mx), sc, inv);
+#pragma unroll
+    for (int i = 0; i < H / LP; ++i) x[i] *= sc;
+    if (sub == 0) c.rsc[row] = inv;
+}
+template <int LP>
 DEVI float grp_sum_lp(float v) {   // all-reduce over the LP (8 or 16) lanes of a row
     v += dpp_mov<0xB1>(v);
     v += dpp_mov<0x4E>(v);
@@ -1317,7 +1339,7 @@ DEVI void row_gate2(const Ctx& c, const DffModelDev& m, const DffLayerDev& lw, i
 }
 
 // RB1: dn (resbuf) through gate2 -> dff (abuf), dn1 partial (resbuf)
-template <int H, int LP, bool SPW>
+template <int H, int LP, bool SPW, bool F16 = false>
 DEVI void rowb_gate2(const Ctx& c, const DffLayerDev& lw, int l) {
     const int tid_ = tid_now();
     constexpr int HC = H / LP, LH = H + 4;
@@ -1345,13 +1367,14 @@ DEVI void rowb_gate2(const Ctx& c, const DffLayerDev& lw, int l) {
             ao[i] = dn[i] * g2 + dz * (w2[0][i] + w2[2][i]);
             nin[i] = dn[i] * (1.0f - g2) + dz * (w2[1][i] - w2[2][i]);
         }
-        rstore_a<H, LP, SPW>(c, row, ao, sub);
+        if constexpr (F16) row_pow2_scale<H, LP>(c, row, ao, sub);   // (the FFN backward chain runs in scaled units)
+        rstore_a<H, LP, SPW, F16>(c, row, ao, sub);
         rstore<H, LP>(c.resbuf + row * LH, nin, sub);
     }
 }
 
 // RB2: tbuf = df ; dn1 = resbuf + LN2bwd(df) ; gate1 bwd -> dattn (abuf), dn_in partial (resbuf)
-template <int H, int LP, bool SPW>
+template <int H, int LP, bool SPW, bool FIN = false, bool FOUT = false>
 DEVI void rowb_ln2_gate1(const Ctx& c, const DffLayerDev& lw, int l, const float* tbuf) {
     const int tid_ = tid_now();
     constexpr int HC = H / LP, LH = H + 4;
@@ -1364,6 +1387,11 @@ DEVI void rowb_ln2_gate1(const Ctx& c, const DffLayerDev& lw, int l, const float
         gate_weights<H, LP>(w, lw.g1, sub);
         rload<H, LP>(gam, lw.ln2_g, sub);
         rload<H, LP>(df, tbuf + row * LH, sub);
+        if constexpr (FIN) {   // fp16 engine: the FFN backward chain ran in this row's scaled units (rowb_gate2)
+            const float rinv = c.rsc[row];
+#pragma unroll
+            for (int i = 0; i < HC; ++i) df[i] *= rinv;
+        }
         rload<H, LP>(dnp, c.resbuf + row * LH, sub);
         const float g1 = gate_value<H, LP>(ao, nin, w);
 #pragma unroll
@@ -2221,6 +2249,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
     constexpr size_t UB = SPW ? 3072 : 1024;          // bytes of one (tile, k-block) unit
     constexpr bool FWD16 = SPW && (DFF_F16G & 1);     // forward weight GEMMs on the two-piece fp16 format
     constexpr size_t UBF = FWD16 ? 2048 : UB;         // ... whose images have 2 KB units
+    constexpr bool FFB16 = SPW && (DFF_F16G & 2);     // FFN backward (W2T, W1T) likewise, on row-scaled operands
+    constexpr size_t UBB2 = FFB16 ? 2048 : UB;
     constexpr int KQ = SPW ? 32 : 16;                 // rows of a k-block
     const int wave_l2 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     auto l2w = [&](const void* base, size_t off, int ntiles, size_t stride, size_t bytes) {
@@ -2230,7 +2260,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
     auto l2w_flat = [&](const void* base, size_t off, size_t bytes) { l2w(base, off, 8, bytes / 8, bytes / 8); };
     constexpr size_t QKV_HG = (size_t)HGS * 13 * (H / KQ) * UBF;    // Wqkvx: a head group's 13 HGS tiles, contiguous
     constexpr size_t GX_HG = (size_t)HGS * 5 * (H / KQ) * UB;       // WoxT: its 5 HGS tiles
-    constexpr size_t FFW_CH = (size_t)(LL::FC / 16) * (H / KQ) * UB;   // W2T: a chunk's tiles
+    constexpr size_t FFW_CH = (size_t)(LL::FC / 16) * (H / KQ) * UBB2;  // W2T: a chunk's tiles
     constexpr size_t FFW1_CH = (size_t)(LL::FC / 16) * (H / KQ) * UBF;  // W1: likewise
     auto l2_wqkv = [&](const DffLayerDev& w, int hg) { l2w_flat(SPW ? (const void*)w.Wqkvx_s : (const void*)w.Wqkvx_p, hg * QKV_HG, QKV_HG); };
     auto l2_wgx = [&](const DffLayerDev& w, int hg) { l2w_flat(SPW ? (const void*)w.WoxT_s : (const void*)w.WoxT_p, hg * GX_HG, GX_HG); };
@@ -2239,13 +2269,14 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
     // "tall" images (Nout = H): a few k-blocks of every one of the H / 16 tiles
     auto l2_tall = [&](const void* base, int kb0, int nkb, int kbtot, size_t ub = (SPW ? 3072 : 1024)) { l2w(base, (size_t)kb0 * ub, H / 16, (size_t)kbtot * ub, (size_t)nkb * ub); };
     auto l2_w2 = [&](const DffLayerDev& w, int ch) { l2_tall(SPW ? (const void*)w.W2_s : (const void*)w.W2_p, ch * (LL::FC / KQ), LL::FC / KQ, LL::F / KQ, UBF); };
-    auto l2_w1t = [&](const DffLayerDev& w, int ch) { l2_tall(SPW ? (const void*)w.W1T_s : (const void*)w.W1T_p, ch * (LL::FC / KQ), LL::FC / KQ, LL::F / KQ); };
+    auto l2_w1t = [&](const DffLayerDev& w, int ch) { l2_tall(SPW ? (const void*)w.W1T_s : (const void*)w.W1T_p, ch * (LL::FC / KQ), LL::FC / KQ, LL::F / KQ, UBB2); };
     constexpr int WO_KB = SPW ? 2 : 5, WQT_KB = SPW ? 6 : 13;       // k-blocks per head (split: the 64 regular rows only)
     auto l2_wo = [&](const DffLayerDev& w, int hg) { l2_tall(SPW ? (const void*)w.Wox_s : (const void*)w.Wox_p, hg * HGS * WO_KB, HGS * WO_KB, DFF_HEADS * WO_KB, UBF); };
     auto l2_wqkvT = [&](const DffLayerDev& w, int hg) { l2_tall(SPW ? (const void*)w.WqkvxT_s : (const void*)w.WqkvxT_p, hg * HGS * WQT_KB, HGS * WQT_KB, DFF_HEADS * WQT_KB); };
     c.xst = smem + ll.xst; c.xs = smem + ll.xs; c.dxs = smem + ll.dxs; c.vst = smem + ll.vst;
     c.cm = smem + ll.cm; c.tn = smem + ll.tn;
     c.abuf = smem + ll.abuf;
+    c.rsc = smem + ll.rsc;
     c.asp = asplit; c.RNa = c.G * c.N;
     c.Pbuf = smem + ll.Pbuf; c.dSbuf = smem + ll.dSbuf; c.Rg = smem + ll.Rg;
     c.sl = dff_stash_layout(c.N, c.G, H, m.L, MT);
@@ -2701,7 +2732,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             const DffLayerDev& lw = m.layer[l];
             const float* sb = c.stash + (size_t)l * c.sl.layer_stride;
             if (l < m.L - 1) l2_w2t(lw, ch_lo);
-            rowb_gate2<H, LPG, SPW>(c, lw, l);
+            rowb_gate2<H, LPG, SPW, FFB16>(c, lw, l);
             wg_sync<SPILL>();
             pf.tick(11);
             // dh = dff W2 ; dh_pre = dh * gelu'(h_pre) ; df = dh_pre W1
@@ -2722,14 +2753,14 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                             const int lane = tid & 63, cl = 16 * nt + 4 * (lane >> 4), row = mt * 16 + (lane & 15);
                             if (valid && row < rows) {
                                 const f32x4 v = acc * (f32x4){aux[mt * 4], aux[mt * 4 + 1], aux[mt * 4 + 2], aux[mt * 4 + 3]};
-                                if constexpr (SPW) store_split4((lu32*)hl, RN, (FC + DFF_SPAD) / 2, row, cl, v);
+                                if constexpr (SPW) store_split4<FFB16>((lu32*)hl, RN, (FC + DFF_SPAD) / 2, row, cl, v);
                                 else *(lf32x4*)(hl + row * LF + cl) = v;
                             }
                         };
                     l2_w1t(lw, ch);
                     if constexpr (SPW)
-                        if constexpr (MT >= 4 && DFF_K2) gemm_wide_split_k2<MT, H / 32, FC / 16, 4 * MT>(asplit, RN, RN, lw.W2T_s, ch * (FC / 16), w2t_pre, w2t_epi);
-                        else gemm_wide_split_st<MT, H / 32, FC / 16, 4 * MT>(asplit, RN, RN, lw.W2T_s, ch * (FC / 16), w2t_pre, w2t_epi);
+                        if constexpr (MT >= 4 && DFF_K2) gemm_wide_split_k2<MT, H / 32, FC / 16, 4 * MT, FFB16>(asplit, RN, RN, lw.W2T_s, ch * (FC / 16), w2t_pre, w2t_epi);
+                        else gemm_wide_split_st<MT, H / 32, FC / 16, 4 * MT, 0, DFF_NWAVES, 3, FFB16>(asplit, RN, RN, lw.W2T_s, ch * (FC / 16), w2t_pre, w2t_epi);
                     else
                         gemm_wide_st<MT, NT_H, FC / 16, 4 * MT>(abufL, LH, RN, lw.W2T_p, ch * (FC / 16), w2t_pre, w2t_epi);
                 }
@@ -2738,7 +2769,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 if (ch + 1 < ch_hi) l2_w2t(lw, ch + 1);
                 else l2_wgx(lw, hg_lo);
                 if constexpr (SPW)
-                    gemm_tall_split_st<MT, NTW, FC / 32>(acc_f, (FC + DFF_SPAD) / 2, (const lu32*)geo.Rg, RN, RN, lw.W1T_s, F / 32, ch * (FC / 32), NT_H);
+                    gemm_tall_split_st<MT, NTW, FC / 32, FFB16>(acc_f, (FC + DFF_SPAD) / 2, (const lu32*)geo.Rg, RN, RN, lw.W1T_s, F / 32, ch * (FC / 32), NT_H);
                 else
                 gemm_tall_kb_st<MT, NTW, 0, FC / 16>(acc_f,
                     [=](int i, int& aoff, int& wkb) { aoff = 16 * i; wkb = ch * (FC / 16) + i; },
@@ -2757,7 +2788,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             CoReload<MT, HGS> rl;
             co_reload_plan<MT, HGS, PLT>(rl, geo, true, tid_now());
             co_reload_issue<MT, HGS>(rl, sqkv + (size_t)hg_lo * HGS * RN * DFF_QKVW, sPl + (size_t)hg_lo * HGS * RN * c.sl.PS);
-            rowb_ln2_gate1<H, LPG, SPW>(c, lw, l, tbuf);
+            rowb_ln2_gate1<H, LPG, SPW, FFB16>(c, lw, l, tbuf);
             wg_sync<SPILL>();
             pf.tick(14);
             f32x4 acc_a[NTW][MT];
