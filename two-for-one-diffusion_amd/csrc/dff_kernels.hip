@@ -29,7 +29,7 @@
 // unit and row tile; dff_device.h split8h) instead of the three-piece bf16 one: bit 0 = the forward images (Wqkvx, Wox, W1, W2;
 // their A operands are O(1) activations: no scaling), bit 1 = the FFN backward (W2T, W1T; row-scaled), bit 2 = G_ext (WoxT).
 #ifndef DFF_F16G
-#define DFF_F16G 3
+#define DFF_F16G 7
 #endif
 #include <type_traits>
 #ifndef DFF_AUXLATE
@@ -456,8 +456,9 @@ DEVI void gemm_wide_split_k2(const lu32* as, int R, int rowsA, const unsigned* _
 // gemm_wide_units on the split operands (few output tiles: (tile, row-tile) units round-robin over the waves, loop-free).
 // Up to two units per wave: all weights requested up front.  More (four row tiles: 5 tiles x 4 = 20 units, three per
 // wave): a ring of two units -- three units of K = 128 weights at once are 144 registers.
-template <int MT, int KB32, int NTN, class Epi>
+template <int MT, int KB32, int NTN, bool F16 = false, class Epi>
 DEVI void gemm_wide_units_split(const lu32* as, int R, int rowsA, const unsigned* __restrict__ Wp, int nt0, Epi epi) {
+    constexpr int NPC = F16 ? 2 : 3;
     const int tid_ = tid_now();
     constexpr int NU = NTN * MT, DU = (NU + DFF_NWAVES - 1) / DFF_NWAVES, DRU = DU < 2 ? DU : 2, LHS2 = (32 * KB32 + DFF_SPAD) / 2;
     const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
@@ -469,7 +470,7 @@ DEVI void gemm_wide_units_split(const lu32* as, int R, int rowsA, const unsigned
 #pragma unroll
         for (int kb = 0; kb < KB32; ++kb)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) slot[kb][p] = wp[(((size_t)(nt0 + nt) * KB32 + kb) * 3 + p) * 64];
+            for (int p = 0; p < NPC; ++p) slot[kb][p] = wp[(((size_t)(nt0 + nt) * KB32 + kb) * NPC + p) * 64];
     };
 #pragma unroll
     for (int d = 0; d < DRU; ++d) fill(b[d], d);
@@ -485,6 +486,11 @@ DEVI void gemm_wide_units_split(const lu32* as, int R, int rowsA, const unsigned
             for (int kb = 0; kb < KB32; ++kb) {
                 const u32x4 ah = *(const lu32x4*)(as + ro + 16 * kb);
                 const u32x4 am = *(const lu32x4*)(as + R * LHS2 + ro + 16 * kb);
+                if constexpr (F16) {   // cs / cs2: the 2^11-scaled cross terms, cb: h.h
+                    cs = mfma_f16(b[d % DRU][kb][0], am, cs);
+                    cs2 = mfma_f16(b[d % DRU][kb][1], ah, cs2);
+                    cb = mfma_f16(b[d % DRU][kb][0], ah, cb);
+                } else {
                 const u32x4 al = *(const lu32x4*)(as + 2 * R * LHS2 + ro + 16 * kb);
                 cs = mfma_bf16(b[d % DRU][kb][0], al, cs);
                 cb = mfma_bf16(b[d % DRU][kb][0], am, cb);
@@ -492,20 +498,23 @@ DEVI void gemm_wide_units_split(const lu32* as, int R, int rowsA, const unsigned
                 cb2 = mfma_bf16(b[d % DRU][kb][1], ah, cb2);
                 cs = mfma_bf16(b[d % DRU][kb][1], am, cs);
                 cb = mfma_bf16(b[d % DRU][kb][0], ah, cb);
+                }
             }
             if constexpr (DU > DRU) {
                 if (d + DRU < DU) { fill(b[d % DRU], d + DRU); __builtin_amdgcn_sched_barrier(0); }
             }
-            epi(nt, mt, (cb + cb2) + (cs + cs2));
+            if constexpr (F16) epi(nt, mt, cb + (cs + cs2) * DFF_F16_LINV);
+            else epi(nt, mt, (cb + cb2) + (cs + cs2));
         }
     }
 }
 
 // The (tile, row-tile) units of a head group's G_ext GEMM (NT = 5 HGS column tiles x MT row tiles) on waves W0 .. W0 + NWV - 1 only,
 // results parked in registers (backward head pipeline: the other waves are busy with dS meanwhile).  Unit u = w + NWV d.
-template <int MT, int KB32, int NT, int W0, int NWV>
+template <int MT, int KB32, int NT, int W0, int NWV, bool F16 = false>
 DEVI void gx_units_hold(const lu32* as, int R, int rowsA, const unsigned* __restrict__ Wp, int nt0,
                         f32x4 (&held)[(NT * MT + NWV - 1) / NWV]) {
+    constexpr int NPC = F16 ? 2 : 3;
     constexpr int NU = NT * MT, DU = (NU + NWV - 1) / NWV, LHS2 = (32 * KB32 + DFF_SPAD) / 2;
     // ring of two entries; at K = 128 an entry is HALF a unit (two k-blocks, 24 registers): whole units -- 96 registers in
     // flight -- were what made trp-cage's shape spill with this pipeline
@@ -520,7 +529,7 @@ DEVI void gx_units_hold(const lu32* as, int R, int rowsA, const unsigned* __rest
 #pragma unroll
         for (int kb = 0; kb < KH; ++kb)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) slot[kb][p] = wp[(((size_t)(nt0 + nt) * KB32 + (e % NHALF) * KH + kb) * 3 + p) * 64];
+            for (int p = 0; p < NPC; ++p) slot[kb][p] = wp[(((size_t)(nt0 + nt) * KB32 + (e % NHALF) * KH + kb) * NPC + p) * 64];
     };
     fill(b[0], 0);
     if (NE > 1) fill(b[1], 1);
@@ -538,6 +547,11 @@ DEVI void gx_units_hold(const lu32* as, int R, int rowsA, const unsigned* __rest
             const int ka = h * KH + kb;
             const u32x4 ah = *(const lu32x4*)(as + ro + 16 * ka);
             const u32x4 am = *(const lu32x4*)(as + R * LHS2 + ro + 16 * ka);
+            if constexpr (F16) {
+                cs = mfma_f16(b[e % 2][kb][0], am, cs);
+                cs2 = mfma_f16(b[e % 2][kb][1], ah, cs2);
+                cb = mfma_f16(b[e % 2][kb][0], ah, cb);
+            } else {
             const u32x4 al = *(const lu32x4*)(as + 2 * R * LHS2 + ro + 16 * ka);
             cs = mfma_bf16(b[e % 2][kb][0], al, cs);
             cb = mfma_bf16(b[e % 2][kb][0], am, cb);
@@ -545,9 +559,10 @@ DEVI void gx_units_hold(const lu32* as, int R, int rowsA, const unsigned* __rest
             cb2 = mfma_bf16(b[e % 2][kb][1], ah, cb2);
             cs = mfma_bf16(b[e % 2][kb][1], am, cs);
             cb = mfma_bf16(b[e % 2][kb][0], ah, cb);
+            }
         }
         if (e + 2 < NE) { fill(b[e % 2], e + 2); __builtin_amdgcn_sched_barrier(0); }
-        if (h == NHALF - 1) held[d] = (cb + cb2) + (cs + cs2);
+        if (h == NHALF - 1) held[d] = F16 ? cb + (cs + cs2) * DFF_F16_LINV : (cb + cb2) + (cs + cs2);
     }
 }
 
@@ -1422,7 +1437,8 @@ DEVI void rowb_ln2_gate1(const Ctx& c, const DffLayerDev& lw, int l, const float
             ao[i] = d1[i] * g1 + dz * (w[0][i] + w[2][i]);
             nin[i] = d1[i] * (1.0f - g1) + dz * (w[1][i] - w[2][i]);
         }
-        rstore_a<H, LP, SPW>(c, row, ao, sub);
+        if constexpr (FOUT) row_pow2_scale<H, LP>(c, row, ao, sub);   // (dattn row-scaled: the G_ext GEMM's epilogues multiply the inverse back)
+        rstore_a<H, LP, SPW, FOUT>(c, row, ao, sub);
         rstore<H, LP>(c.resbuf + row * LH, nin, sub);
     }
 }
@@ -2251,6 +2267,9 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
     constexpr size_t UBF = FWD16 ? 2048 : UB;         // ... whose images have 2 KB units
     constexpr bool FFB16 = SPW && (DFF_F16G & 2);     // FFN backward (W2T, W1T) likewise, on row-scaled operands
     constexpr size_t UBB2 = FFB16 ? 2048 : UB;
+    constexpr bool GX16 = SPW && (DFF_F16G & 4);      // G_ext (WoxT) likewise: dattn row-scaled, unscaled by the GEMM's epilogues
+    constexpr size_t UBG = GX16 ? 2048 : UB;
+    lfloat* const rscl = (lfloat*)smem + ll.rsc;
     constexpr int KQ = SPW ? 32 : 16;                 // rows of a k-block
     const int wave_l2 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     auto l2w = [&](const void* base, size_t off, int ntiles, size_t stride, size_t bytes) {
@@ -2259,7 +2278,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
     };
     auto l2w_flat = [&](const void* base, size_t off, size_t bytes) { l2w(base, off, 8, bytes / 8, bytes / 8); };
     constexpr size_t QKV_HG = (size_t)HGS * 13 * (H / KQ) * UBF;    // Wqkvx: a head group's 13 HGS tiles, contiguous
-    constexpr size_t GX_HG = (size_t)HGS * 5 * (H / KQ) * UB;       // WoxT: its 5 HGS tiles
+    constexpr size_t GX_HG = (size_t)HGS * 5 * (H / KQ) * UBG;      // WoxT: its 5 HGS tiles
     constexpr size_t FFW_CH = (size_t)(LL::FC / 16) * (H / KQ) * UBB2;  // W2T: a chunk's tiles
     constexpr size_t FFW1_CH = (size_t)(LL::FC / 16) * (H / KQ) * UBF;  // W1: likewise
     auto l2_wqkv = [&](const DffLayerDev& w, int hg) { l2w_flat(SPW ? (const void*)w.Wqkvx_s : (const void*)w.Wqkvx_p, hg * QKV_HG, QKV_HG); };
@@ -2788,7 +2807,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             CoReload<MT, HGS> rl;
             co_reload_plan<MT, HGS, PLT>(rl, geo, true, tid_now());
             co_reload_issue<MT, HGS>(rl, sqkv + (size_t)hg_lo * HGS * RN * DFF_QKVW, sPl + (size_t)hg_lo * HGS * RN * c.sl.PS);
-            rowb_ln2_gate1<H, LPG, SPW, FFB16>(c, lw, l, tbuf);
+            rowb_ln2_gate1<H, LPG, SPW, FFB16, GX16>(c, lw, l, tbuf);
             wg_sync<SPILL>();
             pf.tick(14);
             f32x4 acc_a[NTW][MT];
@@ -2806,9 +2825,10 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 const int tid = tid_now();
                 lfloat* const Gl = geo.Rg + 3 * RN * LQ;
                 lfloat* const dxw = geo.dxw;
-                auto gx_epi = [=](int nt, int mt, const f32x4& acc) {
+                auto gx_epi = [=](int nt, int mt, const f32x4& acc0) {
                         const int lane = tid & 63, quad = lane >> 4, row = mt * 16 + (lane & 15);
                         const int hh = nt / 5, tt = nt - 5 * hh;
+                        const f32x4 acc = GX16 ? acc0 * rscl[row] : acc0;   // (fp16 engine: back to true units)
                         if (row < rows) {
                             *(lf32x4*)(Gl + row * LQ + hh * 80 + 16 * tt + 4 * quad) = acc;
                             if (tt == 4 && quad == 0) {   // r = dE/dxrel: columns 64..66 of the head
@@ -2826,10 +2846,10 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     co_fill_x<HGS, GEN>(geo);
                 };
                 if constexpr (NTG == NWH && DFF_GXTILE0)   // (the first head's G_ext, all waves: whole tiles as well)
-                    gemm_wide_split_st<MT, H / 32, NTG, 1>(asplit, RN, RN, lw.WoxT_s, hg_lo * NTG, [](int, float (&)[1]) {},
+                    gemm_wide_split_st<MT, H / 32, NTG, 1, 0, DFF_NWAVES, 3, GX16>(asplit, RN, RN, lw.WoxT_s, hg_lo * NTG, [](int, float (&)[1]) {},
                         [&](int nt, int mt, const f32x4& acc, const float (&)[1], bool valid, int) { if (valid) gx_epi(nt, mt, acc); });
                 else
-                gemm_wide_units_split<MT, H / 32, NTG>(asplit, RN, RN, lw.WoxT_s, hg_lo * NTG, gx_epi);
+                gemm_wide_units_split<MT, H / 32, NTG, GX16>(asplit, RN, RN, lw.WoxT_s, hg_lo * NTG, gx_epi);
                 commit_issue(hg_lo);
                 wg_sync<SPILL>();
                 pf.tick(16);
@@ -2846,10 +2866,10 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         else co_ds<MT, HGS, false, GEN>(geo);
                     } else if (more) {
                         if constexpr (GXTILE)
-                            gemm_wide_split_st<MT, H / 32, NTG, 1, NI, NWH, 2>(asplit, RN, RN, lw.WoxT_s, (hg + 1) * NTG, [](int, float (&)[1]) {},
+                            gemm_wide_split_st<MT, H / 32, NTG, 1, NI, NWH, 2, GX16>(asplit, RN, RN, lw.WoxT_s, (hg + 1) * NTG, [](int, float (&)[1]) {},
                                 [&](int, int mt, const f32x4& acc, const float (&)[1], bool, int i) { gheld[i * MT + mt] = acc; });
                         else
-                        gx_units_hold<MT, H / 32, NTG, NI, NWH>(asplit, RN, RN, lw.WoxT_s, (hg + 1) * NTG, gheld);
+                        gx_units_hold<MT, H / 32, NTG, NI, NWH, GX16>(asplit, RN, RN, lw.WoxT_s, (hg + 1) * NTG, gheld);
                     }
                     if (deep) l2_wqkvT(lw, hg);
                     if (hg + 2 < hg_hi) l2_wgx(lw, hg + 2);
@@ -2897,9 +2917,10 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     const int tid = tid_now();
                     lfloat* const Gl = geo.Rg + 3 * RN * LQ;
                     lfloat* const dxw = geo.dxw;
-                    auto gx_epi = [=](int nt, int mt, const f32x4& acc) {
+                    auto gx_epi = [=](int nt, int mt, const f32x4& acc0) {
                             const int lane = tid & 63, quad = lane >> 4, row = mt * 16 + (lane & 15);
                             const int hh = nt / 5, tt = nt - 5 * hh;
+                            const f32x4 acc = GX16 ? acc0 * rscl[row] : acc0;   // (fp16 engine: back to true units)
                             if (row < rows) {
                                 *(lf32x4*)(Gl + row * LQ + hh * 80 + 16 * tt + 4 * quad) = acc;
                                 if (tt == 4 && quad == 0) {   // r = dE/dxrel: columns 64..66 of the head
@@ -2913,10 +2934,10 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                     if constexpr (SPW && MT == 4 && DFF_GXT)
                         // four row tiles: a wave takes a whole TILE (all row tiles), so its 12 KB of weights come through the CU
                         // once; as (tile, row-tile) units four waves each stream the same tile
-                        gemm_wide_split_st<MT, H / 32, HGS * 5, 1>(asplit, RN, RN, lw.WoxT_s, hg * HGS * 5, [](int, float (&)[1]) {},
+                        gemm_wide_split_st<MT, H / 32, HGS * 5, 1, 0, DFF_NWAVES, 3, GX16>(asplit, RN, RN, lw.WoxT_s, hg * HGS * 5, [](int, float (&)[1]) {},
                             [&](int nt, int mt, const f32x4& acc, const float (&)[1], bool valid, int) { if (valid) gx_epi(nt, mt, acc); });
                     else if constexpr (SPW)
-                        gemm_wide_units_split<MT, H / 32, HGS * 5>(asplit, RN, RN, lw.WoxT_s, hg * HGS * 5, gx_epi);
+                        gemm_wide_units_split<MT, H / 32, HGS * 5, GX16>(asplit, RN, RN, lw.WoxT_s, hg * HGS * 5, gx_epi);
                     else
                         gemm_wide_units<MT, NT_H, HGS * 5>(abufL, LH, RN, lw.WoxT_p, NT_H, 0, hg * HGS * 5, gx_epi, NoHook());
                     co_reload_commit<MT, HGS>(rl, geo);
