@@ -543,7 +543,7 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
             // the 64 regular rows of every head of [W_o ; W_oc] (the extension rows stay on the fp32 image)
             if ((rc_ = upload_u32(m, PB(1, 8 * 64, H, [&](int k, int n) { return wox((k / 64) * 80 + k % 64, n); }), &d.Wox_s))) return rc_;
             // ... and the 192 regular rows [q | k | v] of every head of QKV_ext^T
-            if ((rc_ = upload_u32(m, pack_b_split(8 * 192, H, [&](int c, int n) {
+            if ((rc_ = upload_u32(m, PB(8, 8 * 192, H, [&](int c, int n) {
                      const int h = c / 192, cc = c % 192;
                      return wqkvx(h * 208 + (cc < 64 ? cc : cc + 16), n); }), &d.WqkvxT_s))) return rc_;
         }

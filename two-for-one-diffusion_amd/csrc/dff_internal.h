@@ -113,5 +113,5 @@ struct DffRunArgs {
 bool dff_small_fold_f16();
 
 // bit mask of the <= 64-row split variants' GEMM groups that take two-piece fp16 images (dff_kernels.hip DFF_F16G):
-// 1 = forward (Wqkvx_s, Wox_s, W1_s, W2_s), 2 = FFN backward (W2T_s, W1T_s), 4 = G_ext (WoxT_s)
+// 1 = forward (Wqkvx_s, Wox_s, W1_s, W2_s), 2 = FFN backward (W2T_s, W1T_s), 4 = G_ext (WoxT_s), 8 = QKV_ext^T (WqkvxT_s)
 int dff_fused_f16_mask();

@@ -29,8 +29,9 @@
 // unit and row tile; dff_device.h split8h) instead of the three-piece bf16 one: bit 0 = the forward images (Wqkvx, Wox, W1, W2;
 // their A operands are O(1) activations: no scaling), bit 1 = the FFN backward (W2T, W1T; row-scaled), bit 2 = G_ext (WoxT).
 #ifndef DFF_F16G
-#define DFF_F16G 7
+#define DFF_F16G 15   // ... bit 3 = the QKV_ext^T back-projection (WqkvxT; dQ / dK / dV scaled by one power of two per workgroup)
 #endif
+#define DFF_QT16 ((DFF_F16G & 12) == 12)   // (the block scale is derived from the row scales of G_ext's input: bit 2 as well)
 #include <type_traits>
 #ifndef DFF_AUXLATE
 #define DFF_AUXLATE 1   // wide split GEMMs: the tiles' auxiliary rows are requested behind the ring's first entries (protein G -1.1 %, trp-cage -0.5 %, villin / BBA -0.2 %)
@@ -804,10 +805,13 @@ DEVI void l2_touch(unsigned junk_byte, const void* base, int ntiles, size_t stri
 }
 
 // QSP (round 4): dQ arrives as pieces as well (co_ds: [h | m] in place of the fp32 row of buffer regQ, l in `lsq`).
-template <int MT, int NTW, int HGS, bool KVS = false, bool VSP = false, int PRE = 0, bool QSP = false>
+// F16 (round 5): two-piece fp16 operands -- the in-place pieces are [h | l'] (put_piece16), nothing lives in lsp / lsq, operands
+// that arrive as fp32 rows are scaled by qs and split here (split8h); `acc` collects scaled units (the caller's row stage
+// multiplies the inverse back).
+template <int MT, int NTW, int HGS, bool KVS = false, bool VSP = false, int PRE = 0, bool QSP = false, bool F16 = false>
 DEVI void gemm_tall_qkvT_split(f32x4 (&acc)[NTW][MT], const lfloat* Rg, int regQ, int RN, const unsigned* __restrict__ Ws,
-                               int head0, int ntiles, const lu32* lsp, u32x4 (&b)[4][NTW][3], const lu32* lsq = nullptr) {
-    constexpr int LQ = 80 * HGS + 4, NKB = 6 * HGS, D = 4, KBtot = 6 * DFF_HEADS;
+                               int head0, int ntiles, const lu32* lsp, u32x4 (&b)[4][NTW][3], const lu32* lsq = nullptr, float qs = 1.0f) {
+    constexpr int LQ = 80 * HGS + 4, NKB = 6 * HGS, D = 4, KBtot = 6 * DFF_HEADS, NPC = F16 ? 2 : 3;
     const int tid_ = tid_now();
     const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     const int kg = lane >> 4, mm = lane & 15;
@@ -821,7 +825,7 @@ DEVI void gemm_tall_qkvT_split(f32x4 (&acc)[NTW][MT], const lfloat* Rg, int regQ
     for (int i = 0; i < NTW; ++i) {
         const int nt = wave + DFF_NWAVES * i;
         tok[i] = nt < ntiles;
-        tbase[i] = ((size_t)(tok[i] ? nt : 0) * KBtot + 6 * head0) * 3;
+        tbase[i] = ((size_t)(tok[i] ? nt : 0) * KBtot + 6 * head0) * NPC;
     }
     if (!tok[0]) return;
     {
@@ -830,7 +834,14 @@ DEVI void gemm_tall_qkvT_split(f32x4 (&acc)[NTW][MT], const lfloat* Rg, int regQ
 #pragma unroll
             for (int i = 0; i < NTW; ++i)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) b[d][i][p] = wp[(tbase[i] + 3 * d + p) * 64];
+                for (int p = 0; p < NPC; ++p) b[d][i][p] = wp[(tbase[i] + NPC * d + p) * 64];
+    }
+    f32x4 acc2[F16 ? NTW : 1][F16 ? MT : 1];
+    if constexpr (F16) {
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc2[i][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     __builtin_amdgcn_sched_barrier(0);
     // QTPRE: every operand arrives as pieces (dQ, dK and dV all split by their producers) and the shape has up to three row
@@ -845,7 +856,7 @@ DEVI void gemm_tall_qkvT_split(f32x4 (&acc)[NTW][MT], const lfloat* Rg, int regQ
                                          : (part == 2 ? lsp : lsq) + hh * 32 + 16 * half;
         const int lmul = part == 1 ? LQ : LSV;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) xl[mt] = *(const volatile lu32x4*)(lb + min(mt * 16 + mm, RN - 1) * lmul + 4 * kg);
+        for (int mt = 0; mt < MT; ++mt) if constexpr (!F16) xl[mt] = *(const volatile lu32x4*)(lb + min(mt * 16 + mm, RN - 1) * lmul + 4 * kg);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) xh[mt] = *(const volatile lu32x4*)(hb + rowoff[mt] - 4 * kg);
 #pragma unroll
@@ -870,7 +881,7 @@ DEVI void gemm_tall_qkvT_split(f32x4 (&acc)[NTW][MT], const lfloat* Rg, int regQ
             const int lmul = part == 1 ? LQ : LSV;
             // (l, h, m: the order the products consume them)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) al[mt] = *(const volatile lu32x4*)(lb + min(mt * 16 + mm, RN - 1) * lmul + 4 * kg);
+            for (int mt = 0; mt < MT; ++mt) if constexpr (!F16) al[mt] = *(const volatile lu32x4*)(lb + min(mt * 16 + mm, RN - 1) * lmul + 4 * kg);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) ah[mt] = *(const volatile lu32x4*)(hb + rowoff[mt] - 4 * kg);   // row * LQ + 4 kg
 #pragma unroll
@@ -880,12 +891,21 @@ DEVI void gemm_tall_qkvT_split(f32x4 (&acc)[NTW][MT], const lfloat* Rg, int regQ
             for (int mt = 0; mt < MT; ++mt) {
                 const lfloat* ap = Rg + aoff + rowoff[mt];
                 const f32x4 x0 = *(const lf32x4*)ap, x1 = *(const lf32x4*)(ap + 4);
-                split8(x0, x1, ah[mt], am[mt], al[mt]);
+                if constexpr (F16) split8h(x0 * qs, x1 * qs, ah[mt], am[mt]);
+                else split8(x0, x1, ah[mt], am[mt], al[mt]);
             }
         }
 #pragma unroll
         for (int i = 0; i < NTW; ++i)
             if (i == 0 || tok[i]) {
+                if constexpr (F16) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc2[i][mt] = mfma_f16(b[d][i][0], am[mt], acc2[i][mt]);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc2[i][mt] = mfma_f16(b[d][i][1], ah[mt], acc2[i][mt]);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_f16(b[d][i][0], ah[mt], acc[i][mt]);
+                } else {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][0], al[mt], acc[i][mt]);
 #pragma unroll
@@ -898,14 +918,21 @@ DEVI void gemm_tall_qkvT_split(f32x4 (&acc)[NTW][MT], const lfloat* Rg, int regQ
                 for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][1], ah[mt], acc[i][mt]);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma_bf16(b[d][i][0], ah[mt], acc[i][mt]);
+                }
             }
         if (kb + D < NKB) {
 #pragma unroll
             for (int i = 0; i < NTW; ++i)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) b[d][i][p] = wp[(tbase[i] + 3 * (kb + D) + p) * 64];
+                for (int p = 0; p < NPC; ++p) b[d][i][p] = wp[(tbase[i] + NPC * (kb + D) + p) * 64];
             __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    if constexpr (F16) {
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[i][mt] += acc2[i][mt] * DFF_F16_LINV;
     }
 }
 
@@ -1044,7 +1071,7 @@ DEVI void ext_fetch(ExtW<NTW, NH>& e, WK wk, const float* __restrict__ Wp, int K
     asm volatile("" ::: "memory");
 }
 template <int MT, int NTW, int NH, class AO>
-DEVI void ext_apply(f32x4 (&acc)[NTW][MT], const ExtW<NTW, NH>& e, AO aoff_of, const lfloat* A, int lda, int rowsA, int ntiles) {
+DEVI void ext_apply(f32x4 (&acc)[NTW][MT], const ExtW<NTW, NH>& e, AO aoff_of, const lfloat* A, int lda, int rowsA, int ntiles, float wscale = 1.0f) {
     const int tid_ = tid_now();
     const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     const int kk = lane >> 4, mm = lane & 15;
@@ -1058,7 +1085,7 @@ DEVI void ext_apply(f32x4 (&acc)[NTW][MT], const ExtW<NTW, NH>& e, AO aoff_of, c
             if (t == 0 || wave + DFF_NWAVES * t < ntiles) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(e.b[i][t], ax[mt], acc[t][mt], 0, 0, 0);
+                    acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(e.b[i][t] * wscale, ax[mt], acc[t][mt], 0, 0, 0);
             }
     }
 }
@@ -1445,7 +1472,7 @@ DEVI void rowb_ln2_gate1(const Ctx& c, const DffLayerDev& lw, int l, const float
 
 // RB3: tbuf = d(LN1 out) ; dn = resbuf + LN1bwd
 template <int H, int LP>
-DEVI void rowb_ln1(const Ctx& c, const DffLayerDev& lw, int l, const float* tbuf) {
+DEVI void rowb_ln1(const Ctx& c, const DffLayerDev& lw, int l, const float* tbuf, float in_scale = 1.0f) {   // (in_scale: fp16 engine, CoGeo::qsi)
     const int tid_ = tid_now();
     constexpr int HC = H / LP, LH = H + 4;
     const int grp = tid_ / LP, sub = tid_ % LP;
@@ -1455,6 +1482,8 @@ DEVI void rowb_ln1(const Ctx& c, const DffLayerDev& lw, int l, const float* tbuf
         rload<H, LP>(nin, (l == 0 ? c.l0 : sb) + c.sl.nodes_in + row * H, sub);
         rload<H, LP>(gam, lw.ln1_g, sub);
         rload<H, LP>(dy, tbuf + row * LH, sub);
+#pragma unroll
+        for (int i = 0; i < HC; ++i) dy[i] *= in_scale;
         rload<H, LP>(dnp, c.resbuf + row * LH, sub);
         float mean, rstd;
         ln_stats<H, LP>(nin, mean, rstd);
@@ -1630,7 +1659,28 @@ struct CoGeo {
     lfloat* m12;                            // GEN: [m1 | m2] rows of the head group (backward)
     const int __attribute__((address_space(3))) * prow;   // protein index of each row, -1 for pad rows
     int N, RN, rows;
+    float qs, qsi;                          // fp16 engine: power-of-two scale of the dQ / dK / dV pieces of this layer (and its inverse)
 };
+// dQ / dK / dV (the QKV_ext^T GEMM's A operand) mix the rows of dattn, so they share ONE scale per workgroup and layer: the
+// smallest of the row scales rowb_ln2_gate1 left in rsc[] (as inverses), times 2^-8 -- sums over up to 64 rows and the factors
+// of q, k and P stay far from fp16's 65504, and with subnormals kept the pieces still resolve 3e-11 of the scaled values.
+DEVI void block_pow2_scale(const lfloat* rsc, float& qs, float& qsi) {
+    const int lane = tid_now() & 63;
+    float mx = rsc[lane];
+    mx = row16_max(mx);
+    mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+    int ex = (int)((__float_as_uint(mx) >> 23) & 255u);
+    ex = ex < 20 ? 20 : (ex > 230 ? 230 : ex);
+    qs = __uint_as_float((unsigned)(246 - ex) << 23);    // 2^-(ex - 127) 2^-8
+    qsi = __uint_as_float((unsigned)(ex + 8) << 23);     // 2^(ex - 127) 2^8
+}
+// one element of dQ / dK / dV as the pieces the back-projection multiplies, in place of its fp32 row: [h | m] + l elsewhere (bf16), or
+// -- fp16 engine -- [h | l'] of the scaled value and nothing elsewhere
+DEVI void put_piece16(lu16* hm, float v, float qs) {
+    unsigned short hh, ll;
+    split1h(v * qs, hh, ll);
+    hm[0] = hh; hm[64] = ll;
+}
 
 // K_ext / V_ext extension columns <- x (columns 3..15 zero)
 template <int HGS, bool GEN>
@@ -1962,6 +2012,7 @@ DEVI void co_ds(const CoGeo& g) {
 #pragma unroll
                         for (int nt = 0; nt < 4; ++nt) {
                             const float v = dq[nt][r];
+                            if constexpr (DFF_QT16) { put_piece16(hm + row * 2 * LQ + 16 * nt, v, g.qs); continue; }
                             const unsigned uh = __float_as_uint(v) & 0xffff0000u;
                             const float r1 = v - __uint_as_float(uh);
                             const unsigned um = __float_as_uint(r1) & 0xffff0000u;
@@ -2030,6 +2081,7 @@ DEVI void co_dv_dk(const CoGeo& g, SH hook = SH()) {
 #pragma unroll
                         for (int nt = 0; nt < 4; ++nt) {
                             const float v = acc[nt][r];
+                            if constexpr (DFF_QT16) { put_piece16(hm + row * 2 * LQ + 16 * nt, v, g.qs); continue; }
                             const unsigned uh = __float_as_uint(v) & 0xffff0000u;
                             const float r1 = v - __uint_as_float(uh);
                             const unsigned um = __float_as_uint(r1) & 0xffff0000u;
@@ -2111,6 +2163,8 @@ DEVI void co_dqkv_rows(const CoGeo& g) {
                     lu16* const lb = (WHICH == 1 ? (lu16*)(g.lsq + (nt < 2 ? 0 : 16)) : (lu16*)(g.Rg + (nt < 2 ? 1 : 2) * g.RN * LQ + 64)) + col;
                     const int ls = WHICH == 1 ? 2 * LSV : 2 * LQ;
                     const float v = acc[r];
+                    if constexpr (DFF_QT16) put_piece16(hm + row * 2 * LQ + 16 * nt, v, g.qs);
+                    else {
                     const unsigned uh = __float_as_uint(v) & 0xffff0000u;
                     const float r1 = v - __uint_as_float(uh);
                     const unsigned um = __float_as_uint(r1) & 0xffff0000u;
@@ -2118,6 +2172,7 @@ DEVI void co_dqkv_rows(const CoGeo& g) {
                     hm[row * 2 * LQ + 16 * nt] = (unsigned short)(uh >> 16);
                     hm[row * 2 * LQ + 64 + 16 * nt] = (unsigned short)(um >> 16);
                     lb[row * ls + 16 * (nt & 1)] = (unsigned short)(__float_as_uint(r2) >> 16);
+                    }
                 } else g.Rg[DST * g.RN * LQ + row * LQ + 16 * nt + col] = acc[r];
             }
         }
@@ -2270,6 +2325,8 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
     constexpr bool GX16 = SPW && (DFF_F16G & 4);      // G_ext (WoxT) likewise: dattn row-scaled, unscaled by the GEMM's epilogues
     constexpr size_t UBG = GX16 ? 2048 : UB;
     lfloat* const rscl = (lfloat*)smem + ll.rsc;
+    constexpr bool QT16 = SPW && DFF_QT16 && GX16;    // QKV_ext^T likewise (needs the row scales of G_ext's input to derive its block scale)
+    constexpr size_t UBQ = QT16 ? 2048 : UB;
     constexpr int KQ = SPW ? 32 : 16;                 // rows of a k-block
     const int wave_l2 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     auto l2w = [&](const void* base, size_t off, int ntiles, size_t stride, size_t bytes) {
@@ -2291,7 +2348,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
     auto l2_w1t = [&](const DffLayerDev& w, int ch) { l2_tall(SPW ? (const void*)w.W1T_s : (const void*)w.W1T_p, ch * (LL::FC / KQ), LL::FC / KQ, LL::F / KQ, UBB2); };
     constexpr int WO_KB = SPW ? 2 : 5, WQT_KB = SPW ? 6 : 13;       // k-blocks per head (split: the 64 regular rows only)
     auto l2_wo = [&](const DffLayerDev& w, int hg) { l2_tall(SPW ? (const void*)w.Wox_s : (const void*)w.Wox_p, hg * HGS * WO_KB, HGS * WO_KB, DFF_HEADS * WO_KB, UBF); };
-    auto l2_wqkvT = [&](const DffLayerDev& w, int hg) { l2_tall(SPW ? (const void*)w.WqkvxT_s : (const void*)w.WqkvxT_p, hg * HGS * WQT_KB, HGS * WQT_KB, DFF_HEADS * WQT_KB); };
+    auto l2_wqkvT = [&](const DffLayerDev& w, int hg) { l2_tall(SPW ? (const void*)w.WqkvxT_s : (const void*)w.WqkvxT_p, hg * HGS * WQT_KB, HGS * WQT_KB, DFF_HEADS * WQT_KB, UBQ); };
     c.xst = smem + ll.xst; c.xs = smem + ll.xs; c.dxs = smem + ll.dxs; c.vst = smem + ll.vst;
     c.cm = smem + ll.cm; c.tn = smem + ll.tn;
     c.abuf = smem + ll.abuf;
@@ -2378,6 +2435,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
     const int N = c.N, RN = c.G * N, rows = c.rows;
     const lfloat* const abufL = (const lfloat*)smem + ll.abuf;
     CoGeo geo;
+    geo.qs = 1.0f; geo.qsi = 1.0f;
     {
         lfloat* const sm = (lfloat*)smem;
         geo.Rg = sm + ll.Rg; geo.Pbuf = sm + ll.Pbuf; geo.dSbuf = sm + ll.dSbuf; geo.xs = sm + ll.xs;
@@ -2809,6 +2867,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
             co_reload_issue<MT, HGS>(rl, sqkv + (size_t)hg_lo * HGS * RN * DFF_QKVW, sPl + (size_t)hg_lo * HGS * RN * c.sl.PS);
             rowb_ln2_gate1<H, LPG, SPW, FFB16, GX16>(c, lw, l, tbuf);
             wg_sync<SPILL>();
+            if constexpr (QT16) block_pow2_scale(rscl, geo.qs, geo.qsi);   // (this layer's dQ / dK / dV scale, from dattn's row scales)
             pf.tick(14);
             f32x4 acc_a[NTW][MT];
             acc_zero<MT, NTW>(acc_a);
@@ -2883,9 +2942,9 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         pf.tick(18);
                         ExtW<NTW, HGS> ew;
                         if constexpr (DFF_EXTPRE) ext_fetch<NTW, HGS, MT>(ew, [=](int i) { return (hg * HGS + i) * 13 + 4; }, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
-                        gemm_tall_qkvT_split<MT, NTW, HGS, LL::KVS, LL::VSP, 0, LL::KVS && DFF_QSP>(acc_a, geo.Rg, 4, RN, lw.WqkvxT_s, hg * HGS, NT_H, geo.lsp, bq, geo.lsq);
+                        gemm_tall_qkvT_split<MT, NTW, HGS, LL::KVS, LL::VSP, 0, LL::KVS && DFF_QSP, QT16>(acc_a, geo.Rg, 4, RN, lw.WqkvxT_s, hg * HGS, NT_H, geo.lsp, bq, geo.lsq, geo.qs);
                         if constexpr (!DFF_EXTPRE) ext_fetch<NTW, HGS, MT>(ew, [=](int i) { return (hg * HGS + i) * 13 + 4; }, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
-                        ext_apply<MT, NTW, HGS>(acc_a, ew, [=](int i) { return 4 * RN * LQ + i * 80 + 64; }, geo.Rg, LQ, RN, NT_H);
+                        ext_apply<MT, NTW, HGS>(acc_a, ew, [=](int i) { return 4 * RN * LQ + i * 80 + 64; }, geo.Rg, LQ, RN, NT_H, QT16 ? geo.qs : 1.0f);
                     } else {
                         co_dv_dk<MT, HGS, true, GEN>(geo);
                     }
@@ -2986,10 +3045,10 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         if constexpr (DFF_EXTPRE) ext_fetch<NTW, HGS, MT>(ew, [=](int i) { return (hg * HGS + i) * 13 + 4; }, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
                         {
                             constexpr bool RP = MT == 4 && HGS == 1 && !GEN && DFF_DQKV_ROWS && DFF_PSPLIT;   // co_dqkv_rows<..., PSPLIT>
-                            gemm_tall_qkvT_split<MT, NTW, HGS, LL::KVS || RP, LL::VSP, 0, (LL::KVS && DFF_QSP) || RP>(acc_a, geo.Rg, FIVE ? 4 : 3, RN, lw.WqkvxT_s, hg * HGS, NT_H, geo.lsp, bq, geo.lsq);
+                            gemm_tall_qkvT_split<MT, NTW, HGS, LL::KVS || RP, LL::VSP, 0, (LL::KVS && DFF_QSP) || RP, QT16>(acc_a, geo.Rg, FIVE ? 4 : 3, RN, lw.WqkvxT_s, hg * HGS, NT_H, geo.lsp, bq, geo.lsq, geo.qs);
                         }
                         if constexpr (!DFF_EXTPRE) ext_fetch<NTW, HGS, MT>(ew, [=](int i) { return (hg * HGS + i) * 13 + 4; }, lw.WqkvxT_p, DFF_HEADS * 13, NT_H);
-                        ext_apply<MT, NTW, HGS>(acc_a, ew, [=](int i) { return (FIVE ? 4 : 3) * RN * LQ + i * 80 + 64; }, geo.Rg, LQ, RN, NT_H);
+                        ext_apply<MT, NTW, HGS>(acc_a, ew, [=](int i) { return (FIVE ? 4 : 3) * RN * LQ + i * 80 + 64; }, geo.Rg, LQ, RN, NT_H, QT16 ? geo.qs : 1.0f);
                     } else
                     gemm_tall_kb_st<MT, NTW, 13, 13 * HGS>(acc_a,
                         [=](int i, int& aoff, int& wkb) {
@@ -3013,7 +3072,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 store_tall<MT, NTW>(acc_a, tbuf, LH, rows, NT_H, nullptr);
                 pair_exchange(tbuf, H, LH);
                 wg_sync<SPILL>();
-                rowb_ln1<H, LPG>(c, lw, l, tbuf);
+                rowb_ln1<H, LPG>(c, lw, l, tbuf, QT16 ? geo.qsi : 1.0f);
                 wg_sync<SPILL>();
                 pf.tick(20);
             }
