@@ -3226,6 +3226,12 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_debug_gemm_kernel(const floa
 // ------------------------------------------------------------------------------------------
 // variant table handed to the host dispatcher (dff_host.hip); taking the kernels' addresses instantiates them
 // ------------------------------------------------------------------------------------------
+// how the split variants name their engine: every weight GEMM on the two-piece fp16 format, or (any other DFF_F16G) "split_bf16"
+#if DFF_F16G == 15
+#define DFF_SPN "split_f16"
+#else
+#define DFF_SPN "split_bf16"
+#endif
 template <int H, int MT, int HGS, bool SP, bool SPW>
 static unsigned lds_floats_of(int N, int G) {
     // The TIGHT tile arrays (LdsLayout: 16 MT - 4 = 60 columns, no pad rows) are correct for at most 16 MT - 4 bead rows:
@@ -3242,21 +3248,21 @@ static unsigned lds_floats_of(int N, int G) {
       &lds_floats_of<H, MT, HGS, SP, false>, "dff_fused_kernel<" #H "," #MT "," #HGS "," #SP ",gen>" }
 #define VAR_SPW(H, MT, HGS)                                                                                     \
     { H, MT, HGS, false, false, true, (const void*)&dff_fused_kernel<H, MT, HGS, false, false, true>,           \
-      &lds_floats_of<H, MT, HGS, false, true>, "dff_fused_kernel<" #H "," #MT "," #HGS ",false,split_bf16>" },  \
+      &lds_floats_of<H, MT, HGS, false, true>, "dff_fused_kernel<" #H "," #MT "," #HGS ",false," DFF_SPN ">" },  \
     { H, MT, HGS, false, true, true, (const void*)&dff_fused_kernel<H, MT, HGS, false, true, true>,             \
-      &lds_floats_of<H, MT, HGS, false, true>, "dff_fused_kernel<" #H "," #MT "," #HGS ",false,gen,split_bf16>" }
+      &lds_floats_of<H, MT, HGS, false, true>, "dff_fused_kernel<" #H "," #MT "," #HGS ",false,gen," DFF_SPN ">" }
 #define VAR_SPW_SPILL(H, MT, HGS)                                                                               \
     { H, MT, HGS, true, false, true, (const void*)&dff_fused_kernel<H, MT, HGS, true, false, true>,             \
-      &lds_floats_of<H, MT, HGS, true, true>, "dff_fused_kernel<" #H "," #MT "," #HGS ",true,split_bf16>" }
+      &lds_floats_of<H, MT, HGS, true, true>, "dff_fused_kernel<" #H "," #MT "," #HGS ",true," DFF_SPN ">" }
 #define VAR_PAIR_SPW_SPILL(H, MT, HGS)                                                                            \
     { H, MT, HGS, true, false, true, (const void*)&dff_fused_kernel<H, MT, HGS, true, false, true, true>,         \
-      &lds_floats_of<H, MT, HGS, true, true>, "dff_fused_kernel<" #H "," #MT "," #HGS ",true,split_bf16,pair>", true }
+      &lds_floats_of<H, MT, HGS, true, true>, "dff_fused_kernel<" #H "," #MT "," #HGS ",true," DFF_SPN ",pair>", true }
 #define VAR_PAIR(H, MT, HGS, SP)                                                                                  \
     { H, MT, HGS, SP, false, false, (const void*)&dff_fused_kernel<H, MT, HGS, SP, false, false, true>,           \
       &lds_floats_of<H, MT, HGS, SP, false>, "dff_fused_kernel<" #H "," #MT "," #HGS "," #SP ",pair>", true }
 #define VAR_PAIR_SPW(H, MT, HGS)                                                                                  \
     { H, MT, HGS, false, false, true, (const void*)&dff_fused_kernel<H, MT, HGS, false, false, true, true>,       \
-      &lds_floats_of<H, MT, HGS, false, true>, "dff_fused_kernel<" #H "," #MT "," #HGS ",false,split_bf16,pair>", true }
+      &lds_floats_of<H, MT, HGS, false, true>, "dff_fused_kernel<" #H "," #MT "," #HGS ",false," DFF_SPN ",pair>", true }
 static const Variant g_variants[] = {
 #ifndef DFF_FAST_BUILD
     VAR(64, 1, 4, false),  VAR(64, 2, 2, false),  VAR(96, 1, 4, false),  VAR(96, 2, 2, false),
