@@ -48,6 +48,12 @@
 #ifndef DFF_TPRE_MT
 #define DFF_TPRE_MT 3   // tall split GEMMs: A fragments one k-block ahead, up to this many row tiles (four: measured neutral)
 #endif
+#ifndef DFF_K2_MT
+#define DFF_K2_MT 3    // two output tiles per wave in the wide split GEMMs from this many row tiles on (three: -0.3 % with the fp16 engine; it spilled with three pieces)
+#endif
+#ifndef DFF_ARES_LIM
+#define DFF_ARES_LIM 8 // A operand register-resident in the wide split GEMMs while MT * KB32 <= this
+#endif
 #ifndef DFF_ARES
 #define DFF_ARES 1
 #endif
@@ -237,7 +243,7 @@ DEVI void gemm_wide_split_st(const lu32* as, int R, int rowsA, const unsigned* _
     // registers while the wave's tiles stream by.  Otherwise every wave re-reads all of A for every tile: at MT = 2 that is
     // as many LDS cycles as the GEMM has MFMA cycles, and the two do not overlap (trp-cage's QKV_ext GEMM: 14.5 k cycles per
     // call against 5 k of products).
-    constexpr bool ARES = MT * KB32 <= 8 && DFF_ARES;
+    constexpr bool ARES = MT * KB32 <= DFF_ARES_LIM && DFF_ARES;
     constexpr int DR0 = HALVES ? (DRMAX < 3 ? DRMAX : 3) : 2, DR = NE < DR0 ? NE : DR0;
     constexpr int NA = 3;
     const int tid_ = tid_now();
@@ -2714,7 +2720,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                             st_ntg4<DFF_SITE_ST(MT, 2)>(ok ? sq + (size_t)hh * RN * DFF_QKVW + (size_t)row * DFF_QKVW + 16 * tt + c4 : junk, v);
                         };
                     if constexpr (SPW)
-                        if constexpr (MT >= 4 && DFF_K2) gemm_wide_split_k2<MT, H / 32, HGS * 13, 4, FWD16>(asplit, RN, RN, lw.Wqkvx_s, hg * HGS * 13, qkv_pre, qkv_epi);
+                        if constexpr (MT >= DFF_K2_MT && DFF_K2) gemm_wide_split_k2<MT, H / 32, HGS * 13, 4, FWD16>(asplit, RN, RN, lw.Wqkvx_s, hg * HGS * 13, qkv_pre, qkv_epi);
                         else gemm_wide_split_st<MT, H / 32, HGS * 13, 4, 0, DFF_NWAVES, 3, FWD16>(asplit, RN, RN, lw.Wqkvx_s, hg * HGS * 13, qkv_pre, qkv_epi);
                     else
                         gemm_wide_st<MT, NT_H, HGS * 13, 4>(abufL, LH, RN, lw.Wqkvx_p, hg * HGS * 13, qkv_pre, qkv_epi);
@@ -2778,7 +2784,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         };
                     l2_w2(lw, ch);
                     if constexpr (SPW)
-                        if constexpr (MT >= 4 && DFF_K2) gemm_wide_split_k2<MT, H / 32, FC / 16, 4, FWD16>(asplit, RN, RN, lw.W1_s, ch * (FC / 16), w1_pre, w1_epi);
+                        if constexpr (MT >= DFF_K2_MT && DFF_K2) gemm_wide_split_k2<MT, H / 32, FC / 16, 4, FWD16>(asplit, RN, RN, lw.W1_s, ch * (FC / 16), w1_pre, w1_epi);
                         else gemm_wide_split_st<MT, H / 32, FC / 16, 4, 0, DFF_NWAVES, 3, FWD16>(asplit, RN, RN, lw.W1_s, ch * (FC / 16), w1_pre, w1_epi);
                     else
                         gemm_wide_st<MT, NT_H, FC / 16, 4>(abufL, LH, RN, lw.W1_p, ch * (FC / 16), w1_pre, w1_epi);
@@ -2836,7 +2842,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                         };
                     l2_w1t(lw, ch);
                     if constexpr (SPW)
-                        if constexpr (MT >= 4 && DFF_K2) gemm_wide_split_k2<MT, H / 32, FC / 16, 4 * MT, FFB16>(asplit, RN, RN, lw.W2T_s, ch * (FC / 16), w2t_pre, w2t_epi);
+                        if constexpr (MT >= DFF_K2_MT && DFF_K2) gemm_wide_split_k2<MT, H / 32, FC / 16, 4 * MT, FFB16>(asplit, RN, RN, lw.W2T_s, ch * (FC / 16), w2t_pre, w2t_epi);
                         else gemm_wide_split_st<MT, H / 32, FC / 16, 4 * MT, 0, DFF_NWAVES, 3, FFB16>(asplit, RN, RN, lw.W2T_s, ch * (FC / 16), w2t_pre, w2t_epi);
                     else
                         gemm_wide_st<MT, NT_H, FC / 16, 4 * MT>(abufL, LH, RN, lw.W2T_p, ch * (FC / 16), w2t_pre, w2t_epi);
