@@ -153,7 +153,7 @@ int dff_set_group(dff_model* m, int proteins_per_workgroup);
 /* Debugging: on != 0 disables the rows<=16 fast-path kernel so the generic kernel runs. */
 int dff_debug_force_generic(dff_model* m, int on);
 /* Debugging: waves per workgroup of the rows<=16 kernel: 0 auto (8 where it applies), 4 or 8.  A non-zero value also keeps
- * hidden-96 models on that kernel (by default they run the one-row-tile split variant of the <= 64-row kernel, which is faster). */
+ * hidden-96 / 128 models on that kernel (by default they run the one-row-tile split variant of the <= 64-row kernel, which is faster). */
 int dff_debug_small_waves(dff_model* m, int waves);
 /* Workgroups per kernel launch (default 2048).  Proteins are independent, so a batch that needs more
  * workgroups runs as consecutive launches over one bounded scratch "stash" (n x stash slot) instead

@@ -8,7 +8,10 @@ from dff_amd.score import GraphTransformer
 from dff_amd.ddpm import GaussianDiffusion
 from dff_amd.langevin import LangevinDiffusion
 cfg = sys.argv[1]; force = int(sys.argv[2]); P = int(sys.argv[3]) if len(sys.argv) > 3 else 256
-_, N, H, L = synth.SHIPPED_CONFIGS[cfg]
+if cfg.startswith("custom:"):   # custom:N:H:L
+    N, H, L = (int(v) for v in cfg.split(":")[1:])
+else:
+    _, N, H, L = synth.SHIPPED_CONFIGS[cfg]
 model = GraphTransformer(N, H, device="cuda:0", n_layers=L, use_intrinsic_coords=True, use_abs_coords=False, use_distances=False,
                          conservative=True, state_dict=synth.synth_gnn_params(N, H, L, decoder_scale=1e-2))
 if force:

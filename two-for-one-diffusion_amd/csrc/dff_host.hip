@@ -903,12 +903,13 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
     const void* sfn_; unsigned slds_; const char* snm_;
     const bool have_small = dff_small_pick(DFF_MODE_SCORE, H, 4, gen, false, &sfn_, &slds_, &snm_) ||
                             dff_small_pick(DFF_MODE_SCORE, H, 8, gen, false, &sfn_, &slds_, &snm_);   // (hidden = 256: generic kernel only)
-    // Hidden 96 (ala2): the <= 16-row kernel has no split variant for it (its split engine is written for hidden 64's unit
+    // Hidden 96 (ala2) and 128: the <= 16-row kernel has no split variant for them (its split engine is written for hidden 64's unit
     // counts) and is bound by the fp32 matrix pipe; the one-row-tile split_f16 variant of the <= 64-row kernel is faster
     // (round 5: 81 vs 86 us / step at 256 per GPU, 89 vs 138 at 768 -- three proteins per workgroup --, 60 vs 85 at 128, where it
-    // runs as two workgroups per protein).  DFF_SMALL_H96=1 keeps the <= 16-row kernel.
+    // runs as two workgroups per protein; hidden 128 at 5 / 10 / 16 rows: 90 / 150 / 157 vs 184 / 300 / 307).  DFF_SMALL_H96=1 keeps the
+    // <= 16-row kernel.
     static const bool small_h96 = [] { const char* e = getenv("DFF_SMALL_H96"); return e && e[0] == '1'; }();
-    const bool prefer_generic = H == 96 && m->split && !small_h96 && m->small_waves == 0;   // (dff_debug_small_waves(m, 4 | 8) asks for the <= 16-row kernel)
+    const bool prefer_generic = (H == 96 || H == 128) && m->split && !small_h96 && m->small_waves == 0;   // (dff_debug_small_waves(m, 4 | 8) asks for the <= 16-row kernel)
     if (G * N <= 16 && !m->force_generic && have_small && !prefer_generic) {
         if (want_tab) {
             int rc = ensure_l0_table(m, a.mode == DFF_MODE_DDPM ? 2 : 1, a.t_norm, G, nullptr, stream);

@@ -3278,7 +3278,7 @@ static const Variant g_variants[] = {
     VAR(256, 1, 4, false), VAR(256, 2, 1, true),
     VAR_SPW(96, 2, 2), VAR_SPW(128, 2, 2), VAR_SPW(128, 3, 1), VAR_SPW_SPILL(128, 4, 1),
     VAR_SPW(64, 1, 4), VAR_SPW(96, 1, 4), VAR_SPW(128, 1, 4),
-    VAR_PAIR(128, 4, 1, true), VAR_PAIR_SPW(128, 3, 1), VAR_PAIR_SPW(128, 2, 2), VAR_PAIR_SPW(96, 2, 2), VAR_PAIR_SPW_SPILL(128, 4, 1), VAR_PAIR_SPW(96, 1, 4),
+    VAR_PAIR(128, 4, 1, true), VAR_PAIR_SPW(128, 3, 1), VAR_PAIR_SPW(128, 2, 2), VAR_PAIR_SPW(96, 2, 2), VAR_PAIR_SPW_SPILL(128, 4, 1), VAR_PAIR_SPW(96, 1, 4), VAR_PAIR_SPW(128, 1, 4),
 #elif defined(DFF_ONLY)   // development builds: one named variant, e.g. -DDFF_ONLY="VAR_SPW(128,3,1)"
     DFF_ONLY,
 #else   // development builds: one variant, so that the <= 16-row kernel can be iterated on quickly
