@@ -606,6 +606,29 @@ def test_fp16_engine_over_gradient_magnitudes(dff, cfg, dec, xs, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["chignolin", "villin"])
+def test_fp16_engine_steps_aside_for_models_out_of_its_range(dff, cfg):
+    """The forward GEMM inputs are split into fp16 pieces as they are; their worst-case magnitudes follow from the weights
+    (LayerNorm gains, the L1 norms of W_v's and W1's rows).  A model that could take them past 1.6e4 -- here: a LayerNorm gain
+    of 5000 -- is given the fp32-MFMA engine at dff_model_create (one line on stderr), and its forces are still the
+    reference's (twin, float64)."""
+    from dff_amd.score import GraphTransformer
+    _, N, H, L = synth.SHIPPED_CONFIGS[cfg]
+    params = dict(synth.synth_gnn_params(N, H, L, seed=99, decoder_scale=1e-2))
+    k = "graphtransformer.layers.1.1.0.norm.weight"            # LN2 of layer 1: the FFN's input would reach ~ 5000 sqrt(H)
+    params[k] = (params[k] * 5000.0).astype(np.float32)
+    model = GraphTransformer(N, H, device="cuda:0", n_layers=L, use_intrinsic_coords=True, use_abs_coords=False,
+                             use_distances=False, conservative=True, state_dict=params)
+    x = synth.normal((5, N, 3), 3, 3).astype(np.float32)
+    t = np.array([0.01, 0.02, 0.3, 0.7, 0.99], np.float32)
+    f = model.native.score(torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()).cpu().numpy()
+    kname = model.native.last_launch()[0]
+    assert "split_" not in kname, kname
+    ref32, ref64 = twin_refs(params, x, t, L)
+    assert np.isfinite(f).all() and rel(f, ref64) <= max(1e-5, GUARD * rel(ref32, ref64)), (rel(f, ref64), rel(ref32, ref64))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg", ["chignolin", "trp_cage", "bba", "villin", "protein_g"])
 def test_split_bf16_weight_gemms_are_fp32_exact(dff, cfg, golden, monkeypatch):
     """Default variants where they exist (chignolin: all eight weight GEMMs of the <= 16-row kernel; trp-cage, BBA, villin

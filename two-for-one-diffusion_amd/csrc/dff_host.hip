@@ -349,10 +349,47 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
     m->cfg = *cfg;
     m->device = device;
     HIPCHK(hipDeviceGetAttribute(&m->n_cus, hipDeviceAttributeMultiprocessorCount, device));
-    {   // weight GEMMs on the bf16 pipe via the exact three-way split of every fp32 operand, wherever a kernel variant
-        // exists for the shape (default); DFF_SPLIT_BF16=0: every GEMM on v_mfma_f32_16x16x4_f32
+    {   // weight GEMMs on the fp16 / bf16 pipe via the split of every fp32 operand, wherever a kernel variant exists for the
+        // shape (default); DFF_SPLIT_BF16=0: every GEMM on v_mfma_f32_16x16x4_f32
         const char* e = getenv("DFF_SPLIT_BF16");
         m->split = !(e && e[0] == '0');
+        // The fp16 pieces of the FORWARD GEMM inputs are taken of the activations as they are (dff_device.h split8h): LayerNorm
+        // outputs, attention outputs (averages of v), GELU(hidden).  Their worst-case magnitudes follow from the weights alone;
+        // a model that could take them past fp16's range (|x| < 1.6e4 keeps x and its 2^11-scaled low piece finite) runs the
+        // fp32 engine instead.  (The backward's inputs are scaled on the device.)  Trained models are orders of magnitude away.
+        if (m->split) {
+            const float* q = w;
+            auto skip = [&](size_t n) { const float* r = q; q += n; return r; };
+            const int NI_ = N + 1 + 3 * cfg->use_abs_coords, nfe_ = (3 * cfg->use_intrinsic_coords + cfg->use_distances) ? (3 * cfg->use_intrinsic_coords + cfg->use_distances) : 1;
+            skip((size_t)H * NI_); skip(H); skip((size_t)H * nfe_); skip(H); skip((size_t)(cfg->conservative ? 1 : 3) * H); skip(cfg->conservative ? 1 : 3);
+            auto amax = [](const float* a, size_t n) { double mx = 0; for (size_t i = 0; i < n; ++i) mx = std::max(mx, (double)fabsf(a[i])); return mx; };
+            auto rowl1 = [](const float* a, int rows, int cols) {   // largest L1 norm of a row of a (rows x cols) matrix
+                double mx = 0;
+                for (int r = 0; r < rows; ++r) { double t = 0; for (int c = 0; c < cols; ++c) t += fabs((double)a[(size_t)r * cols + c]); mx = std::max(mx, t); }
+                return mx;
+            };
+            double worst = 0;
+            for (int l = 0; l < L; ++l) {
+                skip((size_t)I * H); skip(I);
+                const float* Wkv = skip((size_t)2 * I * H); const float* bkv = skip(2 * I);
+                skip((size_t)I * H); skip(I); skip((size_t)H * I); skip(H);
+                const float* ln1g = skip(H); const float* ln1b = skip(H);
+                skip(3 * H);
+                const float* W1 = skip((size_t)F * H); const float* b1 = skip(F);
+                skip((size_t)H * F); skip(H);
+                const float* ln2g = skip(H); const float* ln2b = skip(H);
+                skip(3 * H);
+                const double m1 = sqrt((double)H) * amax(ln1g, H) + amax(ln1b, H);
+                const double m2 = sqrt((double)H) * amax(ln2g, H) + amax(ln2b, H);
+                const double vb = rowl1(Wkv + (size_t)I * H, I, H) * m1 + amax(bkv + I, I);   // |v| (and their attention averages)
+                const double hb = rowl1(W1, F, H) * m2 + amax(b1, F);                            // |h_pre| >= |GELU(h_pre)|
+                worst = std::max(std::max(worst, m1), std::max(std::max(m2, vb), hb));
+            }
+            if (!(worst < 1.6e4)) {
+                fprintf(stderr, "dff: forward activations of this model may reach %.3g (> 1.6e4): the fp16 split engine is off, weight GEMMs run on the fp32 matrix pipe\n", worst);
+                m->split = false;
+            }
+        }
         const char* ef = getenv("DFF_FOLD_KV");
         // (the <= 16-row FOLD kernel keeps a model's forward activations in LDS / registers: built for <= 3 layers, which is
         // every shipped configuration; a deeper hidden-64 model runs the unfolded kernels)
