@@ -571,18 +571,23 @@ def test_ddpm_chain_variance_at_full_size(dff):
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg,dec,xs", [("chignolin", 1e-6, 1.0), ("chignolin", 1e-2, 0.05), ("chignolin", 1.0, 3.0), ("chignolin", 1e2, 1.0),
                                         ("chignolin", 1e4, 10.0), ("villin", 1e-6, 1.0), ("villin", 1e2, 1.0), ("villin", 1e4, 10.0),
-                                        ("protein_g", 1e-6, 1.0), ("protein_g", 1e4, 10.0), ("trp_cage", 1e-6, 0.05), ("bba", 1e4, 3.0)])
+                                        ("protein_g", 1e-6, 1.0), ("protein_g", 1e4, 10.0), ("trp_cage", 1e-6, 0.05), ("bba", 1e4, 3.0),
+                                        ("chignolin-unfolded", 1e-6, 1.0), ("chignolin-unfolded", 1.0, 0.05), ("chignolin-unfolded", 1e4, 10.0)])
 def test_fp16_engine_over_gradient_magnitudes(dff, cfg, dec, xs, monkeypatch):
     """Round 5: the split variants (chignolin: dff_small_kernel<64,8,split_f16,fold_kv>; trp-cage ... protein G:
     dff_fused_kernel<...,split_f16[,pair]>) run their weight GEMMs on a TWO-piece fp16 split (22 bits per operand, three MFMAs
     per product).  fp16 has five exponent bits, so the backward's GEMM inputs -- gradients, whose size follows the energy
     head's weights -- are scaled by powers of two before they are split (row-wise: dff_small.hip a_store_row, dff_kernels.hip
-    row_pow2_scale; dQ / dK / dV of the <= 64-row kernels by one scale per workgroup and layer: block_pow2_scale).  Energy-head scales from 1e-6 to 1e4 (forces from 1e-7 to 1e3) and coordinates from 0.05 to
+    row_pow2_scale; dQ / dK / dV of the <= 64-row kernels and of the unfolded <= 16-row variants -- DFF_FOLD_KV=0 here, models with
+    absolute coordinates or distances otherwise -- by one scale per workgroup and layer: block_pow2_scale, stall_run).  Energy-head scales from 1e-6 to 1e4 (forces from 1e-7 to 1e3) and coordinates from 0.05 to
     10 sigma: forces against the reference twin's float64 run stay within the usual bar -- 2.5 x the distance of the twin's
     own float32 run on the same inputs -- and within 5e-6, the SAME relative error at every magnitude (a missing or wrong
     row scale shows up as 1e-3 .. 1e-2 at the small end, profiles/r05/f16_engine); the fp32-MFMA engine (DFF_SPLIT_BF16=0)
     runs next to it."""
     from dff_amd.score import GraphTransformer
+    if cfg.endswith("-unfolded"):
+        cfg = cfg[:-len("-unfolded")]
+        monkeypatch.setenv("DFF_FOLD_KV", "0")
     _, N, H, L = synth.SHIPPED_CONFIGS[cfg]
     params = synth.synth_gnn_params(N, H, L, seed=4321, decoder_scale=dec)
     x = (synth.normal((7, N, 3), 17, 5) * xs).astype(np.float32)
@@ -597,6 +602,7 @@ def test_fp16_engine_over_gradient_magnitudes(dff, cfg, dec, xs, monkeypatch):
         f = model.native.score(torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()).cpu().numpy()
         kname = model.native.last_launch()[0]
         assert ("split_f16" in kname) == split, kname
+        assert ("fold_kv" in kname) == (split and cfg == "chignolin" and os.environ.get("DFF_FOLD_KV") != "0"), kname
         assert np.isfinite(f).all()
         out[split] = rel(f, f64)
     print(f"{cfg} {kname}: decoder x{dec:g}, x x{xs:g}: rel(fp16 engine, f64)={out[True]:.3e} rel(fp32 engine, f64)={out[False]:.3e} "

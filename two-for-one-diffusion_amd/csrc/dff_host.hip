@@ -591,7 +591,7 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
             // back-projects dQ only (2 k-blocks per head); k = v = LayerNorm output never goes through a GEMM there
             const bool sfold = m->fold_kv && intr && !dist && !ab;
             // the FOLD variant's engine decides the image format: two fp16 pieces (round 5) or three bf16 pieces
-            const bool f16img = sfold && dff_small_fold_f16();
+            const bool f16img = dff_small_f16_level() >= 2 || (sfold && dff_small_f16_level() == 1);
             auto PU = [&](const std::vector<std::pair<int, int>>& un, int nout, const std::function<double(int, int)>& wf) {
                 return f16img ? pack_units_f16(un, nout, wf) : pack_units(un, nout, wf);
             };

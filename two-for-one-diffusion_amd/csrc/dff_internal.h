@@ -108,9 +108,9 @@ struct DffRunArgs {
     int xslow;       // tests: never take the same-XCD fast path of the exchanges (the agent-scope protocol a cross-XCD pair runs)
 };
 
-// true when the <= 16-row FOLD kernels were compiled with the two-piece fp16 engine (dff_small.hip DFF_F16): the host packs
-// that variant's weight images accordingly (dff_host.hip pack_units_f16)
-bool dff_small_fold_f16();
+// which split variants of the <= 16-row kernel were compiled with the two-piece fp16 engine (dff_small.hip DFF_F16): 0 none,
+// 1 the FOLD variant, 2 all -- the host packs their weight images accordingly (dff_host.hip pack_units_f16)
+int dff_small_f16_level();
 
 // bit mask of the <= 64-row split variants' GEMM groups that take two-piece fp16 images (dff_kernels.hip DFF_F16G):
 // 1 = forward (Wqkvx_s, Wox_s, W1_s, W2_s), 2 = FFN backward (W2T_s, W1T_s), 4 = G_ext (WoxT_s), 8 = QKV_ext^T (WqkvxT_s)

@@ -52,11 +52,13 @@ DEVI void phase_prio(int wave) {
         }
     }
 }
-// DFF_F16 (round 5): the FOLD variant (chignolin: the headline) runs its weight GEMMs on the TWO-piece fp16 split (dff_device.h
-// split8h): stream kind -1 = host-split fp16 image, 4 B per weight, 2 KB units, three v_mfma_f32_16x16x32_f16 per unit.
+// DFF_F16 (round 5): the split variants run their weight GEMMs on the TWO-piece fp16 split (dff_device.h split8h): stream kind -1 =
+// host-split fp16 image, 4 B per weight, 2 KB units, three v_mfma_f32_16x16x32_f16 per unit.  1: the FOLD variant only (chignolin:
+// the headline), 2: every split variant of this kernel, 0: the three-piece bf16 engine of rounds 2-4.
 #ifndef DFF_F16
-#define DFF_F16 1
+#define DFF_F16 2
 #endif
+#define DFF_F16_ON(FOLD_) (DFF_F16 >= 2 || (DFF_F16 == 1 && (FOLD_)))
 #ifndef DFF_SDR
 #define DFF_SDR 4   // split-ring depth in units (SPW variants)
 #endif
@@ -494,7 +496,8 @@ DEVI void stall_from(SRing<DR>& ring, f32x4 (&acc)[E], f32x4 (&acc2)[E], f32x4& 
 // s[row] before they are split, `acc` -- which may already hold true-unit terms -- enters and leaves in true units.
 template <int I0, int NKB, int E, bool EXT, int DR, class Q, class FA>
 DEVI void stall_run(SRing<DR>& ring, f32x4 (&acc)[E], const FA fa, const Q& q, int lane,
-                    const lfloat* ext_a = nullptr, const gfloat* ext_w = nullptr, int ext_ts = 0, const lfloat* rsc = nullptr) {
+                    const lfloat* ext_a = nullptr, const gfloat* ext_w = nullptr, int ext_ts = 0, const lfloat* rsc = nullptr,
+                    bool common = false) {
     constexpr bool F16 = Q::kind(I0) < 0;
     float bx[E];
     if constexpr (EXT) {
@@ -504,9 +507,20 @@ DEVI void stall_run(SRing<DR>& ring, f32x4 (&acc)[E], const FA fa, const Q& q, i
     float sa = 1.0f;
     f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, si4 = {1.f, 1.f, 1.f, 1.f};
     if (F16 && rsc) {
-        sa = rsc[lane & 15];
-        const int q4 = (lane >> 4) * 4;
-        sc4 = *(const lf32x4*)(rsc + q4); si4 = *(const lf32x4*)(rsc + 16 + q4);
+        if (common) {
+            // rows that mix the rows of the chain's input (dK, dV of the unfolded variants: sums over i) cannot carry per-row
+            // scales: ONE power of two for the tile -- the smallest row scale (= 1 / the largest inverse), times 2^-8 of headroom
+            float mx = row16_max(rsc[16 + (lane & 15)]);
+            int ex = (int)((__float_as_uint(mx) >> 23) & 255u);
+            ex = ex < 20 ? 20 : (ex > 230 ? 230 : ex);
+            sa = __uint_as_float((unsigned)(246 - ex) << 23);
+            const float si = __uint_as_float((unsigned)(ex + 8) << 23);
+            sc4 = (f32x4){sa, sa, sa, sa}; si4 = (f32x4){si, si, si, si};
+        } else {
+            sa = rsc[lane & 15];
+            const int q4 = (lane >> 4) * 4;
+            sc4 = *(const lf32x4*)(rsc + q4); si4 = *(const lf32x4*)(rsc + 16 + q4);
+        }
 #pragma unroll
         for (int nt = 0; nt < E; ++nt) acc[nt] *= sc4;
     }
@@ -816,7 +830,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             const int kb = cl >> 5, kk = cl & 31, kg = (kk & 15) >> 2, j = ((kk >> 4) << 2) | (kk & 3);
             lu16* const q = asp16 + ((((kb * 4 + kg) * 16 + row) * 4 + (j >> 1)) * 2 + (j & 1));
             constexpr int PS = (H / 32) * 256 * 2;   // halfwords per piece
-            if constexpr (FOLD && DFF_F16) {   // fp16 engine: (h, l') -- callers scale the backward's rows first
+            if constexpr (SPW && DFF_F16_ON(FOLD)) {   // fp16 engine: (h, l') -- callers scale the backward's rows first
                 unsigned short hh, ll;
                 split1h(v, hh, ll);
                 q[0] = hh; q[PS] = ll;
@@ -844,7 +858,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         for (int kb = 0; kb < H / 32; ++kb) {
             ah[kb] = *(const lu32x4*)(q + kb * 256);
             am[kb] = *(const lu32x4*)(q + PS + kb * 256);
-            if constexpr (FOLD && DFF_F16) al[kb] = am[kb];   // (two pieces: h, l')
+            if constexpr (SPW && DFF_F16_ON(FOLD)) al[kb] = am[kb];   // (two pieces: h, l')
             else al[kb] = *(const lu32x4*)(q + 2 * PS + kb * 256);
         }
     };
@@ -1064,7 +1078,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     auto a_store_row = [&](int rrow, int sub, const float (&v)[HC], float& inv, bool publish) {
         float sc = 1.0f;
         inv = 1.0f;
-        if constexpr (FOLD && DFF_F16) {
+        if constexpr (SPW && DFF_F16_ON(FOLD)) {
             float mx = 0.f;
 #pragma unroll
             for (int i = 0; i < HC; ++i) mx = fmaxf(mx, fabsf(v[i]));
@@ -1224,7 +1238,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #define DFF_KO 0
 #define DFF_KT 0
 #endif
-    constexpr bool F16E = FOLD && DFF_F16;   // fp16 two-piece engine (kind -1 streams)
+    constexpr bool F16E = SPW && DFF_F16_ON(FOLD);   // fp16 two-piece engine (kind -1 streams)
     constexpr int KS = F16E ? -1 : 0;        // kind of the host-split images
     constexpr int KQ = F16E ? -1 : DFF_KQ ? 1 : 0, KO = F16E ? -1 : DFF_KO ? DFF_HEADS * 5 : 0, KT = F16E ? -1 : DFF_KT ? DFF_HEADS * 13 : 0;
     constexpr int UST = F16E ? 128 : 192;    // 16-byte slots per unit of a host-split image
@@ -1984,7 +1998,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 float n1[HC], d1[HC], dyg[HC], xh[HC], ps[HC], ao[HC], ni[HC];
                 rows_of(l, ao, ni, nullptr, 0);
                 psum_all(ps, rrow * LH + sub);
-                if constexpr (FOLD && DFF_F16) {   // the FFN backward chain ran in this row's scaled units
+                if constexpr (SPW && DFF_F16_ON(FOLD)) {   // the FFN backward chain ran in this row's scaled units
 #pragma unroll
                     for (int i = 0; i < HC; ++i) ps[i] *= invD;
                 }
@@ -2231,7 +2245,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         dqkv();
                         pf.tick(17); DFF_MARK(17); phase_prio<17>(wave);
                         if constexpr (SPW) stall_run<U_GX, NKT, E, true>(sring, acc_a, qkvt_fa32, sqa, lane, qkvt_xa, qkvt_ext(lw, wave, lane), DFF_HEADS * 13 * 256,
-                                                                         F16E ? rsc : nullptr);   // (dQ' rows re-scaled by their dattn row's scale)
+                                                                         F16E ? rsc : nullptr, !FOLD);   // (dQ' rows re-scaled by their dattn row's scale; unfolded: [dQ | dK | dV] by one common scale)
                         else tall_run<5 % DR, 13, E, 4>(ring, acc_a, qkvt_fa, s_qkvt(lw, wave), after, lane);   // 18 entries: phase 0
                         pf.tick(18); DFF_MARK(18); phase_prio<18>(wave);
                     }
@@ -2508,7 +2522,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #error "compile dff_small.hip with -DDFF_SMALL_MODE=0|1|2 (DFF_MODE_SCORE / LANGEVIN / DDPM): build.sh builds all three"
 #endif
 #if DFF_SMALL_MODE == 0
-bool dff_small_fold_f16() { return DFF_F16 != 0; }
+int dff_small_f16_level() { return DFF_F16; }
 #endif
 #define DFF_CAT2(a, b) a##b
 #define DFF_CAT(a, b) DFF_CAT2(a, b)
@@ -2523,7 +2537,8 @@ bool DFF_CAT(dff_small_pick_m, DFF_SMALL_MODE)(int H, int NW, bool gen, bool spw
     if (H == 64 && NW == 8 && spw) {
         *fn = gen ? (const void*)&dff_small_kernel<64, 8, true, true, false, MD> : (const void*)&dff_small_kernel<64, 8, false, true, false, MD>;
         *lds_floats = SmallLds<64, 8>::total;
-        *name = gen ? "dff_small_kernel<64,8,gen,split_bf16>" : "dff_small_kernel<64,8,split_bf16>";
+        *name = DFF_F16 >= 2 ? (gen ? "dff_small_kernel<64,8,gen,split_f16>" : "dff_small_kernel<64,8,split_f16>")
+                             : (gen ? "dff_small_kernel<64,8,gen,split_bf16>" : "dff_small_kernel<64,8,split_bf16>");
         return true;
     }
 #define SMALL_CASE(H_, NW_)                                                                                          \
