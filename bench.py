@@ -123,7 +123,7 @@ def profile_figures(kname, cfg, P, chunk, lib_sha=None):
 # Said ONCE per line (`notes`), not once per entry: the driver keeps only the tail of stdout.
 NOTES = {
     "dtype": "f32 everywhere.  Weight GEMMs of split_bf16 kernels: exact 3-way bf16 split of every fp32 operand (six "
-             "v_mfma_f32_16x16x32_bf16 per product); split_f16: 2-way fp16 split (22 bits per operand, three v_mfma_f32_16x16x32_f16, "
+             "v_mfma_f32_16x16x32_bf16 per product); split_f16: 2-way fp16 split (2^-22 per operand, three v_mfma_f32_16x16x32_f16, "
              "gradients row-scaled by powers of two); fp32 accumulate, held to the fp32 reference's own error.  Attention products, "
              "other kernels: v_mfma_f32_16x16x4_f32 / fp32 VALU",
     "roofline": "bound = fp32 compute (SURVEY 8d): frac = algorithmic TFLOP/s (factorised FLOP count x proteins x steps / HIP-event "

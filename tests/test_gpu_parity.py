@@ -575,7 +575,7 @@ def test_ddpm_chain_variance_at_full_size(dff):
                                         ("chignolin-unfolded", 1e-6, 1.0), ("chignolin-unfolded", 1.0, 0.05), ("chignolin-unfolded", 1e4, 10.0)])
 def test_fp16_engine_over_gradient_magnitudes(dff, cfg, dec, xs, monkeypatch):
     """Round 5: the split variants (chignolin: dff_small_kernel<64,8,split_f16,fold_kv>; trp-cage ... protein G:
-    dff_fused_kernel<...,split_f16[,pair]>) run their weight GEMMs on a TWO-piece fp16 split (22 bits per operand, three MFMAs
+    dff_fused_kernel<...,split_f16[,pair]>) run their weight GEMMs on a TWO-piece fp16 split (2^-22 per operand, three MFMAs
     per product).  fp16 has five exponent bits, so the backward's GEMM inputs -- gradients, whose size follows the energy
     head's weights -- are scaled by powers of two before they are split (row-wise: dff_small.hip a_store_row, dff_kernels.hip
     row_pow2_scale; dQ / dK / dV of the <= 64-row kernels and of the unfolded <= 16-row variants -- DFF_FOLD_KV=0 here, models with

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Development: random model shapes / batch shapes / magnitudes on the shipped input branch against the oracle twin (float64):
+forces (dff_score; all input branches) and a few fused Langevin steps on supplied noise (shipped branch).  usage: tools_fuzz.py [n_cases] [seed]
+(on the GPU box; the bars are the tests': GUARD x the twin's own float32 distance for forces, STEP_TOL per step for the loops)"""
+import os, sys, json
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import dff_amd  # noqa: F401
+from oracle import synth, reference_twin as twin
+from dff_amd.score import GraphTransformer
+from dff_amd.ddpm import GaussianDiffusion
+from dff_amd.langevin import LangevinDiffusion
+
+GUARD, STEP_TOL = 2.5, 2e-5
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+rel = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))  # noqa: E731
+bad = 0
+for case in range(n_cases):
+    H = int(rng.choice([64, 96, 128]))
+    N = int(rng.integers(2, (61 if H == 128 else 32) + 1))
+    L = int(rng.integers(1, 5))
+    B = int(rng.integers(1, 12))
+    dec = float(10.0 ** rng.uniform(-6, 4)); xs = float(10.0 ** rng.uniform(-1.3, 1.0))
+    G = int(rng.choice([0, 0, 1, 2, 3]))
+    split = bool(rng.integers(0, 4) > 0)
+    os.environ["DFF_SPLIT_BF16"] = "1" if split else "0"
+    os.environ["DFF_FOLD_KV"] = "1" if rng.integers(0, 3) > 0 else "0"
+    flags = [(1, 0, 0), (1, 0, 0), (1, 0, 0), (0, 1, 1), (1, 1, 1), (1, 0, 1), (1, 1, 0), (0, 1, 0)][int(rng.integers(0, 8))]
+    intr, dist, ab = flags
+    shipped = flags == (1, 0, 0)
+    if not shipped: dec = 1.0   # (the other branches' bar is absolute in the reference's float32: keep the test's magnitudes)
+    params = synth.synth_gnn_params(N, H, L, seed=int(rng.integers(1, 1 << 30)), decoder_scale=dec, node_in=N + 1 + 3 * ab, edge_in=(3 * intr + dist) or 1)
+    tag = dict(case=case, H=H, N=N, L=L, B=B, dec=float("%.2g" % dec), xs=float("%.2g" % xs), G=G, split=int(split), fold=int(os.environ["DFF_FOLD_KV"]), flags="%d%d%d" % flags)
+    fl = tuple(bool(v) for v in flags)
+    try:
+        model = GraphTransformer(N, H, device="cuda:0", n_layers=L, use_intrinsic_coords=fl[0], use_abs_coords=fl[2], use_distances=fl[1],
+                                 conservative=True, state_dict=params)
+        model.native.set_group(G)
+        x = (synth.normal((B, N, 3), 11 + case, N) * xs).astype(np.float32)
+        t = rng.uniform(0.0, 1.0, B).astype(np.float32)
+        f = model.native.score(torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()).cpu().numpy()
+        kn = model.native.last_launch()[0]
+        r64ref = twin.score(twin.to_torch(params, torch.float64), torch.from_numpy(x).double(), torch.from_numpy(t).double(), L, flags=fl).numpy()
+        r32 = rel(twin.score(twin.to_torch(params), torch.from_numpy(x), torch.from_numpy(t), L, flags=fl).numpy(), r64ref)
+        r = rel(f, r64ref)
+        # (other branches: the tests' 2e-5 at unit coordinates; distance features at |x| ~ 10 sigma are ill-conditioned in float32 --
+        # the reference's own float32 run is then 1e-4 from its float64 one -- so the bar follows that distance there)
+        ok = np.isfinite(f).all() and (r <= 1e-5 and r <= GUARD * max(r32, 4e-7) if shipped else r <= max(2e-5, 5.0 * r32))
+        tag.update(kernel=kn, rel=float("%.3g" % r), r32=float("%.3g" % r32))
+        if not shipped:   # (the twin's integrator runs the shipped branch only: tests/test_input_branches.py covers the loops there)
+            bad += not ok
+            print(("ok   " if ok else "FAIL ") + json.dumps(tag), flush=True)
+            continue
+        # a few fused Langevin steps
+        K, P, norm, tlev, temp = 4, min(B, 4), 3.0, int(rng.integers(1, 60)), 300
+        diff = GaussianDiffusion(model, num_atoms=N, timesteps=1000, norm_factor=norm)
+        x0 = synth.normal((P, N, 3), 43 + case, N).astype(np.float32)
+        x0 = (x0 - x0.mean(1, keepdims=True)) * norm
+        noises = synth.normal((K, P, N, 3), 44 + case, N).astype(np.float32)
+        masses = [12.0] * N
+        ld = LangevinDiffusion(diff, torch.from_numpy(x0), K, save_interval=2, t=tlev, diffusion_steps=1000, temp_data=temp, temp_sim=temp,
+                               dt=None, masses=masses, friction=1.0, kb="consistent", verbose=False)
+        traj = ld.sample(noises=torch.from_numpy(noises)).numpy().reshape(P, K // 2, N, 3)
+        c = twin.langevin_constants(norm, tlev, twin.make_schedule(), temp, temp, masses, 1.0, None)
+        fr, ke, xl, vl = twin.simulate(twin.to_torch(params, torch.float64), torch.from_numpy(x0).double() / norm, torch.from_numpy(noises).double(), masses, c, L, 2)
+        ref = (fr * norm).numpy()
+        el = float(np.abs(traj - ref).max() / max(np.abs(ref).max(), 1e-30))
+        kl = model.native.last_launch()[0]
+        tag.update(langevin_err=float("%.3g" % el), status=int(model.native.status()))
+        if kl != kn: tag.update(kernel_l=kl)
+        ok = ok and el <= STEP_TOL * K and model.native.status() == 0
+    except Exception as e:  # noqa: BLE001
+        tag.update(error=repr(e)[:300]); ok = False
+    bad += not ok
+    print(("ok   " if ok else "FAIL ") + json.dumps(tag), flush=True)
+print(f"{n_cases - bad} / {n_cases} ok")

@@ -416,13 +416,14 @@ DEVI f32x4 mfma_bf16(const u32x4 a, const u32x4 b, const f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// ---- two-piece fp16 split (round 5, the <= 16-row FOLD kernel): x = h + l' / 2048 with h = RTZ_f16(x), l' = RTZ_f16((x - h) 2048):
-// 22 significant bits, and  a.b ~ ah.bh + (ah.bl' + al'.bh) / 2048  -- THREE v_mfma_f32_16x16x32_f16 instead of six bf16 ones
-// and 4 instead of 6 bytes per weight.  Dropped: al.bl (2^-22) and the pieces' truncation (2^-22 each); measured against
-// float64 the products are as accurate as an fp32 FMA chain (tools: profiles/r05/f16_engine).  fp16 has 5 exponent bits:
-// the hardware keeps subnormals in v_cvt_pkrtz_f16_f32 and in the MFMA inputs (tools_ubench/f16_denorm.hip), so a piece
-// resolves 2^-24 / 2048 = 3e-11 ABSOLUTE whatever the element's size -- negligible next to O(1) forward activations and
-// O(0.1) weights; the backward's operands (gradients, any magnitude) are scaled row-wise by a power of two first.
+// ---- two-piece fp16 split (round 5): x = h + l' / 2048 with h = RN_f16(x), l' = RN_f16((x - h) 2048), both rounded to nearest
+// (split2h), and  a.b ~ ah.bh + (ah.bl' + al'.bh) / 2048  -- THREE v_mfma_f32_16x16x32_f16 instead of six bf16 ones and 4 instead
+// of 6 bytes per weight.  Dropped: al.bl (2^-22) and the pieces' rounding (<= 2^-22 each, unbiased); measured against float64
+// the products are as accurate as an fp32 FMA chain (profiles/r05/f16_engine), and end to end the forces are closer to the
+// reference's float64 run than its own float32 run is.  fp16 has 5 exponent bits: the hardware keeps subnormals in
+// v_cvt_pk_f16_f32 and in the MFMA inputs (tools_ubench/f16_denorm.hip), so a piece resolves 2^-24 / 2048 = 3e-11 ABSOLUTE
+// whatever the element's size -- negligible next to O(1) forward activations and O(0.1) weights; the backward's operands
+// (gradients, any magnitude) are scaled row-wise by a power of two first.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 DEVI f32x4 mfma_f16(const u32x4 a, const u32x4 b, const f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -430,11 +431,16 @@ DEVI f32x4 mfma_f16(const u32x4 a, const u32x4 b, const f32x4 c) {
 #define DFF_F16_LSCALE 2048.0f
 #define DFF_F16_LINV (1.0f / 2048.0f)
 // one pair of values -> (h pair, l' pair), element 0 in the low half
+// (both pieces rounded to NEAREST, v_cvt_pk_f16_f32: |x - h| <= 2^-11 |x| is exact in fp32, l' carries it to 2^-11 of itself, so
+// h + l' / 2048 = x (1 + e), |e| <= 2^-22 and unbiased; the truncating v_cvt_pkrtz_f16_f32 this started with leaves e in (-2^-20, 0]
+// -- one-sided, so the errors of a long dot product add up instead of cancelling)
 DEVI void split2h(float e0, float e1, unsigned& h, unsigned& l) {
-    const auto ph = __builtin_amdgcn_cvt_pkrtz(e0, e1);
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+    const f16x2_ ph = __builtin_convertvector(((f32x2_){e0, e1}), f16x2_);
     const float r0 = e0 - (float)ph[0], r1 = e1 - (float)ph[1];
     h = __builtin_bit_cast(unsigned, ph);
-    l = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0 * DFF_F16_LSCALE, r1 * DFF_F16_LSCALE));
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(((f32x2_){r0 * DFF_F16_LSCALE, r1 * DFF_F16_LSCALE}), f16x2_));
 }
 // eight consecutive fp32 -> the two fp16 operands (the layout of split8 below)
 DEVI void split8h(const f32x4& x0, const f32x4& x1, u32x4& h, u32x4& l) {

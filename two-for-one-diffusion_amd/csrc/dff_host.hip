@@ -103,7 +103,7 @@ static std::vector<uint32_t> pack_b_split(int K, int Nout, const std::function<d
 // 16-column output tile nt x 32 A-columns starting at c0, stored [piece h | m | l][lane][8 bf16].  Element j of lane
 // (n = lane & 15, kg = lane >> 4) is W(c0 + 16 (j >> 2) + 4 kg + (j & 3), 16 nt + n): the k order in which that kernel's A
 // fragments hold a 32-column block (two ds_read_b128, at columns 4 kg and 16 + 4 kg).  w = h + m + l exactly.
-static uint16_t f32_to_f16_rtz(float f);
+static uint16_t f32_to_f16_rn(float f);
 static float f16_to_f32(uint16_t h);
 // pack_b_split in the two-piece fp16 format of the round-5 engine: per (tile, 32-row k-block, piece h | l', lane) eight fp16
 static std::vector<uint32_t> pack_b_split_f16(int K, int Nout, const std::function<double(int, int)>& w) {
@@ -115,8 +115,8 @@ static std::vector<uint32_t> pack_b_split_f16(int K, int Nout, const std::functi
                 for (int j = 0; j < 8; ++j) {
                     const int k = 32 * kb + 8 * (lane >> 4) + j, n = 16 * nt + (lane & 15);
                     const float v = n < Nout ? (float)w(k, n) : 0.f;
-                    const uint16_t h = f32_to_f16_rtz(v);
-                    const uint16_t l = f32_to_f16_rtz((v - f16_to_f32(h)) * 2048.0f);
+                    const uint16_t h = f32_to_f16_rn(v);
+                    const uint16_t l = f32_to_f16_rn((v - f16_to_f32(h)) * 2048.0f);
                     out[((((size_t)nt * KB + kb) * 2 + 0) * 64 + lane) * 4 + (j >> 1)] |= (uint32_t)h << (16 * (j & 1));
                     out[((((size_t)nt * KB + kb) * 2 + 1) * 64 + lane) * 4 + (j >> 1)] |= (uint32_t)l << (16 * (j & 1));
                 }
@@ -143,17 +143,22 @@ static std::vector<uint32_t> pack_units(const std::vector<std::pair<int, int>>& 
     }
     return out;
 }
-// fp16 (binary16) with round-toward-zero, subnormals kept: what v_cvt_pkrtz_f16_f32 does on the device
-static uint16_t f32_to_f16_rtz(float f) {
+// fp32 -> fp16 (binary16), round to nearest even, subnormals kept: what v_cvt_pk_f16_f32 does on the device (dff_device.h split2h)
+static uint16_t f32_to_f16_rn(float f) {
     uint32_t u; memcpy(&u, &f, 4);
     const uint32_t sign = (u >> 16) & 0x8000u, a = u & 0x7fffffffu;
     if (a >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | ((a > 0x7f800000u) ? 0x200u : 0u));   // inf / nan
+    if (a >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);             // >= 65520 rounds to infinity (the range guard keeps models away)
     const int e = (int)(a >> 23) - 127;
-    if (e > 15) return (uint16_t)(sign | 0x7bffu);                      // beyond fp16: the largest finite value (toward zero)
-    if (e >= -14) return (uint16_t)(sign | (uint32_t)(e + 15) << 10 | ((a >> 13) & 0x3ffu));
-    if (e < -25) return (uint16_t)sign;
-    const uint32_t mant = (a & 0x7fffffu) | 0x800000u;                    // subnormal: value = mant 2^(e - 23) = m16 2^-24
-    return (uint16_t)(sign | (mant >> (-e - 1)));                         // mant >> (23 - (e + 24)) = mant >> (-e - 1)
+    if (e < -25) return (uint16_t)sign;                                   // < 2^-25: zero
+    uint32_t r, rem, half;
+    if (e >= -14) { r = (uint32_t)(e + 15) << 10 | ((a >> 13) & 0x3ffu); rem = a & 0x1fffu; half = 0x1000u; }
+    else {                                                                // subnormal: value = mant 2^(e - 23) = r 2^-24
+        const uint32_t mant = (a & 0x7fffffu) | 0x800000u; const int sh = -e - 1;   // 14 .. 24
+        r = mant >> sh; rem = mant & ((1u << sh) - 1u); half = 1u << (sh - 1);
+    }
+    if (rem > half || (rem == half && (r & 1u))) ++r;                     // (a carry out of the mantissa lands in the exponent: right)
+    return (uint16_t)(sign | r);
 }
 static float f16_to_f32(uint16_t h) {
     const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, mnt = h & 0x3ffu;
@@ -164,7 +169,7 @@ static float f16_to_f32(uint16_t h) {
     return f;
 }
 // The same unit sequence as TWO fp16 pieces per weight for the <= 16-row FOLD kernel's fp16 engine (dff_small.hip, stream kind
-// -1): [piece h | l'][lane][8 fp16], h = RTZ_f16(w), l' = RTZ_f16((w - h) 2048): w = h + l' / 2048 to 22 bits (3e-11 absolute).
+// -1): [piece h | l'][lane][8 fp16], h = RN_f16(w), l' = RN_f16((w - h) 2048): w = h + l' / 2048 to 2^-22 relative (3e-11 absolute).
 static std::vector<uint32_t> pack_units_f16(const std::vector<std::pair<int, int>>& units, int Nout,
                                             const std::function<double(int, int)>& w) {
     std::vector<uint32_t> out(units.size() * 2 * 64 * 4, 0u);
@@ -174,8 +179,8 @@ static std::vector<uint32_t> pack_units_f16(const std::vector<std::pair<int, int
             for (int j = 0; j < 8; ++j) {
                 const int c = c0 + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3), n = 16 * nt + (lane & 15);
                 const float v = n < Nout ? (float)w(c, n) : 0.f;
-                const uint16_t h = f32_to_f16_rtz(v);
-                const uint16_t l = f32_to_f16_rtz((v - f16_to_f32(h)) * 2048.0f);
+                const uint16_t h = f32_to_f16_rn(v);
+                const uint16_t l = f32_to_f16_rn((v - f16_to_f32(h)) * 2048.0f);
                 out[((u * 2 + 0) * 64 + lane) * 4 + (j >> 1)] |= (uint32_t)h << (16 * (j & 1));
                 out[((u * 2 + 1) * 64 + lane) * 4 + (j >> 1)] |= (uint32_t)l << (16 * (j & 1));
             }
