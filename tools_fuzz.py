@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Development: random model shapes / batch shapes / magnitudes on the shipped input branch against the oracle twin (float64):
-forces (dff_score; all input branches) and a few fused Langevin steps on supplied noise (shipped branch).  usage: tools_fuzz.py [n_cases] [seed]
+forces (dff_score; all input branches, energy and force heads, batches of 1 .. 900) and a few fused Langevin and reverse-DDPM
+steps on supplied noise (shipped branch, energy head).  usage: tools_fuzz.py [n_cases] [seed]
 (on the GPU box; the bars are the tests': GUARD x the twin's own float32 distance for forces, STEP_TOL per step for the loops)"""
 import os, sys, json
 import numpy as np, torch
@@ -20,7 +21,8 @@ for case in range(n_cases):
     H = int(rng.choice([64, 96, 128]))
     N = int(rng.integers(2, (61 if H == 128 else 32) + 1))
     L = int(rng.integers(1, 5))
-    B = int(rng.integers(1, 12))
+    B = int(rng.integers(1, 12)) if rng.integers(0, 4) else int(rng.integers(200, 900))   # (one in four: several launch rounds / groups)
+    cons = bool(rng.integers(0, 6) > 0)
     dec = float(10.0 ** rng.uniform(-6, 4)); xs = float(10.0 ** rng.uniform(-1.3, 1.0))
     G = int(rng.choice([0, 0, 1, 2, 3]))
     split = bool(rng.integers(0, 4) > 0)
@@ -29,26 +31,28 @@ for case in range(n_cases):
     flags = [(1, 0, 0), (1, 0, 0), (1, 0, 0), (0, 1, 1), (1, 1, 1), (1, 0, 1), (1, 1, 0), (0, 1, 0)][int(rng.integers(0, 8))]
     intr, dist, ab = flags
     shipped = flags == (1, 0, 0)
-    if not shipped: dec = 1.0   # (the other branches' bar is absolute in the reference's float32: keep the test's magnitudes)
-    params = synth.synth_gnn_params(N, H, L, seed=int(rng.integers(1, 1 << 30)), decoder_scale=dec, node_in=N + 1 + 3 * ab, edge_in=(3 * intr + dist) or 1)
-    tag = dict(case=case, H=H, N=N, L=L, B=B, dec=float("%.2g" % dec), xs=float("%.2g" % xs), G=G, split=int(split), fold=int(os.environ["DFF_FOLD_KV"]), flags="%d%d%d" % flags)
+    if not shipped: dec, cons = 1.0, True   # (the other branches' bar is absolute in the reference's float32: keep the test's magnitudes)
+    params = synth.synth_gnn_params(N, H, L, seed=int(rng.integers(1, 1 << 30)), decoder_scale=dec, decoder_out=1 if cons else 3, node_in=N + 1 + 3 * ab, edge_in=(3 * intr + dist) or 1)
+    tag = dict(case=case, H=H, N=N, L=L, B=B, dec=float("%.2g" % dec), xs=float("%.2g" % xs), G=G, split=int(split), fold=int(os.environ["DFF_FOLD_KV"]), flags="%d%d%d" % flags, cons=int(cons))
     fl = tuple(bool(v) for v in flags)
     try:
         model = GraphTransformer(N, H, device="cuda:0", n_layers=L, use_intrinsic_coords=fl[0], use_abs_coords=fl[2], use_distances=fl[1],
-                                 conservative=True, state_dict=params)
+                                 conservative=cons, state_dict=params)
         model.native.set_group(G)
         x = (synth.normal((B, N, 3), 11 + case, N) * xs).astype(np.float32)
         t = rng.uniform(0.0, 1.0, B).astype(np.float32)
         f = model.native.score(torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()).cpu().numpy()
         kn = model.native.last_launch()[0]
-        r64ref = twin.score(twin.to_torch(params, torch.float64), torch.from_numpy(x).double(), torch.from_numpy(t).double(), L, flags=fl).numpy()
-        r32 = rel(twin.score(twin.to_torch(params), torch.from_numpy(x), torch.from_numpy(t), L, flags=fl).numpy(), r64ref)
-        r = rel(f, r64ref)
+        sub = np.arange(B) if B <= 12 else np.sort(rng.choice(B, 8, replace=False))   # (a sample's forces depend on that sample only)
+        xs_, ts_ = torch.from_numpy(x[sub]), torch.from_numpy(t[sub])
+        r64ref = twin.score(twin.to_torch(params, torch.float64), xs_.double(), ts_.double(), L, conservative=cons, flags=fl).numpy()
+        r32 = rel(twin.score(twin.to_torch(params), xs_, ts_, L, conservative=cons, flags=fl).numpy(), r64ref)
+        r = rel(f[sub], r64ref)
         # (other branches: the tests' 2e-5 at unit coordinates; distance features at |x| ~ 10 sigma are ill-conditioned in float32 --
         # the reference's own float32 run is then 1e-4 from its float64 one -- so the bar follows that distance there)
         ok = np.isfinite(f).all() and (r <= 1e-5 and r <= GUARD * max(r32, 4e-7) if shipped else r <= max(2e-5, 5.0 * r32))
         tag.update(kernel=kn, rel=float("%.3g" % r), r32=float("%.3g" % r32))
-        if not shipped:   # (the twin's integrator runs the shipped branch only: tests/test_input_branches.py covers the loops there)
+        if not shipped or not cons:   # (the twin's integrator runs the shipped branch only: tests/test_input_branches.py covers the loops there)
             bad += not ok
             print(("ok   " if ok else "FAIL ") + json.dumps(tag), flush=True)
             continue
@@ -70,6 +74,15 @@ for case in range(n_cases):
         tag.update(langevin_err=float("%.3g" % el), status=int(model.native.status()))
         if kl != kn: tag.update(kernel_l=kl)
         ok = ok and el <= STEP_TOL * K and model.native.status() == 0
+        # ... and of the reverse-DDPM loop, t = K - 1 .. 0
+        xd = synth.normal((P, N, 3), 45 + case, N).astype(np.float32)
+        xd = (xd - xd.mean(1, keepdims=True)) * 0.6
+        y = diff.p_sample_loop_from(torch.from_numpy(xd), K - 1, 0, noises=torch.from_numpy(noises)).cpu().numpy()
+        refd = twin.p_sample_loop(twin.to_torch(params, torch.float64), {k: v.double() for k, v in twin.make_schedule().items()},
+                                  torch.from_numpy(xd).double(), torch.from_numpy(noises).double(), K - 1, L).numpy()
+        ed = float(np.abs(y - refd).max() / max(np.abs(refd).max(), 1e-30))
+        tag.update(ddpm_err=float("%.3g" % ed))
+        ok = ok and ed <= STEP_TOL * K and model.native.status() == 0
     except Exception as e:  # noqa: BLE001
         tag.update(error=repr(e)[:300]); ok = False
     bad += not ok
