@@ -1,23 +1,37 @@
 #!/usr/bin/env python3
-"""Development: random model shapes / batch shapes / magnitudes on the shipped input branch against the oracle twin (float64):
-forces (dff_score; all input branches, energy and force heads, batches of 1 .. 900) and a few fused Langevin and reverse-DDPM
-steps on supplied noise (shipped branch, energy head).  usage: tools_fuzz.py [n_cases] [seed]
-(on the GPU box; the bars are the tests': GUARD x the twin's own float32 distance for forces, STEP_TOL per step for the loops)"""
+"""Random model shapes / batch shapes / magnitudes against the oracle twin (float64): forces (dff_score; all input branches, energy
+and force heads, batches of 1 .. 900) and a few fused Langevin and reverse-DDPM steps on supplied noise (shipped branch, energy
+head).  The bars are the tests': GUARD x the twin's own float32 distance for forces, STEP_TOL per step for the loops.
+test_gpu_parity.py::test_random_shapes runs a short sweep; `python tests/fuzz_shapes.py [n_cases] [seed]` a long one (GPU box)."""
 import os, sys, json
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-import dff_amd  # noqa: F401
-from oracle import synth, reference_twin as twin
-from dff_amd.score import GraphTransformer
-from dff_amd.ddpm import GaussianDiffusion
-from dff_amd.langevin import LangevinDiffusion
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dff_amd  # noqa: F401,E402
+from oracle import synth, reference_twin as twin  # noqa: E402
+from dff_amd.score import GraphTransformer  # noqa: E402
+from dff_amd.ddpm import GaussianDiffusion  # noqa: E402
+from dff_amd.langevin import LangevinDiffusion  # noqa: E402
 
 GUARD, STEP_TOL = 2.5, 2e-5
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 rel = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))  # noqa: E731
-bad = 0
-for case in range(n_cases):
+
+
+def run(n_cases, seed, log=print):
+    """Returns the number of cases outside the bars (each case is logged as one line)."""
+    rng = np.random.default_rng(seed)
+    env = {k: os.environ.get(k) for k in ("DFF_SPLIT_BF16", "DFF_FOLD_KV")}
+    bad = 0
+    try:
+        for case in range(n_cases):
+            bad += not _case(case, rng, log)
+    finally:
+        for k, v in env.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+    return bad
+
+
+def _case(case, rng, log):
     H = int(rng.choice([64, 96, 128]))
     N = int(rng.integers(2, (61 if H == 128 else 32) + 1))
     L = int(rng.integers(1, 5))
@@ -53,9 +67,8 @@ for case in range(n_cases):
         ok = np.isfinite(f).all() and (r <= 1e-5 and r <= GUARD * max(r32, 4e-7) if shipped else r <= max(2e-5, 5.0 * r32))
         tag.update(kernel=kn, rel=float("%.3g" % r), r32=float("%.3g" % r32))
         if not shipped or not cons:   # (the twin's integrator runs the shipped branch only: tests/test_input_branches.py covers the loops there)
-            bad += not ok
-            print(("ok   " if ok else "FAIL ") + json.dumps(tag), flush=True)
-            continue
+            log(("ok   " if ok else "FAIL ") + json.dumps(tag))
+            return bool(ok)
         # a few fused Langevin steps
         K, P, norm, tlev, temp = 4, min(B, 4), 3.0, int(rng.integers(1, 60)), 300
         diff = GaussianDiffusion(model, num_atoms=N, timesteps=1000, norm_factor=norm)
@@ -85,6 +98,11 @@ for case in range(n_cases):
         ok = ok and ed <= STEP_TOL * K and model.native.status() == 0
     except Exception as e:  # noqa: BLE001
         tag.update(error=repr(e)[:300]); ok = False
-    bad += not ok
-    print(("ok   " if ok else "FAIL ") + json.dumps(tag), flush=True)
-print(f"{n_cases - bad} / {n_cases} ok")
+    log(("ok   " if ok else "FAIL ") + json.dumps(tag))
+    return bool(ok)
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    nbad = run(n, int(sys.argv[2]) if len(sys.argv) > 2 else 1, lambda m: print(m, flush=True))
+    print(f"{n - nbad} / {n} ok")

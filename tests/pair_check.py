@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Two workgroups per protein (PAIR variants) against one: step time at a batch that leaves half the CUs idle, and
-agreement of the forces with the oracle.  usage: tools_pair_test.py [cfg ...]"""
+agreement of the forces with the oracle.  usage: tests/pair_check.py [cfg ...]"""
 import sys, os, time, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dff_amd
 from dff_amd.score import GraphTransformer
 from dff_amd.ddpm import GaussianDiffusion

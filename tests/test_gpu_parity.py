@@ -1043,6 +1043,19 @@ def test_small_models_at_odd_sizes(dff, H, N, G, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_random_shapes(dff):
+    """tests/fuzz_shapes.py, 30 cases: random hidden size / bead count / depth / input branch / head / magnitudes / batch / packing /
+    engine against the oracle twin in float64 -- forces on every case, four fused Langevin and reverse-DDPM steps on the shipped
+    branch -- at the bars of the fixed-shape tests.  (Round 5: a 120-case sweep is what showed the truncated fp16 pieces 2 % past
+    the force bar on one shape; profiles/r05/fuzz*.txt hold the long sweeps.)"""
+    import fuzz_shapes
+    lines = []
+    bad = fuzz_shapes.run(30, 2025, lines.append)
+    print("\n".join(lines))
+    assert bad == 0, [ln for ln in lines if ln.startswith("FAIL")]
+
+
+@pytest.mark.gpu
 def test_pair_failure_word_is_sticky_reported_once_and_never_syncs_the_launch_path(dff, golden):
     """The two-workgroups-per-protein variants' failure word (round 4): the launch path does not read it (stays
     asynchronous); a launch queued on top of a failure leaves at kernel entry with its OUTPUTS set to NaN (round 5, ADVICE

@@ -9,7 +9,7 @@ python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 python tools_bench_configs.py > gpurun_out/${TAG}_configs.jsonl 2>/dev/null
 python tools_bench_configs.py --P 128 > gpurun_out/${TAG}_configs_p128.jsonl 2>/dev/null
 python tools_e2e_cli.py > gpurun_out/${TAG}_e2e_cli.jsonl 2>/dev/null
-python tools_pair_check.py protein_g villin trp_cage bba > gpurun_out/${TAG}_pair_check.txt 2>&1
+python tests/pair_check.py protein_g villin trp_cage bba > gpurun_out/${TAG}_pair_check.txt 2>&1
 python tools_stress_repeat.py > gpurun_out/${TAG}_stress_repeat.txt 2>&1
 bash tools_rocprof.sh ${TAG}_head > /dev/null 2>&1
 bash tools_rocprof.sh ${TAG}_villin --cfg villin > /dev/null 2>&1
