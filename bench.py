@@ -418,7 +418,7 @@ def main():
         traj_steps = world * P * K / h["elapsed"]
         value = traj_steps / 256.0
         res = {
-            "metric": "Langevin MD-steps/sec at batch 256 (chignolin, score fwd+VJP + BAOAB per step)",
+            "metric": f"Langevin MD-steps/sec at batch 256 ({cfg}, score fwd+VJP + BAOAB per step)",
             "value": value, "unit": "MD-steps/s (batch-256 steps, whole job)", "n_gpus": world, "steps": K,
             "warmup": W, "ms_per_step": 1e3 * h["elapsed"] / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": kernel_dtype(h["kernel"]),

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Two workgroups per protein (PAIR variants) against one: step time at a batch that leaves half the CUs idle, and
-agreement of the forces with the oracle.  usage: tests/pair_check.py [cfg ...]"""
+agreement of the forces with the oracle.  usage: tests/pair_check.py [cfg[:P] ...]  (P: trajectories, default 128)"""
 import sys, os, time, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dff_amd
@@ -10,6 +10,8 @@ from dff_amd.langevin import LangevinDiffusion
 import synth_weights as synth
 from oracle import reference_twin as twin
 for cfg in (sys.argv[1:] or ["protein_g", "villin", "trp_cage"]):
+    cfg, _, P = cfg.partition(":")
+    P = int(P or 128)
     _, N, H, L = synth.SHIPPED_CONFIGS[cfg]
     params = synth.synth_gnn_params(N, H, L, decoder_scale=1.0)
     model = GraphTransformer(N, H, device="cuda:0", n_layers=L, use_intrinsic_coords=True, use_abs_coords=False, use_distances=False, conservative=True, state_dict=params)
@@ -22,10 +24,10 @@ for cfg in (sys.argv[1:] or ["protein_g", "villin", "trp_cage"]):
     p2 = synth.synth_gnn_params(N, H, L, decoder_scale=1e-2)
     m2 = GraphTransformer(N, H, device="cuda:0", n_layers=L, use_intrinsic_coords=True, use_abs_coords=False, use_distances=False, conservative=True, state_dict=p2)
     diff = GaussianDiffusion(m2, num_atoms=N, norm_factor=3.0)
-    x0 = torch.randn(128, N, 3); x0 = (x0 - x0.mean(1, keepdim=True)) * 3.0
+    x0 = torch.randn(P, N, 3); x0 = (x0 - x0.mean(1, keepdim=True)) * 3.0
     for on in (True, False):
         m2.native.pair(on)
         for rep in range(2):
-            ld = LangevinDiffusion(diff, x0, 100, save_interval=100, t=5, temp_data=350, temp_sim=350, dt=None, masses=[12.0] * N, friction=1.0, verbose=False, seed=3)
+            ld = LangevinDiffusion(diff, x0, 400, save_interval=400, t=5, temp_data=350, temp_sim=350, dt=None, masses=[12.0] * N, friction=1.0, verbose=False, seed=3)
             torch.cuda.synchronize(); t0 = time.perf_counter(); tr = ld.simulate(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        print(cfg, "P=128 pair", on, m2.native.last_launch()[0], "status", m2.native.pair_status(), f"{1e6*dt/100:.1f} us/step")
+        print(cfg, f"P={P} pair", on, m2.native.last_launch()[:2], "status", m2.native.pair_status(), f"{1e6*dt/400:.1f} us/step")

@@ -401,10 +401,16 @@ def test_many_workgroups_identical_copies(dff, cfg, golden):
     copies = 48
     x = torch.from_numpy(np.tile(g["x"], (copies, 1, 1))).cuda()
     t = torch.from_numpy(np.tile(g["t"], copies)).cuda()
-    for rep in range(4):
-        f = model.native.score(x, t).reshape(copies, 3, N, 3)
-        assert torch.equal(f, f[:1].expand_as(f)), f"copies differ (rep {rep})"
-        assert rel(f[0].cpu().numpy(), g["forces64"]) <= 1e-5
+    # (ala2: two or three proteins share a workgroup's 16-row tile -- since round 5 also at this batch, as groups of two on two
+    # workgroups each -- and a protein's k-steps depend on where in the tile it sits: copies are bit-identical when they sit at the
+    # same place, i.e. every 6th copy whatever the group size; with one protein per workgroup, all of them)
+    for group, period in ((0, 6), (1, 1)):
+        model.native.set_group(group)
+        for rep in range(4):
+            f = model.native.score(x, t).reshape(copies, 3, N, 3)
+            assert torch.equal(f[period:], f[:-period]), f"copies differ (group {group}, rep {rep})"
+            assert max(rel(f[c].cpu().numpy(), g["forces64"]) for c in range(period)) <= 1e-5
+    model.native.set_group(0)
 
 
 def test_small_kernel_wave_variants(dff, golden):
@@ -1152,6 +1158,67 @@ def test_device_flag_word_persists_and_reports_centre(dff):
         diff.p_sample_loop_from(big, 999, 999)
     with pytest.raises(AssertionError, match="Center not at zero"):
         diff.p_sample_loop_from(bad, 1, 0)
+
+
+@pytest.mark.gpu
+def test_pairs_of_groups_for_proteins_that_share_a_row_tile(dff):
+    """ala2 (5 beads: up to three proteins in a 16-row tile).  Round 5: the two-workgroups variant takes a GROUP of proteins per
+    pair -- the smallest group size whose pairs fit the CUs: 256 trajectories run as 128 groups of two on 256 workgroups (64 vs
+    80 us per step), 300 and 384 as groups of three, 512 no longer fits and runs one workgroup per group of three.  Dispatch,
+    forces against the twin (float64) on a ragged batch whose last group is short, agreement with the one-workgroup path, the
+    exchange status, run-to-run bit-identity, and the fused Langevin loop on supplied noise."""
+    from dff_amd.score import GraphTransformer
+    from dff_amd.ddpm import GaussianDiffusion
+    from dff_amd.langevin import LangevinDiffusion
+    cfg = "ala2"
+    _, N, H, L = synth.SHIPPED_CONFIGS[cfg]
+    params = synth.synth_gnn_params(N, H, L, seed=515, decoder_scale=1e-2)
+    model = GraphTransformer(N, H, device="cuda:0", n_layers=L, use_intrinsic_coords=True, use_abs_coords=False,
+                             use_distances=False, conservative=True, state_dict=params)
+    if torch.cuda.get_device_properties(0).multi_processor_count < 256:
+        pytest.skip("needs the full 256 CUs")
+    try:
+        for B, grid, paired in ((128, 256, True), (256, 256, True), (299, 208, True), (384, 256, True), (512, 171, False)):
+            x = (synth.normal((B, N, 3), 77, B) * 1.2).astype(np.float32)
+            t = (0.001 + 0.9 * synth.uniform((B,), 78, B, 0.0, 1.0)).astype(np.float32)
+            xd, td = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
+            model.native.pair(True)
+            f = model.native.score(xd, td).cpu().numpy()
+            name, g_, _ = model.native.last_launch()
+            assert ("pair" in name) == paired and g_ == grid, (B, name, g_)
+            assert model.native.pair_status() == 0
+            assert np.array_equal(f, model.native.score(xd, td).cpu().numpy())
+            sub = np.r_[0:4, B - 5:B]
+            f64 = twin.score(twin.to_torch(params, torch.float64), torch.from_numpy(x[sub]).double(), torch.from_numpy(t[sub]).double(), L).numpy()
+            r32 = rel(twin.score(twin.to_torch(params), torch.from_numpy(x[sub]), torch.from_numpy(t[sub]), L).numpy(), f64)
+            r64 = rel(f[sub], f64)
+            model.native.pair(False)
+            f1 = model.native.score(xd, td).cpu().numpy()
+            assert "pair" not in model.native.last_launch()[0]
+            print(f"ala2 B={B}: {name} grid {g_}: rel(hip,ref64)={r64:.3e} rel(ref32,ref64)={r32:.3e} rel(pair, one workgroup)={rel(f, f1):.3e}")
+            assert r64 <= 1e-5 and r64 <= GUARD * max(r32, 4e-7)
+            assert rel(f, f1) <= 5e-6
+        # the fused loop: 6 steps, 256 trajectories (groups of two), against the twin on the first and last three
+        model.native.pair(True)
+        K, P, norm, tlev, temp = 6, 256, 3.0, 20, 300
+        diff = GaussianDiffusion(model, num_atoms=N, timesteps=1000, norm_factor=norm)
+        x0 = synth.normal((P, N, 3), 43, 5).astype(np.float32)
+        x0 = (x0 - x0.mean(1, keepdims=True)) * norm
+        noises = synth.normal((K, P, N, 3), 44, 5).astype(np.float32)
+        masses = [12.0] * N
+        ld = LangevinDiffusion(diff, torch.from_numpy(x0), K, save_interval=2, t=tlev, diffusion_steps=1000, temp_data=temp,
+                               temp_sim=temp, dt=None, masses=masses, friction=1.0, kb="consistent", verbose=False)
+        traj = ld.sample(noises=torch.from_numpy(noises)).numpy().reshape(P, K // 2, N, 3)
+        assert "pair" in model.native.last_launch()[0] and model.native.pair_status() == 0
+        sub = np.r_[0:3, P - 3:P]
+        c = twin.langevin_constants(norm, tlev, twin.make_schedule(), temp, temp, masses, 1.0, None)
+        fr, _, _, _ = twin.simulate(twin.to_torch(params), torch.from_numpy(x0[sub]) / norm, torch.from_numpy(noises[:, sub]), masses, c, L, 2)
+        ref = (fr * norm).numpy()
+        err = np.abs(traj[sub] - ref).max() / np.abs(ref).max()
+        print(f"ala2 P={P} {model.native.last_launch()[0]}: {K}-step Langevin rel err {err:.3e}")
+        assert err <= STEP_TOL * K
+    finally:
+        model.native.pair(True)
 
 
 @pytest.mark.gpu

@@ -810,8 +810,9 @@ static int launch_generic(dff_model* m, DffRunArgs& a, int G, const Variant* v, 
     if (lds > 160 * 1024) return fail(DFF_EINVAL, "LDS budget exceeded (%u bytes) for N=%d G=%d H=%d", lds, N, G, H);
     // PAIR variants: blocks b and b + 8 share a protein (dff_kernels.hip), 16 blocks per 8 proteins, ONE launch: the caller
     // has checked that every block gets a CU of its own (both blocks of a pair must be resident at once)
-    const int npairs = v->pair ? 8 * ((a.B + 7) / 8) : 0;
-    const int grid_all = v->pair ? 2 * npairs : (a.B + G - 1) / G;
+    const int ngroups = (a.B + G - 1) / G;   // (a pair shares a GROUP of G proteins: ala2 two or three to a 16-row tile)
+    const int npairs = v->pair ? 8 * ((ngroups + 7) / 8) : 0;
+    const int grid_all = v->pair ? 2 * npairs : ngroups;
     const int grid_max = v->pair ? grid_all : (grid_all < m->max_wgs ? grid_all : m->max_wgs);
     const StashLayout sl = dff_stash_layout(N, G, H, L, v->MT);
     { int rc = ensure_stash(m, (size_t)grid_max * sl.total); if (rc) return rc; }
@@ -929,9 +930,10 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
     // 120 vs 179 us / step).  Spilling into a second row tile never pays: chignolin three to a 32-row tile of the generic
     // kernel runs at 0.20-0.26 of the fp32 roof against 0.40 for one per workgroup on the <= 16-row kernel, at every batch.
     int G = m->group_override;
-    if (G <= 0) {
+    const bool auto_group = G <= 0;
+    const int cap = (16 * mt_min) / N;  // proteins that fit the padded rows anyway
+    if (auto_group) {
         G = 1;
-        const int cap = (16 * mt_min) / N;  // proteins that fit the padded rows anyway
         if (cap > 1 && a.B > 256) G = cap;
     }
     if (G > 16) G = 16;
@@ -993,31 +995,42 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
         v = pick_up(mt_min);
     }
     if (!v) return fail(DFF_EINVAL, "no kernel variant for hidden=%d rows=%d", H, G * N);
-    if (want_tab) {
-        int rc = ensure_l0_table(m, a.mode == DFF_MODE_DDPM ? 2 : 1, a.t_norm, G, v, stream);
-        if (rc) return rc;
-        a.l0_tab = m->l0[a.mode == DFF_MODE_DDPM ? 1 : 0].tab;
-    }
     // Two workgroups per protein when one per protein would leave at least half the CUs idle (protein G at 128 per GPU:
     // 1087 -> ~700 us / step).  Both blocks of a pair must be RESIDENT at once, and the launch is not cooperative: the
     // variant is used only when the whole grid fits the device's CUs one block each (hipDeviceAttributeMultiprocessorCount
     // of THIS device -- a partitioned or CU-masked GPU reports fewer than 256 and gets the one-workgroup variant), and
     // only on the conservative, shipped input branch.  A previous PAIR launch that gave up on a partner (co-tenancy: another
     // process held the CUs) is reported here, before anything else is launched on top of its garbage.  (The layer-0 table
-    // above is built by the one-workgroup variant: the stash layout is the same.)
+    // below is built by the one-workgroup variant: the stash layout is the same.)
+    // Proteins that share a row tile anyway (ala2: up to three in 16 rows) are paired as a GROUP: the smallest group size
+    // whose pairs fit the CUs -- ala2 at 256 per GPU runs as 128 groups of two on 256 workgroups instead of 256 single
+    // proteins on 256 workgroups that each do all the heads.
     const int cu_cap = m->n_cus < m->max_wgs ? m->n_cus : m->max_wgs;
-    if (G == 1 && !gen && m->cfg.conservative && !m->pair_off && 2 * 8 * ((a.B + 7) / 8) <= cu_cap) {
-        const Variant* vp = pick_pair(mt, v->spw);
-        if (vp) {
-            // (no device access here: the launch path stays asynchronous.  The word the HOST last saw refuses; one it has
-            // not seen yet makes the kernel itself leave at entry, and the next status call reports it.)
-            if (m->sticky)
-                return fail(DFF_EHIP, "an earlier two-workgroups-per-protein launch timed out waiting for its partner "
-                                      "workgroup (the GPU is shared or partitioned?): its results are invalid; "
-                                      "dff_model_status_clear(m) re-arms, dff_debug_pair(m, 0) selects the one-workgroup kernels");
-            v = vp;
+    const Variant* vp = nullptr;
+    if (!gen && m->cfg.conservative && !m->pair_off) {
+        const Variant* const cand = pick_pair(mt, v->spw);
+        const int g_lo = auto_group ? 1 : G, g_hi = auto_group ? (cap > 1 ? cap : 1) : G;
+        for (int g = g_lo; cand && g <= g_hi; ++g) {
+            const int ngr = (a.B + g - 1) / g;
+            if (2 * 8 * ((ngr + 7) / 8) > cu_cap || (g * N + 15) / 16 > mt || cand->lds_floats(N, g) * sizeof(float) > 160u * 1024u) continue;
+            vp = cand; G = g;
+            break;
         }
     }
+    if (vp) {
+        // (no device access here: the launch path stays asynchronous.  The word the HOST last saw refuses; one it has
+        // not seen yet makes the kernel itself leave at entry, and the next status call reports it.)
+        if (m->sticky)
+            return fail(DFF_EHIP, "an earlier two-workgroups-per-protein launch timed out waiting for its partner "
+                                  "workgroup (the GPU is shared or partitioned?): its results are invalid; "
+                                  "dff_model_status_clear(m) re-arms, dff_debug_pair(m, 0) selects the one-workgroup kernels");
+    }
+    if (want_tab) {
+        int rc = ensure_l0_table(m, a.mode == DFF_MODE_DDPM ? 2 : 1, a.t_norm, G, v, stream);
+        if (rc) return rc;
+        a.l0_tab = m->l0[a.mode == DFF_MODE_DDPM ? 1 : 0].tab;
+    }
+    if (vp) v = vp;
     return launch_generic(m, a, G, v, stream);
 }
 
