@@ -11,7 +11,8 @@ from dff_amd.ddpm import GaussianDiffusion
 from dff_amd.langevin import LangevinDiffusion
 import synth_weights as synth
 for cfg, P in (("villin", 256), ("protein_g", 128), ("trp_cage", 256), ("bba", 256), ("chignolin", 256),
-               ("villin", 128), ("trp_cage", 128), ("bba", 128), ("protein_g", 60)):   # 128 / 60: the two-workgroups-per-protein variants
+               ("villin", 128), ("trp_cage", 128), ("bba", 128), ("protein_g", 60),   # 128 / 60: the two-workgroups-per-protein variants
+               ("ala2", 256), ("ala2", 383), ("ala2", 128), ("ala2", 768)):          # ... on groups of two / three / one protein; three per workgroup
     _, N, H, L = synth.SHIPPED_CONFIGS[cfg]
     model = GraphTransformer(N, H, device="cuda:0", n_layers=L, use_intrinsic_coords=True, use_abs_coords=False,
                              use_distances=False, conservative=True, state_dict=synth.synth_gnn_params(N, H, L, decoder_scale=1e-2))
