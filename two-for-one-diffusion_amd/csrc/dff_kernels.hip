@@ -1600,7 +1600,10 @@ DEVI f32x4 co_mm(const lfloat* T, int mo, const lfloat* B, int ldb, int RN, int 
 // hook(step), step = 0 .. 4 MT - 1, runs once per k-step: a place to spread another phase's weight requests over this one's
 // MFMAs (a burst of them stalls the wave at issue while the CU's one texture-address unit takes 16 cycles per KiB).
 struct NoStepHook { DEVI void operator()(int) const {} };
-template <int MT, bool TRANS, int NT, int PL_ = 16 * MT + 4, class SH = NoStepHook>
+// SWAP: the two operands change places in the MFMA, which transposes the output tile: lane (quad, col) then holds row 16 mo + col,
+// columns 16 nt + 4 quad .. + 3 -- four CONSECUTIVE columns of one row, so an epilogue writes 8- or 16-byte LDS words instead of four
+// 2- or 4-byte ones (round 5: the dQ / dK / dV pieces of the fp16 engine).
+template <int MT, bool TRANS, int NT, int PL_ = 16 * MT + 4, class SH = NoStepHook, bool SWAP = false>
 DEVI void co_mmN(f32x4 (&c)[NT], const lfloat* T, int mo, const lfloat* B, int ldb, int RN, int rows, int lane, SH hook = SH()) {
     constexpr int PL = PL_, NS = 4 * MT;
     constexpr bool TIGHT = PL_ < 16 * MT;   // (see co_mm)
@@ -1642,14 +1645,16 @@ DEVI void co_mmN(f32x4 (&c)[NT], const lfloat* T, int mo, const lfloat* B, int l
         }
         if (st % 4 == 0 || 4 * st < rows) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) c[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_c, b_c[nt], c[nt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt)
+                c[nt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x4f32(b_c[nt], a_c, c[nt], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_16x16x4f32(a_c, b_c[nt], c[nt], 0, 0, 0);
         }
         hook(st);
     }
 }
-template <int MT, bool TRANS, int PL_ = 16 * MT + 4, class SH = NoStepHook>
+template <int MT, bool TRANS, int PL_ = 16 * MT + 4, class SH = NoStepHook, bool SWAP = false>
 DEVI void co_mm5(f32x4 (&c)[5], const lfloat* T, int mo, const lfloat* B, int ldb, int RN, int rows, int lane, SH hook = SH()) {
-    co_mmN<MT, TRANS, 5, PL_, SH>(c, T, mo, B, ldb, RN, rows, lane, hook);
+    co_mmN<MT, TRANS, 5, PL_, SH, SWAP>(c, T, mo, B, ldb, RN, rows, lane, hook);
 }
 
 
@@ -1686,6 +1691,17 @@ DEVI void put_piece16(lu16* hm, float v, float qs) {
     unsigned short hh, ll;
     split1h(v * qs, hh, ll);
     hm[0] = hh; hm[64] = ll;
+}
+// ... four consecutive elements of a row at once (the transposed tiles of co_mmN<..., SWAP>): two 8-byte stores; hm2 = the dword that
+// holds the first element's h piece (the l' pieces sit 64 elements = 32 dwords further on)
+typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+DEVI void put_piece16x4(lu32* hm2, const f32x4& v, float qs) {
+    unsigned h0, l0, h1, l1;
+    split2h(v[0] * qs, v[1] * qs, h0, l0);
+    split2h(v[2] * qs, v[3] * qs, h1, l1);
+    typedef u32x2_ __attribute__((address_space(3))) lu32x2;
+    *(lu32x2*)hm2 = (u32x2_){h0, h1};
+    *(lu32x2*)(hm2 + 32) = (u32x2_){l0, l1};
 }
 
 // K_ext / V_ext extension columns <- x (columns 3..15 zero)
@@ -1895,14 +1911,22 @@ DEVI void co_softmax_pv_t(const CoGeo& g, gfloat* sP /* P block of head hg*HGS *
             }
         den = xquad_sum(den);
         const float rden = gi >= 0 ? fast_rcp(den) : 0.f;
-        gfloat* const ps = gi >= 0 ? sP + ((size_t)hh * g.RN + i) * PS + quad : junk;
+        // The stash row of bead i: a lane holds every fourth probability (j = 16 jt + 4 r + quad), so writing them as they lie is 4 MT
+        // dword stores per lane, each instruction scattering 64 dwords over 16 rows (measured: 1.5 - 1.7 k cycles of a head's 9.6 k on
+        // the softmax waves, which are the critical path of the head pipeline).  A 4 x 4 transpose across the four lanes of a row --
+        // v_permlane32_swap, then v_permlane16_swap: four instructions per tile -- leaves lane (i, quad) with j = 16 jt + 4 quad .. + 3:
+        // one 16-byte store per tile, 64 contiguous bytes per row.  (P V_ext below keeps using the untransposed registers.)
+        gfloat* const ps = gi >= 0 ? sP + ((size_t)hh * g.RN + i) * PS + 4 * quad : junk;
 #pragma unroll
-        for (int jt = 0; jt < MT; ++jt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                p[jt][r] *= rden;
-                st_ntg<DFF_SITE_ST(MT, 4)>(gi >= 0 ? ps + 16 * jt + 4 * r : junk, p[jt][r]);
-            }
+        for (int jt = 0; jt < MT; ++jt) {
+            p[jt] *= rden;
+            const auto a02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(p[jt][0]), __float_as_uint(p[jt][2]), false, false);
+            const auto a13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(p[jt][1]), __float_as_uint(p[jt][3]), false, false);
+            const auto c01 = __builtin_amdgcn_permlane16_swap(a02[0], a13[0], false, false);
+            const auto c23 = __builtin_amdgcn_permlane16_swap(a02[1], a13[1], false, false);
+            const f32x4 row4 = {__uint_as_float(c01[0]), __uint_as_float(c01[1]), __uint_as_float(c23[0]), __uint_as_float(c23[1])};
+            st_ntg4<DFF_SITE_ST(MT, 4)>(gi >= 0 ? ps + 16 * jt : junk, row4);
+        }
         // o^T = (P V_ext)^T: first operand = V_ext (k = bead, column n), second = P from the registers
         f32x4 o[5];
 #pragma unroll
@@ -1999,6 +2023,18 @@ DEVI void co_ds(const CoGeo& g) {
                     if (!TIGHT || (i < g.RN && 16 * jt + col < PL)) dl[16 * jt] = 0.125f * (p[jt] * (acc[jt][r] - sm));
             }
         }
+        if constexpr (DQ && QSP && DFF_QT16 && !GEN) {
+            // transposed tiles: this lane holds row 16 it + col, columns 16 nt + 4 quad .. + 3 of dQ_ext
+            f32x4 dq[5];
+            co_mm5<MT, false, 16 * MT + 4, NoStepHook, true>(dq, g.dSbuf + hh * PT, it, g.Rg + g.RN * LQ + hh * 80, LQ, g.RN, g.rows, lane);
+            const int row = 16 * it + col;
+            if (row < g.rows) {
+                lfloat* const d = g.Rg + 4 * g.RN * LQ + row * LQ + hh * 80;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) put_piece16x4((lu32*)d + 8 * nt + 2 * quad, dq[nt], g.qs);
+                *(lf32x4*)(d + 64 + 4 * quad) = dq[4];
+            }
+        } else
         if (DQ) {
             f32x4 dq[5];
             co_mm5<MT, false>(dq, g.dSbuf + hh * PT, it, g.Rg + g.RN * LQ + hh * 80, LQ, g.RN, g.rows, lane);
@@ -2071,6 +2107,22 @@ DEVI void co_dv_dk(const CoGeo& g, SH hook = SH()) {
             const int hh = r0 / MT, mo = r0 - hh * MT;
             const lfloat* T = (which ? g.dSbuf : g.Pbuf) + hh * PT;
             f32x4 acc[5];
+            if constexpr (KVS && VSP && DFF_QT16 && !GEN) {
+                // transposed tiles (see co_ds): row 16 mo + col, columns 16 nt + 4 quad .. + 3; the extension tile's columns 0..2 = quad 0
+                co_mm5<MT, true, 16 * MT + 4, SH, true>(acc, T, mo, g.Rg + (which ? 0 : 3) * g.RN * LQ + hh * 80, LQ, g.RN, g.rows, lane, hook);
+                const int row = 16 * mo + col;
+                if (row < g.rows) {
+                    lu32* const d2 = (lu32*)(g.Rg + (which ? 1 : 2) * g.RN * LQ + row * LQ + hh * 80);
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) put_piece16x4(d2 + 8 * nt + 2 * quad, acc[nt], g.qs);
+                    if (quad == 0) {
+                        g.dxw[row * 4 + 0] += acc[4][0];
+                        g.dxw[row * 4 + 1] += acc[4][1];
+                        g.dxw[row * 4 + 2] += acc[4][2];
+                    }
+                }
+                continue;
+            }
             co_mm5<MT, true>(acc, T, mo, g.Rg + (which ? 0 : 3) * g.RN * LQ + hh * 80, LQ, g.RN, g.rows, lane, hook);
             lfloat* const dst = g.Rg + (which ? 1 : 2) * g.RN * LQ + hh * 80 + col;
             lu16* const hm = (lu16*)(g.Rg + (which ? 1 : 2) * g.RN * LQ + hh * 80) + col;
@@ -2183,14 +2235,26 @@ DEVI void co_dqkv_rows(const CoGeo& g) {
             }
         }
     };
+    // fp16 engine: dQ / dK as transposed tiles (co_mmN<..., SWAP>): this lane holds row 16 mo + col, columns 16 nt + 4 quad .. + 3
+    constexpr bool SW = PSPLIT && WHICH != 0 && DFF_QT16;
+    auto put_t = [&](int nt, const f32x4& acc) {
+        const int row = 16 * mo + col;
+        if (row >= g.rows) return;
+        lfloat* const d = g.Rg + DST * g.RN * LQ + row * LQ;
+        if (nt < 4) put_piece16x4((lu32*)d + 8 * nt + 2 * quad, acc, g.qs);
+        else if (WHICH == 1) *(lf32x4*)(d + 64 + 4 * quad) = acc;
+        else if (quad == 0) { g.dxw[row * 4 + 0] += acc[0]; g.dxw[row * 4 + 1] += acc[1]; g.dxw[row * 4 + 2] += acc[2]; }
+    };
     if (wave < MT) {
         f32x4 c[3];
-        co_mmN<MT, WHICH != 1, 3, PL_>(c, T, mo, g.Rg + SRC * g.RN * LQ, LQ, g.RN, g.rows, lane);
-        put(0, c[0]); put(1, c[1]); put(2, c[2]);
+        co_mmN<MT, WHICH != 1, 3, PL_, NoStepHook, SW>(c, T, mo, g.Rg + SRC * g.RN * LQ, LQ, g.RN, g.rows, lane);
+        if constexpr (SW) { put_t(0, c[0]); put_t(1, c[1]); put_t(2, c[2]); }
+        else { put(0, c[0]); put(1, c[1]); put(2, c[2]); }
     } else {
         f32x4 c[2];
-        co_mmN<MT, WHICH != 1, 2, PL_>(c, T, mo, g.Rg + SRC * g.RN * LQ + 48, LQ, g.RN, g.rows, lane);
-        put(3, c[0]); put(4, c[1]);
+        co_mmN<MT, WHICH != 1, 2, PL_, NoStepHook, SW>(c, T, mo, g.Rg + SRC * g.RN * LQ + 48, LQ, g.RN, g.rows, lane);
+        if constexpr (SW) { put_t(3, c[0]); put_t(4, c[1]); }
+        else { put(3, c[0]); put(4, c[1]); }
     }
 }
 
@@ -2729,7 +2793,7 @@ __global__ __launch_bounds__(DFF_NTHREADS) void dff_fused_kernel(const DffModelD
                 wg_sync<SPILL>();
                 pf.tick(3);
                 l2_wo(lw, hg);
-                if constexpr (GEN || MT == 4)   // MT = 4 (protein G): measured 1.3 % slower transposed (16 probabilities per lane)
+                if constexpr (GEN)   // (MT = 4, protein G, ran the C-layout version until the transposed one's stash stores were vectorised: 377.6 -> 373.1 us at 128 per GPU, 648 -> 634 at 256)
                     co_softmax_pv<MT, HGS, GEN, SPW, PLT>(geo, sPl + (size_t)hg * HGS * RN * c.sl.PS,
                                                      (gfloat*)sb + c.sl.m12 + (size_t)hg * HGS * RN * 4, oxt);
                 else
