@@ -122,23 +122,51 @@ def profile_figures(kname, cfg, P, chunk, lib_sha=None):
 
 # Said ONCE per line (`notes`), not once per entry: the driver keeps only the tail of stdout.
 NOTES = {
-    "dtype": "f32 everywhere.  Weight GEMMs of split_bf16 kernels: exact 3-way bf16 split of every fp32 operand (six "
-             "v_mfma_f32_16x16x32_bf16 per product); split_f16: 2-way fp16 split (2^-22 per operand, three v_mfma_f32_16x16x32_f16, "
-             "gradients row-scaled by powers of two); fp32 accumulate, held to the fp32 reference's own error.  Attention products, "
-             "other kernels: v_mfma_f32_16x16x4_f32 / fp32 VALU",
+    "dtype": "derived from the kernel that ran.  State, activations, accumulators: f32 everywhere.  split_f16: weight GEMMs on a 2-way "
+             "fp16 split of every f32 operand (2^-22 per operand, three v_mfma_f32_16x16x32_f16 per product, gradients row-scaled by powers "
+             "of two); split_bf16: exact 3-way bf16 split (six products); held to the fp32 reference's own error.  "
+             "Attention, other kernels, DFF_SPLIT_BF16=0: v_mfma_f32_16x16x4_f32 / f32 VALU",
     "roofline": "bound = fp32 compute (SURVEY 8d): frac = algorithmic TFLOP/s (factorised FLOP count x proteins x steps / HIP-event "
-                "launch time) / 157.3.  split_peak_frac: vs the split GEMMs' own roof (dense bf16 / 6 = 416.7, fp16 / 3 = 833).  traffic "
-                "(HBM bytes per launch), hbm_tbps, mfma_busy, l2_hit: rocprofv3 PMC passes of the same workload under `profile`; None "
-                "+ profile_stale when that profile's sources (src_sha) are not the running library's",
+                "launch time) / 157.3.  mixed_peak_frac: vs the running engine's own roof (weight-GEMM FLOPs at fp16 / 3 = 833 or bf16 / 6 "
+                "= 416.7 TFLOP/s, the rest at 157.3).  traffic (HBM bytes per launch), hbm_tbps, mfma_busy, l2_hit: rocprofv3 PMC passes of "
+                "the same workload under `profile`; None + profile_stale when that profile's sources (src_sha) are not the running library's",
     "fold_kv": "hidden == head dim: k / v projections folded into q / out (exact); ~26 % fewer MFMAs issued than the FLOP count used",
-    "timing": "persistent launches of `chunk` fused steps; --steps / --warmup rounded up to whole launches, >= 8 timed launches",
+    "timing": "persistent launches of `chunk` fused steps; --steps / --warmup rounded up to whole launches, >= 8 timed",
     "cpu": "oracle/reference_twin.py (torch CPU port of the reference, materialised formulation), thread count picked by a probe",
-    "also": "roofline objects there omit bound / peak / unit (= the headline's: mfma, 157.3, TFLOP/s)",
+    "also": "roofline objects there omit bound / peak / unit (= the headline's)",
 }
 
 
 def kernel_dtype(kname):
+    """The arithmetic the kernel that ran multiplies its weights in (its name says which engine): inputs, outputs, accumulators
+    and everything outside the weight GEMMs are f32 in every variant."""
+    if "split_f16" in kname:
+        return "f32 (weight GEMMs: 2xf16 split, f32 acc)"
+    if "split_bf16" in kname:
+        return "f32 (weight GEMMs: 3xbf16 split, f32 acc)"
     return "f32"
+
+
+SHAPES = {"ala2": (5, 96, 2), "chignolin": (10, 64, 3), "trp_cage": (20, 128, 3), "bba": (28, 96, 3), "villin": (35, 128, 3),
+          "protein_g": (56, 128, 3)}   # (beads, hidden, layers): synth_weights.SHIPPED_CONFIGS
+
+
+def weight_gemm_mflop(cfg):
+    """The share of MFLOP_PER_CALL[cfg] that is weight GEMMs (q, k, v, out projections + FFN, forward and VJP): SURVEY.md 8(d)'s
+    closed form, 2 L lin with lin = 8 N H I + 16 N H^2, I = 512 -- what the split engines run on the fp16 / bf16 pipe."""
+    N, H, L = SHAPES[cfg]
+    return 2.0 * L * (8.0 * N * H * 512 + 16.0 * N * H * H) / 1e6
+
+
+def mixed_peak_frac(cfg, P, steps_per_launch, avg_launch_ms, kname):
+    """Against the running engine's OWN roof: the time one launch would take with its weight-GEMM FLOPs at the split products'
+    rate (dense fp16 / 3 = 833 TFLOP/s, bf16 / 6 = 416.7; the fp32 engine: 157.3) and every other FLOP (attention, gates,
+    heads) at the fp32 rate, over the measured time.  `frac` (all FLOPs at 157.3) stays the headline figure."""
+    g = weight_gemm_mflop(cfg) * 1e6
+    rest = MFLOP_PER_CALL[cfg] * 1e6 - g
+    rate = PEAK_BF16_DENSE_TFLOPS / 3.0 if "split_f16" in kname else PEAK_BF16_DENSE_TFLOPS / 6.0 if "split_bf16" in kname else PEAK_FP32_TFLOPS
+    ideal_s = (g / (rate * 1e12) + rest / (PEAK_FP32_TFLOPS * 1e12)) * P * steps_per_launch
+    return ideal_s / (avg_launch_ms * 1e-3)
 
 
 def roofline(cfg, P, steps_per_launch, launch_ms, kname, brief=False):
@@ -159,10 +187,7 @@ def roofline(cfg, P, steps_per_launch, launch_ms, kname, brief=False):
             del r[k]
     else:
         r["algorithmic_flops_per_launch"] = flops
-    if "split_bf16" in kname:
-        r["split_peak_frac"] = round(ach / (PEAK_BF16_DENSE_TFLOPS / 6.0), 4)
-    elif "split_f16" in kname:
-        r["split_peak_frac"] = round(ach / (PEAK_BF16_DENSE_TFLOPS / 3.0), 4)
+    r["mixed_peak_frac"] = round(mixed_peak_frac(cfg, P, steps_per_launch, avg, kname), 4)
     return r
 
 
@@ -238,14 +263,25 @@ def cpu_baseline_iid(cfg, P, budget_s=8.0, max_steps=20, threads=8):
             "sample": f"{n} reverse steps (t = 998 .. {t}), batch {P}, {cfg}; a sample = 1000 such steps"}
 
 
-def make_model(cfg, dev):
+def make_model(cfg, dev, fp32_engine=False):
+    """fp32_engine: DFF_SPLIT_BF16=0 while the model is created -- every weight GEMM on v_mfma_f32_16x16x4_f32."""
     import synth_weights as synth
     from dff_amd.ddpm import GaussianDiffusion
     from dff_amd.score import GraphTransformer
     _, N, H, L = synth.SHIPPED_CONFIGS[cfg]
-    model = GraphTransformer(N, H, device=dev, n_layers=L, use_intrinsic_coords=True, use_abs_coords=False,
-                             use_distances=False, conservative=True,
-                             state_dict=synth.synth_gnn_params(N, H, L, seed=1234, decoder_scale=1e-2))
+    old = os.environ.get("DFF_SPLIT_BF16")
+    if fp32_engine:
+        os.environ["DFF_SPLIT_BF16"] = "0"
+    try:
+        model = GraphTransformer(N, H, device=dev, n_layers=L, use_intrinsic_coords=True, use_abs_coords=False,
+                                 use_distances=False, conservative=True,
+                                 state_dict=synth.synth_gnn_params(N, H, L, seed=1234, decoder_scale=1e-2))
+    finally:
+        if fp32_engine:
+            if old is None:
+                os.environ.pop("DFF_SPLIT_BF16", None)
+            else:
+                os.environ["DFF_SPLIT_BF16"] = old
     return model, GaussianDiffusion(model, num_atoms=N, timesteps=1000, norm_factor=NORM_STD[cfg], defer_checks=True), (N, H, L)
 
 
@@ -282,10 +318,10 @@ class Timer:
         return elapsed, [a.elapsed_time(b) for a, b in ev]
 
 
-def langevin_entry(cfg, P, chunk, n_warm, n_timed, dev, rank, world, noise_level=20, group=0):
+def langevin_entry(cfg, P, chunk, n_warm, n_timed, dev, rank, world, noise_level=20, group=0, fp32_engine=False):
     """Langevin MD-steps/s of `cfg` at P trajectories per GPU: n_timed launches of `chunk` fused steps each."""
     from dff_amd.langevin import LangevinDiffusion
-    model, diff, (N, H, L) = make_model(cfg, dev)
+    model, diff, (N, H, L) = make_model(cfg, dev, fp32_engine)
     if group:
         model.native.set_group(group)
     x0 = torch.randn(P, N, 3, generator=torch.Generator().manual_seed(2024 + rank))
@@ -393,11 +429,14 @@ def main():
     if not args.no_extras:
         also = {}
         try:    # secondary figures must never cost the headline line
-            for name, c2, P2, ch2, nt in (("villin_langevin", "villin", 256, 250, MIN_LAUNCHES),
-                                          ("protein_g_langevin", "protein_g", 128, 250, MIN_LAUNCHES)):
-                e = langevin_entry(c2, P2, ch2, 1, nt, dev, rank, world)
+            # chignolin_langevin_fp32_engine: the headline workload with every weight GEMM on the fp32 matrix pipe (DFF_SPLIT_BF16=0)
+            for name, c2, P2, ch2, nt, f32e in (("villin_langevin", "villin", 256, 250, MIN_LAUNCHES, False),
+                                                ("protein_g_langevin", "protein_g", 128, 250, MIN_LAUNCHES, False),
+                                                ("chignolin_langevin_fp32_engine", "chignolin", 256, 250, MIN_LAUNCHES, True)):
+                e = langevin_entry(c2, P2, ch2, 1, nt, dev, rank, world, fp32_engine=f32e)
                 also[name] = {
-                    "workload": f"{c2} ({e['N']} beads, H={e['H']}, L={e['L']}) Langevin, {P2}/GPU",
+                    "workload": f"{c2} ({e['N']} beads, H={e['H']}, L={e['L']}) Langevin, {P2}/GPU" + (", DFF_SPLIT_BF16=0" if f32e else ""),
+                    "dtype": kernel_dtype(e["kernel"]),
                     "value": round(world * e["K"] / e["elapsed"], 2), "unit": f"MD-steps/s (batch {P2}, whole job)",
                     "ms_per_step": round(1e3 * e["elapsed"] / e["K"], 5), "steps": e["K"], "finite": e["finite"],
                     "roofline": roofline(c2, P2, ch2, e["launch_ms"], e["kernel"], brief=True)}
@@ -406,7 +445,7 @@ def main():
                                      ("villin_iid", "villin", 256, 4)):
                 e = iid_entry(c2, P2, 1, nt, dev, rank, world)
                 also[name] = {
-                    "workload": f"{c2} iid, batch {P2}/GPU, complete 1000-step reverse chains",
+                    "workload": f"{c2} iid, batch {P2}/GPU, complete 1000-step reverse chains", "dtype": kernel_dtype(e["kernel"]),
                     "value": round(world * P2 * nt / e["elapsed"], 2), "unit": "samples/s (whole job)",
                     "ms_per_reverse_step": round(1e3 * e["elapsed"] / (nt * 1000), 5), "chains_timed": nt,
                     "roofline": roofline(c2, P2, 1000, e["launch_ms"], e["kernel"], brief=True)}

@@ -12,7 +12,7 @@ from dff_amd.score import GraphTransformer  # noqa: E402
 from dff_amd.ddpm import GaussianDiffusion  # noqa: E402
 from dff_amd.langevin import LangevinDiffusion  # noqa: E402
 
-GUARD, STEP_TOL = 2.5, 2e-5
+GUARD, GUARD_FP32, STEP_TOL = 2.0, 2.5, 5e-6   # tests/test_gpu_parity.py: the split engine's bar, the fp32-MFMA engine's, the loops'
 rel = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))  # noqa: E731
 
 
@@ -66,7 +66,7 @@ def _case(case, rng, log):
         r = rel(f[sub], r64ref)
         # (other branches: the tests' 2e-5 at unit coordinates; distance features at |x| ~ 10 sigma are ill-conditioned in float32 --
         # the reference's own float32 run is then 1e-4 from its float64 one -- so the bar follows that distance there)
-        ok = np.isfinite(f).all() and (r <= 1e-5 and r <= GUARD * max(r32, 4e-7) if shipped else r <= max(2e-5, 5.0 * r32))
+        ok = np.isfinite(f).all() and (r <= 1e-5 and r <= (GUARD if "split_" in kn else GUARD_FP32) * max(r32, 4e-7) if shipped else r <= max(2e-5, 5.0 * r32))
         tag.update(kernel=kn, rel=float("%.3g" % r), r32=float("%.3g" % r32))
         if not shipped or not cons:   # (the twin's integrator runs the shipped branch only: tests/test_input_branches.py covers the loops there)
             log(("ok   " if ok else "FAIL ") + json.dumps(tag))

@@ -4,8 +4,11 @@ golden vectors recorded from the reference.  Run with ``-m gpu`` on an MI355X.
 Tolerances (fp32 path): the reference's own float32 run differs from its
 float64 run by ~1.1-1.7e-6 relative (printed by tests/golden/make_golden.py).  The HIP path uses
 a different (factorised) formulation and MFMA k-order, so it is held to
-    ||F_hip - F_ref64|| / ||F_ref64||  <=  GUARD x ||F_ref32 - F_ref64|| / ||F_ref64||     (GUARD = 2.5: "no worse than
-                                           the reference's own float32 run, up to a small factor"; and <= 1e-5 absolutely)
+    ||F_hip - F_ref64|| / ||F_ref64||  <=  GUARD x ||F_ref32 - F_ref64|| / ||F_ref64||     (and <= 1e-5 absolutely)
+GUARD = 2.0 for the split engine -- every shipped architecture's default path (SURVEY 8c's "2x, tighten after measuring";
+measured 0.5-1.7x over 870 random shapes) -- and 2.5 for the fp32-MFMA engine (DFF_SPLIT_BF16=0, the `gen` input branches,
+hidden 256): its k-order inside a 16-block is a fixed permutation of the reference's and it measures up to 2.1x on random
+shapes (profiles/r05/fuzz4.txt), 1.5x on trp-cage.
     max|F_hip - F_ref32|               <=  1e-4 * max|F_ref32|
 single integrator / reverse steps on identical noise to 2e-5 relative (measured ~1e-7), and K-step fused trajectories to
 STEP_TOL x K = 5e-6 K relative (round 3: tightened from 2e-5 K; a 5x regression of the measured error no longer passes).
@@ -51,7 +54,13 @@ def get_model(dff, cfg, decoder_scale=1.0):
     return _models[key]
 
 
-GUARD = 2.5        # rel(hip, ref64) <= GUARD * rel(ref32, ref64)
+GUARD = 2.0        # rel(hip, ref64) <= GUARD * rel(ref32, ref64): the split engine (every shipped architecture's default path)
+GUARD_FP32 = 2.5   # ... the fp32-MFMA engine (DFF_SPLIT_BF16=0, `gen` branches, hidden 256)
+
+
+def guard_for(kname):
+    """The bar that goes with the kernel that ran (its name says which engine multiplied the weights)."""
+    return GUARD if "split_" in kname else GUARD_FP32
 STEP_TOL = 5e-6    # per fused step, relative to the trajectory's largest entry
 
 
@@ -92,7 +101,7 @@ def test_score_vs_reference_golden(dff, cfg, golden):
     r64 = rel(f, g["forces64"])
     r32 = rel(g["forces32"], g["forces64"])
     print(f"{cfg}: rel(hip,ref64)={r64:.3e} rel(ref32,ref64)={r32:.3e} kernel={model.native.last_launch()}")
-    assert r64 <= 1e-5 and r64 <= GUARD * r32
+    assert r64 <= 1e-5 and r64 <= guard_for(model.native.last_launch()[0]) * r32
     assert np.abs(f - g["forces32"]).max() <= 1e-4 * np.abs(g["forces32"]).max()
     np.testing.assert_allclose(e[..., None], g["energy32"], rtol=0, atol=2e-5)
     assert np.abs(f.sum(1)).max() < 2e-6  # mean-free forces
@@ -150,10 +159,11 @@ def test_grouping_and_ragged_batches(dff, cfg, G):
     model.native.set_group(G)
     try:
         f = model.native.score(torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()).cpu().numpy()
+        kname = model.native.last_launch()[0]
         print(cfg, G, model.native.last_launch(), rel(f, ref64), rel(ref32, ref64))
     finally:
         model.native.set_group(0)
-    assert rel(f, ref64) <= min(1e-5, GUARD * rel(ref32, ref64))
+    assert rel(f, ref64) <= min(1e-5, guard_for(kname) * rel(ref32, ref64))
 
 
 @pytest.mark.parametrize("cfg", ["ala2", "chignolin"])
@@ -614,7 +624,7 @@ def test_fp16_engine_over_gradient_magnitudes(dff, cfg, dec, xs, monkeypatch):
     print(f"{cfg} {kname}: decoder x{dec:g}, x x{xs:g}: rel(fp16 engine, f64)={out[True]:.3e} rel(fp32 engine, f64)={out[False]:.3e} "
           f"rel(ref32, ref64)={r32:.3e} |F|max={np.abs(f64).max():.3e}")
     assert out[True] <= 5e-6 and out[True] <= GUARD * max(r32, 4e-7)
-    assert out[False] <= 5e-6 and out[False] <= GUARD * max(r32, 4e-7)
+    assert out[False] <= 5e-6 and out[False] <= GUARD_FP32 * max(r32, 4e-7)
 
 
 @pytest.mark.gpu
@@ -637,7 +647,7 @@ def test_fp16_engine_steps_aside_for_models_out_of_its_range(dff, cfg):
     kname = model.native.last_launch()[0]
     assert "split_" not in kname, kname
     ref32, ref64 = twin_refs(params, x, t, L)
-    assert np.isfinite(f).all() and rel(f, ref64) <= max(1e-5, GUARD * rel(ref32, ref64)), (rel(f, ref64), rel(ref32, ref64))
+    assert np.isfinite(f).all() and rel(f, ref64) <= max(1e-5, GUARD_FP32 * rel(ref32, ref64)), (rel(f, ref64), rel(ref32, ref64))
 
 
 @pytest.mark.gpu
@@ -667,7 +677,7 @@ def test_split_bf16_weight_gemms_are_fp32_exact(dff, cfg, golden, monkeypatch):
         f, e = f.cpu().numpy(), e.cpu().numpy()
         r64, r32 = rel(f, g["forces64"]), rel(g["forces32"], g["forces64"])
         print(f"{cfg}: split={split} rel(hip,ref64)={r64:.3e} rel(ref32,ref64)={r32:.3e}")
-        assert r64 <= 1e-5 and r64 <= 2.5 * r32
+        assert r64 <= 1e-5 and r64 <= (GUARD if split else GUARD_FP32) * r32
         assert np.abs(f - g["forces32"]).max() <= 1e-4 * np.abs(g["forces32"]).max()
         np.testing.assert_allclose(e[..., None], g["energy32"], rtol=0, atol=2e-5)
     # 20 fused Langevin steps on supplied noise: split variant vs fp32-MFMA variant
@@ -714,7 +724,7 @@ def test_kv_fold_matches_the_unfolded_network(dff, golden, monkeypatch):
             assert ("fold_kv" in name) == (fold and path == "small8"), (fold, path, name)
             r64 = rel(f.cpu().numpy(), g["forces64"])
             print(f"fold={fold} {path}: {name} rel(hip,ref64)={r64:.3e} rel(ref32,ref64)={r32:.3e}")
-            assert r64 <= 1e-5 and r64 <= 2.5 * r32
+            assert r64 <= 1e-5 and r64 <= guard_for(name) * r32
             np.testing.assert_allclose(e.cpu().numpy()[..., None], g["energy32"], rtol=0, atol=2e-5)
         model.native.force_generic(False)
         model.native.small_waves(0)
@@ -971,7 +981,7 @@ def test_four_row_tiles_at_odd_bead_counts(dff, N, monkeypatch):
                 assert ("split_" in kname) == (split and N <= 56), (N, kname)      # 57+ rows: the split A operand does not fit
                 r64 = rel(f, ref64)
                 print(f"N={N} {kname}: rel(hip,ref64)={r64:.3e} rel(ref32,ref64)={r32:.3e}")
-                assert r64 <= 1e-5 and r64 <= GUARD * r32, (N, kname, r64, r32)
+                assert r64 <= 1e-5 and r64 <= guard_for(kname) * r32, (N, kname, r64, r32)
                 assert model.native.status() == 0
         finally:
             model.native.pair(True)
@@ -1008,7 +1018,7 @@ def test_two_and_three_row_tiles_at_odd_bead_counts(dff, H, N, monkeypatch):
                 seen.add(kname)
                 r64 = rel(f, ref64)
                 print(f"H={H} N={N} {kname}: rel(hip,ref64)={r64:.3e} rel(ref32,ref64)={r32:.3e}")
-                assert r64 <= 1e-5 and r64 <= GUARD * r32, (N, kname, r64, r32)
+                assert r64 <= 1e-5 and r64 <= guard_for(kname) * r32, (N, kname, r64, r32)
                 assert model.native.status() == 0
         finally:
             model.native.pair(True)
@@ -1045,7 +1055,7 @@ def test_small_models_at_odd_sizes(dff, H, N, G, monkeypatch):
         assert ("small" in kname) == (H != 256 and G * N <= 16 and not (H in (96, 128) and split)), kname
         r64 = rel(f, ref64)
         print(f"H={H} N={N} G={G} {kname}: rel(hip,ref64)={r64:.3e} rel(ref32,ref64)={r32:.3e}")
-        assert r64 <= 1e-5 and r64 <= GUARD * max(r32, 4e-7), (H, N, G, kname, r64, r32)
+        assert r64 <= 1e-5 and r64 <= guard_for(kname) * max(r32, 4e-7), (H, N, G, kname, r64, r32)
 
 
 @pytest.mark.gpu
@@ -1196,7 +1206,7 @@ def test_pairs_of_groups_for_proteins_that_share_a_row_tile(dff):
             f1 = model.native.score(xd, td).cpu().numpy()
             assert "pair" not in model.native.last_launch()[0]
             print(f"ala2 B={B}: {name} grid {g_}: rel(hip,ref64)={r64:.3e} rel(ref32,ref64)={r32:.3e} rel(pair, one workgroup)={rel(f, f1):.3e}")
-            assert r64 <= 1e-5 and r64 <= GUARD * max(r32, 4e-7)
+            assert r64 <= 1e-5 and r64 <= guard_for(name) * max(r32, 4e-7)
             assert rel(f, f1) <= 5e-6
         # the fused loop: 6 steps, 256 trajectories (groups of two), against the twin on the first and last three
         model.native.pair(True)
@@ -1245,7 +1255,7 @@ def test_pair_variant_equals_one_workgroup_variant(dff, cfg, golden):
             assert model.native.pair_status() == 0
             r64, r32 = rel(f, g["forces64"]), rel(g["forces32"], g["forces64"])
             print(f"{cfg}: pair={on} rel(hip,ref64)={r64:.3e} rel(ref32,ref64)={r32:.3e}")
-            assert r64 <= 1e-5 and r64 <= GUARD * r32
+            assert r64 <= 1e-5 and r64 <= guard_for(model.native.last_launch()[0]) * r32
             out[on] = f
         assert rel(out[True], out[False]) <= 5e-6
         assert np.array_equal(out[True], out[2])     # same sums in the same order, whichever way the tiles travel

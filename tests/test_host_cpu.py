@@ -202,7 +202,15 @@ def test_bench_finds_the_profiled_traffic_for_the_shipped_kernels():
     assert t3 is not None and t3 < 0.1 * t2
     r = bench.roofline("chignolin", 256, 250, [20.8, 20.9], "dff_small_kernel<64,8,split_bf16>")
     assert abs(r["frac"] - 1.408e12 / 20.85e-3 / 157.3e12) < 1e-3 and r["traffic"] == t2
-    assert abs(r["split_peak_frac"] - r["achieved"] / (2500.0 / 6)) < 1e-3
+    # the engine's own roof: weight-GEMM FLOPs (2 L (8 N H I + 16 N H^2) = 19.66 of chignolin's 22.00
+    # MFLOP) at the split products' rate, the rest at the fp32 rate, over the measured time
+    assert abs(bench.weight_gemm_mflop("chignolin") - 2 * 3 * (8 * 10 * 64 * 512 + 16 * 10 * 64 * 64) / 1e6) < 1e-9
+    ideal = lambda rate: (19.6608e6 / rate + (22.00e6 - 19.6608e6) / 157.3e12) * 256 * 250   # noqa: E731
+    assert abs(r["mixed_peak_frac"] - ideal(2500e12 / 6) / 20.85e-3) < 2e-4
+    r16 = bench.roofline("chignolin", 256, 250, [11.54] * 8, "dff_small_kernel<64,8,split_f16,fold_kv>")
+    assert abs(r16["mixed_peak_frac"] - ideal(2500e12 / 3) / 11.54e-3) < 2e-4 and 0.20 < r16["mixed_peak_frac"] < 0.23
+    r32 = bench.roofline("chignolin", 256, 250, [20.0] * 8, "dff_small_kernel<64,8>")
+    assert abs(r32["mixed_peak_frac"] - r32["frac"]) < 2e-4          # the fp32 engine: one roof
     # round 4: the rocprof-reported MFMA utilisation and HBM rate ride in the roofline object (north_star), read from the
     # same profile directory as the traffic
     h = bench.roofline("chignolin", 256, 250, [13.3] * 8, "dff_small_kernel<64,8,split_bf16,fold_kv>")
@@ -213,10 +221,13 @@ def test_bench_finds_the_profiled_traffic_for_the_shipped_kernels():
     # ... and the line must fit the driver's stdout tail: every `also` entry <= 700 bytes, what they share said once
     import json
     entry = {"workload": "villin (35 beads, H=128, L=3) Langevin, 256/GPU", "value": 1897.33, "unit": "MD-steps/s (batch 256, whole job)",
-             "ms_per_step": 0.52712, "steps": 2000, "finite": True, "roofline": v,
+             "dtype": bench.kernel_dtype("dff_fused_kernel<128,3,1,false,split_f16>"), "ms_per_step": 0.52712, "steps": 2000, "finite": True, "roofline": v,
              "cpu_baseline": {"value": 0.3312, "cores": 16, "kind": "port", "sample": "3 Langevin steps, same workload (P=256, villin), 16 of 256 logical cores"}}
     assert len(json.dumps(entry)) <= 700 and len(json.dumps(bench.NOTES)) <= 1400
-    assert bench.kernel_dtype("dff_small_kernel<64,8,split_bf16>") == "f32" and "3-way bf16 split" in bench.NOTES["dtype"]
+    # `dtype` says which engine multiplied the weights (derived from the kernel name)
+    assert bench.kernel_dtype("dff_small_kernel<64,8>") == "f32" and "3-way bf16 split" in bench.NOTES["dtype"]
+    assert "2xf16" in bench.kernel_dtype("dff_small_kernel<64,8,split_f16,fold_kv>") and bench.kernel_dtype("x<split_f16>").startswith("f32")
+    assert "3xbf16" in bench.kernel_dtype("dff_fused_kernel<128,3,1,false,split_bf16>")
     # algorithmic FLOPs per launch of the headline config: 22.00 MFLOP x 256 x 250
     assert abs(bench.MFLOP_PER_CALL["chignolin"] * 1e6 * 256 * 250 - 1.408e12) < 1e6
 

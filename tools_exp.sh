@@ -15,7 +15,10 @@ if [ "$cmd" = build ]; then
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-result -DDFF_FAST_BUILD -DDFF_SMALL_MODE=$md ${DFF_SMALL_SCHED--mllvm -amdgpu-sched-strategy=max-ilp -mllvm -amdgpu-use-amdgpu-trackers} $flags -c $SRC/dff_small.hip -o $d/dff_small_m$md.o
     objs=""
     for k in 0 1 2; do if [ $k = $md ]; then objs="$objs $d/dff_small_m$k.o"; else objs="$objs build/obj/dff_small_m$k.o"; fi; done
-    hipcc --offload-arch=gfx950 -shared -fPIC build/obj/dff_kernels.o $objs build/obj/dff_host.o -o $d/libdff_amd.so
+    host=build/obj/dff_host.o
+    case "$flags" in *DFF_PROF=1*)   # the host half refuses dff_debug_profile unless it was built with the stage ticks too
+        hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-result -DDFF_PROF=1 -c $SRC/dff_host.hip -o $d/dff_host.o; host=$d/dff_host.o;; esac
+    hipcc --offload-arch=gfx950 -shared -fPIC build/obj/dff_kernels.o $objs $host -o $d/libdff_amd.so
     echo "$flags" > $d/flags
     echo "built $d ($flags)"
 elif [ "$cmd" = buildk ]; then   # the <= 64-row kernel TU instead (e.g. flags: -DDFF_FAST_BUILD -DDFF_ONLY="VAR_SPW(128,3,1)")

@@ -1242,6 +1242,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     constexpr int KS = F16E ? -1 : 0;        // kind of the host-split images
     constexpr int KQ = F16E ? -1 : DFF_KQ ? 1 : 0, KO = F16E ? -1 : DFF_KO ? DFF_HEADS * 5 : 0, KT = F16E ? -1 : DFF_KT ? DFF_HEADS * 13 : 0;
     constexpr int UST = F16E ? 128 : 192;    // 16-byte slots per unit of a host-split image
+    constexpr bool EARLY = SPW && KQ == KS && KO == KS;   // a block's tail refills can fetch either first stream of a step (one unit format)
     auto ss_qkv = [&](const DffLayerDev& lw, int h) { return KQ > 0 ? SStream{(const gu32x4*)lw.Wqkvx_p + (size_t)h * 13 * E * 64} : sstream(lw.Wqkvx_w, h * U_QKV, UST); };
     auto ss_wox = [&](const DffLayerDev& lw, int h) { return KO > 0 ? SStream{(const gu32x4*)lw.Wox_p + (size_t)h * 5 * 64} : sstream(lw.Wox_t, h * 2 * E, UST); };
     auto ss_w1 = [&](const DffLayerDev& lw) { return sstream(lw.W1_w, wave * NTS * KB32, UST); };
@@ -1366,6 +1367,13 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             } else sring_prefetch<SDR, KQ, E>(sring, ss_qkv(m.layer[0], wave), lane);
         }
     };
+    // this (bead, component) thread's mass and noise amplitude, once per launch: indexed per lane they are global loads from the
+    // kernel-argument segment, whose latency the update stage of every step used to wait out in front of the whole workgroup
+    float mass_i = 1.0f, nsig_i = 0.0f;
+    if (MODE == DFF_MODE_LANGEVIN && tid < rows * 4) {
+        const int i_ = (tid >> 2) % N;
+        mass_i = a.mass[i_]; nsig_i = a.noise_sigma[i_];
+    }
     for (int step = 0; step < a.n_steps; ++step) {
         int t_int = 0;
         if (MODE == DFF_MODE_DDPM) {
@@ -1381,6 +1389,12 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                                       : (const gfloat*)stash;
         const bool full0 = GEN && m.in_abs;   // absolute coordinates: layer 0 depends on x (no caching, VJP through layer 0)
         const bool cached0 = !full0 && (tab || ((MODE == DFF_MODE_LANGEVIN) && step > 0));
+        // the step after this one: is there one, does its layer 0 come from the table / the stash, and from which entry
+        const bool nxt = step + 1 < a.n_steps;
+        const bool c0n = !full0 && (tab || MODE == DFF_MODE_LANGEVIN);
+        const gfloat* const l0n = tab ? (const gfloat*)a.l0_tab + (size_t)(MODE == DFF_MODE_DDPM ? a.t_start - step - 1 : 0) * sl.layer_stride
+                                      : (const gfloat*)stash;
+        bool early_done = false;   // the backward sweep requested the next step's first weights / head rows (EARLY)
         // First weights of the first block, and layer 0's q_ext | k | v rows of this head (shared table entry) by LDS-DMA
         // (measured: 86.8 vs 87.3 us / step with a register fetch inside the attention block).  SPW: step 0 only -- every
         // later step's were requested in the shadow of the update stage of the step before it (step_prefetch).
@@ -1418,7 +1432,11 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             const gfloat* const sbq = l == 0 ? l0e : (const gfloat*)sb;   // where this layer's nodes_in / q|k|v are read from
             const bool cached = cached0 && l == 0;
             // ---- row stage A (layer 0 only; later layers get LN1 fused into stage C) ----
-            if (l == 0) {
+            // KEEPROWS at a fixed noise level (Langevin), steps after the first: the stage would only copy layer 0's kept node
+            // inputs to resbuf (its LayerNorm rows are still in `nx`: stage E of layer 0 put them back for its backward attention
+            // block, and nothing wrote there since) -- stage E of the step before did that too (`skipA` below): no stage, no barrier
+            const bool skipA = KEEPROWS && MODE == DFF_MODE_LANGEVIN && step > 0 && cached0 && m.conservative;
+            if (l == 0 && !skipA) {
                 DFF_ROW_CONSTS
                 // KEEPROWS: layer 0's node inputs and LayerNorm rows are kept in this thread's registers for the backward stages;
                 // with a fixed noise level (Langevin) they do not change from step to step: read / computed on step 0 only
@@ -1696,6 +1714,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 if (l + 1 < m.L) { ro_load(4, m.layer[l + 1].ln1_g, sub); ro_load(5, m.layer[l + 1].ln1_b, sub); }
             } }
             if constexpr (DFF_XI_STAGE == 1) { if (l == 0) draw_xi(t_int, step); }
+            else { if (l == 0 && skipA) draw_xi(t_int, step); }   // (no stage A to draw under)
             __syncthreads();
             pf.tick(3); DFF_MARK(3); phase_prio<3>(wave);
             // ---- FFN: wave w owns hidden columns [w H, (w+1) H) ----
@@ -2035,7 +2054,10 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 for (int i = 0; i < HC; ++i) {
                     const int cl = sub + LPR * i;
                     dav[i] = d1[i] * g1 + dz * (ro[3][i] + ro[5][i]);
-                    resbuf[rrow * LH + cl] = d1[i] * (1.0f - g1) + dz * (ro[4][i] - ro[5][i]);
+                    // (layer 0 of a cached-layer-0 model: nobody reads d(nodes_0); KEEPROWS Langevin leaves the NEXT step's residual
+                    // stream there instead -- layer 0's node inputs -- so that step starts without a row stage A)
+                    if (KEEPROWS && MODE == DFF_MODE_LANGEVIN && l == 0 && !full0) resbuf[rrow * LH + cl] = ni[i];
+                    else resbuf[rrow * LH + cl] = d1[i] * (1.0f - g1) + dz * (ro[4][i] - ro[5][i]);
                 }
                 a_store_row(rrow, sub, dav, invE, true);   // (scale and inverse -> rsc: the attention backward block's waves)
                 (void)invE;
@@ -2059,7 +2081,10 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 }
                 // stage F operands: nodes_in stays in ro[1]; LN1 gamma -> ro[2]  (KEEPROWS: + gate-2 weights of layer l - 1 for its stage D)
                 if (l > 0 || full0) ro_load(2, lw.ln1_g, sub);
-                if constexpr (KEEPROWS) { if (l > 0) ro_load3(6, m.layer[l - 1].g2, sub); }
+                if constexpr (KEEPROWS) {
+                    if (l > 0) ro_load3(6, m.layer[l - 1].g2, sub);
+                    else if (MODE == DFF_MODE_LANGEVIN && !full0) pre_B(lw, sub);   // stage B operands of the next step's layer 0 (no stage A there)
+                }
             } }
             __syncthreads();
             pf.tick(8); DFF_MARK(8); phase_prio<8>(wave);
@@ -2080,7 +2105,13 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 // what follows: FFN backward of layer l - 1 (W2^T, W1^T); after layer 0 the next step re-stages its own first units
                 const DffLayerDev& lwp = m.layer[l > 0 ? l - 1 : 0];
                 const SSeq<U_GX, U_QKVT, MW, KS, KT, KS, KS, E, 4 * KB32> sqa{ss_woxt(lw, wave), ss_qkvt(lw, wave), ss_w2t(lwp), ss_w1t(lwp)};   // tile 4 of 5: [r | g_D]
-                const SSeq<U_GX, 0, MW, KS, KS, KS, KS, E, 4 * KB32> sqa0{ss_woxt(lw, wave), ss_woxt(lw, wave), ss_w2t(lwp), ss_w1t(lwp)};
+                // ... and after layer 0 (x-independent inputs: no back-projection) the NEXT STEP's first units -- [W_o;W_oc] of layer 0
+                // when its q' comes from the table / the stash, QKV_ext otherwise -- requested by the G_ext GEMM's last refills,
+                // a whole update stage before the step that needs them begins (they used to be requested at the END of the update
+                // stage: with no row stage A in front of it -- Langevin, `skipA` -- the first attention block then opened with
+                // an exposed L2 round trip)
+                const SStream nx0 = EARLY ? (c0n ? ss_wox(m.layer[0], wave) : ss_qkv(m.layer[0], wave)) : ss_w2t(lwp);
+                const SSeq<U_GX, 0, EARLY ? SDR : MW, KS, KS, KS, KS, E, 4 * KB32> sqa0{ss_woxt(lw, wave), ss_woxt(lw, wave), nx0, EARLY ? nx0 : ss_w1t(lwp)};
                 u32x4 dah[KB32], dam[KB32], dal[KB32];   // SPW: dattn as bf16 pieces
                 if constexpr (SPW) a_load(dah, dam, dal, lane);
                 // this lane's share of the head's dE/dx terms (extension tiles of G_ext, dV_ext, dK_ext: rows quad * 4 + r,
@@ -2294,8 +2325,21 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     gfix();
                     ds_math();
                     dx_only();
+                    if constexpr (EARLY) {
+                        // the ring holds the next step's first units; its layer-0 q' rows follow by LDS-DMA into this wave's own
+                        // (now dead) Q region
+                        early_done = true;
+                        if constexpr (HDMA) {
+                            if (nxt && c0n) head_dma<LL::DMA_N>(dmatab, Qx, l0n + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, lane);
+                        }
+                    }
                 }
-                {
+                if (!GEN && l == m.L - 1) {
+                    // the first layer of the backward sweep STORES (the GEN variants also add to dxw from inside the block: they
+                    // start from the zeros the update stage leaves)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dxw[dxi[r]] = dxr[r];
+                } else {
                     float t4[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) t4[r] = dxw[dxi[r]];
@@ -2371,8 +2415,13 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             if (a.noise) xib[tq] = a.noise[(((size_t)step * a.B + item) * N + i) * 3 + cc];
             else xib[tq] = philox_normal(a.seed, a.item_offset + item, MODE == DFF_MODE_DDPM ? (uint64_t)t_int : a.step_offset + step, i, cc);
         }
-        __syncthreads();
-        { const int ln = lane_id(); dxw[ln] = 0.f; dxw[64 + ln] = 0.f; }   // (this wave's dx partials of the NEXT step start from zero)
+        // Everything the update reads was written by wave 0 itself just above (dxs, supplied noise: LDS operations of one wave
+        // complete in order) or before the barrier that ended the backward sweep (the waves' partials, the pre-drawn normals): no
+        // workgroup barrier here.  The GEN variants zero their partials for the next step, which must wait for wave 0's reads.
+        if constexpr (GEN) {
+            __syncthreads();
+            { const int ln = lane_id(); dxw[ln] = 0.f; dxw[64 + ln] = 0.f; }   // (this wave's dx partials of the NEXT step start from zero)
+        } else __builtin_amdgcn_wave_barrier();
         if constexpr (GEN) {
             if (full0 && m.conservative) {   // absolute coordinates: dE/dx_i += d(nodes_0)_i . W_node[:, x columns]
                 DFF_ROW_CONSTS
@@ -2413,9 +2462,9 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 if (a.overdamped) {
                     xn = x + f * a.dtau + a.brown_sigma * xi;
                 } else {
-                    vn = vst[tq] + (a.dt * f) / a.mass[i];
+                    vn = vst[tq] + (a.dt * f) / mass_i;
                     xn = x + (vn * a.dt) / 2.0f;
-                    const float nz = a.noise_sigma[i] * xi;
+                    const float nz = nsig_i * xi;
                     vn = vn * a.vscale;
                     vn = vn + a.noisescale * nz;
                     xn = xn + (vn * a.dt) / 2.0f;
@@ -2489,13 +2538,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         // wait for wave 0's integrator update (wave 0 requests its own once it is through); the ring and the Q region are
         // dead since the last attention block.
         if constexpr (SPW) {
-            if (step + 1 < a.n_steps) {
-                const bool tab_ = a.l0_tab != nullptr;
-                const bool c0n = !(GEN && m.in_abs) && (tab_ || MODE == DFF_MODE_LANGEVIN);
-                const gfloat* const l0n = tab_ ? (const gfloat*)a.l0_tab + (size_t)(MODE == DFF_MODE_DDPM ? a.t_start - step - 1 : 0) * sl.layer_stride
-                                               : (const gfloat*)stash;
-                step_prefetch(c0n, l0n);
-            }
+            if (nxt && !early_done) step_prefetch(c0n, l0n);   // (models whose layer 0 has a VJP, force-head models: the backward sweep did not)
         }
         __syncthreads();
         }
