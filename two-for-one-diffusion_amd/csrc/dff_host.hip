@@ -375,13 +375,14 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
             };
             double worst = 0;
             for (int l = 0; l < L; ++l) {
-                skip((size_t)I * H); skip(I);
+                const float* Wq = skip((size_t)I * H); const float* bq = skip(I);
                 const float* Wkv = skip((size_t)2 * I * H); const float* bkv = skip(2 * I);
-                skip((size_t)I * H); skip(I); skip((size_t)H * I); skip(H);
+                const float* Wek = skip((size_t)I * H); skip(I);
+                const float* Wo = skip((size_t)H * I); skip(H);
                 const float* ln1g = skip(H); const float* ln1b = skip(H);
                 skip(3 * H);
                 const float* W1 = skip((size_t)F * H); const float* b1 = skip(F);
-                skip((size_t)H * F); skip(H);
+                const float* W2 = skip((size_t)H * F); skip(H);
                 const float* ln2g = skip(H); const float* ln2b = skip(H);
                 skip(3 * H);
                 const double m1 = sqrt((double)H) * amax(ln1g, H) + amax(ln1b, H);
@@ -389,6 +390,32 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
                 const double vb = rowl1(Wkv + (size_t)I * H, I, H) * m1 + amax(bkv + I, I);   // |v| (and their attention averages)
                 const double hb = rowl1(W1, F, H) * m2 + amax(b1, F);                            // |h_pre| >= |GELU(h_pre)|
                 worst = std::max(std::max(worst, m1), std::max(std::max(m2, vb), hb));
+                // the weights themselves become fp16 pieces too (f32_to_f16_rn maps |w| >= 65520 to infinity)
+                worst = std::max(worst, std::max(std::max(amax(Wq, (size_t)I * H), amax(Wkv, (size_t)2 * I * H)),
+                                                 std::max(std::max(amax(Wek, (size_t)I * H), amax(Wo, (size_t)H * I)),
+                                                          std::max(amax(W1, (size_t)F * H), amax(W2, (size_t)H * F)))));
+                if (H == DFF_DH && L <= 3) {
+                    // the k / v fold's kernel (round 6) splits two more activations as they are: q' = W_k,h^T (W_q,h n + b_q,h), an operand
+                    // of the logits -- |q'| <= (L1 norm of a row of W_k,h^T W_q,h) max|n| + |W_k,h^T b_q,h| -- and the rows of
+                    // G = dattn (W_o,h W_v,h), an operand of dA, whose input rows arrive scaled to a maximum below 32
+                    double qb = 0, gb = 0;
+                    for (int h = 0; h < DFF_HEADS; ++h)
+                        for (int e = 0; e < DFF_DH; ++e) {
+                            double l1 = 0, cqv = 0, g1 = 0;
+                            for (int c = 0; c < H; ++c) {
+                                double sq = 0, so = 0;
+                                for (int dd = 0; dd < DFF_DH; ++dd) {
+                                    sq += (double)Wkv[(size_t)(h * 64 + dd) * H + e] * Wq[(size_t)(h * 64 + dd) * H + c];
+                                    so += (double)Wo[(size_t)c * I + h * 64 + dd] * Wkv[(size_t)(I + h * 64 + dd) * H + e];
+                                }
+                                l1 += fabs(sq); g1 += fabs(so);
+                            }
+                            for (int dd = 0; dd < DFF_DH; ++dd) cqv += (double)Wkv[(size_t)(h * 64 + dd) * H + e] * bq[h * 64 + dd];
+                            qb = std::max(qb, l1 * m1 + fabs(cqv));
+                            gb = std::max(gb, 32.0 * g1);
+                        }
+                    worst = std::max(worst, std::max(qb, gb));
+                }
             }
             if (!(worst < 1.6e4)) {
                 fprintf(stderr, "dff: forward activations of this model may reach %.3g (> 1.6e4): the fp16 split engine is off, weight GEMMs run on the fp32 matrix pipe\n", worst);

@@ -103,7 +103,12 @@ struct SmallLds {
                               asp = resbuf + (FOLD ? RLA : 16) * LH, asp_size = (NW == 8 && H == 64) ? 3 * (H / 32) * 256 : 0,   // (only H = 64 has SPW variants)
                               // source-offset table of the LDS-DMA head fetch (head_dma): DMA_N instructions x 64 lanes
                               dmatab = asp + asp_size, dmatab_size = (NW == 8 && H == 64) ? DMA_N * 64 : 0,
-                              nx = dmatab + dmatab_size, nx_size = FOLD ? RS : 0,
+                              // FOLD: the fp16 pieces of the LayerNorm rows `nx` holds in fp32 ([h | l'], the layout of `asp`): the A operand
+                              // of the QKV' GEMM and an operand of the logits (forward) and of dA (backward) -- kept apart from `asp`,
+                              // which the other row stages overwrite before the backward attention block of the layer comes round
+                              nsp = dmatab + dmatab_size, nsp_size = FOLD ? 2 * (H / 32) * 256 : 0,
+                              // (nx stays in front of the wave regions: operand reads of its rows 11..15 land in wave 0's Q region, fp32 data)
+                              nx = nsp + nsp_size, nx_size = FOLD ? RS : 0,
                               wreg = nx + nx_size, total = wreg + NW * WREG + 64;
     static_assert(!FOLD || total * 4 <= 160 * 1024, "LDS budget");
 };
@@ -546,6 +551,93 @@ DEVI void stall_run(SRing<DR>& ring, f32x4 (&acc)[E], const FA fa, const Q& q, i
     }
 }
 
+// ---- register-chained forms (fp16 engine, FOLD kernel: round 6).  Swapping the two operands of an MFMA transposes its output tile:
+// mfma(W, a) leaves lane (row = lane & 15, quad) with output columns 16 t + 4 quad .. + 3 of THAT row -- and two such tiles (2 kb,
+// 2 kb + 1) are exactly the eight elements of the row's A fragment for 32-column block kb in the k-permutation every image of this
+// engine uses (element j <-> column 32 kb + 16 (j >> 2) + 4 quad + (j & 3)).  So a GEMM whose output is the next product's operand
+// hands it over in registers: no LDS store / barrier-free LDS load / wait between the two.
+// swideT: the wide GEMM (K = H = 32 KB32) in that orientation; out[t] = tile t + bias (bp[16 t + 4 quad ..], 16-byte aligned).
+template <int I0, int T, int N, int KB32, bool BIAS = true, int DR, class Q>
+DEVI void swideT_from(SRing<DR>& ring, f32x4 (&out)[N], f32x4 (&bq)[2], const gfloat* bp, const u32x4 (&ah)[KB32], const u32x4 (&al)[KB32],
+                      const Q& q, int lane) {
+    if constexpr (T < N) {
+        static_assert(Q::kind(I0 + T * KB32) < 0 && KB32 == 2, "fp16 units, H = 64");
+        f32x4 cs = {0.f, 0.f, 0.f, 0.f}, cb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KB32; ++kb) {
+            const u32x4 (&u)[3] = ring.b[(I0 + T * KB32 + kb) % DR];
+            cs = mfma_f16(u[0], al[kb], cs);
+            cs = mfma_f16(u[1], ah[kb], cs);
+            cb = mfma_f16(u[0], ah[kb], cb);
+        }
+        seq_refill<DR, I0 + T * KB32 + 0>(ring, q, lane);
+        seq_refill<DR, I0 + T * KB32 + 1>(ring, q, lane);
+        if constexpr (BIAS) {
+            const f32x4 b = bq[T % 2];
+            if constexpr (T + 2 < N) bq[T % 2] = *(const gf32x4*)(bp + 16 * (T + 2));
+            out[T] = cb + cs * DFF_F16_LINV + b;
+        } else out[T] = cb + cs * DFF_F16_LINV;
+        swideT_from<I0, T + 1, N, KB32, BIAS>(ring, out, bq, bp, ah, al, q, lane);
+    }
+}
+// stallR: the tall GEMM (Nout = H) whose A operand arrives as such register tiles: xr[2 kb], xr[2 kb + 1] = block kb.  EXT: one fp32
+// k-step on top (element *ext_a, weights ext_w[nt ext_ts]), requested first, used last -- as stall_run.
+template <int I0, int KB, int NKB, int E, int DR, class Q>
+DEVI void stallR_from(SRing<DR>& ring, f32x4 (&acc)[E], f32x4 (&acc2)[E], const f32x4 (&xr)[2 * NKB], const Q& q, int lane, float sa) {
+    if constexpr (KB < NKB) {
+        static_assert(Q::kind(I0 + KB * E) < 0 && E == 4, "fp16 units, H = 64");
+        u32x4 ah, al;
+        split8h(xr[2 * KB] * sa, xr[2 * KB + 1] * sa, ah, al);
+#pragma unroll
+        for (int nt = 0; nt < E; ++nt) acc2[nt] = mfma_f16(al, ring.b[(I0 + KB * E + nt) % DR][0], acc2[nt]);
+#pragma unroll
+        for (int nt = 0; nt < E; ++nt) acc2[nt] = mfma_f16(ah, ring.b[(I0 + KB * E + nt) % DR][1], acc2[nt]);
+#pragma unroll
+        for (int nt = 0; nt < E; ++nt) acc[nt] = mfma_f16(ah, ring.b[(I0 + KB * E + nt) % DR][0], acc[nt]);
+        seq_refill<DR, I0 + KB * E + 0>(ring, q, lane);
+        seq_refill<DR, I0 + KB * E + 1>(ring, q, lane);
+        seq_refill<DR, I0 + KB * E + 2>(ring, q, lane);
+        seq_refill<DR, I0 + KB * E + 3>(ring, q, lane);
+        stallR_from<I0, KB + 1, NKB, E>(ring, acc, acc2, xr, q, lane, sa);
+    }
+}
+// rsc (backward): the A rows -- row lane & 15 in the register tiles -- are multiplied by rsc[row] (a power of two) before they are
+// split; `acc`, which may hold true-unit terms already, enters and leaves in true units (rows 4 quad + r of the C layout: as stall_run)
+template <int I0, int NKB, int E, bool EXT, int DR, class Q>
+DEVI void stallR_run(SRing<DR>& ring, f32x4 (&acc)[E], const f32x4 (&xr)[2 * NKB], const Q& q, int lane,
+                     const lfloat* ext_a = nullptr, const gfloat* ext_w = nullptr, int ext_ts = 0, const lfloat* rsc = nullptr) {
+    float bx[E];
+    if constexpr (EXT) {
+#pragma unroll
+        for (int nt = 0; nt < E; ++nt) bx[nt] = ext_w[(size_t)nt * ext_ts];
+    }
+    float sa = 1.0f;
+    f32x4 si4 = {1.f, 1.f, 1.f, 1.f};
+    if (rsc) {
+        sa = rsc[lane & 15];
+        const int q4 = (lane >> 4) * 4;
+        const f32x4 sc4 = *(const lf32x4*)(rsc + q4);
+        si4 = *(const lf32x4*)(rsc + 16 + q4);
+#pragma unroll
+        for (int nt = 0; nt < E; ++nt) acc[nt] *= sc4;
+    }
+    f32x4 acc2[E];
+#pragma unroll
+    for (int nt = 0; nt < E; ++nt) acc2[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    stallR_from<I0, 0, NKB, E>(ring, acc, acc2, xr, q, lane, sa);
+#pragma unroll
+    for (int nt = 0; nt < E; ++nt) acc[nt] += acc2[nt] * DFF_F16_LINV;
+    if constexpr (EXT) {
+        const float ax = *ext_a * sa;
+#pragma unroll
+        for (int nt = 0; nt < E; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, bx[nt], acc[nt], 0, 0, 0);
+    }
+    if (rsc) {
+#pragma unroll
+        for (int nt = 0; nt < E; ++nt) acc[nt] *= si4;
+    }
+}
+
 // C layout: acc[r] <-> (row 4*(lane>>4)+r, col lane&15); unconditional (pad rows hold finite junk)
 // rmax: last row of dst (pad lanes beyond it store to that dummy row)
 DEVI void c_store_all(lfloat* dst, int ld, int col0, const f32x4& acc, int lane, int rmax = 15) {
@@ -867,7 +959,27 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     // FOLD: K_ext = V_ext = ONE shared fp32 copy of the LayerNorm rows (+ x in the extension columns), region `nx`
     lfloat* const Nx = sm + LL::nx;
     lfloat* const Qx = wr; lfloat* const Kx = FOLD ? Nx : wr + RS; lfloat* const Vx = FOLD ? Nx : wr + 2 * RS;
-    auto n_store = [=](int row, int cl, float v) { if constexpr (FOLD) Nx[row * XLD + cl] = v; };
+    constexpr bool NSP = FOLD && SPW && DFF_F16_ON(FOLD);   // the attention input's fp16 pieces live in their own region (SmallLds::nsp)
+    lu16* const nsp16 = (lu16*)(sm + LL::nsp);
+    auto n_store = [=](int row, int cl, float v) {
+        if constexpr (FOLD) Nx[row * XLD + cl] = v;
+        if constexpr (NSP) {
+            const int kb = cl >> 5, kk = cl & 31, kg = (kk & 15) >> 2, j = ((kk >> 4) << 2) | (kk & 3);
+            lu16* const q = nsp16 + ((((kb * 4 + kg) * 16 + row) * 4 + (j >> 1)) * 2 + (j & 1));
+            unsigned short hh, ll;
+            split1h(v, hh, ll);
+            q[0] = hh; q[(H / 32) * 256 * 2] = ll;
+        }
+    };
+    // (the A fragments of them: as a_load)
+    auto an_load = [=](u32x4 (&ah)[H / 32], u32x4 (&al)[H / 32], int lane) {
+        const lu32* const q = (const lu32*)nsp16 + ((lane >> 4) * 16 + (lane & 15)) * 4;
+#pragma unroll
+        for (int kb = 0; kb < H / 32; ++kb) {
+            ah[kb] = *(const lu32x4*)(q + kb * 256);
+            al[kb] = *(const lu32x4*)(q + (H / 32) * 256 + kb * 256);
+        }
+    };
     // RELAY (8 waves, H = 64): region order [Q | K | V | P | G | dS] ([Q | P | G | dS | ...] in the FOLD layout, SmallLds),
     // and everything that is not an attention operand -- o_ext = P V_ext, the FFN hidden slice, the wave's partial H-wide
     // outputs -- lives in G | dS.  q_ext, k, v and P of the LAST layer then survive in LDS from its forward to its backward
@@ -1464,7 +1576,10 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #pragma unroll
                         for (int i = 0; i < HC; ++i) {
                             resbuf[rrow * LH + sub + LPR * i] = x[i];
-                            if constexpr (FOLD) n_store(rrow, sub + LPR * i, nva[i]);
+                            if constexpr (FOLD) {
+                                n_store(rrow, sub + LPR * i, nva[i]);   // (fp32 row + its fp16 pieces: the logits' 64-column part runs on the
+                                                                        // pieces whether q' was just computed or comes from the table)
+                            }
                         }
                     }
                 } else if (ract) {
@@ -1480,7 +1595,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     for (int i = 0; i < HC; ++i) {
                         const int cl = sub + LPR * i;
                         nva[i] = (x[i] - mean) * rstd * lw.ln1_g[cl] + lw.ln1_b[cl];
-                        a_store(rrow, cl, nva[i]);
+                        if constexpr (!NSP) a_store(rrow, cl, nva[i]);
                         n_store(rrow, cl, nva[i]);
                     }
                     if constexpr (KEEPROWS) { keep_put(0, KN{}, x); keep_put(0, KL{}, nva); }
@@ -1563,7 +1678,128 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 auto wox_fa = [=](int kb) { return wox_a + 16 * kb; };
                 auto wox_fa32 = [=](int kb) { return wox_a + 32 * kb; };
                 const lfloat* const wox_xa = Ox + col * XLD + 64 + quad;   // extension column `quad` of row `col`
-                if constexpr (SPW) {
+                // REGCHAIN (FOLD kernel on the fp16 engine, round 6): QKV' -> S -> softmax -> P.V -> [W_o;W_oc] with every hand-over in
+                // registers.  The logits are computed TRANSPOSED, S^T[j][i] = n_j . q'_i: lane (i = col, quad) then holds row i's
+                // logits for the keys j = 4 quad .. + 3, the softmax of a row is an in-lane reduction + two lane swaps, and the
+                // probabilities are, as they stand, the B operand of O^T = V_ext^T P^T (k-step r contracts j = 4 kk + r: any
+                // permutation of the contraction index does, applied to both operands) -- whose output tiles are the A fragments of
+                // the output projection.  q' and P still go to LDS (the backward's operands), off the chain.
+                constexpr bool REGCHAIN = FOLD && F16E;
+                const int lroT = min(col, RLA - 1) * XLD;   // this lane's row in the transposed-output tiles (pad rows -> the dummy row)
+                auto head_rest = [&](int h, const f32x4 Sb, f32x4 (&ot)[5]) {
+                    // extension k-step: S^T[j][i] += x_j . u_i
+                    const f32x4 S = wv_dot_ext<XLD>(Kx, Qx, lane, Sb);
+                    float sv[4], ev[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sv[r] = ((okmask >> r) & 1u) ? S[r] * 0.125f : -INFINITY;   // (the mask is symmetric in i, j)
+                    auto quads = [](float v, auto op) {   // all-reduce over lanes l, l ^ 16, l ^ 32, l ^ 48
+                        const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                        v = op(__uint_as_float(a[0]), __uint_as_float(a[1]));
+                        const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                        return op(__uint_as_float(b[0]), __uint_as_float(b[1]));
+                    };
+                    const float mx = quads(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), [](float a_, float b_) { return fmaxf(a_, b_); });
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ev[r] = ((okmask >> r) & 1u) ? fast_exp(sv[r] - mx) : 0.f;
+                    const float den = quads((ev[0] + ev[1]) + (ev[2] + ev[3]), [](float a_, float b_) { return a_ + b_; });
+                    const float inv = den > 0.f ? fast_rcp(den) : 0.f;
+                    f32x4 p;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p[r] = ev[r] * inv;
+                    *(lf32x4*)(pb + col * DFF_PLD + 4 * quad) = p;   // P[i = col][j = 4 quad ..]: the backward's layout
+                    if (p0keep) p0_copy(true, pcij);
+                    else if (st_qkv) *(gf32x4*)(sb + sl.P + (size_t)h * 256 + 4 * lane) = *(const lf32x4*)(pb + (lane >> 2) * DFF_PLD + 4 * (lane & 3));
+                    // O^T = V_ext^T P^T: A = V_ext[j = 4 kk + r][16 nt + m], B = this lane's p[r]
+                    const f32x4 xi4 = *(const lf32x4*)(xs + col * 4);   // x_i of this lane's row (component 3 is zero)
+                    typedef const volatile lfloat* vlp;
+                    float bv[5][4];
+#pragma unroll
+                    for (int nt = 0; nt < 5; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) bv[nt][r] = *(vlp)(Vx + (4 * quad + r) * XLD + 16 * nt + col);
+#pragma unroll
+                    for (int nt = 0; nt < 5; ++nt) ot[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int nt = 0; nt < 5; ++nt) ot[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[nt][r], p[r], ot[nt], 0, 0, 0);
+                    // extension tile: [xbar | 0 ...] -> xrel = xbar - x_i (quad 0: columns 64 .. 67), to LDS for the projection's fp32 k-step
+                    if (quad == 0) ot[4] -= xi4;
+                    *(lf32x4*)(Ox + lroT + 64 + 4 * quad) = ot[4];
+                };
+                if constexpr (SPW && REGCHAIN) {
+                    f32x4 ot[5];
+                    if (cached) {
+                        if constexpr (HDMA) head_dma_wait();
+                        pf.tick(12); DFF_MARK(12); phase_prio<12>(wave);
+                        // layer 0 at a fixed noise level (Langevin): q' and the LayerNorm rows are the same every step, so is the
+                        // 64-column part of the logits -- computed on step 0 of the launch (fp32 products on the table's q' rows)
+                        f32x4 Sb;
+                        if (KEEPROWS && MODE == DFF_MODE_LANGEVIN && l == 0 && step > 0) Sb = s0keep;
+                        else {
+                            // the same fp16 products as below, on the table's q' rows (fp32 in the Q region) and the pieces row stage A
+                            // made of the LayerNorm rows: bit-identical to the path that computes q' itself
+                            u32x4 nh[KB32], nl[KB32];
+                            an_load(nh, nl, lane);
+                            f32x4 cs = {0.f, 0.f, 0.f, 0.f}, cb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int kb = 0; kb < 2; ++kb) {
+                                u32x4 qh, ql;
+                                const f32x4 q0 = *(const lf32x4*)(Qx + lroT + 32 * kb + 4 * quad), q1 = *(const lf32x4*)(Qx + lroT + 32 * kb + 16 + 4 * quad);
+                                split8h(q0, q1, qh, ql);
+                                cs = mfma_f16(nl[kb], qh, cs);
+                                cs = mfma_f16(nh[kb], ql, cs);
+                                cb = mfma_f16(nh[kb], qh, cb);
+                            }
+                            Sb = cb + cs * DFF_F16_LINV;
+                            if (KEEPROWS && MODE == DFF_MODE_LANGEVIN && l == 0) s0keep = Sb;
+                        }
+                        head_rest(wave, Sb, ot);
+                        pf.tick(13); DFF_MARK(13); phase_prio<13>(wave);
+                        const SSeq<U_WOX, 0, MW, KO, KO, KS, KS, E> sq{ss_wox(lw, wave), ss_wox(lw, wave), sn0, sn1};
+                        const f32x4 (&o4)[4] = *reinterpret_cast<const f32x4 (*)[4]>(&ot[0]);
+                        stallR_run<0, 2, E, true>(sring, acc_o, o4, sq, lane, wox_xa, wox_ext(lw, wave, lane), DFF_HEADS * 5 * 256);
+                        pf.tick(14); DFF_MARK(14); phase_prio<14>(wave);
+                    } else {
+                        u32x4 ah[KB32], am[KB32];
+                        an_load(ah, am, lane);
+                        const gfloat* const bp = (const gfloat*)lw.bqkvx + wave * 13 * 16 + 4 * quad;
+                        f32x4 bq[2] = {*(const gf32x4*)bp, *(const gf32x4*)(bp + 16)};
+                        pf.tick(1); DFF_MARK(1); phase_prio<1>(wave);
+                        const SSeq<U_QKV, U_WOX, MW, KQ, KO, KS, KS, E, 4 * KB32> sq{ss_qkv(lw, wave), ss_wox(lw, wave), sn0, sn1};   // tile 4 of 5: [u | s]
+                        f32x4 qt[5];
+                        swideT_from<0, 0, NQT, KB32>(sring, qt, bq, bp, ah, am, sq, lane);
+                        // q'_ext rows -> Q region: the backward's dK operand, the source of the stash / Qsave copies and of the
+                        // extension-column reads; one 16-byte store per tile
+#pragma unroll
+                        for (int t = 0; t < 5; ++t) *(lf32x4*)(Qx + lroT + 16 * t + 4 * quad) = qt[t];
+                        if (st_qkv) head_store<FOLD>(Qx, Kx, Vx, sb + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, RA, lane, RLA, XLD);
+                        pf.tick(12); DFF_MARK(12); phase_prio<12>(wave);
+                        // S^T = n q'^T on the fp16 pipe: both operands are in registers already (the LayerNorm rows' pieces were this
+                        // GEMM's A operand, q' is its output)
+                        f32x4 Sb;
+                        {
+                            u32x4 qh[2], ql[2];
+                            split8h(qt[0], qt[1], qh[0], ql[0]);
+                            split8h(qt[2], qt[3], qh[1], ql[1]);
+                            f32x4 cs = {0.f, 0.f, 0.f, 0.f}, cb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int kb = 0; kb < 2; ++kb) {
+                                cs = mfma_f16(am[kb], qh[kb], cs);
+                                cs = mfma_f16(ah[kb], ql[kb], cs);
+                                cb = mfma_f16(ah[kb], qh[kb], cb);
+                            }
+                            Sb = cb + cs * DFF_F16_LINV;
+                        }
+                        if (KEEPROWS && MODE == DFF_MODE_LANGEVIN && l == 0) s0keep = Sb;
+                        head_rest(wave, Sb, ot);
+                        if constexpr (KEEP2) { if (keep2) keep2_copy(Qx, Qsave, true, lane, pcij); }
+                        pf.tick(13); DFF_MARK(13); phase_prio<13>(wave);
+                        const f32x4 (&o4)[4] = *reinterpret_cast<const f32x4 (*)[4]>(&ot[0]);
+                        stallR_run<U_QKV, 2, E, true>(sring, acc_o, o4, sq, lane, wox_xa, wox_ext(lw, wave, lane), DFF_HEADS * 5 * 256);
+                        pf.tick(14); DFF_MARK(14); phase_prio<14>(wave);
+                    }
+                } else if constexpr (SPW) {
                     if (cached) {
                         if constexpr (HDMA) head_dma_wait();
                         else {
@@ -1755,7 +1991,9 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                             hb[16 * t] = g0; hb[LF + 16 * t] = g1; hb[2 * LF + 16 * t] = g2; hb[3 * LF + 16 * t] = g3;
                             gq[go0 + 16 * t] = p0; gq[go1 + 16 * t] = p1; gq[go2 + 16 * t] = p2; gq[go3 + 16 * t] = p3;
                         };
-                    if constexpr (SPW) {
+                    if constexpr (NSP) {
+                        // (register chain, below)
+                    } else if constexpr (SPW) {
                         u32x4 ah[KB32], am[KB32], al[KB32];
                         a_load(ah, am, al, lane);
                         pf.tick(19); DFF_MARK(19); phase_prio<19>(wave);
@@ -1770,7 +2008,30 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 for (int nt = 0; nt < E; ++nt) acc_f[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 {
                     const lfloat* const ha = hbuf + col * LF + 4 * quad;
-                    if constexpr (SPW) {
+                    if constexpr (NSP) {
+                        // W1 -> GELU -> W2 in registers: the W1 slice with its operands swapped leaves lane (row = col, quad) with hidden
+                        // columns 16 t + 4 quad .. of that row -- the A fragment of W2's one 32-column block; GELU' goes to its LDS tile
+                        // ([row][32 hidden columns], as before) with one 16-byte store per tile
+                        static_assert(NTS == 2 && FS == 32, "one 32-column k-block per wave");
+                        u32x4 ah[KB32], am[KB32], al[KB32];
+                        a_load(ah, am, al, lane);
+                        const gfloat* const b1q = (const gfloat*)lw.b1 + wave * FS + 4 * quad;
+                        f32x4 bq[2] = {*(const gf32x4*)b1q, *(const gf32x4*)(b1q + 16)};
+                        pf.tick(19); DFF_MARK(19); phase_prio<19>(wave);
+                        f32x4 ht[2], gd[2];
+                        if (lastl) swideT_from<0, 0, NTS, KB32>(sring, ht, bq, b1q, ah, am, sqf_last, lane);
+                        else swideT_from<0, 0, NTS, KB32>(sring, ht, bq, b1q, ah, am, sqf_next, lane);
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { float g, gp; gelu_both(ht[t][r], g, gp); ht[t][r] = g; gd[t][r] = gp; }
+                        lfloat* const gq = gp_lds ? gp_tile(l, m.L) + min(col, LL::GPR - 1) * LL::GPS : hbuf + 16 * LF + col * LF;
+                        *(lf32x4*)(gq + 4 * quad) = gd[0];
+                        *(lf32x4*)(gq + 16 + 4 * quad) = gd[1];
+                        pf.tick(20); DFF_MARK(20); phase_prio<20>(wave);
+                        if (lastl) stallR_run<U_W1, 1, E, false>(sring, acc_f, ht, sqf_last, lane);
+                        else stallR_run<U_W1, 1, E, false>(sring, acc_f, ht, sqf_next, lane);
+                    } else if constexpr (SPW) {
                         if (lastl) stall_run<U_W1, FS / 32, E, false>(sring, acc_f, [=](int kb) { return ha + 32 * kb; }, sqf_last, lane);
                         else stall_run<U_W1, FS / 32, E, false>(sring, acc_f, [=](int kb) { return ha + 32 * kb; }, sqf_next, lane);
                     }
@@ -1852,7 +2113,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         resbuf[rrow * LH + cl] = n2[i];
                         if constexpr (!KEEPROWS) st_ntg(sbn + sl.nodes_in + rrow * H + cl, n2[i]);
                         const float nv = (n2[i] - mean) * rstd * ro[4][i] + ro[5][i];
-                        a_store(rrow, cl, nv);
+                        if constexpr (!NSP) a_store(rrow, cl, nv);
                         n_store(rrow, cl, nv);
                         nva[i] = nv;
                     }
@@ -1979,7 +2240,9 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                             hb[16 * t] = acc[0] * ax[0]; hb[LF + 16 * t] = acc[1] * ax[1];
                             hb[2 * LF + 16 * t] = acc[2] * ax[2]; hb[3 * LF + 16 * t] = acc[3] * ax[3];
                         };
-                    if constexpr (SPW) {
+                    if constexpr (NSP) {
+                        // (register chain, below)
+                    } else if constexpr (SPW) {
                         u32x4 ah[KB32], am[KB32], al[KB32];
                         a_load(ah, am, al, lane);
                         swide_run<0, NTS, KB32, 4>(sring, hp, ah, am, al, sqb, lane, hp_load, w2t_epi);
@@ -1991,6 +2254,24 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 for (int nt = 0; nt < E; ++nt) acc_f[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 {
                     const lfloat* const ha = hbuf + col * LF + 4 * quad;
+                    if constexpr (NSP) {
+                        // W2^T -> x GELU' -> W1^T in registers (as the forward FFN): GELU'(h_pre) of (row = col, hidden columns 16 t + 4 quad ..)
+                        // is one 16-byte read per tile of the LDS tile the forward left (sampling loops) or of the stash row (score mode)
+                        f32x4 gd[2];
+                        if constexpr (MODE != DFF_MODE_SCORE) {
+                            const lfloat* const gq = gp_tile(l, m.L) + min(col, LL::GPR - 1) * LL::GPS + 4 * quad;
+                            gd[0] = *(const lf32x4*)gq; gd[1] = *(const lf32x4*)(gq + 16);
+                        } else {
+                            const gfloat* const gq = sb + sl.h_pre + (size_t)(col < rows ? col : RA) * F + wave * FS + 4 * quad;
+                            gd[0] = ld_ntg4(gq); gd[1] = ld_ntg4(gq + 16);
+                        }
+                        u32x4 ah[KB32], am[KB32], al[KB32];
+                        a_load(ah, am, al, lane);
+                        f32x4 dh[2], nob[2];
+                        swideT_from<0, 0, NTS, KB32, false>(sring, dh, nob, nullptr, ah, am, sqb, lane);
+                        dh[0] *= gd[0]; dh[1] *= gd[1];
+                        stallR_run<U_W1, 1, E, false>(sring, acc_f, dh, sqb, lane);
+                    } else
                     if constexpr (SPW) stall_run<U_W1, FS / 32, E, false>(sring, acc_f, [=](int kb) { return ha + 32 * kb; }, sqb, lane);
                     else tall_run<NTS % DR, NTS, E, -1>(ring, acc_f, [=](int kb) { return ha + 16 * kb; }, s_w1t(lw), after, lane);
                 }
@@ -2222,6 +2503,116 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         });
                     }
                 };
+                // ---- REGCHAIN (FOLD kernel, fp16 engine; round 6): the backward chain in registers, transposed like the forward one.
+                //   G_ext^T (swapped MFMA: lane (i = col, quad) holds row i, columns 16 t + 4 quad ..) -> its pieces are the B operand of
+                //   dA^T = n G^T on the fp16 pipe (A = the LayerNorm rows' pieces, region nsp) -> softmax backward of row i in the
+                //   lane group (i, quad 0..3) -> dS^T is, as it stands, the B operand of dQ_ext^T = K_ext^T dS^T, whose tiles are the A
+                //   fragments of the back-projection.  dV and dK contract over i and stay on the LDS-operand path (P, dS, true-unit G
+                //   rows are stored for them, 16 bytes per store).
+                f32x4 dxT = {0.f, 0.f, 0.f, 0.f};   // dE/dx terms held as (row i = col, components 0..3) by the quad-0 lanes
+                const int lroT = min(col, RLA - 1) * XLD;
+                auto quads_sum = [](float v) {   // all-reduce over lanes l, l ^ 16, l ^ 32, l ^ 48
+                    const auto a2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                    v = __uint_as_float(a2[0]) + __uint_as_float(a2[1]);
+                    const auto b2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                    return __uint_as_float(b2[0]) + __uint_as_float(b2[1]);
+                };
+                // G_ext^T -> true-unit rows in the G region (all tiles, or the extension tile only), dxT -= r_i, returns dS^T
+                auto gds_T = [&](const auto& sq, bool all_tiles) -> f32x4 {
+                    f32x4 gt[5], nob[2];
+                    swideT_from<0, 0, 5, KB32, false>(sring, gt, nob, nullptr, dah, dam, sq, lane);
+                    const float gi = rsc[16 + min(col, RLA - 1)];   // dattn came in row-scaled (stage E): 1 / scale of row i
+                    if (all_tiles) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) *(lf32x4*)(Gx + lroT + 16 * t + 4 * quad) = gt[t] * gi;
+                    }
+                    const f32x4 gx4 = gt[4] * gi;
+                    *(lf32x4*)(Gx + lroT + 64 + 4 * quad) = gx4;
+                    if (quad == 0) dxT -= gx4;
+                    pf.tick(15); DFF_MARK(15); phase_prio<15>(wave);
+                    // dA^T[j][i] = n_j . G_i (64 columns, fp16 pieces; in units of row i's scale) + x_j . r_i (fp32 k-step)
+                    u32x4 nh[KB32], nl[KB32], gh[2], gl[2];
+                    an_load(nh, nl, lane);
+                    split8h(gt[0], gt[1], gh[0], gl[0]);
+                    split8h(gt[2], gt[3], gh[1], gl[1]);
+                    f32x4 cs = {0.f, 0.f, 0.f, 0.f}, cb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        cs = mfma_f16(nl[kb], gh[kb], cs);
+                        cs = mfma_f16(nh[kb], gl[kb], cs);
+                        cb = mfma_f16(nh[kb], gh[kb], cb);
+                    }
+                    const f32x4 dA = wv_dot_ext<XLD>(Kx, Gx, lane, (cb + cs * DFF_F16_LINV) * gi);
+                    const f32x4 p4 = *(const lf32x4*)(pb + col * DFF_PLD + 4 * quad);   // P[i = col][j = 4 quad ..]
+                    const float sm = quads_sum((p4[0] * dA[0] + p4[1] * dA[1]) + (p4[2] * dA[2] + p4[3] * dA[3]));
+                    f32x4 dS;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dS[r] = 0.125f * p4[r] * (dA[r] - sm);
+                    *(lf32x4*)(dsb + col * DFF_PLD + 4 * quad) = dS;   // [i][j]: dK's operand
+                    pf.tick(16); DFF_MARK(16); phase_prio<16>(wave);
+                    return dS;
+                };
+#ifndef DFF_RCB
+#define DFF_RCB 1
+#endif
+                if constexpr (NSP && DFF_RCB) {
+                    if constexpr (HDMA) {
+                        head_dma_wait();   // (requested before row stage E; nothing for the last layer)
+                        if constexpr (KEEP2) {
+                            if (l == m.L - 2 && l > 0 && MODE != DFF_MODE_SCORE) keep2_copy(Qsave, Qx, false, lane, pcij);
+                            if (l == 0 && m.L > 2 && MODE != DFF_MODE_SCORE && rows <= 10) p0_copy(false, pcij);
+                        }
+                    }
+                    pf.tick(8); DFF_MARK(8); phase_prio<8>(wave);
+                    if (l > 0) {
+                        const f32x4 dS = gds_T(sqa, true);
+                        // dV_ext = P^T G_ext: v = n, so dV is a term of d(LayerNorm output); extension columns -> dx_j
+                        wv_mm5<false, true, XLD>(pb, Gx, lane, ks4, [&](int nt, const f32x4& acc) {
+                            if (nt < 4) acc_a[nt < 4 ? nt : 0] += acc;
+                            else dxr += acc;
+                        });
+                        // dQ_ext^T = K_ext^T dS^T: A = K_ext[j = 4 kk + r][16 nt + m], B = this lane's dS[r]
+                        f32x4 dq[5];
+                        {
+                            typedef const volatile lfloat* vlp;
+                            float bv[5][4];
+#pragma unroll
+                            for (int nt = 0; nt < 5; ++nt)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) bv[nt][r] = *(vlp)(Kx + (4 * quad + r) * XLD + 16 * nt + col);
+#pragma unroll
+                            for (int nt = 0; nt < 5; ++nt) dq[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                                for (int nt = 0; nt < 5; ++nt) dq[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[nt][r], dS[r], dq[nt], 0, 0, 0);
+                        }
+                        *(lf32x4*)(Gx + lroT + 64 + 4 * quad) = dq[4];   // du: the back-projection's fp32 k-step reads it (r_i is spent)
+                        // dK_ext = dS^T Q_ext: k = n, likewise; extension columns -> dx_j
+                        wv_mm5<false, true, XLD>(dsb, Qx, lane, ks4, [&](int nt, const f32x4& acc) {
+                            if (nt < 4) acc_a[nt < 4 ? nt : 0] += acc;
+                            else dxr += acc;
+                        });
+                        pf.tick(17); DFF_MARK(17); phase_prio<17>(wave);
+                        const f32x4 (&dq4)[4] = *reinterpret_cast<const f32x4 (*)[4]>(&dq[0]);
+                        stallR_run<U_GX, NKT, E, true>(sring, acc_a, dq4, sqa, lane, Gx + col * XLD + 64 + quad, qkvt_ext(lw, wave, lane),
+                                                       DFF_HEADS * 13 * 256, rsc);
+                        pf.tick(18); DFF_MARK(18); phase_prio<18>(wave);
+#pragma unroll
+                        for (int nt = 0; nt < E; ++nt) c_store_offs(mypart, mro, 16 * nt, acc_a[nt], lane);
+                    } else {
+                        (void)gds_T(sqa0, false);
+                        // layer 0's node inputs do not depend on x: only the extension tiles of dV_ext and dK_ext (the dx_j terms)
+                        wv_mm<4, 5, true, XLD>(pb, Gx, lane, ks4, [&](int, const f32x4& acc) { dxr += acc; });
+                        wv_mm<4, 5, true, XLD>(dsb, Qx, lane, ks4, [&](int, const f32x4& acc) { dxr += acc; });
+                        if constexpr (EARLY) {
+                            early_done = true;
+                            if constexpr (HDMA) {
+                                if (nxt && c0n) head_dma<LL::DMA_N>(dmatab, Qx, l0n + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, lane);
+                            }
+                        }
+                    }
+                }
                 const int h1 = wave + 4;
                 (void)h1;
                 // GEN: [m1 | m2] of the head whose buffers are live (hr.m is overwritten by the next head's prefetch),
@@ -2230,6 +2621,9 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 auto m12p = [&](int h) -> const gfloat* { return GEN ? sb + sl.m12 + h * 64 : nullptr; };
                 auto committed = [&]() { if constexpr (GEN) { m_cur = hr.m; fix_q(lane); } };
                 auto gfix = [&]() { if constexpr (GEN) fix_g(lane, m_cur); };
+                if constexpr (NSP && DFF_RCB) {
+                    // (done above)
+                } else
                 if (l > 0 || full0) {
                     if constexpr (HPW == 2) {
                         head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA, XLD);
@@ -2345,6 +2739,15 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     for (int r = 0; r < 4; ++r) t4[r] = dxw[dxi[r]];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dxw[dxi[r]] = t4[r] + dxr[r];
+                }
+                if constexpr (NSP) {
+                    // ... and what the quad-0 lanes hold by row: (row col, components 0..3) is one 16-byte slot of the same array (LDS
+                    // operations of a wave complete in order: this read-modify-write sees the stores above)
+                    if (quad == 0 && col < rows) {
+                        lf32x4* const d4 = (lf32x4*)(dxw + col * 4);
+                        const f32x4 t = *(volatile lf32x4*)d4;
+                        *(volatile lf32x4*)d4 = t + dxT;
+                    }
                 }
             }
             __syncthreads();
