@@ -182,9 +182,12 @@ def roofline(cfg, P, steps_per_launch, launch_ms, kname, brief=False):
     r["profile"] = pf["profile"]
     if pf["profile_stale"]:
         r["profile_stale"] = True
-    if brief:   # `also` entries: bound / peak / unit are the headline's
+    if brief:   # `also` entries: bound / peak / unit are the headline's; counters of a stale / missing profile are not spelled out
         for k in ("bound", "peak", "unit", "min_launch_ms", "launches"):
             del r[k]
+        if pf["traffic"] is None:
+            for k in ("traffic", "hbm_tbps", "mfma_busy", "l2_hit"):
+                del r[k]
     else:
         r["algorithmic_flops_per_launch"] = flops
     r["mixed_peak_frac"] = round(mixed_peak_frac(cfg, P, steps_per_launch, avg, kname), 4)

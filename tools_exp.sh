@@ -15,9 +15,13 @@ if [ "$cmd" = build ]; then
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-result -DDFF_FAST_BUILD -DDFF_SMALL_MODE=$md ${DFF_SMALL_SCHED--mllvm -amdgpu-sched-strategy=max-ilp -mllvm -amdgpu-use-amdgpu-trackers} $flags -c $SRC/dff_small.hip -o $d/dff_small_m$md.o
     objs=""
     for k in 0 1 2; do if [ $k = $md ]; then objs="$objs $d/dff_small_m$k.o"; else objs="$objs build/obj/dff_small_m$k.o"; fi; done
-    host=build/obj/dff_host.o
-    case "$flags" in *DFF_PROF=1*)   # the host half refuses dff_debug_profile unless it was built with the stage ticks too
-        hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-result -DDFF_PROF=1 -c $SRC/dff_host.hip -o $d/dff_host.o; host=$d/dff_host.o;; esac
+    # its own host half: dff_version() of an experiment names it (src=exp-<name>: never the product build's hash) and its flags;
+    # the stage ticks need the host half built with them too
+    printf '#define DFF_BUILD_FLAGS "%s"\n' "$(printf '%s' "$flags" | sed 's/[\\"]/\\&/g')" > $d/dff_build_info.h
+    pf=""; case "$flags" in *DFF_PROF=1*) pf="-DDFF_PROF=1";; esac
+    case "$flags" in *DFF_EXPERIMENT*) pf="$pf -DDFF_EXPERIMENT";; esac
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-result $pf -DDFF_SRC_SHA=exp-$name -include $d/dff_build_info.h -c $SRC/dff_host.hip -o $d/dff_host.o
+    host=$d/dff_host.o
     hipcc --offload-arch=gfx950 -shared -fPIC build/obj/dff_kernels.o $objs $host -o $d/libdff_amd.so
     echo "$flags" > $d/flags
     echo "built $d ($flags)"

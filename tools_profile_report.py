@@ -110,12 +110,9 @@ def main():
     try:
         traffic["src_sha"] = open(os.path.join(src, "src_sha.txt")).read().strip() or "unknown"
     except OSError:
-        import sys
-        sys.path.insert(0, ROOT)
-        import dff_amd  # noqa: F401
-        from dff_amd import srcsha
-        traffic["src_sha"] = srcsha.tree_sha()
-        print(f"warning: no src_sha.txt in {src}; stamped the working tree's hash {traffic['src_sha']}")
+        # (the working tree's hash would certify counters that may have been taken on an older library)
+        traffic["src_sha"] = "unknown"
+        print(f"warning: no src_sha.txt in {src}: stamped 'unknown' -- bench.py will report this profile as stale")
     json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"))
     wc = C.get("SQ_WAVE_CYCLES", 1.0)
     lines = []

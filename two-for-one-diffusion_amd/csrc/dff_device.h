@@ -90,22 +90,14 @@ struct WPtr {
 #endif
 #define DFF_SITE_LD(MT, bit) (DFF_STASH_SITES >= 0 ? ((DFF_STASH_SITES & (bit)) ? 1 : 0) : (DFF_STASH_POL(MT) & 1))
 #define DFF_SITE_ST(MT, bit) (DFF_STASH_SITES >= 0 ? ((DFF_STASH_SITES & (bit)) ? 2 : 0) : (DFF_STASH_POL(MT) & 2))
-// (DFF_TIMING_NOSTASH: timing-only builds -- bit 0 drops the policy-site stores, bit 1 the policy-site loads: upper bounds of what
-// the stash traffic costs)
-#ifndef DFF_TIMING_NOSTASH
-#define DFF_TIMING_NOSTASH 0
-#endif
 template <int POL = 0> DEVI void st_ntg(gfloat* p, float v) {
-    if constexpr (DFF_TIMING_NOSTASH & 1) { asm volatile("" ::"v"(p), "v"(v)); return; }
     if constexpr (POL & 2) __builtin_nontemporal_store(v, p); else *p = v;
 }
 template <int POL = 0> DEVI float ld_ntg(const gfloat* p) { if constexpr (POL & 1) return __builtin_nontemporal_load(p); else return *p; }
 template <int POL = 0> DEVI f32x4 ld_ntg4(const gfloat* p) {
-    if constexpr (DFF_TIMING_NOSTASH & 2) { f32x4 z = {1.f, 0.5f, 0.25f, 0.125f}; asm volatile("" : "+v"(z) : "v"(p)); return z; }
     if constexpr (POL & 1) return __builtin_nontemporal_load((const gf32x4*)p); else return *(const gf32x4*)p;
 }
 template <int POL = 0> DEVI void st_ntg4(gfloat* p, const f32x4 v) {
-    if constexpr (DFF_TIMING_NOSTASH & 1) { asm volatile("" ::"v"(p), "v"(v)); return; }
     if constexpr (POL & 2) __builtin_nontemporal_store(v, (gf32x4*)p); else *(gf32x4*)p = v;
 }
 // four consecutive floats (16-byte aligned) into a scalar aux array of an epilogue
@@ -269,45 +261,14 @@ DEVI float grp_sum(float v, int np) {
     return v;
 }
 // GELU(erf) value and derivative in one go: the forward FFN epilogue stashes gelu'(h_pre) so that the
-// backward epilogue is a single multiply (one erf + one exp per element per step instead of two + one)
-// Branch-free erf: |x| <= 0.8: x * P5(x^2);  else 1 - exp(P8(|x|)) with P8 ~ log erfc on [0.8, 4.2]
-// (least-squares fits on Chebyshev nodes; max abs error 1.2e-7 against scipy.special.erf over
-// [-6, 6] in float32 -- the same 1-2 ulp class as the library erff, at about half its instructions).
-#ifndef DFF_FAST_ERF
-#define DFF_FAST_ERF 0   // measured: no faster than the library erff here (the FFN epilogue is not erf-bound)
-#endif
-DEVI float erf_fast(float x) {
-#if DFF_FAST_ERF
-    const float t = fminf(fabsf(x), 4.2f), s = x * x;
-    float a = -6.546706740e-04f;
-    a = fmaf(a, s, 5.086977565e-03f); a = fmaf(a, s, -2.682184972e-02f); a = fmaf(a, s, 1.128313692e-01f);
-    a = fmaf(a, s, -3.761260335e-01f); a = fmaf(a, s, 1.128379164e+00f);
-    a *= x;
-    float b = 1.534366307e-06f;
-    b = fmaf(b, t, -4.404490910e-05f); b = fmaf(b, t, 5.800263089e-04f); b = fmaf(b, t, -4.682034248e-03f);
-    b = fmaf(b, t, 2.620414818e-02f); b = fmaf(b, t, -1.097046865e-01f); b = fmaf(b, t, -6.322175036e-01f);
-    b = fmaf(b, t, -1.130008818e+00f); b = fmaf(b, t, 2.658824129e-04f);
-    b = copysignf(1.0f - __expf(b), x);
-    return t <= 0.8f ? a : b;
-#else
-    return erff(x);
-#endif
-}
+// backward epilogue is a single multiply
 // One exponential serves both: erfc(z) = exp(-z^2) t P(t), t = 1 / (1 + p z) (the Abramowitz-Stegun 7.1.26 form with a
 // degree-7 polynomial, least-squares fit of the absolute error on z in [0, 8]: 1.9e-10 in exact arithmetic), z = |x| / sqrt 2,
 // so  cdf = 1 - erfc(z) / 2 (x >= 0) or erfc(z) / 2,  pdf = exp(-z^2) / sqrt(2 pi).  ~24 VALU instructions (one v_rcp_f32,
 // one v_exp_f32) instead of ~110 for erff + expf; evaluated in fp32 its error against float64 is that of the libm-based
 // form (g: 6.1e-7 at |x| = 12, 3.4e-7 for |x| < 4; g': 2.0e-7 vs 1.5e-7).  The FFN epilogue was the largest single VALU
 // item of the sampler kernels (a third of all VALU instructions of a chignolin step).
-#ifndef DFF_GELU_LIBM
-#define DFF_GELU_LIBM 0   // 1: erff / expf
-#endif
 DEVI void gelu_both(float x, float& g, float& gp) {
-#if DFF_GELU_LIBM
-    const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
-    g = x * cdf;
-    gp = cdf + x * expf(-0.5f * x * x) * 0.39894228040143267794f;
-#else
     const float z = fabsf(x) * 0.70710678118654752440f;
     const float t = __builtin_amdgcn_rcpf(fmaf(0.505f, z, 1.0f));
     float P = -5.364335749e-02f;
@@ -319,7 +280,6 @@ DEVI void gelu_both(float x, float& g, float& gp) {
     const float cdf = x >= 0.f ? 1.0f - q : q;
     g = x * cdf;
     gp = fmaf(x * 0.39894228040143267794f, E, cdf);
-#endif
 }
 
 // Hardware transcendentals (v_exp_f32, v_rcp_f32, v_rsq_f32: ~1 ulp each) for the softmax, the gates and the LayerNorm

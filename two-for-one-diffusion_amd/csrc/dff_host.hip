@@ -233,7 +233,9 @@ struct dff_model {
         float tnorm = 0.f;
         const void* variant = nullptr;
         bool split = false;
-    } l0[2];
+        unsigned long long used = 0;           // last use (dff_model::l0_clock): the slot that was idle longest is rebuilt
+    } l0[2][3];                                // a few per kind: batches that alternate between group sizes / variants (ADVICE r05:
+    unsigned long long l0_clock = 0;           // ala2 crossing 128 / 256 / 384 per GPU) keep their tables instead of rebuilding one slot
     bool l0_off = false;                       // debugging: never use the table
     int max_wgs = 2048;                        // workgroups per launch: bounds the stash (grid x stash slot) for big batches
     int last_base = 0;
@@ -420,6 +422,20 @@ extern "C" int dff_model_create(const dff_config* cfg, const float* w, size_t n_
             if (!(worst < 1.6e4)) {
                 fprintf(stderr, "dff: forward activations of this model may reach %.3g (> 1.6e4): the fp16 split engine is off, weight GEMMs run on the fp32 matrix pipe\n", worst);
                 m->split = false;
+            }
+        }
+        // Two workgroups per protein (PAIR variants) need both blocks of a pair resident at once, and the launches are not cooperative
+        // (ADVICE r05): never where the GPU is known to be shared -- more local ranks than visible devices (torchrun's
+        // LOCAL_WORLD_SIZE) -- or where the caller says so (DFF_PAIR=0).  dff_debug_pair(m, 1) turns them back on.
+        {
+            const char* ep = getenv("DFF_PAIR");
+            const char* lw = getenv("LOCAL_WORLD_SIZE");
+            int ndev = 0;
+            if (ep && ep[0] == '0') m->pair_off = true;
+            else if (lw && hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && atoi(lw) > ndev) {
+                m->pair_off = true;
+                static bool said = false;
+                if (!said) { said = true; fprintf(stderr, "dff: %s local ranks share %d GPU(s): the two-workgroups-per-protein kernels are off\n", lw, ndev); }
             }
         }
         const char* ef = getenv("DFF_FOLD_KV");
@@ -669,7 +685,7 @@ extern "C" void dff_model_destroy(dff_model* m) {
     if (m->xchg) (void)hipFree(m->xchg);
     if (m->xflag) (void)hipFree(m->xflag);
     if (m->prof) (void)hipFree(m->prof);
-    for (auto& t : m->l0) if (t.tab) (void)hipFree(t.tab);
+    for (auto& k : m->l0) for (auto& t : k) if (t.tab) (void)hipFree(t.tab);
     delete m;
 }
 
@@ -893,12 +909,20 @@ static int launch_generic(dff_model* m, DffRunArgs& a, int G, const Variant* v, 
 // L2-resident copy instead of one per workgroup.  Langevin: one entry (its fixed t); DDPM: T entries,
 // built in chunks so that the stash does not grow beyond what sampling needs anyway.
 // v == nullptr: rows<=16 kernel, else that variant of the generic kernel.
-static int ensure_l0_table(dff_model* m, int kind, float t_norm, int G, const Variant* v, hipStream_t stream) {
+static int ensure_l0_table(dff_model* m, int kind, float t_norm, int G, const Variant* v, hipStream_t stream, const float** out) {
     const int N = m->cfg.n_beads, H = m->cfg.hidden, L = m->cfg.n_layers, T = m->cfg.timesteps;
-    dff_model::L0Table& tb = m->l0[kind - 1];
-    if (tb.valid && tb.G == G && tb.waves == m->small_waves && tb.variant == (const void*)v && tb.split == m->small_split &&
-        (kind == 2 || tb.tnorm == t_norm))
-        return DFF_OK;
+    dff_model::L0Table* slot = nullptr;
+    for (auto& c : m->l0[kind - 1]) {
+        if (c.valid && c.G == G && c.waves == m->small_waves && c.variant == (const void*)v && c.split == m->small_split &&
+            (kind == 2 || c.tnorm == t_norm)) {
+            c.used = ++m->l0_clock;
+            *out = c.tab;
+            return DFF_OK;
+        }
+        if (!slot || (!c.valid && slot->valid) || (c.valid == slot->valid && c.used < slot->used)) slot = &c;
+    }
+    dff_model::L0Table& tb = *slot;
+    *out = nullptr;
     const int nent = kind == 2 ? T : 1;
     size_t layer_stride, total;
     if (v) { const StashLayout sl = dff_stash_layout(N, G, H, L, v->MT); layer_stride = sl.layer_stride; total = sl.total; }
@@ -943,6 +967,8 @@ static int ensure_l0_table(dff_model* m, int kind, float t_norm, int G, const Va
         HIPCHK(hipStreamSynchronize(stream));
     }
     tb.valid = true; tb.G = G; tb.waves = m->small_waves; tb.tnorm = t_norm; tb.variant = (const void*)v; tb.split = m->small_split;
+    tb.used = ++m->l0_clock;
+    *out = tb.tab;
     return DFF_OK;
 }
 
@@ -983,9 +1009,8 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
     const bool prefer_generic = (H == 96 || H == 128) && m->split && !small_h96 && m->small_waves == 0;   // (dff_debug_small_waves(m, 4 | 8) asks for the <= 16-row kernel)
     if (G * N <= 16 && !m->force_generic && have_small && !prefer_generic) {
         if (want_tab) {
-            int rc = ensure_l0_table(m, a.mode == DFF_MODE_DDPM ? 2 : 1, a.t_norm, G, nullptr, stream);
+            int rc = ensure_l0_table(m, a.mode == DFF_MODE_DDPM ? 2 : 1, a.t_norm, G, nullptr, stream, &a.l0_tab);
             if (rc) return rc;
-            a.l0_tab = m->l0[a.mode == DFF_MODE_DDPM ? 1 : 0].tab;
         }
         return launch_small(m, a, G, stream);
     }
@@ -1034,28 +1059,37 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
     // proteins on 256 workgroups that each do all the heads.
     const int cu_cap = m->n_cus < m->max_wgs ? m->n_cus : m->max_wgs;
     const Variant* vp = nullptr;
-    if (!gen && m->cfg.conservative && !m->pair_off) {
+    // (no device access here: the launch path stays asynchronous.  A failure word the HOST has seen -- an earlier PAIR launch
+    // timed out waiting for its partner: the GPU is shared or partitioned -- takes the PAIR variants out of the choice: the model
+    // keeps working on the one-workgroup kernels (it used to refuse every launch until dff_model_status_clear).  One
+    // the host has not seen yet makes a PAIR kernel leave at entry with NaN outputs, and the next status call reports it.)
+    if (m->sticky && !m->pair_off) {
+        static bool said = false;
+        if (!said) {
+            said = true;
+            fprintf(stderr, "dff: an earlier two-workgroups-per-protein launch timed out waiting for its partner workgroup (its results were "
+                            "invalid and have been reported): continuing on the one-workgroup kernels; dff_model_status_clear(m) re-arms\n");
+        }
+    }
+    if (!gen && m->cfg.conservative && !m->pair_off && !m->sticky) {
         const Variant* const cand = pick_pair(mt, v->spw);
         const int g_lo = auto_group ? 1 : G, g_hi = auto_group ? (cap > 1 ? cap : 1) : G;
+        const int G0 = G;
         for (int g = g_lo; cand && g <= g_hi; ++g) {
             const int ngr = (a.B + g - 1) / g;
             if (2 * 8 * ((ngr + 7) / 8) > cu_cap || (g * N + 15) / 16 > mt || cand->lds_floats(N, g) * sizeof(float) > 160u * 1024u) continue;
-            vp = cand; G = g;
+            // the one-workgroup variant of the same shape builds the layer-0 table at THIS group size: it must fit there too
+            // (it had been picked and LDS-checked at the old G)
+            G = g;
+            const Variant* const v1 = pick(mt);
+            if (!v1) { G = G0; continue; }
+            v = v1; vp = cand;
             break;
         }
     }
-    if (vp) {
-        // (no device access here: the launch path stays asynchronous.  The word the HOST last saw refuses; one it has
-        // not seen yet makes the kernel itself leave at entry, and the next status call reports it.)
-        if (m->sticky)
-            return fail(DFF_EHIP, "an earlier two-workgroups-per-protein launch timed out waiting for its partner "
-                                  "workgroup (the GPU is shared or partitioned?): its results are invalid; "
-                                  "dff_model_status_clear(m) re-arms, dff_debug_pair(m, 0) selects the one-workgroup kernels");
-    }
     if (want_tab) {
-        int rc = ensure_l0_table(m, a.mode == DFF_MODE_DDPM ? 2 : 1, a.t_norm, G, v, stream);
+        int rc = ensure_l0_table(m, a.mode == DFF_MODE_DDPM ? 2 : 1, a.t_norm, G, v, stream, &a.l0_tab);
         if (rc) return rc;
-        a.l0_tab = m->l0[a.mode == DFF_MODE_DDPM ? 1 : 0].tab;
     }
     if (vp) v = vp;
     return launch_generic(m, a, G, v, stream);
@@ -1329,4 +1363,17 @@ extern "C" const char* dff_last_error(void) { return g_err.c_str(); }
 #endif
 #define DFF_STR2(x) #x
 #define DFF_STR(x) DFF_STR2(x)
-extern "C" const char* dff_version(void) { return "dff-amd 0.1 (gfx950, mfma_f32_16x16x4f32) src=" DFF_STR(DFF_SRC_SHA); }
+// DFF_BUILD_FLAGS (build.sh, generated header): DFF_EXTRA_FLAGS / scheduler overrides the translation units were compiled with -- a
+// development build names its knobs; they are hashed into DFF_SRC_SHA as well, so that it never shares the product build's hash.
+// DFF_EXPERIMENT: the build says of itself that it may compute wrong numbers (timing experiments).
+#ifndef DFF_BUILD_FLAGS
+#define DFF_BUILD_FLAGS ""
+#endif
+#ifdef DFF_EXPERIMENT
+#define DFF_EXP_TAG " EXPERIMENT"
+#else
+#define DFF_EXP_TAG ""
+#endif
+extern "C" const char* dff_version(void) {
+    return "dff-amd 0.1 (gfx950; f16-split / f32 MFMA)" DFF_EXP_TAG " flags=[" DFF_BUILD_FLAGS "] src=" DFF_STR(DFF_SRC_SHA);
+}

@@ -57,6 +57,9 @@
 #ifndef DFF_ARES
 #define DFF_ARES 1
 #endif
+// The image formats of the host (dff_fused_f16_mask) and the kernels are coupled through DFF_F16G: the QKV_ext^T image is read as
+// fp16 pieces only when the G_ext group is too (DFF_QT16) -- a build with bit 3 but not bit 2 would multiply a two-piece image as three
+static_assert((DFF_F16G & 8) == 0 || (DFF_F16G & 4) != 0, "DFF_F16G: bit 3 (QKV_ext^T) needs bit 2 (G_ext)");
 
 // ------------------------------------------------------------------------------------------
 // MFMA GEMM stages.  A (rows x K) lives in LDS with leading dimension lda (multiple of 4);
@@ -786,6 +789,13 @@ DEVI void gemm_tall_split_st(f32x4 (&acc)[NTW][MT], int LS2, const lu32* as, int
 #endif
 #ifndef DFF_QSP
 #define DFF_QSP 1   // dQ leaves co_ds as bf16 pieces (0: fp32, split by every wave of the back-projection)
+#endif
+// The knobs above are measured decisions (DESIGN.md / DESIGN_HISTORY.md name each A/B); a build that changes one is a development
+// build and has to say so: -DDFF_EXPERIMENT, which dff_version() reports next to the flags.
+#if !defined(DFF_EXPERIMENT) && (DFF_F16G != 15 || DFF_AUXLATE != 1 || DFF_APRE != 1 || DFF_PIPEB_128_2 != 1 || DFF_QTPRE != 1 || DFF_TPRE_MT != 3 || \
+     DFF_K2_MT != 3 || DFF_ARES_LIM != 8 || DFF_ARES != 1 || DFF_WOPRE != 1 || DFF_L2W != 1 || DFF_PSPLIT != 1 || DFF_DQKV_ROWS != 1 || \
+     DFF_GXTILE0 != 1 || DFF_GXTILE != 1 || DFF_XFAST != 1 || DFF_GXT != 1 || DFF_K2 != 1 || DFF_EXTPRE != 1 || DFF_QSP != 1)
+#error "non-default tuning knobs: a development build -- add -DDFF_EXPERIMENT (dff_version() then says so)"
 #endif
 // L2 warm-up.  The weights of a phase are what all 32 workgroups of an XCD ask their L2 for at about the same time; they are
 // 15 MB per step (villin) against 4 MB of L2, so whoever is first pays the trip to memory and the others queue behind the

@@ -31,27 +31,6 @@
 #else
 #define DFF_MARK(n) ((void)0)
 #endif
-// DFF_PRIO (experiments): s_setprio by phase and SIMD sibling.  The two waves of a SIMD (w, w + 4) share its issue ports and
-// matrix pipe; the hardware favours the older one, the block between two barriers ends with the slower one.
-//   1 / 2: waves >= 4 / < 4 raised inside the wave-private blocks;  3 / 4: raised in the GEMM phases for waves >= 4 / < 4 and
-//   in the attention-math phases for the other half (skews the siblings against each other: GEMM of one under attention of the other)
-#ifndef DFF_PRIO
-#define DFF_PRIO 0
-#endif
-template <int N>
-DEVI void phase_prio(int wave) {
-    if constexpr (DFF_PRIO != 0) {
-        constexpr bool att = N == 12 || N == 15;
-        constexpr bool gemm = N == 1 || N == 13 || N == 17 || N == 8 || N == 3 || N == 6 || N == 19;
-        constexpr bool row = N == 2 || N == 4 || N == 7 || N == 9 || N == 5 || N == 10;
-        const bool hiw = (wave >= 4) == (DFF_PRIO == 1 || DFF_PRIO == 3);
-        if (row) __builtin_amdgcn_s_setprio(0);
-        else if (att || gemm) {
-            const bool up = (DFF_PRIO <= 2) ? hiw : (gemm ? hiw : !hiw);
-            if (up) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
-        }
-    }
-}
 // DFF_F16 (round 5): the split variants run their weight GEMMs on the TWO-piece fp16 split (dff_device.h split8h): stream kind -1 =
 // host-split fp16 image, 4 B per weight, 2 KB units, three v_mfma_f32_16x16x32_f16 per unit.  1: the FOLD variant only (chignolin:
 // the headline), 2: every split variant of this kernel, 0: the three-piece bf16 engine of rounds 2-4.
@@ -702,12 +681,7 @@ DEVI f32x4 wv_dot_rows(const lfloat* A, const lfloat* B, int lane) {
 template <int NT0, int NT1, bool TRANS, int XLD = DFF_XLD, class Epi>
 DEVI void wv_mm(const lfloat* T, const lfloat* B, int lane, int ks, Epi epi) {
     const int kk = lane >> 4, mm = lane & 15;
-    // (DFF_TIMING_NOCONF: timing-only builds for the bank-conflict question -- the column reads of B and the transposed reads of T
-    // use a row stride of 16 mod 64 dwords, which is conflict-free for them (and reads the wrong data): bit 0 = B, bit 1 = T)
-#ifndef DFF_TIMING_NOCONF
-#define DFF_TIMING_NOCONF 0
-#endif
-    constexpr int XB = (DFF_TIMING_NOCONF & 1) ? 80 : XLD, TP = (DFF_TIMING_NOCONF & 2) ? 16 : DFF_PLD;
+    constexpr int XB = XLD, TP = DFF_PLD;
     // k-step s covers k = 4 s .. 4 s + 3 (lane: k = 4 s + kk), so trailing all-zero k-steps can be dropped
     // (volatile: the operands of k-steps 1..3 are only used inside the row-count branches below, and the compiler sinks a
     // plain LDS read into the branch that uses it -- every product then waits out the latency of its own operands)
@@ -932,12 +906,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             const float r = v - __uint_as_float(b & 0xffff0000u);
             const unsigned c = __float_as_uint(r);
             const float s2 = r - __uint_as_float(c & 0xffff0000u);
-#if DFF_TIMING_NOCONF & 4   // timing-only: the three 16-bit stores of a lane land in its own bank (wrong layout)
-            lu16* const q2 = asp16 + ((threadIdx.x & 63) * 2 + ((cl >> 5) & 1) * 128) % (3 * PS - 2 * 128);
-            q2[0] = (unsigned short)(b >> 16); q2[256] = (unsigned short)(c >> 16); q2[512] = (unsigned short)(__float_as_uint(s2) >> 16);
-#else
             q[0] = (unsigned short)(b >> 16); q[PS] = (unsigned short)(c >> 16); q[2 * PS] = (unsigned short)(__float_as_uint(s2) >> 16);
-#endif
         } else {
             abuf[row * LH + cl] = v;
         }
@@ -1157,12 +1126,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             const int ln = lane_id();
             if (ln < rows * 4 && (ln & 3) < 3) {
                 const int row = ln >> 2, g = row / N;
-#ifdef DFF_TIMING_NONOISE
-                xib[ln] = 0.5f;
-#else
                 xib[ln] = philox_normal(a.seed, a.item_offset + (size_t)b0 + g,
                                         MODE == DFF_MODE_DDPM ? (uint64_t)t_int_ : a.step_offset + step_, row - g * N, ln & 3);
-#endif
             }
         }
     };
@@ -1342,27 +1307,21 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     auto s_woxt = [&](const DffLayerDev& lw, int h) { return wide_stream(lw.WoxT_p, E, h * 5); };
     auto s_qkvt = [&](const DffLayerDev& lw, int h) { return tall_stream(lw.WqkvxT_p, DFF_HEADS * 13, h * 13); };
     // the same streams of the split images (units, see the split engine above)
-    // stream kinds (unit_addr) of QKV_ext, [W_o;W_oc], QKV_ext^T: 1 = fp32 image split in registers (4 B per weight, +44 VALU per unit),
-    // 0 = host-split image (6 B).  Measured (us / step, chignolin P = 256; Q,O,T): 000 90.1, 100 90.3, 010 90.4, 001 92.0, 011 92.3, 111 94.1:
-    // the extra VALU costs what the smaller stream saves, so all three stay host-split.
-#ifndef DFF_KQ
-#define DFF_KQ 0
-#define DFF_KO 0
-#define DFF_KT 0
-#endif
+    // (every stream is a host-split image: fp32 images split in registers by the consuming wave -- 4 B per weight, +44 VALU per unit --
+    // measured 90.3 - 94.1 us / step against 90.1 in round 3: the extra VALU costs what the smaller stream saves)
     constexpr bool F16E = SPW && DFF_F16_ON(FOLD);   // fp16 two-piece engine (kind -1 streams)
     constexpr int KS = F16E ? -1 : 0;        // kind of the host-split images
-    constexpr int KQ = F16E ? -1 : DFF_KQ ? 1 : 0, KO = F16E ? -1 : DFF_KO ? DFF_HEADS * 5 : 0, KT = F16E ? -1 : DFF_KT ? DFF_HEADS * 13 : 0;
+    constexpr int KQ = KS, KO = KS, KT = KS;
     constexpr int UST = F16E ? 128 : 192;    // 16-byte slots per unit of a host-split image
     constexpr bool EARLY = SPW && KQ == KS && KO == KS;   // a block's tail refills can fetch either first stream of a step (one unit format)
-    auto ss_qkv = [&](const DffLayerDev& lw, int h) { return KQ > 0 ? SStream{(const gu32x4*)lw.Wqkvx_p + (size_t)h * 13 * E * 64} : sstream(lw.Wqkvx_w, h * U_QKV, UST); };
-    auto ss_wox = [&](const DffLayerDev& lw, int h) { return KO > 0 ? SStream{(const gu32x4*)lw.Wox_p + (size_t)h * 5 * 64} : sstream(lw.Wox_t, h * 2 * E, UST); };
+    auto ss_qkv = [&](const DffLayerDev& lw, int h) { return sstream(lw.Wqkvx_w, h * U_QKV, UST); };
+    auto ss_wox = [&](const DffLayerDev& lw, int h) { return sstream(lw.Wox_t, h * 2 * E, UST); };
     auto ss_w1 = [&](const DffLayerDev& lw) { return sstream(lw.W1_w, wave * NTS * KB32, UST); };
     auto ss_w2 = [&](const DffLayerDev& lw) { return sstream(lw.W2_t, wave * (FS / 32) * E, UST); };
     auto ss_w2t = [&](const DffLayerDev& lw) { return sstream(lw.W2T_w, wave * NTS * KB32, UST); };
     auto ss_w1t = [&](const DffLayerDev& lw) { return sstream(lw.W1T_t, wave * (FS / 32) * E, UST); };
     auto ss_woxt = [&](const DffLayerDev& lw, int h) { return sstream(lw.WoxT_w, h * 5 * KB32, UST); };
-    auto ss_qkvt = [&](const DffLayerDev& lw, int h) { return KT > 0 ? SStream{(const gu32x4*)lw.WqkvxT_p + (size_t)h * 13 * 64} : sstream(lw.WqkvxT_t, h * U_QKVT, UST); };
+    auto ss_qkvt = [&](const DffLayerDev& lw, int h) { return sstream(lw.WqkvxT_t, h * U_QKVT, UST); };
     // extension-block weights of the tall GEMMs for the fp32 k-step (s = 0 slots of the fp32 images)
     auto wox_ext = [&](const DffLayerDev& lw, int h, int lane) { return (const gfloat*)lw.Wox_p + ((size_t)(5 * h + 4) * 64 + lane) * 4; };
     auto qkvt_ext = [&](const DffLayerDev& lw, int h, int lane) { return (const gfloat*)lw.WqkvxT_p + ((size_t)(13 * h + 4) * 64 + lane) * 4; };
@@ -1522,7 +1481,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         } }
         if (step == 0) centre();
         if (step == 0 || !cached0) __syncthreads();   // (later steps: the barrier that ended the previous update stage)
-        pf.tick(0); DFF_MARK(0); phase_prio<0>(wave);
+        pf.tick(0); DFF_MARK(0);
 
         // =============================== forward ===============================
         if (!cached0) {
@@ -1604,7 +1563,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 if constexpr (DFF_XI_STAGE == 0) draw_xi(t_int, step);
                 __syncthreads();
             }
-            pf.tick(1); DFF_MARK(1); phase_prio<1>(wave);
+            pf.tick(1); DFF_MARK(1);
             // ---- attention block: wave w owns heads w and w+4 (ring holds the first entries) ----
             {
                 DFF_LANE_CONSTS
@@ -1731,7 +1690,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     f32x4 ot[5];
                     if (cached) {
                         if constexpr (HDMA) head_dma_wait();
-                        pf.tick(12); DFF_MARK(12); phase_prio<12>(wave);
+                        pf.tick(12); DFF_MARK(12);
                         // layer 0 at a fixed noise level (Langevin): q' and the LayerNorm rows are the same every step, so is the
                         // 64-column part of the logits -- computed on step 0 of the launch (fp32 products on the table's q' rows)
                         f32x4 Sb;
@@ -1755,17 +1714,17 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                             if (KEEPROWS && MODE == DFF_MODE_LANGEVIN && l == 0) s0keep = Sb;
                         }
                         head_rest(wave, Sb, ot);
-                        pf.tick(13); DFF_MARK(13); phase_prio<13>(wave);
+                        pf.tick(13); DFF_MARK(13);
                         const SSeq<U_WOX, 0, MW, KO, KO, KS, KS, E> sq{ss_wox(lw, wave), ss_wox(lw, wave), sn0, sn1};
                         const f32x4 (&o4)[4] = *reinterpret_cast<const f32x4 (*)[4]>(&ot[0]);
                         stallR_run<0, 2, E, true>(sring, acc_o, o4, sq, lane, wox_xa, wox_ext(lw, wave, lane), DFF_HEADS * 5 * 256);
-                        pf.tick(14); DFF_MARK(14); phase_prio<14>(wave);
+                        pf.tick(14); DFF_MARK(14);
                     } else {
                         u32x4 ah[KB32], am[KB32];
                         an_load(ah, am, lane);
                         const gfloat* const bp = (const gfloat*)lw.bqkvx + wave * 13 * 16 + 4 * quad;
                         f32x4 bq[2] = {*(const gf32x4*)bp, *(const gf32x4*)(bp + 16)};
-                        pf.tick(1); DFF_MARK(1); phase_prio<1>(wave);
+                        pf.tick(1); DFF_MARK(1);
                         const SSeq<U_QKV, U_WOX, MW, KQ, KO, KS, KS, E, 4 * KB32> sq{ss_qkv(lw, wave), ss_wox(lw, wave), sn0, sn1};   // tile 4 of 5: [u | s]
                         f32x4 qt[5];
                         swideT_from<0, 0, NQT, KB32>(sring, qt, bq, bp, ah, am, sq, lane);
@@ -1774,7 +1733,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #pragma unroll
                         for (int t = 0; t < 5; ++t) *(lf32x4*)(Qx + lroT + 16 * t + 4 * quad) = qt[t];
                         if (st_qkv) head_store<FOLD>(Qx, Kx, Vx, sb + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, RA, lane, RLA, XLD);
-                        pf.tick(12); DFF_MARK(12); phase_prio<12>(wave);
+                        pf.tick(12); DFF_MARK(12);
                         // S^T = n q'^T on the fp16 pipe: both operands are in registers already (the LayerNorm rows' pieces were this
                         // GEMM's A operand, q' is its output)
                         f32x4 Sb;
@@ -1794,10 +1753,10 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         if (KEEPROWS && MODE == DFF_MODE_LANGEVIN && l == 0) s0keep = Sb;
                         head_rest(wave, Sb, ot);
                         if constexpr (KEEP2) { if (keep2) keep2_copy(Qx, Qsave, true, lane, pcij); }
-                        pf.tick(13); DFF_MARK(13); phase_prio<13>(wave);
+                        pf.tick(13); DFF_MARK(13);
                         const f32x4 (&o4)[4] = *reinterpret_cast<const f32x4 (*)[4]>(&ot[0]);
                         stallR_run<U_QKV, 2, E, true>(sring, acc_o, o4, sq, lane, wox_xa, wox_ext(lw, wave, lane), DFF_HEADS * 5 * 256);
-                        pf.tick(14); DFF_MARK(14); phase_prio<14>(wave);
+                        pf.tick(14); DFF_MARK(14);
                     }
                 } else if constexpr (SPW) {
                     if (cached) {
@@ -1806,12 +1765,12 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                             head_fetch(hr, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, RA, true, lane);
                             head_commit(hr, Qx, Kx, Vx, pb, true, false, lane, RLA, XLD);
                         }
-                        pf.tick(12); DFF_MARK(12); phase_prio<12>(wave);
+                        pf.tick(12); DFF_MARK(12);
                         head_math(wave);
-                        pf.tick(13); DFF_MARK(13); phase_prio<13>(wave);
+                        pf.tick(13); DFF_MARK(13);
                         const SSeq<U_WOX, 0, MW, KO, KO, KS, KS, E> sq{ss_wox(lw, wave), ss_wox(lw, wave), sn0, sn1};
                         stall_run<0, 2, E, true>(sring, acc_o, wox_fa32, sq, lane, wox_xa, wox_ext(lw, wave, lane), DFF_HEADS * 5 * 256);
-                        pf.tick(14); DFF_MARK(14); phase_prio<14>(wave);
+                        pf.tick(14); DFF_MARK(14);
                     } else {
                         u32x4 ah[KB32], am[KB32], al[KB32];
                         a_load(ah, am, al, lane);
@@ -1821,7 +1780,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         lfloat* const wq = wr + col;
                         float bq[2][1];
                         bq[0][0] = bh[0]; bq[1][0] = bh[16];
-                        pf.tick(1); DFF_MARK(1); phase_prio<1>(wave);
+                        pf.tick(1); DFF_MARK(1);
                         const SSeq<U_QKV, U_WOX, MW, KQ, KO, KS, KS, E, 4 * KB32> sq{ss_qkv(lw, wave), ss_wox(lw, wave), sn0, sn1};   // tile 4 of 13: [u | s]
                         swide_run<0, NQT, KB32, 1>(sring, bq, ah, am, al, sq, lane,
                             [=](int t, float (&ax)[1]) { ax[0] = bh[t * 16]; },
@@ -1833,12 +1792,12 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                                 dl[l0] = v0; dl[l1] = v1; dl[l2] = v2; dl[l3] = v3;
                             });
                         if (st_qkv) head_store<FOLD>(Qx, Kx, Vx, sb + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, RA, lane, RLA, XLD);
-                        pf.tick(12); DFF_MARK(12); phase_prio<12>(wave);
+                        pf.tick(12); DFF_MARK(12);
                         head_math(wave);
                         if constexpr (KEEP2) { if (keep2) keep2_copy(Qx, Qsave, true, lane, pcij); }
-                        pf.tick(13); DFF_MARK(13); phase_prio<13>(wave);
+                        pf.tick(13); DFF_MARK(13);
                         stall_run<U_QKV, 2, E, true>(sring, acc_o, wox_fa32, sq, lane, wox_xa, wox_ext(lw, wave, lane), DFF_HEADS * 5 * 256);
-                        pf.tick(14); DFF_MARK(14); phase_prio<14>(wave);
+                        pf.tick(14); DFF_MARK(14);
                     }
                 } else if (cached) {
                     // layer-0 q_ext / k / v are x-independent and t is fixed: re-read, no GEMM
@@ -1890,28 +1849,28 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     };
                     float bq[DR][1];
                     qkv_bias(std::integral_constant<int, 0>{}, wave, bq);
-                    pf.tick(1); DFF_MARK(1); phase_prio<1>(wave);
+                    pf.tick(1); DFF_MARK(1);
                     if constexpr (HPW == 2) {
                         qkv(std::integral_constant<int, 0>{}, wave, bq, s_wox(lw, wave));
-                        pf.tick(12); DFF_MARK(12); phase_prio<12>(wave);
+                        pf.tick(12); DFF_MARK(12);
                         qkv_bias(std::integral_constant<int, 2>{}, wave + 4, bq);
                         head_math(wave);
-                        pf.tick(13); DFF_MARK(13); phase_prio<13>(wave);
+                        pf.tick(13); DFF_MARK(13);
                         tall_run<1, 5, E, 4>(ring, acc_o, wox_fa, s_wox(lw, wave), s_qkv(lw, wave + 4), lane);
-                        pf.tick(14); DFF_MARK(14); phase_prio<14>(wave);
+                        pf.tick(14); DFF_MARK(14);
                         qkv(std::integral_constant<int, 2>{}, wave + 4, bq, s_wox(lw, wave + 4));
-                        pf.tick(12); DFF_MARK(12); phase_prio<12>(wave);
+                        pf.tick(12); DFF_MARK(12);
                         head_math(wave + 4);
-                        pf.tick(13); DFF_MARK(13); phase_prio<13>(wave);
+                        pf.tick(13); DFF_MARK(13);
                         tall_run<3, 5, E, 4>(ring, acc_o, wox_fa, s_wox(lw, wave + 4), after, lane);   // ends at phase 0
-                        pf.tick(14); DFF_MARK(14); phase_prio<14>(wave);
+                        pf.tick(14); DFF_MARK(14);
                     } else {
                         qkv(std::integral_constant<int, 0>{}, wave, bq, s_wox(lw, wave));
-                        pf.tick(12); DFF_MARK(12); phase_prio<12>(wave);
+                        pf.tick(12); DFF_MARK(12);
                         head_math(wave);
-                        pf.tick(13); DFF_MARK(13); phase_prio<13>(wave);
+                        pf.tick(13); DFF_MARK(13);
                         tall_run<13 % DR, 5, E, 4>(ring, acc_o, wox_fa, s_wox(lw, wave), after, lane);       // 18 entries: phase 0
-                        pf.tick(14); DFF_MARK(14); phase_prio<14>(wave);
+                        pf.tick(14); DFF_MARK(14);
                         static_assert(18 % DR == 0, "ring phase");
                     }
                 }
@@ -1919,7 +1878,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 for (int nt = 0; nt < E; ++nt) c_store_offs(mypart, mro, 16 * nt, acc_o[nt], lane);
             }
             __syncthreads();
-            pf.tick(2); DFF_MARK(2); phase_prio<2>(wave);
+            pf.tick(2); DFF_MARK(2);
             // ---- row stage B: attn_out = sum_w part + bo ; gate1 ; LN2 -> abuf ----
             { DFF_ROW_CONSTS
             if (ract) {
@@ -1952,7 +1911,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             if constexpr (DFF_XI_STAGE == 1) { if (l == 0) draw_xi(t_int, step); }
             else { if (l == 0 && skipA) draw_xi(t_int, step); }   // (no stage A to draw under)
             __syncthreads();
-            pf.tick(3); DFF_MARK(3); phase_prio<3>(wave);
+            pf.tick(3); DFF_MARK(3);
             // ---- FFN: wave w owns hidden columns [w H, (w+1) H) ----
             {
                 DFF_LANE_CONSTS
@@ -1996,10 +1955,10 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     } else if constexpr (SPW) {
                         u32x4 ah[KB32], am[KB32], al[KB32];
                         a_load(ah, am, al, lane);
-                        pf.tick(19); DFF_MARK(19); phase_prio<19>(wave);
+                        pf.tick(19); DFF_MARK(19);
                         if (lastl) swide_run<0, NTS, KB32, 1>(sring, b1r, ah, am, al, sqf_last, lane, w1_pre, w1_epi);
                         else swide_run<0, NTS, KB32, 1>(sring, b1r, ah, am, al, sqf_next, lane, w1_pre, w1_epi);
-                        pf.tick(20); DFF_MARK(20); phase_prio<20>(wave);
+                        pf.tick(20); DFF_MARK(20);
                     } else
                     wide_run<0, NTS, E, 1>(ring, b1r, afr, s_w1(lw), s_w2(lw), lane, w1_pre, w1_epi);
                 }
@@ -2017,7 +1976,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         a_load(ah, am, al, lane);
                         const gfloat* const b1q = (const gfloat*)lw.b1 + wave * FS + 4 * quad;
                         f32x4 bq[2] = {*(const gf32x4*)b1q, *(const gf32x4*)(b1q + 16)};
-                        pf.tick(19); DFF_MARK(19); phase_prio<19>(wave);
+                        pf.tick(19); DFF_MARK(19);
                         f32x4 ht[2], gd[2];
                         if (lastl) swideT_from<0, 0, NTS, KB32>(sring, ht, bq, b1q, ah, am, sqf_last, lane);
                         else swideT_from<0, 0, NTS, KB32>(sring, ht, bq, b1q, ah, am, sqf_next, lane);
@@ -2028,7 +1987,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         lfloat* const gq = gp_lds ? gp_tile(l, m.L) + min(col, LL::GPR - 1) * LL::GPS : hbuf + 16 * LF + col * LF;
                         *(lf32x4*)(gq + 4 * quad) = gd[0];
                         *(lf32x4*)(gq + 16 + 4 * quad) = gd[1];
-                        pf.tick(20); DFF_MARK(20); phase_prio<20>(wave);
+                        pf.tick(20); DFF_MARK(20);
                         if (lastl) stallR_run<U_W1, 1, E, false>(sring, acc_f, ht, sqf_last, lane);
                         else stallR_run<U_W1, 1, E, false>(sring, acc_f, ht, sqf_next, lane);
                     } else if constexpr (SPW) {
@@ -2036,7 +1995,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         else stall_run<U_W1, FS / 32, E, false>(sring, acc_f, [=](int kb) { return ha + 32 * kb; }, sqf_next, lane);
                     }
                     else tall_run<NTS % DR, NTS, E, -1>(ring, acc_f, [=](int kb) { return ha + 16 * kb; }, s_w2(lw), after, lane);
-                    pf.tick(21); DFF_MARK(21); phase_prio<21>(wave);
+                    pf.tick(21); DFF_MARK(21);
                     // gelu'(h_pre) rows of this wave's hidden slice: LDS tile -> stash, 16 bytes per lane (rows beyond the real
                     // ones go to the dummy stash row); before the partial sums below reuse the tile
                     if (!gp_lds) {
@@ -2054,7 +2013,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 for (int nt = 0; nt < E; ++nt) c_store_offs(mypart, mro, 16 * nt, acc_f[nt], lane);
             }
             __syncthreads();
-            pf.tick(4); DFF_MARK(4); phase_prio<4>(wave);
+            pf.tick(4); DFF_MARK(4);
             // ---- row stage C: ff = sum_w part + b2 ; gate2 ; next layer's LN1 or the energy head ----
             { DFF_ROW_CONSTS
             if (ract) {
@@ -2125,7 +2084,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             // the stash written in the forward pass is re-read below by other lanes / waves
             if (l == m.L - 1) __threadfence_block();
             __syncthreads();
-            pf.tick(5); DFF_MARK(5); phase_prio<5>(wave);
+            pf.tick(5); DFF_MARK(5);
         }
 
         // =============================== backward ===============================
@@ -2194,7 +2153,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             }
             __syncthreads();
             }
-            pf.tick(6); DFF_MARK(6); phase_prio<6>(wave);
+            pf.tick(6); DFF_MARK(6);
             // ---- FFN backward slice: dh = dff W2[:, slice] ; * gelu'(h_pre) ; partial df = dh_pre W1[slice, :] ----
             {
                 DFF_LANE_CONSTS
@@ -2279,7 +2238,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 for (int nt = 0; nt < E; ++nt) c_store_offs(mypart, mro, 16 * nt, acc_f[nt], lane);
             }
             __syncthreads();
-            pf.tick(7); DFF_MARK(7); phase_prio<7>(wave);
+            pf.tick(7); DFF_MARK(7);
             // first head of this layer's attention backward: start the stash read (hidden by row stage E)
             if constexpr (HDMA) {
                 if (!(KEEP_LAST && l == m.L - 1 && l > 0) && !(KEEP2 && l == m.L - 2 && l > 0 && MODE != DFF_MODE_SCORE))
@@ -2302,11 +2261,11 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #pragma unroll
                     for (int i = 0; i < HC; ++i) ps[i] *= invD;
                 }
-                pf.tick(22); DFF_MARK(22); phase_prio<22>(wave);
+                pf.tick(22); DFF_MARK(22);
                 float g1;
                 if constexpr (KEEPROWS) g1 = gate_get(l, std::integral_constant<int, 0>{});
                 else g1 = ro_gate(ao, ni, 3);
-                pf.tick(23); DFF_MARK(23); phase_prio<23>(wave);
+                pf.tick(23); DFF_MARK(23);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) n1[i] = ao[i] * g1 + ni[i] * (1.0f - g1);
                 float mean, rstd;
@@ -2368,7 +2327,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 }
             } }
             __syncthreads();
-            pf.tick(8); DFF_MARK(8); phase_prio<8>(wave);
+            pf.tick(8); DFF_MARK(8);
             // ---- attention backward: wave w owns heads w and w+4 ----
             {
                 DFF_LANE_CONSTS
@@ -2529,7 +2488,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     const f32x4 gx4 = gt[4] * gi;
                     *(lf32x4*)(Gx + lroT + 64 + 4 * quad) = gx4;
                     if (quad == 0) dxT -= gx4;
-                    pf.tick(15); DFF_MARK(15); phase_prio<15>(wave);
+                    pf.tick(15); DFF_MARK(15);
                     // dA^T[j][i] = n_j . G_i (64 columns, fp16 pieces; in units of row i's scale) + x_j . r_i (fp32 k-step)
                     u32x4 nh[KB32], nl[KB32], gh[2], gl[2];
                     an_load(nh, nl, lane);
@@ -2549,13 +2508,10 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dS[r] = 0.125f * p4[r] * (dA[r] - sm);
                     *(lf32x4*)(dsb + col * DFF_PLD + 4 * quad) = dS;   // [i][j]: dK's operand
-                    pf.tick(16); DFF_MARK(16); phase_prio<16>(wave);
+                    pf.tick(16); DFF_MARK(16);
                     return dS;
                 };
-#ifndef DFF_RCB
-#define DFF_RCB 1
-#endif
-                if constexpr (NSP && DFF_RCB) {
+                if constexpr (NSP) {
                     if constexpr (HDMA) {
                         head_dma_wait();   // (requested before row stage E; nothing for the last layer)
                         if constexpr (KEEP2) {
@@ -2563,7 +2519,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                             if (l == 0 && m.L > 2 && MODE != DFF_MODE_SCORE && rows <= 10) p0_copy(false, pcij);
                         }
                     }
-                    pf.tick(8); DFF_MARK(8); phase_prio<8>(wave);
+                    pf.tick(8); DFF_MARK(8);
                     if (l > 0) {
                         const f32x4 dS = gds_T(sqa, true);
                         // dV_ext = P^T G_ext: v = n, so dV is a term of d(LayerNorm output); extension columns -> dx_j
@@ -2593,11 +2549,11 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                             if (nt < 4) acc_a[nt < 4 ? nt : 0] += acc;
                             else dxr += acc;
                         });
-                        pf.tick(17); DFF_MARK(17); phase_prio<17>(wave);
+                        pf.tick(17); DFF_MARK(17);
                         const f32x4 (&dq4)[4] = *reinterpret_cast<const f32x4 (*)[4]>(&dq[0]);
                         stallR_run<U_GX, NKT, E, true>(sring, acc_a, dq4, sqa, lane, Gx + col * XLD + 64 + quad, qkvt_ext(lw, wave, lane),
                                                        DFF_HEADS * 13 * 256, rsc);
-                        pf.tick(18); DFF_MARK(18); phase_prio<18>(wave);
+                        pf.tick(18); DFF_MARK(18);
 #pragma unroll
                         for (int nt = 0; nt < E; ++nt) c_store_offs(mypart, mro, 16 * nt, acc_a[nt], lane);
                     } else {
@@ -2621,7 +2577,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 auto m12p = [&](int h) -> const gfloat* { return GEN ? sb + sl.m12 + h * 64 : nullptr; };
                 auto committed = [&]() { if constexpr (GEN) { m_cur = hr.m; fix_q(lane); } };
                 auto gfix = [&]() { if constexpr (GEN) fix_g(lane, m_cur); };
-                if constexpr (NSP && DFF_RCB) {
+                if constexpr (NSP) {
                     // (done above)
                 } else
                 if (l > 0 || full0) {
@@ -2629,27 +2585,27 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA, XLD);
                         committed();
                         head_fetch(hr, sbq + sl.qkv + (size_t)h1 * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)h1 * 256, RA, true, lane, m12p(h1));
-                        pf.tick(8); DFF_MARK(8); phase_prio<8>(wave);
+                        pf.tick(8); DFF_MARK(8);
                         gext(std::integral_constant<int, 0>{}, wave, s_qkvt(lw, wave));
                         gfix();
-                        pf.tick(15); DFF_MARK(15); phase_prio<15>(wave);
+                        pf.tick(15); DFF_MARK(15);
                         ds_math();
-                        pf.tick(16); DFF_MARK(16); phase_prio<16>(wave);
+                        pf.tick(16); DFF_MARK(16);
                         dqkv();
-                        pf.tick(17); DFF_MARK(17); phase_prio<17>(wave);
+                        pf.tick(17); DFF_MARK(17);
                         tall_run<1, 13, E, 4>(ring, acc_a, qkvt_fa, s_qkvt(lw, wave), s_woxt(lw, h1), lane);
-                        pf.tick(18); DFF_MARK(18); phase_prio<18>(wave);
+                        pf.tick(18); DFF_MARK(18);
                         head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA, XLD);
                         committed();
                         gext(std::integral_constant<int, 2>{}, h1, s_qkvt(lw, h1));
                         gfix();
-                        pf.tick(15); DFF_MARK(15); phase_prio<15>(wave);
+                        pf.tick(15); DFF_MARK(15);
                         ds_math();
-                        pf.tick(16); DFF_MARK(16); phase_prio<16>(wave);
+                        pf.tick(16); DFF_MARK(16);
                         dqkv();
-                        pf.tick(17); DFF_MARK(17); phase_prio<17>(wave);
+                        pf.tick(17); DFF_MARK(17);
                         tall_run<3, 13, E, 4>(ring, acc_a, qkvt_fa, s_qkvt(lw, h1), after, lane);   // ends at phase 0
-                        pf.tick(18); DFF_MARK(18); phase_prio<18>(wave);
+                        pf.tick(18); DFF_MARK(18);
                     } else {
                         if constexpr (HDMA) {
                             head_dma_wait();   // (requested before row stage E; nothing for the last layer)
@@ -2660,19 +2616,19 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                             head_commit(hr, Qx, Kx, Vx, pb, true, true, lane, RLA, XLD);
                         }
                         committed();
-                        pf.tick(8); DFF_MARK(8); phase_prio<8>(wave);
+                        pf.tick(8); DFF_MARK(8);
                         if constexpr (SPW) sgext(sqa);
                         else gext(std::integral_constant<int, 0>{}, wave, s_qkvt(lw, wave));
                         gfix();
-                        pf.tick(15); DFF_MARK(15); phase_prio<15>(wave);
+                        pf.tick(15); DFF_MARK(15);
                         ds_math();
-                        pf.tick(16); DFF_MARK(16); phase_prio<16>(wave);
+                        pf.tick(16); DFF_MARK(16);
                         dqkv();
-                        pf.tick(17); DFF_MARK(17); phase_prio<17>(wave);
+                        pf.tick(17); DFF_MARK(17);
                         if constexpr (SPW) stall_run<U_GX, NKT, E, true>(sring, acc_a, qkvt_fa32, sqa, lane, qkvt_xa, qkvt_ext(lw, wave, lane), DFF_HEADS * 13 * 256,
                                                                          F16E ? rsc : nullptr, !FOLD);   // (dQ' rows re-scaled by their dattn row's scale; unfolded: [dQ | dK | dV] by one common scale)
                         else tall_run<5 % DR, 13, E, 4>(ring, acc_a, qkvt_fa, s_qkvt(lw, wave), after, lane);   // 18 entries: phase 0
-                        pf.tick(18); DFF_MARK(18); phase_prio<18>(wave);
+                        pf.tick(18); DFF_MARK(18);
                     }
 #pragma unroll
                     for (int nt = 0; nt < E; ++nt) c_store_offs(mypart, mro, 16 * nt, acc_a[nt], lane);
@@ -2751,7 +2707,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 }
             }
             __syncthreads();
-            pf.tick(9); DFF_MARK(9); phase_prio<9>(wave);
+            pf.tick(9); DFF_MARK(9);
             // ---- row stage F: dn = dn_in partial + LN1 backward(sum_w part)  (l > 0) ----
             // operands: ro[1] nodes_in, ro[2] ln1 gamma
             if (l > 0 || full0) {
@@ -2797,7 +2753,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 }
                 __syncthreads();
             }
-            pf.tick(10); DFF_MARK(10); phase_prio<10>(wave);
+            pf.tick(10); DFF_MARK(10);
         }
         { const int tq = tid_id();   // (opaque: the per-lane addresses below are re-derived every step, not hoisted and spilled)
         // dxs = sum of the waves' partial x-gradients (the force head wrote dxs itself); supplied / not yet drawn noise -> xib
@@ -2951,7 +2907,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             __syncthreads();
             if (tid < gcnt * 4 && (tid & 3) < 3 && !(fabsf(cm[tid]) < 1e-3f)) atomicOr(a.clamp_flag, 2);
         }
-        pf.tick(11); DFF_MARK(11); phase_prio<11>(wave);
+        pf.tick(11); DFF_MARK(11);
     }
     if (pf.on)
         for (int i = 0; i < DFF_NPROF; ++i) a.prof[i] = pf.acc[i];
