@@ -435,7 +435,9 @@ def main():
             # chignolin_langevin_fp32_engine: the headline workload with every weight GEMM on the fp32 matrix pipe (DFF_SPLIT_BF16=0)
             for name, c2, P2, ch2, nt, f32e in (("villin_langevin", "villin", 256, 250, MIN_LAUNCHES, False),
                                                 ("protein_g_langevin", "protein_g", 128, 250, MIN_LAUNCHES, False),
-                                                ("chignolin_langevin_fp32_engine", "chignolin", 256, 250, MIN_LAUNCHES, True)):
+                                                ("chignolin_langevin_fp32_engine", "chignolin", 256, 250, MIN_LAUNCHES, True),
+                                                # the reference's published protocol: --parallel_sim 100 (evaluate/sampling_commands.md:13)
+                                                ("chignolin_langevin_p100", "chignolin", 100, 250, MIN_LAUNCHES, False)):
                 e = langevin_entry(c2, P2, ch2, 1, nt, dev, rank, world, fp32_engine=f32e)
                 also[name] = {
                     "workload": f"{c2} ({e['N']} beads, H={e['H']}, L={e['L']}) Langevin, {P2}/GPU" + (", DFF_SPLIT_BF16=0" if f32e else ""),

@@ -881,12 +881,15 @@ if int(os.environ["RANK"]) == 0:
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["iid", "langevin"])
-def test_two_ranks_on_one_gpu_equal_one_rank(dff, tmp_path, mode):
+def test_two_ranks_on_one_gpu_equal_one_rank(dff, tmp_path, mode, monkeypatch):
     import socket
     import subprocess
     import sys
     from dff_amd import cli
     params, (N, H, L) = _write_model_dir(tmp_path, "chignolin")
+    # (ranks that share a GPU run the one-workgroup kernels -- sampling.dist_env, DFF_PAIR=0 -- and so does the one-rank reference
+    # here: the two-workgroups variants sum a protein's heads in another order)
+    monkeypatch.setenv("DFF_PAIR", "0")
     argv = ["--model_path", str(tmp_path), "--gen_mode", mode, "--seed", "5", "--batch_size_gen", "4"]
     argv += (["--num_samples_eval", "12"] if mode == "iid" else
              ["--parallel_sim", "6", "--n_timesteps", "20", "--save_interval", "5", "--masses", "[12.0]*10"])
@@ -1279,3 +1282,68 @@ def test_pair_variant_equals_one_workgroup_variant(dff, cfg, golden):
         assert rel(runs[0], model.native.score(xb, tb).cpu().numpy()) <= 5e-6
     finally:
         model.native.pair(True)
+
+
+@pytest.mark.gpu
+def test_small_kernel_two_workgroups_per_protein(dff, monkeypatch):
+    """Round 6: the <= 16-row FOLD kernel as TWO workgroups per protein for per-GPU batches that leave half
+    the CUs idle (the reference's published protocol is --parallel_sim 100, evaluate/sampling_commands.md:13).  Blocks b and b + 8
+    own heads / FFN slices 0-3 and 4-7 on four waves each and exchange the row stages' partial sums + the final dE/dx.  Fused
+    Langevin and reverse-DDPM runs at 100 per GPU against the one-workgroup kernel and against the twin (float64) on a subset;
+    the exchange protocols (same XCD; agent scope forced; partners really on different XCDs) give the same bits; repeated
+    launches are identical; past 128 per GPU the one-workgroup kernel runs by itself.  Measured: no faster than one workgroup per
+    protein (45.8 vs 44.4 us per step at 128 per GPU, profiles/r06/pair_small/) -- the variant is opt-in, DFF_SMALL_PAIR=1."""
+    from dff_amd.langevin import LangevinDiffusion
+    monkeypatch.setenv("DFF_SMALL_PAIR", "1")
+    diff, params = _diffusion(dff, "chignolin", decoder_scale=1e-2, norm=NORM_STD["chignolin"])
+    nat = diff.model.native
+    _, N, H, L = synth.SHIPPED_CONFIGS["chignolin"]
+    P, K = 100, 8
+    x0 = synth.normal((P, N, 3), 31, 5).astype(np.float32)
+    x0 = (x0 - x0.mean(1, keepdims=True)) * NORM_STD["chignolin"]
+    noises = synth.normal((K, P, N, 3), 32, 5).astype(np.float32)
+    masses = [12.0] * N
+
+    def run(pair):
+        nat.pair(pair)
+        ld = LangevinDiffusion(diff, torch.from_numpy(x0), K, save_interval=2, t=20, temp_data=340, temp_sim=340, dt=None,
+                               masses=masses, friction=1.0, verbose=False)
+        out = ld.sample(noises=torch.from_numpy(noises)).numpy().reshape(P, K // 2, N, 3)
+        return out, nat.last_launch()
+    try:
+        out = {}
+        for on in (True, 2, 3, False):
+            out[on], (kname, grid, _) = run(on)
+            assert ("pair" in kname) == bool(on) and "fold_kv" in kname, kname
+            assert grid == (2 * 8 * 13 if on else P) and nat.pair_status() == 0, (on, grid)
+            assert np.isfinite(out[on]).all()
+        assert np.array_equal(out[True], out[2]) and np.array_equal(out[True], out[3])
+        assert np.abs(out[True] - out[False]).max() <= STEP_TOL * K * np.abs(out[False]).max()
+        again, _ = run(True)
+        assert np.array_equal(again, out[True])
+        # against the twin in float64 on the first, a middle and the last trajectories
+        sub = [0, 1, 49, 98, 99]
+        c = twin.langevin_constants(NORM_STD["chignolin"], 20, twin.make_schedule(), 340, 340, masses, 1.0, None)
+        fr, _, _, _ = twin.simulate(twin.to_torch(params, torch.float64), torch.from_numpy(x0[sub]).double() / NORM_STD["chignolin"],
+                                    torch.from_numpy(noises[:, sub]).double(), masses, c, L, 2)
+        ref = (fr * NORM_STD["chignolin"]).numpy()
+        err = np.abs(out[True][sub] - ref).max() / np.abs(ref).max()
+        print(f"two workgroups per protein, {P} trajectories x {K} steps: rel err vs twin (float64) {err:.3e}")
+        assert err <= STEP_TOL * K
+        # in-kernel Philox noise + the reverse-DDPM loop (the layer-0 table has 1000 entries there)
+        nat.pair(True)
+        diff.seed(3)
+        y1 = diff.p_sample_loop_from(torch.from_numpy(x0[:37] / NORM_STD["chignolin"]), 11, 0).cpu().numpy()
+        assert "pair" in nat.last_launch()[0]
+        nat.pair(False)
+        diff.seed(3)
+        y0 = diff.p_sample_loop_from(torch.from_numpy(x0[:37] / NORM_STD["chignolin"]), 11, 0).cpu().numpy()
+        assert "pair" not in nat.last_launch()[0] and np.abs(y1 - y0).max() <= STEP_TOL * 12 * np.abs(y0).max()
+        # 129 .. : one workgroup per protein by itself
+        nat.pair(True)
+        ld = LangevinDiffusion(diff, torch.from_numpy(np.concatenate([x0, x0[:40]])), 2, save_interval=2, t=20, temp_data=340, temp_sim=340,
+                               dt=None, masses=masses, friction=1.0, verbose=False, seed=1)
+        ld.sample()
+        assert "pair" not in nat.last_launch()[0]
+    finally:
+        nat.pair(True)

@@ -549,11 +549,13 @@ const Variant* dff_fused_variants(int* count);                                  
 int dff_debug_gemm_launch(int K, const float* dA, const float* dW, int M, int Nout, float* dO, size_t lds);   // dff_kernels.hip
 // the <= 16-row kernel for (H, NW waves, input-branch variant, split-bf16 weight GEMMs); false if not built
 // (one translation unit per sampler mode, DFF_MODE_SCORE / LANGEVIN / DDPM = 0 / 1 / 2: dff_small.hip compiled three times)
-bool dff_small_pick_m0(int H, int NW, bool gen, bool spw, const void** fn, unsigned* lds_floats, const char** name, bool fold);
-bool dff_small_pick_m1(int H, int NW, bool gen, bool spw, const void** fn, unsigned* lds_floats, const char** name, bool fold);
-bool dff_small_pick_m2(int H, int NW, bool gen, bool spw, const void** fn, unsigned* lds_floats, const char** name, bool fold);
-inline bool dff_small_pick(int mode, int H, int NW, bool gen, bool spw, const void** fn, unsigned* lds_floats, const char** name, bool fold = false) {
-    return mode == 0 ? dff_small_pick_m0(H, NW, gen, spw, fn, lds_floats, name, fold)
-         : mode == 1 ? dff_small_pick_m1(H, NW, gen, spw, fn, lds_floats, name, fold)
-                     : dff_small_pick_m2(H, NW, gen, spw, fn, lds_floats, name, fold);
+// (pair: the two-workgroups-per-protein variant -- the FOLD kernel of the sampling loops only; 4 waves per workgroup)
+bool dff_small_pick_m0(int H, int NW, bool gen, bool spw, const void** fn, unsigned* lds_floats, const char** name, bool fold, bool pair);
+bool dff_small_pick_m1(int H, int NW, bool gen, bool spw, const void** fn, unsigned* lds_floats, const char** name, bool fold, bool pair);
+bool dff_small_pick_m2(int H, int NW, bool gen, bool spw, const void** fn, unsigned* lds_floats, const char** name, bool fold, bool pair);
+inline bool dff_small_pick(int mode, int H, int NW, bool gen, bool spw, const void** fn, unsigned* lds_floats, const char** name, bool fold = false,
+                           bool pair = false) {
+    return mode == 0 ? dff_small_pick_m0(H, NW, gen, spw, fn, lds_floats, name, fold, pair)
+         : mode == 1 ? dff_small_pick_m1(H, NW, gen, spw, fn, lds_floats, name, fold, pair)
+                     : dff_small_pick_m2(H, NW, gen, spw, fn, lds_floats, name, fold, pair);
 }

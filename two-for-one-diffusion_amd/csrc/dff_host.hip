@@ -807,7 +807,25 @@ static int ensure_stash(dff_model* m, size_t need) {
 }
 
 // rows <= 16: one-head-per-wave kernel (dff_small.hip)
-static int launch_small(dff_model* m, DffRunArgs& a, int G, hipStream_t stream) {
+static int ensure_pair_buffers(dff_model* m, int npairs, size_t need, hipStream_t stream);
+// pair: two workgroups per protein (dff_small_kernel<..., PAIR>: blocks b and b + 8 share a protein, 16 blocks per 8 proteins, ONE
+// launch -- the caller has checked that every block gets a CU of its own)
+static bool small_pair_available(const dff_model* m, int mode, int G) {
+    const int N = m->cfg.n_beads, H = m->cfg.hidden;
+    const void* fn; unsigned lds; const char* name;
+    const bool gen = !(m->cfg.use_intrinsic_coords == 1 && m->cfg.use_distances == 0 && m->cfg.use_abs_coords == 0);
+    // OPT-IN (DFF_SMALL_PAIR=1, read per launch): built and measured in round 6 -- chignolin at 128 / 100 / 32 per GPU 45.8 / 45.9 / 45.4 us
+    // per step against 44.4 with one workgroup per protein.  The wave-private blocks do shrink (-19 k cycles per step: four waves,
+    // one per SIMD), but each of the 12 exchanges costs ~1.8 k cycles inside its row stage -- a store's s_waitcnt vmcnt(0) also
+    // waits for the weight units the wave has just requested for the next block (loads and stores retire through one in-order
+    // counter), 0.25 - 0.45 us in tools_ubench/pair_exchange.hip without that -- and the 16-lanes-per-row stages issue more per thread
+    // (profiles/r06/pair_small/).  Kept as a tested variant; not the default.
+    const char* const en = getenv("DFF_SMALL_PAIR");
+    if (!(en && en[0] == '1')) return false;
+    return H == 64 && G * N <= 10 && m->small_waves == 0 && m->small_split && m->fold_kv && !gen && m->cfg.conservative &&
+           dff_small_pick(mode, H, 8, false, true, &fn, &lds, &name, true, true);
+}
+static int launch_small(dff_model* m, DffRunArgs& a, int G, hipStream_t stream, bool pair = false) {
     const int N = m->cfg.n_beads, H = m->cfg.hidden, L = m->cfg.n_layers;
     const void* fn; unsigned lds; const char* name; int nthreads = 256;
     // 8 waves (two per SIMD, one head per wave) when the rows fit its 11-row head buffers
@@ -815,16 +833,25 @@ static int launch_small(dff_model* m, DffRunArgs& a, int G, hipStream_t stream) 
     const bool gen = !(m->cfg.use_intrinsic_coords == 1 && m->cfg.use_distances == 0 && m->cfg.use_abs_coords == 0);
     const int NW = eight ? 8 : 4;
     const bool spw = eight && m->small_split;
-    if (!dff_small_pick(a.mode, H, NW, gen, spw, &fn, &lds, &name, m->fold_kv))
+    if (!dff_small_pick(a.mode, H, NW, gen, spw, &fn, &lds, &name, m->fold_kv, pair))
         return fail(DFF_EINVAL, "no <= 16-row kernel for hidden=%d waves=%d in this build", H, NW);
-    nthreads = NW * 64;
+    nthreads = pair ? 256 : NW * 64;
     lds *= (unsigned)sizeof(float);
     if (lds > 160 * 1024) return fail(DFF_EINVAL, "LDS budget exceeded (%u bytes)", lds);
-    const int grid_all = (a.B + G - 1) / G;
-    const int grid_max = grid_all < m->max_wgs ? grid_all : m->max_wgs;
+    const int ngroups = (a.B + G - 1) / G;
+    const int npairs = pair ? 8 * ((ngroups + 7) / 8) : 0;
+    const int grid_all = pair ? 2 * npairs : ngroups;
+    const int grid_max = pair ? grid_all : (grid_all < m->max_wgs ? grid_all : m->max_wgs);
     const SmallStash sl = dff_small_stash(N, G, H, L);
     int rc = ensure_stash(m, (size_t)grid_max * sl.total);
     if (rc) return rc;
+    a.xchg = nullptr; a.xflag = nullptr; a.xpairs = npairs; a.xslow = m->pair_slow;
+    if (pair) {
+        rc = ensure_pair_buffers(m, npairs, (size_t)npairs * 4 * 1024, stream);   // [pair][half][parity][256 threads x 4 floats]
+        if (rc) return rc;
+        a.xchg = m->xchg; a.xflag = m->xflag;
+    }
+    m->last_pair = pair;
     a.G = G;
     a.prof = m->prof_on ? m->prof : nullptr;
     a.prof_wave = m->prof_wave < NW ? m->prof_wave : 0;
@@ -835,7 +862,7 @@ static int launch_small(dff_model* m, DffRunArgs& a, int G, hipStream_t stream) 
     // same stash), each over the whole step range
     for (int w0 = 0; w0 < grid_all; w0 += grid_max) {
         const int grid = grid_all - w0 < grid_max ? grid_all - w0 : grid_max;
-        a.b_base = w0 * G;
+        a.b_base = pair ? 0 : w0 * G;
         void* args[] = {(void*)&m->dev, (void*)&a};
         HIPCHK(hipLaunchKernel(fn, dim3(grid), dim3(nthreads), args, lds, stream));
         m->last_grid = grid; m->last_base = a.b_base;
@@ -843,6 +870,28 @@ static int launch_small(dff_model* m, DffRunArgs& a, int G, hipStream_t stream) 
     }
     m->last_kernel = name; m->last_lds = (int)lds; m->last_G = G; m->last_B = a.B;
     m->last_stride = sl.total; m->last_small = true;
+    return DFF_OK;
+}
+
+// PAIR launches (either kernel): the exchange slots (`need` floats) and the flag words -- error word, [pair][half] sequence flags,
+// [pair][half] XCD ids; the sequence numbers restart at every launch, the error word at [0] is NOT touched
+static int ensure_pair_buffers(dff_model* m, int npairs, size_t need, hipStream_t stream) {
+    const size_t nflag = (size_t)4 * npairs + 1;
+    if (need > m->xchg_floats) {
+        if (m->xchg) HIPCHK(hipFree(m->xchg));
+        m->xchg = nullptr; m->xchg_floats = 0;
+        HIPCHK(hipMalloc((void**)&m->xchg, need * sizeof(float)));
+        m->xchg_floats = need;
+    }
+    if (!m->xflag) {   // once per model, sized for the largest grid a PAIR launch can have (one block per CU): no
+                       // re-allocation -- and so no synchronisation -- on the launch path afterwards
+        const size_t cap = 2 * (size_t)(m->n_cus > 256 ? m->n_cus : 256) + 1;   // 4 words per pair, at most n_cus / 2 pairs
+        HIPCHK(hipMalloc((void**)&m->xflag, cap * sizeof(unsigned)));
+        HIPCHK(hipMemsetAsync(m->xflag, 0, sizeof(unsigned), stream));
+        m->xflag_n = cap;
+    }
+    if (nflag > m->xflag_n) return fail(DFF_EINVAL, "PAIR grid of %d pairs exceeds the flag array", npairs);
+    HIPCHK(hipMemsetAsync(m->xflag + 1, 0, (nflag - 1) * sizeof(unsigned), stream));
     return DFF_OK;
 }
 
@@ -861,23 +910,8 @@ static int launch_generic(dff_model* m, DffRunArgs& a, int G, const Variant* v, 
     { int rc = ensure_stash(m, (size_t)grid_max * sl.total); if (rc) return rc; }
     a.xchg = nullptr; a.xflag = nullptr; a.xpairs = npairs; a.xslow = m->pair_slow;
     if (v->pair) {
-        const size_t need = (size_t)npairs * 4 * (size_t)(G * N) * (H + 4), nflag = (size_t)4 * npairs + 1;   // error word, [pair][half] sequence flags, [pair][half] XCD ids
-        if (need > m->xchg_floats) {
-            if (m->xchg) HIPCHK(hipFree(m->xchg));
-            m->xchg = nullptr; m->xchg_floats = 0;
-            HIPCHK(hipMalloc((void**)&m->xchg, need * sizeof(float)));
-            m->xchg_floats = need;
-        }
-        if (!m->xflag) {   // once per model, sized for the largest grid a PAIR launch can have (one block per CU): no
-                           // re-allocation -- and so no synchronisation -- on the launch path afterwards
-            const size_t cap = 2 * (size_t)(m->n_cus > 256 ? m->n_cus : 256) + 1;   // 4 words per pair, at most n_cus / 2 pairs
-            HIPCHK(hipMalloc((void**)&m->xflag, cap * sizeof(unsigned)));
-            HIPCHK(hipMemsetAsync(m->xflag, 0, sizeof(unsigned), stream));
-            m->xflag_n = cap;
-        }
-        if (nflag > m->xflag_n) return fail(DFF_EINVAL, "PAIR grid of %d pairs exceeds the flag array", npairs);
-        // sequence numbers restart at every launch; the error word at [0] is NOT touched
-        HIPCHK(hipMemsetAsync(m->xflag + 1, 0, (nflag - 1) * sizeof(unsigned), stream));
+        const int rc = ensure_pair_buffers(m, npairs, (size_t)npairs * 4 * (size_t)(G * N) * (H + 4), stream);
+        if (rc) return rc;
         a.xchg = m->xchg; a.xflag = m->xflag;
     }
     m->last_small = false;
@@ -1012,7 +1046,14 @@ static int launch(dff_model* m, DffRunArgs& a, hipStream_t stream) {
             int rc = ensure_l0_table(m, a.mode == DFF_MODE_DDPM ? 2 : 1, a.t_norm, G, nullptr, stream, &a.l0_tab);
             if (rc) return rc;
         }
-        return launch_small(m, a, G, stream);
+        // Two workgroups per protein when one per protein would leave at least half the CUs idle (round 6: the reference's published
+        // protocol runs 100 trajectories, evaluate/sampling_commands.md:13; config 2 over 8 GPUs is 32 per GPU) -- same conditions as
+        // the <= 64-row PAIR variants below: the whole grid resident one block per CU, no failure word seen, not switched off.
+        const int cu_cap_s = m->n_cus < m->max_wgs ? m->n_cus : m->max_wgs;
+        const int ngr_s = (a.B + G - 1) / G;
+        const bool spair = a.mode != DFF_MODE_SCORE && !m->pair_off && !m->sticky && 2 * 8 * ((ngr_s + 7) / 8) <= cu_cap_s &&
+                           small_pair_available(m, a.mode, G);
+        return launch_small(m, a, G, stream, spair);
     }
     const Variant* v = nullptr;
     auto pick = [&](int mt_) {

@@ -46,7 +46,9 @@
 // regions in 160 KB the head buffers hold RLA = 11 rows (10 real + 1 dummy row that absorbs the
 // pad lanes' stores; MFMA operand reads of rows 11..15 run into the next buffer, which is finite
 // data multiplied by exact zeros of P / dS or landing in discarded output rows).
-template <int H, int NW, bool FOLD = false>
+// NWR: the waves that are really there.  PAIR variant (round 6: two workgroups per protein, FOLD kernel only): NW = 8 stays the
+// DECOMPOSITION (eight heads, eight FFN slices, the 11-row layout), each workgroup runs four of them on NWR = 4 waves.
+template <int H, int NW, bool FOLD = false, int NWR = NW>
 struct SmallLds {
     static constexpr int LH = H + 4;
     static constexpr int RLA = NW == 4 ? 16 : 11;
@@ -75,7 +77,7 @@ struct SmallLds {
     static constexpr int DMA_N = FOLD ? 6 : 13;      // head_dma: global_load_lds instructions per head ([Q | P] or [Q | K | V | P])
     static constexpr unsigned xst = 0, xs = 64, dxs = 128, vst = 192, cm = 256, tn = 384, prof = 400,
                               dxw = 448,                      // [NW][128] per-wave dx partials (+ dummies)
-                              abuf = 448 + NW * 128, resbuf = abuf + (FOLD ? 0 : 16 * LH),
+                              abuf = 448 + NWR * 128, resbuf = abuf + (FOLD ? 0 : 16 * LH),
                               // SPW variants (8 waves): the K = H GEMM input as bf16 pieces, written by the row stages:
                               // [piece 3][k-block H/32][kg 4][row 16][4 dwords] -- a wave's ds_read_b128 of (row, kg)
                               // then touches 16 rows x 4 dwords = every bank once, whatever the lane group
@@ -88,7 +90,7 @@ struct SmallLds {
                               nsp = dmatab + dmatab_size, nsp_size = FOLD ? 2 * (H / 32) * 256 : 0,
                               // (nx stays in front of the wave regions: operand reads of its rows 11..15 land in wave 0's Q region, fp32 data)
                               nx = nsp + nsp_size, nx_size = FOLD ? RS : 0,
-                              wreg = nx + nx_size, total = wreg + NW * WREG + 64;
+                              wreg = nx + nx_size, total = wreg + NWR * WREG + 64;
     static_assert(!FOLD || total * 4 <= 160 * 1024, "LDS budget");
 };
 
@@ -848,12 +850,21 @@ DEVI void head_dma(const lu32* tab, const lfloat* Qx /* wave-uniform; the region
 // and their mode tests inside one step loop the register allocator and the scheduler paid for all of them everywhere
 // (the Langevin step ran 1.5 us slower next to the reverse-DDPM update's code than without it); each mode is its own
 // translation unit (build.sh compiles this file three times, -DDFF_SMALL_MODE=0|1|2).
-template <int H, int NW, bool GEN, bool SPW, bool FOLD, int MODE>
-__global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m, const DffRunArgs a) {
+// PAIR (round 6; FOLD kernel on the fp16 engine): TWO workgroups per protein for per-GPU batches that leave half the CUs idle
+// (the reference's published protocol is --parallel_sim 100, evaluate/sampling_commands.md:13; BASELINE config 2 over 8 GPUs is 32 per
+// GPU).  Blocks b and b + 8 (one XCD under the observed placement) own heads / FFN slices 0-3 and 4-7, on four waves -- one per SIMD --
+// each; the row stages run redundantly in both; the H-wide partial sums a row stage collects (four per layer) and the final dE/dx are
+// exchanged through global memory with the protocol of dff_fused_kernel<..., PAIR> (csrc/dff_kernels.hip): 16-byte stores, flag,
+// poll, 16-byte loads, a + b = b + a so both blocks stay bit-identical.  tools_ubench/pair_exchange.hip: 0.25 - 0.45 us per exchange
+// on one XCD, 1.0 - 1.2 us across XCDs.
+template <int H, int NW, bool GEN, bool SPW, bool FOLD, int MODE, bool PAIR = false>
+__global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const DffModelDev m, const DffRunArgs a) {
     static_assert(!FOLD || (SPW && !GEN && H == DFF_DH), "FOLD: the split, shipped-branch, hidden == 64 variant");
-    using LL = SmallLds<H, NW, FOLD>;
+    static_assert(!PAIR || (FOLD && NW == 8 && DFF_F16_ON(FOLD)), "PAIR: the FOLD kernel on the fp16 engine");
+    constexpr int NWR = PAIR ? 4 : NW;       // waves of this workgroup
+    using LL = SmallLds<H, NW, FOLD, NWR>;
     constexpr int LH = LL::LH, F = 4 * H, E = H / 16;
-    constexpr int NTHR = NW * 64;            // threads
+    constexpr int NTHR = NWR * 64;           // threads
     constexpr int HPW = DFF_HEADS / NW;      // heads per wave (2 or 1)
     constexpr int DR = NW == 4 ? 4 : 2;      // weight-ring depth (2 waves/SIMD need less run-ahead)
     constexpr int RLA = LL::RLA;             // rows allocated per head buffer
@@ -874,9 +885,15 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     const int tid = threadIdx.x;
     // the wave index is wave-uniform: say so (readfirstlane), so that every per-wave pointer and
     // weight-stream base lives in SGPRs and its arithmetic runs on the scalar unit
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rwave = __builtin_amdgcn_readfirstlane(tid >> 6);                 // this wave's LDS region / dx partial
+    // PAIR: blocks b and b + 8 form pair (b & 7) + 8 (b >> 4); hf = which half of the heads / FFN slices (tests, a.xslow == 2:
+    // partners are blocks b and b + 1 -- different XCDs under round-robin placement -- to drive the agent-scope protocol)
+    const bool adj = PAIR && a.xslow == 2;
+    const int hf = PAIR ? (int)(adj ? (blockIdx.x & 1) : ((blockIdx.x >> 3) & 1)) : 0;
+    const int unit = PAIR ? (int)(adj ? (blockIdx.x >> 1) : ((blockIdx.x & 7) + 8 * (blockIdx.x >> 4))) : (int)blockIdx.x;
+    const int wave = PAIR ? rwave + 4 * hf : rwave;                             // the head / FFN slice this wave owns
     const int N = m.N, G = a.G;
-    const int b0 = a.b_base + blockIdx.x * G;
+    const int b0 = a.b_base + unit * G;
     const int gcnt = min(G, a.B - b0);
     if (gcnt <= 0) return;
     const int rows = gcnt * N, RA = G * N;   // real rows of this workgroup / dummy stash row index
@@ -923,8 +940,8 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             else al[kb] = *(const lu32x4*)(q + 2 * PS + kb * 256);
         }
     };
-    lfloat* const dxw = sm + LL::dxw + wave * 128;
-    lfloat* const wr = sm + LL::wreg + wave * LL::WREG;
+    lfloat* const dxw = sm + LL::dxw + rwave * 128;
+    lfloat* const wr = sm + LL::wreg + rwave * LL::WREG;
     // FOLD: K_ext = V_ext = ONE shared fp32 copy of the LayerNorm rows (+ x in the extension columns), region `nx`
     lfloat* const Nx = sm + LL::nx;
     lfloat* const Qx = wr; lfloat* const Kx = FOLD ? Nx : wr + RS; lfloat* const Vx = FOLD ? Nx : wr + 2 * RS;
@@ -1009,11 +1026,11 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     // sum of the NW waves' partial outputs for this lane's HC columns of a row: ALL NW x HC LDS reads are
     // issued first (one latency), then added in wave order (left to itself the compiler issues one read,
     // waits, adds, issues the next: NW/2 serial LDS latencies inside a stage every other wave waits for)
-    auto psum_all = [=](float (&out)[(H / (NW == 8 ? 32 : 16))], int o0) {
-        constexpr int HC_ = H / (NW == 8 ? 32 : 16), LPR_ = NW == 8 ? 32 : 16;
-        float pv[NW][HC_];
+    auto psum_all = [=](float (&out)[(H / (NWR == 8 ? 32 : 16))], int o0) {
+        constexpr int HC_ = H / (NWR == 8 ? 32 : 16), LPR_ = NWR == 8 ? 32 : 16;
+        float pv[NWR][HC_];
 #pragma unroll
-        for (int w = 0; w < NW; ++w)
+        for (int w = 0; w < NWR; ++w)
 #pragma unroll
             for (int i = 0; i < HC_; ++i) pv[w][i] = sm[LL::wreg + w * LL::WREG + MPO + o0 + LPR_ * i];
         __builtin_amdgcn_sched_barrier(0);
@@ -1021,9 +1038,69 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         for (int i = 0; i < HC_; ++i) {
             float t = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) t += pv[w][i];
+            for (int w = 0; w < NWR; ++w) t += pv[w][i];
             out[i] = t;
         }
+    };
+    // ---- PAIR: the exchanges.  Slot layout [pair][half][parity][thread][4 floats]: a row-stage thread's four column sums travel as
+    // one 16-byte store / load (the partner's threads hold the same (row, columns)); a + b = b + a keeps the two blocks bit-identical.
+    // Same-XCD pairs (decided once per launch, below): plain stores acknowledged by the L2 both blocks share + L1-bypassing loads;
+    // otherwise agent-scope (sc1) stores.  A bounded spin replaces a hang and sets the model's sticky word (dff_model_status).
+    unsigned xseq = 0;
+    bool xfast = false;
+    constexpr unsigned XSLOT = 4 * 64 * 4;   // floats per slot (four waves x 64 lanes x 4)
+    auto pair_flag = [&](unsigned* const flags) {   // one lane: publish exchange xseq, wait for the partner's
+        if (xfast) asm volatile("global_store_dword %0, %1, off" ::"v"(flags + hf), "v"(xseq + 1) : "memory");
+        else __hip_atomic_store(flags + hf, xseq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned* const err = a.xflag;
+        unsigned spins = 0;
+        while (__hip_atomic_load(flags + (1 - hf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < xseq + 1) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 1023u) == 0 && (spins > (1u << 21) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                atomicOr(err, 1u);
+                break;
+            }
+        }
+    };
+    auto pair_rows = [&](float (&ps)[(H / (NWR == 8 ? 32 : 16))], int rrow_, int sub_, bool ract_, int tq_) {
+        if constexpr (PAIR) {
+            static_assert(!PAIR || H / 16 == 4, "one 16-byte slot entry per thread");
+            float* const mine = a.xchg + ((size_t)(2 * unit + hf) * 2 + (xseq & 1)) * XSLOT + 4 * tq_;
+            const float* const theirs = a.xchg + ((size_t)(2 * unit + (1 - hf)) * 2 + (xseq & 1)) * XSLOT + 4 * tq_;
+            if (ract_) {
+                psum_all(ps, rrow_ * LH + sub_);
+                const f32x4 v = {ps[0], ps[1], ps[2], ps[3]};
+                if (xfast) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(mine), "v"(v) : "memory");
+                else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(mine), "v"(v) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            if (tq_ == 0) pair_flag(a.xflag + 1 + 2 * unit);
+            __syncthreads();
+            if (ract_) {
+                f32x4 pv;
+                asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(pv) : "v"(theirs) : "memory");
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ps[i] += pv[i];
+            }
+            ++xseq;
+        }
+    };
+    auto pair_dx = [&](float t, int tq_) -> float {   // wave 0's lanes (tq < 64) only: the final dE/dx partial sums
+        float r = t;
+        if constexpr (PAIR) {
+            float* const mine = a.xchg + ((size_t)(2 * unit + hf) * 2 + (xseq & 1)) * XSLOT + tq_;
+            const float* const theirs = a.xchg + ((size_t)(2 * unit + (1 - hf)) * 2 + (xseq & 1)) * XSLOT + tq_;
+            if (xfast) asm volatile("global_store_dword %0, %1, off" ::"v"(mine), "v"(t) : "memory");
+            else asm volatile("global_store_dword %0, %1, off sc1" ::"v"(mine), "v"(t) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (tq_ == 0) pair_flag(a.xflag + 1 + 2 * unit);
+            __builtin_amdgcn_wave_barrier();
+            float pv;
+            asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(pv) : "v"(theirs) : "memory");
+            r = t + pv;   // (the caller counts the exchange: every thread of the block must)
+        }
+        return r;
     };
     const SmallStash sl = dff_small_stash(N, G, H, m.L);
     gfloat* const stash = (gfloat*)a.stash + (size_t)blockIdx.x * a.stash_stride;
@@ -1036,8 +1113,56 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         for (int i = tid; i < (int)LL::dmatab_size; i += NTHR) dmatab[i] = head_dma_entry<LL::RLA, FOLD, LL::XLD>(i, G * m.N);
         __syncthreads();
     }
+    if constexpr (PAIR) {
+        // A launch on top of a failed one (sticky word set: an earlier PAIR launch lost a partner) leaves at once with its OUTPUTS
+        // set to NaN; otherwise the two blocks tell each other which XCD they run on (as dff_fused_kernel<..., PAIR>).
+        lu32* const scr = (lu32*)(sm + LL::prof);
+        if (tid == 0) scr[0] = __hip_atomic_load(a.xflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned failed = scr[0];
+        __syncthreads();
+        if (failed) {
+            const float qnan = __builtin_nanf("");
+            const int nr3 = rows * 3;
+            const size_t o3 = (size_t)b0 * N * 3;
+            if (hf == 0) {
+                if (MODE == DFF_MODE_SCORE) {
+                    for (int i = tid; i < nr3; i += NTHR) a.force_out[o3 + i] = qnan;
+                    if (a.energy_out) for (int i = tid; i < rows; i += NTHR) a.energy_out[(size_t)b0 * N + i] = qnan;
+                } else if (MODE == DFF_MODE_LANGEVIN) {
+                    const int nf = a.n_steps / (a.save_interval > 0 ? a.save_interval : 1);
+                    for (int f = 0; f < nf; ++f) {
+                        if (a.frames) for (int i = tid; i < nr3; i += NTHR) a.frames[(size_t)f * a.B * N * 3 + o3 + i] = qnan;
+                        if (a.ke && tid < gcnt) a.ke[(size_t)f * a.B + b0 + tid] = qnan;
+                    }
+                } else {
+                    for (int i = tid; i < nr3; i += NTHR) a.x_io[o3 + i] = qnan;
+                }
+            }
+            return;
+        }
+        unsigned* const xw = a.xflag + 1 + 2 * a.xpairs + 2 * unit;
+        if (tid == 0) {
+            const unsigned my_xcc = (__builtin_amdgcn_s_getreg(20 | ((4 - 1) << 11)) & 15u) + 1u;
+            __hip_atomic_store(xw + hf, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned* const err = a.xflag;
+            unsigned theirs = 0, spins = 0;
+            while ((theirs = __hip_atomic_load(xw + (1 - hf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+                __builtin_amdgcn_s_sleep(2);
+                if ((++spins & 1023u) == 0 && (spins > (1u << 21) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                    atomicOr(err, 1u);
+                    break;
+                }
+            }
+            scr[0] = (theirs == my_xcc && a.xslow != 1) ? 1u : 0u;
+        }
+        __syncthreads();
+        xfast = scr[0] != 0u;
+        __syncthreads();
+        if (tid == 0) scr[0] = 0u;   // (the stage-tick accumulators live here)
+    }
     Prof pf;
-    pf.on = (a.prof != nullptr) && blockIdx.x == 0 && tid == 64 * a.prof_wave;   // one wave's view (wave 0 unless dff_debug_profile asked for another)
+    pf.on = (a.prof != nullptr) && blockIdx.x == 0 && tid == 64 * (a.prof_wave < NWR ? a.prof_wave : 0);   // one wave's view (wave 0 unless dff_debug_profile asked for another)
     pf.acc = (unsigned long long*)(smem + LL::prof);
     pf.last = __builtin_readcyclecounter();
 
@@ -1107,7 +1232,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     // Row stages: LPR lanes per row, HC columns per lane.  They run between barriers while every other
     // wave waits, so their critical path is pure loss: the 8-wave variant spreads a row over 32 lanes
     // (all 16 possible rows then use the 512 threads) and halves the per-lane work of the 4-wave layout.
-    constexpr int LPR = NW == 8 ? 32 : 16;
+    constexpr int LPR = NWR == 8 ? 32 : 16;
     constexpr int HC = H / LPR;
     // In-kernel noise (Philox + Box-Muller: a ~300-instruction dependent chain per lane) does not depend on the forces: when
     // the last wave has no rows in the row stages (chignolin: rows 0..9 are waves 0..4) it draws the step's normals during
@@ -1118,11 +1243,11 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
 #ifndef DFF_XI_STAGE
 #define DFF_XI_STAGE 0
 #endif
-    const bool xi_pre = DFF_XI_PRE && MODE != DFF_MODE_SCORE && !a.noise && rows * LPR <= (NW - 1) * 64;
+    const bool xi_pre = DFF_XI_PRE && MODE != DFF_MODE_SCORE && !a.noise && rows * LPR <= (NWR - 1) * 64;
     static_assert(H % LPR == 0, "row layout");
     // (DFF_XI_STAGE: the row stage of layer 0 in whose shadow the idle wave draws -- 0: A, 1: B, 2: C)
     auto draw_xi = [&](int t_int_, int step_) {
-        if (xi_pre && wave == NW - 1) {
+        if (xi_pre && rwave == NWR - 1) {
             const int ln = lane_id();
             if (ln < rows * 4 && (ln & 3) < 3) {
                 const int row = ln >> 2, g = row / N;
@@ -1167,13 +1292,24 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     };
     float invD = 1.0f;   // inverse row scale of the FFN backward chain in flight (stage D -> stage E of the same layer)
     auto ln_stats_row = [&](const float (&x)[HC], float& mean, float& rstd) {   // LayerNorm statistics of one row
+        // (16 lanes x 4 columns: summed as (x0 + x2) + (x1 + x3) -- columns s, s + 32 | s + 16, s + 48 -- which is the order the
+        // 32-lane layout reaches through its first lane swap: the two layouts give the same bits, so a layer-0 table built by the
+        // 8-wave score kernel serves the two-workgroups variant bit for bit)
         float t = 0.f;
+        if constexpr (HC == 4) t = (x[0] + x[2]) + (x[1] + x[3]);
+        else {
 #pragma unroll
-        for (int i = 0; i < HC; ++i) t += x[i];
+            for (int i = 0; i < HC; ++i) t += x[i];
+        }
         mean = rsum(t) * (1.0f / H);
         float q = 0.f;
+        if constexpr (HC == 4) {
+            const float d0 = x[0] - mean, d1 = x[1] - mean, d2 = x[2] - mean, d3 = x[3] - mean;
+            q = (d0 * d0 + d2 * d2) + (d1 * d1 + d3 * d3);
+        } else {
 #pragma unroll
-        for (int i = 0; i < HC; ++i) { const float d = x[i] - mean; q += d * d; }
+            for (int i = 0; i < HC; ++i) { const float d = x[i] - mean; q += d * d; }
+        }
         const float var = rsum(q) * (1.0f / H);
         rstd = fast_rsqrt(var + 1e-5f);
     };
@@ -1881,9 +2017,12 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             pf.tick(2); DFF_MARK(2);
             // ---- row stage B: attn_out = sum_w part + bo ; gate1 ; LN2 -> abuf ----
             { DFF_ROW_CONSTS
+            float psx[HC];
+            if constexpr (PAIR) pair_rows(psx, rrow, sub, ract, tq_);   // (this block's four partials + the partner's: barriers inside)
             if (ract) {
                 float x[HC], res[HC], n1[HC];
                 float ps[HC];
+                if constexpr (PAIR) { for (int i = 0; i < HC; ++i) ps[i] = psx[i]; } else
                 psum_all(ps, rrow * LH + sub);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
@@ -2016,10 +2155,13 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             pf.tick(4); DFF_MARK(4);
             // ---- row stage C: ff = sum_w part + b2 ; gate2 ; next layer's LN1 or the energy head ----
             { DFF_ROW_CONSTS
+            float psx[HC];
+            if constexpr (PAIR) pair_rows(psx, rrow, sub, ract, tq_);
             if (ract) {
                 const bool last = l == m.L - 1;
                 float x[HC], res[HC], n2[HC];
                 float ps[HC];
+                if constexpr (PAIR) { for (int i = 0; i < HC; ++i) ps[i] = psx[i]; } else
                 psum_all(ps, rrow * LH + sub);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
@@ -2045,7 +2187,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                     }
                     if (a.energy_out) {
                         e = rsum(e);
-                        if (sub == 0) a.energy_out[(size_t)b0 * N + rrow] = e + m.bdec;
+                        if (sub == 0 && hf == 0) a.energy_out[(size_t)b0 * N + rrow] = e + m.bdec;
                     }
                     if constexpr (KEEPROWS) {
                         // stage D of this (last) layer right here: dn = the energy head's weights; gate-2 weights are in ro[1..3]
@@ -2253,9 +2395,12 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             // ---- row stage E: df = sum_w part ; LN2 backward ; gate1 backward -> dattn (abuf), dn_in partial (resbuf) ----
             // operands: ro[0] attn_out, ro[1] nodes_in, ro[2] ln2 gamma, ro[3..5] g1
             { DFF_ROW_CONSTS
+            float psx[HC];
+            if constexpr (PAIR) pair_rows(psx, rrow, sub, ract, tq_);
             if (ract) {
                 float n1[HC], d1[HC], dyg[HC], xh[HC], ps[HC], ao[HC], ni[HC];
                 rows_of(l, ao, ni, nullptr, 0);
+                if constexpr (PAIR) { for (int i = 0; i < HC; ++i) ps[i] = psx[i]; } else
                 psum_all(ps, rrow * LH + sub);
                 if constexpr (SPW && DFF_F16_ON(FOLD)) {   // the FFN backward chain ran in this row's scaled units
 #pragma unroll
@@ -2712,9 +2857,12 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
             // operands: ro[1] nodes_in, ro[2] ln1 gamma
             if (l > 0 || full0) {
                 DFF_ROW_CONSTS
+                float psx[HC];
+                if constexpr (PAIR) pair_rows(psx, rrow, sub, ract, tq_);
                 if (ract) {
                     float dyg[HC], xh[HC], ps[HC], ao[HC], ni[HC];
                     rows_of(l, ao, ni, nullptr, 0);
+                    if constexpr (PAIR) { for (int i = 0; i < HC; ++i) ps[i] = psx[i]; } else
                     psum_all(ps, rrow * LH + sub);
                     float mean, rstd;
                     ln_stats_row(ni, mean, rstd);
@@ -2759,15 +2907,17 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         // dxs = sum of the waves' partial x-gradients (the force head wrote dxs itself); supplied / not yet drawn noise -> xib
         if (tq < 64 && m.conservative) {
             const lfloat* d0 = sm + LL::dxw;
-            float pv[NW];
+            float pv[NWR];
 #pragma unroll
-            for (int w = 0; w < NW; ++w) pv[w] = d0[w * 128 + tq];
+            for (int w = 0; w < NWR; ++w) pv[w] = d0[w * 128 + tq];
             __builtin_amdgcn_sched_barrier(0);   // all reads in flight before the first add
             float t = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) t += pv[w];
+            for (int w = 0; w < NWR; ++w) t += pv[w];
+            if constexpr (PAIR) t = pair_dx(t, tq);   // + the partner's four heads (wave 0 only: no workgroup barrier)
             dxs[tq] = t;
         }
+        if constexpr (PAIR) { if (m.conservative) ++xseq; }
         if (MODE != DFF_MODE_SCORE && !xi_pre && tq < rows * 4 && (tq & 3) < 3) {
             const int row = tq >> 2, cc = tq & 3, g = row / N, i = row - g * N;
             const size_t item = (size_t)b0 + g;
@@ -2806,7 +2956,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
         // =============================== update (as dff_fused_kernel) ===============================
         if (MODE == DFF_MODE_SCORE) {
             if (tq < rows * 4 && (tq & 3) < 3)
-                a.force_out[((size_t)b0 * N + (tq >> 2)) * 3 + (tq & 3)] = -dxs[tq];
+                if (hf == 0) a.force_out[((size_t)b0 * N + (tq >> 2)) * 3 + (tq & 3)] = -dxs[tq];
         } else if (MODE == DFF_MODE_LANGEVIN) {
             const bool save = ((step + 1) % a.save_interval) == 0;
             const int fi = (step + 1) / a.save_interval - 1;
@@ -2830,7 +2980,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                 }
                 xst[tq] = xn;
                 vst[tq] = vn;
-                if (save && a.frames) a.frames[(((size_t)fi * a.B + item) * N + i) * 3 + cc] = xn;
+                if (save && a.frames && hf == 0) a.frames[(((size_t)fi * a.B + item) * N + i) * 3 + cc] = xn;   // (PAIR: both blocks hold the same x)
             }
             if (step + 1 < a.n_steps) { __builtin_amdgcn_wave_barrier(); centre(); }   // (wave 0 reads back what it just wrote)
             if (save && a.ke && !a.overdamped) {
@@ -2841,7 +2991,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
                         const lfloat* vp = vst + (tq * N + i) * 4;
                         ke += a.mass[i] * (vp[0] * vp[0] + vp[1] * vp[1] + vp[2] * vp[2]);
                     }
-                    a.ke[(size_t)fi * a.B + b0 + tq] = 0.5f * ke;
+                    if (hf == 0) a.ke[(size_t)fi * a.B + b0 + tq] = 0.5f * ke;
                 }
             }
         } else {
@@ -2911,7 +3061,7 @@ __global__ __launch_bounds__(NW * 64) void dff_small_kernel(const DffModelDev m,
     }
     if (pf.on)
         for (int i = 0; i < DFF_NPROF; ++i) a.prof[i] = pf.acc[i];
-    if (MODE != DFF_MODE_SCORE && tid < rows * 4 && (tid & 3) < 3) {
+    if (MODE != DFF_MODE_SCORE && tid < rows * 4 && (tid & 3) < 3 && hf == 0) {
         const size_t gi = ((size_t)b0 * N + (tid >> 2)) * 3 + (tid & 3);
         a.x_io[gi] = xst[tid];
         if (MODE == DFF_MODE_LANGEVIN && !a.overdamped) a.v_io[gi] = vst[tid];
@@ -2928,8 +3078,20 @@ int dff_small_f16_level() { return DFF_F16; }
 #endif
 #define DFF_CAT2(a, b) a##b
 #define DFF_CAT(a, b) DFF_CAT2(a, b)
-bool DFF_CAT(dff_small_pick_m, DFF_SMALL_MODE)(int H, int NW, bool gen, bool spw, const void** fn, unsigned* lds_floats, const char** name, bool fold) {
+bool DFF_CAT(dff_small_pick_m, DFF_SMALL_MODE)(int H, int NW, bool gen, bool spw, const void** fn, unsigned* lds_floats, const char** name, bool fold,
+                                               bool pair) {
     constexpr int MD = DFF_SMALL_MODE;
+    if (pair) {   // two workgroups per protein: the FOLD kernel on the fp16 engine, sampling loops only
+#if DFF_F16 >= 1 && DFF_SMALL_MODE != 0
+        if (H == 64 && NW == 8 && spw && fold && !gen) {
+            *fn = (const void*)&dff_small_kernel<64, 8, false, true, true, MD, true>;
+            *lds_floats = SmallLds<64, 8, true, 4>::total;
+            *name = "dff_small_kernel<64,8,split_f16,fold_kv,pair>";
+            return true;
+        }
+#endif
+        return false;
+    }
     if (H == 64 && NW == 8 && spw && fold && !gen) {
         *fn = (const void*)&dff_small_kernel<64, 8, false, true, true, MD>;
         *lds_floats = SmallLds<64, 8, true>::total;

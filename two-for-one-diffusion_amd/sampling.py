@@ -82,6 +82,10 @@ def dist_env() -> Tuple[int, int, int]:
         on = os.environ.get("DFF_TEST_KNOBS") == "1"
         if on and "DFF_DEVICE" in knobs:
             local = int(knobs["DFF_DEVICE"])
+            # several ranks on one GPU: the two-workgroups-per-protein kernels need a GPU to themselves (both blocks of a pair
+            # resident at once) -- off for models created from here on (dff_model_create reads DFF_PAIR)
+            if int(os.environ.get("WORLD_SIZE", 1)) > 1:
+                os.environ.setdefault("DFF_PAIR", "0")
         if rank == 0 and not _warned_knobs:
             import sys
             print(f"dff_amd: test knobs {knobs} are {'IN EFFECT (DFF_TEST_KNOBS=1)' if on else 'IGNORED (set DFF_TEST_KNOBS=1 to use them)'}",
