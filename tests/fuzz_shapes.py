@@ -46,8 +46,6 @@ def _case(case, rng, log):
     intr, dist, ab = flags
     shipped = flags == (1, 0, 0)
     if not shipped: dec, cons = 1.0, True
-    if dist: xs = min(xs, 3.0)   # distance features in the factorised form (|x_i|^2 - 2 x_i.m1 + m2) lose |x|^2 / D digits, in BOTH engines
-    # alike (8 sigma: up to 2 x the reference's own float32 error, profiles/r05/fuzz3.txt); the reference feeds normalised coordinates   # (the other branches' bar is absolute in the reference's float32: keep the test's magnitudes)
     params = synth.synth_gnn_params(N, H, L, seed=int(rng.integers(1, 1 << 30)), decoder_scale=dec, decoder_out=1 if cons else 3, node_in=N + 1 + 3 * ab, edge_in=(3 * intr + dist) or 1)
     tag = dict(case=case, H=H, N=N, L=L, B=B, dec=float("%.2g" % dec), xs=float("%.2g" % xs), G=G, split=int(split), fold=int(os.environ["DFF_FOLD_KV"]), flags="%d%d%d" % flags, cons=int(cons))
     fl = tuple(bool(v) for v in flags)
@@ -66,7 +64,11 @@ def _case(case, rng, log):
         r = rel(f[sub], r64ref)
         # (other branches: the tests' 2e-5 at unit coordinates; distance features at |x| ~ 10 sigma are ill-conditioned in float32 --
         # the reference's own float32 run is then 1e-4 from its float64 one -- so the bar follows that distance there)
-        ok = np.isfinite(f).all() and (r <= 1e-5 and r <= (GUARD if "split_" in kn else GUARD_FP32) * max(r32, 4e-7) if shipped else r <= max(2e-5, 5.0 * r32))
+        # other input branches: the hot path's bar up to 1.5 sigma; beyond, distance features make the INPUT ill-conditioned -- the
+        # reference's own float32 run is 1e-5 .. 7e-4 from its float64 one there and the same algebra in another summation order
+        # (numpy float32) up to 2.4 x that (profiles/r06/gen_conditioning.txt): 6 x its distance
+        gbar = (GUARD_FP32 if xs <= 1.5 else 6.0) * max(r32, 4e-7)
+        ok = np.isfinite(f).all() and (r <= 1e-5 and r <= (GUARD if "split_" in kn else GUARD_FP32) * max(r32, 4e-7) if shipped else r <= gbar)
         tag.update(kernel=kn, rel=float("%.3g" % r), r32=float("%.3g" % r32))
         if not shipped or not cons:   # (the twin's integrator runs the shipped branch only: tests/test_input_branches.py covers the loops there)
             log(("ok   " if ok else "FAIL ") + json.dumps(tag))

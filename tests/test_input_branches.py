@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from oracle import kernel_model_gen as kg
+from oracle import reference_twin as twin
 from oracle import synth
 
 COMBOS = [(0, 1, 1), (1, 1, 1), (1, 0, 1), (1, 1, 0), (0, 1, 0)]
@@ -85,7 +86,12 @@ def test_hip_forces_vs_reference(cfg, flags, golden):
         print(f"{cfg} intr={intr} dist={dist} abs={ab} [{name}] {model.native.last_launch()[0]}: rel64 {r64:.2e} abs32 {a32:.2e}")
         assert "gen" in model.native.last_launch()[0]
         np.testing.assert_allclose(e, g["energy32"], rtol=0, atol=2e-5 * max(1.0, np.abs(g["energy32"]).max()))
-        assert r64 <= 2e-5 and a32 <= 1e-4
+        # round 6: the hot path's bar (tests/test_gpu_parity.py GUARD_FP32) instead of an absolute 2e-5 -- the `gen` kernels sit at
+        # 0.75 - 0.9 x the reference's own float32 distance in the median over 479 random models (profiles/r05/fuzz*.txt; <= 2.2 x up
+        # to 1.5 sigma); what is ill-conditioned is the INPUT at >= 3 sigma with distance features, for the reference's float32
+        # run as much as for this one (profiles/r06/gen_conditioning.txt, tests/gen_conditioning.py)
+        r32 = rel(g["forces32"], g["forces64"])
+        assert r64 <= 1e-5 and r64 <= 2.5 * max(r32, 4e-7) and a32 <= 1e-4, (r64, r32)
     model.native.small_waves(0); model.native.force_generic(False)
 
 
@@ -106,9 +112,11 @@ def test_hip_vs_factorised_model_other_sizes(cfg, flags, G):
     t = np.linspace(0.01, 0.8, B).astype(np.float32)
     f = model(torch.from_numpy(x).cuda(), None, torch.from_numpy(t).cuda()).cpu().numpy()
     fr, er = kg.score(p, x, t, L, bool(intr), bool(dist), bool(ab))
-    print(f"{cfg} {flags} G={G} {model.native.last_launch()}: rel {rel(f, fr):.2e}")
+    fl = (bool(intr), bool(dist), bool(ab))
+    r32 = rel(twin.score(twin.to_torch(p), torch.from_numpy(x), torch.from_numpy(t), L, flags=fl).numpy(), fr)   # the reference's own float32 run
+    print(f"{cfg} {flags} G={G} {model.native.last_launch()}: rel {rel(f, fr):.2e} rel(ref32, ref64) {r32:.2e}")
     assert "gen" in model.native.last_launch()[0]
-    assert rel(f, fr) <= 2e-5
+    assert rel(f, fr) <= 1e-5 and rel(f, fr) <= 2.5 * max(r32, 4e-7)
 
 
 @pytest.mark.gpu

@@ -1376,12 +1376,15 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
     };
     using KA = std::integral_constant<int, 0>; using KF = std::integral_constant<int, 1>; using KN = std::integral_constant<int, 2>;
     using KL = std::integral_constant<int, 3>;
-    // ... and the two gate values of every layer (one number per row, the same in all lanes of the row)
-    float kg0[2] = {}, kg1[2] = {}, kg2[2] = {};
+    // ... and six numbers per row and layer (the same in all lanes of the row): the two gate values [0, 1] and -- round 6 -- mean and
+    // 1 / std of the two LayerNorms [2, 3: LN1; 4, 5: LN2], so that the backward stages E and F normalise their kept rows without
+    // taking the statistics again (two lane reductions each, on the stage every wave waits for; same inputs, same code: same bits)
+    constexpr int NKG = 6;
+    float kg0[NKG] = {}, kg1[NKG] = {}, kg2[NKG] = {};
     f32x4 s0keep = {0.f, 0.f, 0.f, 0.f};   // layer 0's q' . n logits of this wave's head (Langevin: constant over a launch)
     auto gate_put = [&](int k, int which, float g) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < NKG; ++q) {
             kg0[q] = (k == 0 && which == q) ? g : kg0[q];
             kg1[q] = (k == 1 && which == q) ? g : kg1[q];
             kg2[q] = (k == 2 && which == q) ? g : kg2[q];
@@ -1660,6 +1663,7 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                             if constexpr (FOLD) {   // the attention block needs layer 0's LayerNorm rows even when its q' comes from the table
                                 float mean, rstd;
                                 ln_stats_row(x, mean, rstd);
+                                if constexpr (KEEPROWS) { gate_put(0, 2, mean); gate_put(0, 3, rstd); }
 #pragma unroll
                                 for (int i = 0; i < HC; ++i) {
                                     const int cl = sub + LPR * i;
@@ -1686,6 +1690,7 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                     }
                     float mean, rstd;
                     ln_stats_row(x, mean, rstd);
+                    if constexpr (KEEPROWS) { gate_put(0, 2, mean); gate_put(0, 3, rstd); }
 #pragma unroll
                     for (int i = 0; i < HC; ++i) {
                         const int cl = sub + LPR * i;
@@ -2041,6 +2046,7 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                 }
                 float mean, rstd;
                 ln_stats_row(n1, mean, rstd);
+                if constexpr (KEEPROWS) { gate_put(l, 4, mean); gate_put(l, 5, rstd); }
 #pragma unroll
                 for (int i = 0; i < HC; ++i) a_store(rrow, sub + LPR * i, (n1[i] - mean) * rstd * ro[4][i] + ro[5][i]);
                 // stage C operands: b2, g2 (3), and the next layer's LN1 gamma / beta
@@ -2208,6 +2214,7 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                     gfloat* const sbn = stash + (size_t)(l + 1) * sl.layer_stride;
                     float mean, rstd, nva[HC];
                     ln_stats_row(n2, mean, rstd);
+                    if constexpr (KEEPROWS) { gate_put(l + 1, 2, mean); gate_put(l + 1, 3, rstd); }
 #pragma unroll
                     for (int i = 0; i < HC; ++i) {
                         const int cl = sub + LPR * i;
@@ -2414,7 +2421,8 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
 #pragma unroll
                 for (int i = 0; i < HC; ++i) n1[i] = ao[i] * g1 + ni[i] * (1.0f - g1);
                 float mean, rstd;
-                ln_stats_row(n1, mean, rstd);
+                if constexpr (KEEPROWS) { mean = gate_get(l, std::integral_constant<int, 4>{}); rstd = gate_get(l, std::integral_constant<int, 5>{}); }
+                else ln_stats_row(n1, mean, rstd);
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
@@ -2865,7 +2873,8 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                     if constexpr (PAIR) { for (int i = 0; i < HC; ++i) ps[i] = psx[i]; } else
                     psum_all(ps, rrow * LH + sub);
                     float mean, rstd;
-                    ln_stats_row(ni, mean, rstd);
+                    if constexpr (KEEPROWS) { mean = gate_get(l, std::integral_constant<int, 2>{}); rstd = gate_get(l, std::integral_constant<int, 3>{}); }
+                    else ln_stats_row(ni, mean, rstd);
                     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                     for (int i = 0; i < HC; ++i) {
