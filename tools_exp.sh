@@ -36,6 +36,18 @@ elif [ "$cmd" = buildk ]; then   # the <= 64-row kernel TU instead (e.g. flags: 
     hipcc --offload-arch=gfx950 -shared -fPIC $d/dff_kernels.o build/obj/dff_small_m0.o build/obj/dff_small_m1.o build/obj/dff_small_m2.o $host -o $d/libdff_amd.so
     echo "$flags" > $d/flags
     echo "built $d ($flags)"
+elif [ "$cmd" = buildall ]; then   # EVERY translation unit with the flags (e.g. prof -DDFF_PROF=1: the stage profiles of tools_evidence.sh)
+    name=$1; flags=$2
+    d=build/exp/$name; mkdir -p $d
+    printf '#define DFF_BUILD_FLAGS "%s"\n' "$(printf '%s' "$flags" | sed 's/[\\"]/\\&/g')" > $d/dff_build_info.h
+    C="hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-result $flags"
+    $C -c $SRC/dff_kernels.hip -o $d/dff_kernels.o &
+    for k in 0 1 2; do $C -DDFF_SMALL_MODE=$k ${DFF_SMALL_SCHED--mllvm -amdgpu-sched-strategy=max-ilp -mllvm -amdgpu-use-amdgpu-trackers} -c $SRC/dff_small.hip -o $d/dff_small_m$k.o & done
+    $C -DDFF_SRC_SHA=exp-$name -include $d/dff_build_info.h -c $SRC/dff_host.hip -o $d/dff_host.o &
+    wait
+    hipcc --offload-arch=gfx950 -shared -fPIC $d/dff_kernels.o $d/dff_small_m0.o $d/dff_small_m1.o $d/dff_small_m2.o $d/dff_host.o -o $d/libdff_amd.so
+    echo "$flags" > $d/flags
+    echo "built $d ($flags)"
 elif [ "$cmd" = run ]; then
     mkdir -p gpurun_out
     for name in "$@"; do

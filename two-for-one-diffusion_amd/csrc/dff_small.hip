@@ -1586,9 +1586,13 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
     }
     for (int step = 0; step < a.n_steps; ++step) {
         int t_int = 0;
+        // (the reverse step's schedule constants: requested here, a whole network evaluation before wave 0's update needs them)
+        float sch_sr = 0.f, sch_srm1 = 0.f, sch_c1 = 0.f, sch_c2 = 0.f, sch_lv = 0.f;
         if (MODE == DFF_MODE_DDPM) {
             t_int = a.t_start - step;
             if (tid < gcnt) tn[tid] = (1.0f * (float)t_int) / (float)m.T;
+            sch_sr = m.sqrt_recip_ac[t_int]; sch_srm1 = m.sqrt_recipm1_ac[t_int];
+            sch_c1 = m.post_c1[t_int]; sch_c2 = m.post_c2[t_int]; sch_lv = m.post_logvar[t_int];
         }
         // Layer-0 inputs are x-independent: with a precomputed table entry for this step's t
         // (one entry per noise level, shared by all workgroups and L2-resident; built by the host with this
@@ -1605,6 +1609,10 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
         const gfloat* const l0n = tab ? (const gfloat*)a.l0_tab + (size_t)(MODE == DFF_MODE_DDPM ? a.t_start - step - 1 : 0) * sl.layer_stride
                                       : (const gfloat*)stash;
         bool early_done = false;   // the backward sweep requested the next step's first weights / head rows (EARLY)
+        // reverse DDPM on the table: the NEXT step's row stage A (node inputs of noise level t - 1 -> LayerNorm -> resbuf / nx) has no
+        // input of this step's: stage E of layer 0 does it (its loads issued at the top of the stage), the next step starts with its
+        // attention block
+        const bool hoistA = KEEPROWS && MODE == DFF_MODE_DDPM && tab && !full0 && m.conservative && nxt;
         // First weights of the first block, and layer 0's q_ext | k | v rows of this head (shared table entry) by LDS-DMA
         // (measured: 86.8 vs 87.3 us / step with a register fetch inside the attention block).  SPW: step 0 only -- every
         // later step's were requested in the shadow of the update stage of the step before it (step_prefetch).
@@ -1645,7 +1653,9 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
             // KEEPROWS at a fixed noise level (Langevin), steps after the first: the stage would only copy layer 0's kept node
             // inputs to resbuf (its LayerNorm rows are still in `nx`: stage E of layer 0 put them back for its backward attention
             // block, and nothing wrote there since) -- stage E of the step before did that too (`skipA` below): no stage, no barrier
-            const bool skipA = KEEPROWS && MODE == DFF_MODE_LANGEVIN && step > 0 && cached0 && m.conservative;
+            // (reverse DDPM with the per-noise-level table, round 6: stage E of layer 0 of the step before loaded THIS step's node inputs,
+            // took their LayerNorm and left the rows in the kept registers; the update stage put them into `nx`: `hoistA` below)
+            const bool skipA = KEEPROWS && step > 0 && cached0 && m.conservative && (MODE == DFF_MODE_LANGEVIN || (MODE == DFF_MODE_DDPM && tab));
             if (l == 0 && !skipA) {
                 DFF_ROW_CONSTS
                 // KEEPROWS: layer 0's node inputs and LayerNorm rows are kept in this thread's registers for the backward stages;
@@ -2406,6 +2416,15 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
             if constexpr (PAIR) pair_rows(psx, rrow, sub, ract, tq_);
             if (ract) {
                 float n1[HC], d1[HC], dyg[HC], xh[HC], ps[HC], ao[HC], ni[HC];
+                float nxx[HC], nxg[HC], nxb[HC];   // hoistA: the next step's layer-0 node inputs, LayerNorm-1 gain and bias
+                if (hoistA && l == 0) {
+#pragma unroll
+                    for (int i = 0; i < HC; ++i) {
+                        const int cl = sub + LPR * i;
+                        nxx[i] = ld_ntg(l0n + sl.nodes_in + rrow * H + cl);
+                        nxg[i] = lw.ln1_g[cl]; nxb[i] = lw.ln1_b[cl];
+                    }
+                }
                 rows_of(l, ao, ni, nullptr, 0);
                 if constexpr (PAIR) { for (int i = 0; i < HC; ++i) ps[i] = psx[i]; } else
                 psum_all(ps, rrow * LH + sub);
@@ -2450,6 +2469,7 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                     // (layer 0 of a cached-layer-0 model: nobody reads d(nodes_0); KEEPROWS Langevin leaves the NEXT step's residual
                     // stream there instead -- layer 0's node inputs -- so that step starts without a row stage A)
                     if (KEEPROWS && MODE == DFF_MODE_LANGEVIN && l == 0 && !full0) resbuf[rrow * LH + cl] = ni[i];
+                    else if (hoistA && l == 0) resbuf[rrow * LH + cl] = nxx[i];
                     else resbuf[rrow * LH + cl] = d1[i] * (1.0f - g1) + dz * (ro[4][i] - ro[5][i]);
                 }
                 a_store_row(rrow, sub, dav, invE, true);   // (scale and inverse -> rsc: the attention backward block's waves)
@@ -2476,7 +2496,17 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                 if (l > 0 || full0) ro_load(2, lw.ln1_g, sub);
                 if constexpr (KEEPROWS) {
                     if (l > 0) ro_load3(6, m.layer[l - 1].g2, sub);
-                    else if (MODE == DFF_MODE_LANGEVIN && !full0) pre_B(lw, sub);   // stage B operands of the next step's layer 0 (no stage A there)
+                    else if ((MODE == DFF_MODE_LANGEVIN && !full0) || hoistA) pre_B(lw, sub);   // stage B operands of the next step's layer 0 (no stage A there)
+                    if (hoistA && l == 0) {
+                        // the next step's stage A, on registers (this step's kept layer-0 rows are spent: the LayerNorm rows went back
+                        // to `nx` above, the node inputs into d1 / dg)
+                        float mean0, rstd0, nva[HC];
+                        ln_stats_row(nxx, mean0, rstd0);
+#pragma unroll
+                        for (int i = 0; i < HC; ++i) nva[i] = (nxx[i] - mean0) * rstd0 * nxg[i] + nxb[i];
+                        keep_put(0, KN{}, nxx); keep_put(0, KL{}, nva);
+                        gate_put(0, 2, mean0); gate_put(0, 3, rstd0);
+                    }
                 }
             } }
             __syncthreads();
@@ -2912,6 +2942,17 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
             }
             pf.tick(10); DFF_MARK(10);
         }
+        if constexpr (KEEPROWS && MODE == DFF_MODE_DDPM) {
+            if (hoistA) {   // the next step's LayerNorm rows of layer 0 (+ their fp16 pieces): `nx` is free now that layer 0's attention backward is through
+                DFF_ROW_CONSTS
+                if (ract) {
+                    float nva[HC];
+                    keep_get(0, KL{}, nva);
+#pragma unroll
+                    for (int i = 0; i < HC; ++i) n_store(rrow, sub + LPR * i, nva[i]);
+                }
+            }
+        }
         { const int tq = tid_id();   // (opaque: the per-lane addresses below are re-derived every step, not hoisted and spilled)
         // dxs = sum of the waves' partial x-gradients (the force head wrote dxs itself); supplied / not yet drawn noise -> xib
         if (tq < 64 && m.conservative) {
@@ -3010,9 +3051,9 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
             // (summed in bead order as bead_mean() does): same arithmetic per element as the stage-by-stage form, no barriers.
             if (tq < rows * 4 && (tq & 3) < 3) {
                 const int cc = tq & 3, pb0 = ((tq >> 2) / N) * N;
-                const float sr = m.sqrt_recip_ac[t_int], srm1 = m.sqrt_recipm1_ac[t_int];
-                const float c1 = m.post_c1[t_int], c2 = m.post_c2[t_int];
-                const float sig = ((t_int == 0) ? 0.f : 1.f) * expf(0.5f * m.post_logvar[t_int]);
+                const float sr = sch_sr, srm1 = sch_srm1;
+                const float c1 = sch_c1, c2 = sch_c2;
+                const float sig = ((t_int == 0) ? 0.f : 1.f) * expf(0.5f * sch_lv);
                 const float invn = (float)N;
                 float ev[16], zv[16], xv[16];
 #pragma unroll
