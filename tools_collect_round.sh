@@ -1,7 +1,7 @@
 #!/bin/bash
 # Condense one tools_evidence.sh run (gpurun_out/) into profiles/<round>/.  usage: tools_collect_round.sh r05
 set -e
-R=${1:-r05}
+R=${1:-r06}
 cd "$(dirname "$(readlink -f "$0")")"
 P=tools_profile_report.py
 python $P ${R}_head $R

@@ -2,7 +2,7 @@
 # Everything profiles/<round>/ is made of, in one call on the GPU box (outputs under gpurun_out/; condense with
 # tools_profile_report.py afterwards).  usage: tools_evidence.sh <round tag, e.g. r04>
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
