@@ -132,7 +132,8 @@ int dff_ddpm_run(dff_model* m, int batch, float* x_dev, const float* noise_dev, 
  * dff_debug_pair) gave up waiting for a partner workgroup -- possible only when the GPU is shared with another process or
  * partitioned below the CU count the driver reports; the results of that launch are invalid.  The samplers call this at
  * their host synchronisation points (end of LangevinDiffusion.simulate, GaussianDiffusion.check_clamp, the CLI) and raise;
- * once the host has seen the word, the next such launch on the same model refuses with DFF_EHIP; one queued before that
+ * once the host has seen the word, further launches on the same model run the one-workgroup-per-protein kernels (round 6;
+ * they used to be refused with DFF_EHIP) until dff_model_status_clear re-arms; one queued before that
  * leaves at kernel entry (the word is read on the device) with its OUTPUTS set to NaN (forces / energies, frames / kinetic
  * energies, samples; the Langevin state x, v is left alone), so nothing runs on top of invalid results and a caller that
  * never checks cannot mistake an unwritten buffer for forces.  The entry points

@@ -81,15 +81,19 @@ struct SmallLds {
                               // SPW variants (8 waves): the K = H GEMM input as bf16 pieces, written by the row stages:
                               // [piece 3][k-block H/32][kg 4][row 16][4 dwords] -- a wave's ds_read_b128 of (row, kg)
                               // then touches 16 rows x 4 dwords = every bank once, whatever the lane group
-                              asp = resbuf + (FOLD ? RLA : 16) * LH, asp_size = (NW == 8 && H == 64) ? 3 * (H / 32) * 256 : 0,   // (only H = 64 has SPW variants)
+                              asp = resbuf + (FOLD ? RLA : 16) * LH, asp_size = (NW == 8 && H == 64) ? ((FOLD && DFF_F16_ON(true)) ? 2 * (H / 32) * 256 + 64 : 3 * (H / 32) * 256) : 0,   // (only H = 64 has SPW variants; the fp16 engine has two pieces + the row scales)
                               // source-offset table of the LDS-DMA head fetch (head_dma): DMA_N instructions x 64 lanes
                               dmatab = asp + asp_size, dmatab_size = (NW == 8 && H == 64) ? DMA_N * 64 : 0,
                               // FOLD: the fp16 pieces of the LayerNorm rows `nx` holds in fp32 ([h | l'], the layout of `asp`): the A operand
                               // of the QKV' GEMM and an operand of the logits (forward) and of dA (backward) -- kept apart from `asp`,
                               // which the other row stages overwrite before the backward attention block of the layer comes round
                               nsp = dmatab + dmatab_size, nsp_size = FOLD ? 2 * (H / 32) * 256 : 0,
+                              // ... and the same rows' 64 regular columns once more, TRANSPOSED: [h | l'][16-column tile][4 rows kg][column][row & 3] --
+                              // lane (column m, kg) of a v_mfma_f32_16x16x16_f16 reads its four contraction-index values (rows 4 kg ..) as
+                              // 8 bytes: the operand of O^T = V^T P^T and of dQ^T = K^T dS^T on the fp16 pipe (round 6)
+                              nst = nsp + nsp_size, nst_size = (FOLD && DFF_F16_ON(true)) ? 2 * (H / 16) * 4 * 16 * 2 : 0,
                               // (nx stays in front of the wave regions: operand reads of its rows 11..15 land in wave 0's Q region, fp32 data)
-                              nx = nsp + nsp_size, nx_size = FOLD ? RS : 0,
+                              nx = nst + nst_size, nx_size = FOLD ? RS : 0,
                               wreg = nx + nx_size, total = wreg + NWR * WREG + 64;
     static_assert(!FOLD || total * 4 <= 160 * 1024, "LDS budget");
 };
@@ -586,7 +590,8 @@ DEVI void stallR_from(SRing<DR>& ring, f32x4 (&acc)[E], f32x4 (&acc2)[E], const 
 // split; `acc`, which may hold true-unit terms already, enters and leaves in true units (rows 4 quad + r of the C layout: as stall_run)
 template <int I0, int NKB, int E, bool EXT, int DR, class Q>
 DEVI void stallR_run(SRing<DR>& ring, f32x4 (&acc)[E], const f32x4 (&xr)[2 * NKB], const Q& q, int lane,
-                     const lfloat* ext_a = nullptr, const gfloat* ext_w = nullptr, int ext_ts = 0, const lfloat* rsc = nullptr) {
+                     const lfloat* ext_a = nullptr, const gfloat* ext_w = nullptr, int ext_ts = 0, const lfloat* rsc = nullptr,
+                     bool a_scaled = false /* the register tiles are in scaled units already (the extension element is not) */) {
     float bx[E];
     if constexpr (EXT) {
 #pragma unroll
@@ -605,7 +610,7 @@ DEVI void stallR_run(SRing<DR>& ring, f32x4 (&acc)[E], const f32x4 (&xr)[2 * NKB
     f32x4 acc2[E];
 #pragma unroll
     for (int nt = 0; nt < E; ++nt) acc2[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    stallR_from<I0, 0, NKB, E>(ring, acc, acc2, xr, q, lane, sa);
+    stallR_from<I0, 0, NKB, E>(ring, acc, acc2, xr, q, lane, a_scaled ? 1.0f : sa);
 #pragma unroll
     for (int nt = 0; nt < E; ++nt) acc[nt] += acc2[nt] * DFF_F16_LINV;
     if constexpr (EXT) {
@@ -906,28 +911,8 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
     lfloat* const abuf = sm + LL::abuf; lfloat* const resbuf = sm + LL::resbuf;
     lu16* const asp16 = (lu16*)(sm + LL::asp);
     lu32* const dmatab = (lu32*)(sm + LL::dmatab);
-    // row-stage store of one element of the K = H GEMM input: fp32 (abuf), or its three bf16 pieces at the position
-    // the consuming waves' A fragments expect (element j of lane (row, kg) of k-block kb: column 32 kb + 16 (j >> 2) + 4 kg + (j & 3))
-    auto a_store = [=](int row, int cl, float v) {
-        if constexpr (SPW) {
-            const int kb = cl >> 5, kk = cl & 31, kg = (kk & 15) >> 2, j = ((kk >> 4) << 2) | (kk & 3);
-            lu16* const q = asp16 + ((((kb * 4 + kg) * 16 + row) * 4 + (j >> 1)) * 2 + (j & 1));
-            constexpr int PS = (H / 32) * 256 * 2;   // halfwords per piece
-            if constexpr (SPW && DFF_F16_ON(FOLD)) {   // fp16 engine: (h, l') -- callers scale the backward's rows first
-                unsigned short hh, ll;
-                split1h(v, hh, ll);
-                q[0] = hh; q[PS] = ll;
-                return;
-            }
-            const unsigned b = __float_as_uint(v);
-            const float r = v - __uint_as_float(b & 0xffff0000u);
-            const unsigned c = __float_as_uint(r);
-            const float s2 = r - __uint_as_float(c & 0xffff0000u);
-            q[0] = (unsigned short)(b >> 16); q[PS] = (unsigned short)(c >> 16); q[2 * PS] = (unsigned short)(__float_as_uint(s2) >> 16);
-        } else {
-            abuf[row * LH + cl] = v;
-        }
-    };
+    // (the row stages' stores of the K = H GEMM input -- fp32 `abuf`, or its pieces at the position the consuming waves' A fragments
+    // expect: element j of lane (row, kg) of k-block kb is column 32 kb + 16 (j >> 2) + 4 kg + (j & 3) -- are a_put / n_put below)
     // ... and a wave's A fragments of it (SPW): pieces of k-block kb for row lane & 15, k-group lane >> 4
     auto a_load = [=](u32x4 (&ah)[H / 32], u32x4 (&am)[H / 32], u32x4 (&al)[H / 32], int lane) {
         const lu32* const q = (const lu32*)asp16 + ((lane >> 4) * 16 + (lane & 15)) * 4;
@@ -947,14 +932,61 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
     lfloat* const Qx = wr; lfloat* const Kx = FOLD ? Nx : wr + RS; lfloat* const Vx = FOLD ? Nx : wr + 2 * RS;
     constexpr bool NSP = FOLD && SPW && DFF_F16_ON(FOLD);   // the attention input's fp16 pieces live in their own region (SmallLds::nsp)
     lu16* const nsp16 = (lu16*)(sm + LL::nsp);
-    auto n_store = [=](int row, int cl, float v) {
-        if constexpr (FOLD) Nx[row * XLD + cl] = v;
+    lu16* const nst16 = (lu16*)(sm + LL::nst);
+    // lane (column m = lane & 15 of tile nt, kg = lane >> 4): rows 4 kg .. + 3 of that column as the A operand of a 16x16x16 fp16 MFMA
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    auto nt_load = [=](int nt, int lane, f16x4& vh, f16x4& vl) {
+        const lu32x2* const q = (const lu32x2*)(nst16 + ((nt * 4 + (lane >> 4)) * 16 + (lane & 15)) * 4);
+        vh = __builtin_bit_cast(f16x4, *q);
+        vl = __builtin_bit_cast(f16x4, *(q + (H / 16) * 4 * 16 * 4 / 4));
+    };
+    // ---- this thread's place in the row stages, once per kernel (round 6).  The row stages are issue-bound on the SIMD that carries
+    // two of the five row waves: every instruction they do not issue is ~0.1 % of a step, and a third of them was address
+    // arithmetic re-derived per stage from the thread index (row * LH + column, the piece positions of a_store / n_store).  Four
+    // registers hold them for the kernel's lifetime (opaque, so that they are neither re-derived nor folded into per-stage copies):
+    //   rs_o  resbuf / partial-sum tiles: row * LH + sub          rs_n  `nx`: row * XLD + sub
+    //   rs_a  halfword index of (row, column sub) in asp / nsp    rs_t  ... in the transposed pieces nst
+    // column sub + LPR i is a compile-time offset away from each (RS_AOFF, RS_TOFF below).
+    constexpr int RSL = NWR == 8 ? 32 : 16;   // = LPR
+    int rs_o, rs_n, rs_a, rs_t;
+    {
+        const int rr = (int)((unsigned)tid / (unsigned)RSL), ss = (int)((unsigned)tid % (unsigned)RSL);
+        rs_o = rr * LH + ss;
+        rs_n = rr * XLD + ss;
+        const int kg = (ss & 15) >> 2, j = ((ss >> 4) << 2) | (ss & 3);   // (ss < 32: k-block 0)
+        rs_a = ((((0 * 4 + kg) * 16 + rr) * 4 + (j >> 1)) * 2 + (j & 1));
+        rs_t = ((((ss >> 4) * 4 + (rr >> 2)) * 16 + (ss & 15)) * 4 + (rr & 3));
+        asm volatile("" : "+v"(rs_o), "+v"(rs_n), "+v"(rs_a), "+v"(rs_t));
+    }
+#define RS_AOFF(i) (RSL == 32 ? (i) * 512 : ((i) >> 1) * 512 + ((i) & 1) * 4)   /* halfwords: k-block stride 512; 16-lane rows: column + 16 = element j + 4 */
+#define RS_TOFF(i) (RSL == 32 ? (i) * 512 : (i) * 256)                          /* halfwords: 16-column tile stride 256 */
+    // row-stage stores of this thread's element i (column sub + LPR i): the K = H GEMM input (a_put) / the attention input (n_put)
+    auto a_put = [&](int i /* unrolled loops: a constant */, float v) {
+        if constexpr (SPW) {
+            lu16* const q = asp16 + rs_a + RS_AOFF(i);
+            constexpr int PS = (H / 32) * 256 * 2;
+            if constexpr (DFF_F16_ON(FOLD)) {
+                unsigned short hh, ll;
+                split1h(v, hh, ll);
+                q[0] = hh; q[PS] = ll;
+            } else {
+                const unsigned b = __float_as_uint(v);
+                const float r = v - __uint_as_float(b & 0xffff0000u);
+                const unsigned c = __float_as_uint(r);
+                const float s2 = r - __uint_as_float(c & 0xffff0000u);
+                q[0] = (unsigned short)(b >> 16); q[PS] = (unsigned short)(c >> 16); q[2 * PS] = (unsigned short)(__float_as_uint(s2) >> 16);
+            }
+        } else abuf[rs_o + RSL * i] = v;
+    };
+    auto n_put = [&](int i, float v) {
+        if constexpr (FOLD) Nx[rs_n + RSL * i] = v;
         if constexpr (NSP) {
-            const int kb = cl >> 5, kk = cl & 31, kg = (kk & 15) >> 2, j = ((kk >> 4) << 2) | (kk & 3);
-            lu16* const q = nsp16 + ((((kb * 4 + kg) * 16 + row) * 4 + (j >> 1)) * 2 + (j & 1));
             unsigned short hh, ll;
             split1h(v, hh, ll);
+            lu16* const q = nsp16 + rs_a + RS_AOFF(i);
             q[0] = hh; q[(H / 32) * 256 * 2] = ll;
+            lu16* const qt = nst16 + rs_t + RS_TOFF(i);
+            qt[0] = hh; qt[(H / 16) * 4 * 16 * 4] = ll;
         }
     };
     // (the A fragments of them: as a_load)
@@ -1200,7 +1232,7 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
     (void)srow; (void)dxi; (void)lro; (void)quad; (void)col; (void)mro;
 #define DFF_ROW_CONSTS                                  \
     const int tq_ = tid_id();                           \
-    const int rrow = tq_ / LPR, sub = tq_ % LPR;        \
+    const int rrow = (int)((unsigned)tq_ / (unsigned)LPR), sub = (int)((unsigned)tq_ % (unsigned)LPR);   /* (unsigned: one shift / mask each) */ \
     const bool ract = rrow < rows;
 
     // ---- load state (as dff_fused_kernel) ----
@@ -1288,7 +1320,7 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
             if (publish && sub == 0) { rsc[rrow] = sc; rsc[16 + rrow] = inv; }
         }
 #pragma unroll
-        for (int i = 0; i < HC; ++i) a_store(rrow, sub + LPR * i, v[i] * sc);
+        for (int i = 0; i < HC; ++i) a_put(i, v[i] * sc);
     };
     float invD = 1.0f;   // inverse row scale of the FFN backward chain in flight (stage D -> stage E of the same layer)
     auto ln_stats_row = [&](const float (&x)[HC], float& mean, float& rstd) {   // LayerNorm statistics of one row
@@ -1416,7 +1448,7 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
         for (int i = 0; i < HC; ++i) {
             const int cl = sub + LPR * i;
             dffv[i] = dn[i] * g2 + dz * (ro[W][i] + ro[W + 2][i]);
-            resbuf[rrow * LH + cl] = dn[i] * (1.0f - g2) + dz * (ro[W + 1][i] - ro[W + 2][i]);
+            resbuf[rs_o + LPR * i] = dn[i] * (1.0f - g2) + dz * (ro[W + 1][i] - ro[W + 2][i]);
         }
         a_store_row(rrow, sub, dffv, invD, false);
     };
@@ -1684,9 +1716,9 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                         }
 #pragma unroll
                         for (int i = 0; i < HC; ++i) {
-                            resbuf[rrow * LH + sub + LPR * i] = x[i];
+                            resbuf[rs_o + LPR * i] = x[i];
                             if constexpr (FOLD) {
-                                n_store(rrow, sub + LPR * i, nva[i]);   // (fp32 row + its fp16 pieces: the logits' 64-column part runs on the
+                                n_put(i, nva[i]);   // (fp32 row + its fp16 pieces: the logits' 64-column part runs on the
                                                                         // pieces whether q' was just computed or comes from the table)
                             }
                         }
@@ -1695,7 +1727,7 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                     float x[HC], nva[HC];
 #pragma unroll
                     for (int i = 0; i < HC; ++i) {
-                        x[i] = resbuf[rrow * LH + sub + LPR * i];
+                        x[i] = resbuf[rs_o + LPR * i];
                         st_ntg(sb + sl.nodes_in + rrow * H + sub + LPR * i, x[i]);
                     }
                     float mean, rstd;
@@ -1705,8 +1737,8 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                     for (int i = 0; i < HC; ++i) {
                         const int cl = sub + LPR * i;
                         nva[i] = (x[i] - mean) * rstd * lw.ln1_g[cl] + lw.ln1_b[cl];
-                        if constexpr (!NSP) a_store(rrow, cl, nva[i]);
-                        n_store(rrow, cl, nva[i]);
+                        if constexpr (!NSP) a_put(i, nva[i]);
+                        n_put(i, nva[i]);
                     }
                     if constexpr (KEEPROWS) { keep_put(0, KN{}, x); keep_put(0, KL{}, nva); }
                 }
@@ -1819,20 +1851,35 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                     *(lf32x4*)(pb + col * DFF_PLD + 4 * quad) = p;   // P[i = col][j = 4 quad ..]: the backward's layout
                     if (p0keep) p0_copy(true, pcij);
                     else if (st_qkv) *(gf32x4*)(sb + sl.P + (size_t)h * 256 + 4 * lane) = *(const lf32x4*)(pb + (lane >> 2) * DFF_PLD + 4 * (lane & 3));
-                    // O^T = V_ext^T P^T: A = V_ext[j = 4 kk + r][16 nt + m], B = this lane's p[r]
+                    // O^T = V_ext^T P^T.  The 64 regular columns on the fp16 pipe: the probabilities of lane (i, kg) ARE the B operand of a
+                    // v_mfma_f32_16x16x16_f16 (k = j = 4 kg ..), split here into two pieces; A = the transposed pieces of the LayerNorm rows
+                    // (region nst: 8 bytes per lane, tile and piece).  The extension tile (x-bar) stays on the fp32 pipe:
+                    // A = V_ext[j = 4 kk + r][64 + m], B = p[r].
                     const f32x4 xi4 = *(const lf32x4*)(xs + col * 4);   // x_i of this lane's row (component 3 is zero)
                     typedef const volatile lfloat* vlp;
-                    float bv[5][4];
+                    float bvx[4];
 #pragma unroll
-                    for (int nt = 0; nt < 5; ++nt)
+                    for (int r = 0; r < 4; ++r) bvx[r] = *(vlp)(Vx + (4 * quad + r) * XLD + 64 + col);
+                    f16x4 vh[4], vl[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) bv[nt][r] = *(vlp)(Vx + (4 * quad + r) * XLD + 16 * nt + col);
+                    for (int nt = 0; nt < 4; ++nt) nt_load(nt, lane, vh[nt], vl[nt]);
+                    f16x4 ph, pl;
+                    {
+                        unsigned h0, l0, h1, l1;
+                        split2h(p[0], p[1], h0, l0); split2h(p[2], p[3], h1, l1);
+                        ph = __builtin_bit_cast(f16x4, (u32x2){h0, h1}); pl = __builtin_bit_cast(f16x4, (u32x2){l0, l1});
+                    }
 #pragma unroll
-                    for (int nt = 0; nt < 5; ++nt) ot[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    for (int nt = 0; nt < 4; ++nt) {
+                        f32x4 cs = {0.f, 0.f, 0.f, 0.f}, cb = {0.f, 0.f, 0.f, 0.f};
+                        cs = __builtin_amdgcn_mfma_f32_16x16x16f16(vl[nt], ph, cs, 0, 0, 0);
+                        cs = __builtin_amdgcn_mfma_f32_16x16x16f16(vh[nt], pl, cs, 0, 0, 0);
+                        cb = __builtin_amdgcn_mfma_f32_16x16x16f16(vh[nt], ph, cb, 0, 0, 0);
+                        ot[nt] = cb + cs * DFF_F16_LINV;
+                    }
+                    ot[4] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int nt = 0; nt < 5; ++nt) ot[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[nt][r], p[r], ot[nt], 0, 0, 0);
+                    for (int r = 0; r < 4; ++r) ot[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(bvx[r], p[r], ot[4], 0, 0, 0);
                     // extension tile: [xbar | 0 ...] -> xrel = xbar - x_i (quad 0: columns 64 .. 67), to LDS for the projection's fp32 k-step
                     if (quad == 0) ot[4] -= xi4;
                     *(lf32x4*)(Ox + lroT + 64 + 4 * quad) = ot[4];
@@ -2038,10 +2085,10 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                 float x[HC], res[HC], n1[HC];
                 float ps[HC];
                 if constexpr (PAIR) { for (int i = 0; i < HC; ++i) ps[i] = psx[i]; } else
-                psum_all(ps, rrow * LH + sub);
+                psum_all(ps, rs_o);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
-                    const int cl = sub + LPR * i, o = rrow * LH + cl;
+                    const int cl = sub + LPR * i, o = rs_o + LPR * i;
                     x[i] = ps[i] + ro[0][i];
                     res[i] = resbuf[o];
                     if constexpr (!KEEPROWS) st_ntg(sb + sl.attn_out + rrow * H + cl, x[i]);
@@ -2052,13 +2099,13 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
                     n1[i] = x[i] * g + res[i] * (1.0f - g);
-                    resbuf[rrow * LH + sub + LPR * i] = n1[i];
+                    resbuf[rs_o + LPR * i] = n1[i];
                 }
                 float mean, rstd;
                 ln_stats_row(n1, mean, rstd);
                 if constexpr (KEEPROWS) { gate_put(l, 4, mean); gate_put(l, 5, rstd); }
 #pragma unroll
-                for (int i = 0; i < HC; ++i) a_store(rrow, sub + LPR * i, (n1[i] - mean) * rstd * ro[4][i] + ro[5][i]);
+                for (int i = 0; i < HC; ++i) a_put(i, (n1[i] - mean) * rstd * ro[4][i] + ro[5][i]);
                 // stage C operands: b2, g2 (3), and the next layer's LN1 gamma / beta
                 ro_load(0, lw.b2, sub); ro_load3(1, lw.g2, sub);
                 if (l + 1 < m.L) { ro_load(4, m.layer[l + 1].ln1_g, sub); ro_load(5, m.layer[l + 1].ln1_b, sub); }
@@ -2178,10 +2225,10 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                 float x[HC], res[HC], n2[HC];
                 float ps[HC];
                 if constexpr (PAIR) { for (int i = 0; i < HC; ++i) ps[i] = psx[i]; } else
-                psum_all(ps, rrow * LH + sub);
+                psum_all(ps, rs_o);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
-                    const int cl = sub + LPR * i, o = rrow * LH + cl;
+                    const int cl = sub + LPR * i, o = rs_o + LPR * i;
                     x[i] = ps[i] + ro[0][i];
                     res[i] = resbuf[o];
                     if constexpr (!KEEPROWS) st_ntg(sb + sl.ff + rrow * H + cl, x[i]);
@@ -2199,7 +2246,7 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                         const float wd = m.wdec[cl];
                         wdv[i] = wd;
                         e += n2[i] * wd;
-                        if (!(KEEPROWS && m.conservative)) resbuf[rrow * LH + cl] = m.conservative ? wd : n2[i];   // dn = d(sum e)/d nodes_L (or nodes_L for the force head)
+                        if (!(KEEPROWS && m.conservative)) resbuf[rs_o + LPR * i] = m.conservative ? wd : n2[i];   // dn = d(sum e)/d nodes_L (or nodes_L for the force head)
                     }
                     if (a.energy_out) {
                         e = rsum(e);
@@ -2228,11 +2275,11 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
 #pragma unroll
                     for (int i = 0; i < HC; ++i) {
                         const int cl = sub + LPR * i;
-                        resbuf[rrow * LH + cl] = n2[i];
+                        resbuf[rs_o + LPR * i] = n2[i];
                         if constexpr (!KEEPROWS) st_ntg(sbn + sl.nodes_in + rrow * H + cl, n2[i]);
                         const float nv = (n2[i] - mean) * rstd * ro[4][i] + ro[5][i];
-                        if constexpr (!NSP) a_store(rrow, cl, nv);
-                        n_store(rrow, cl, nv);
+                        if constexpr (!NSP) a_put(i, nv);
+                        n_put(i, nv);
                         nva[i] = nv;
                     }
                     if constexpr (KEEPROWS) { keep_put(l + 1, KN{}, n2); keep_put(l + 1, KL{}, nva); }
@@ -2264,7 +2311,7 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
                     const int cl = sub + LPR * i;
-                    const float nv = resbuf[rrow * LH + cl];
+                    const float nv = resbuf[rs_o + LPR * i];
 #pragma unroll
                     for (int c3 = 0; c3 < 3; ++c3) f[c3] += nv * m.wdec[c3 * H + cl];
                 }
@@ -2289,7 +2336,7 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                 float n1[HC], dn[HC], ao[HC], ni[HC], fv[HC];
                 rows_of(l, ao, ni, &fv, 2);
 #pragma unroll
-                for (int i = 0; i < HC; ++i) dn[i] = resbuf[rrow * LH + sub + LPR * i];
+                for (int i = 0; i < HC; ++i) dn[i] = resbuf[rs_o + LPR * i];
                 const float g1 = ro_gate(ao, ni, 3);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) n1[i] = ao[i] * g1 + ni[i] * (1.0f - g1);
@@ -2304,7 +2351,7 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                 for (int i = 0; i < HC; ++i) {
                     const int cl = sub + LPR * i;
                     dffv[i] = dn[i] * g2 + dz * (ro[6][i] + ro[8][i]);
-                    resbuf[rrow * LH + cl] = dn[i] * (1.0f - g2) + dz * (ro[7][i] - ro[8][i]);
+                    resbuf[rs_o + LPR * i] = dn[i] * (1.0f - g2) + dz * (ro[7][i] - ro[8][i]);
                 }
                 a_store_row(rrow, sub, dffv, invD, false);
                 // stage E operands: attn_out, nodes_in, g1 stay; LN2 gamma -> ro[2]
@@ -2427,7 +2474,7 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                 }
                 rows_of(l, ao, ni, nullptr, 0);
                 if constexpr (PAIR) { for (int i = 0; i < HC; ++i) ps[i] = psx[i]; } else
-                psum_all(ps, rrow * LH + sub);
+                psum_all(ps, rs_o);
                 if constexpr (SPW && DFF_F16_ON(FOLD)) {   // the FFN backward chain ran in this row's scaled units
 #pragma unroll
                     for (int i = 0; i < HC; ++i) ps[i] *= invD;
@@ -2445,7 +2492,7 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
-                    const int o = rrow * LH + sub + LPR * i;
+                    const int o = rs_o + LPR * i;
                     xh[i] = (n1[i] - mean) * rstd;
                     dyg[i] = ps[i] * ro[2][i];
                     s1 += dyg[i];
@@ -2456,7 +2503,7 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                 float dg = 0.f;
 #pragma unroll
                 for (int i = 0; i < HC; ++i) {
-                    d1[i] = resbuf[rrow * LH + sub + LPR * i] + rstd * (dyg[i] - s1 - xh[i] * s2);
+                    d1[i] = resbuf[rs_o + LPR * i] + rstd * (dyg[i] - s1 - xh[i] * s2);
                     dg += d1[i] * (ao[i] - ni[i]);
                 }
                 dg = rsum(dg);
@@ -2468,9 +2515,9 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                     dav[i] = d1[i] * g1 + dz * (ro[3][i] + ro[5][i]);
                     // (layer 0 of a cached-layer-0 model: nobody reads d(nodes_0); KEEPROWS Langevin leaves the NEXT step's residual
                     // stream there instead -- layer 0's node inputs -- so that step starts without a row stage A)
-                    if (KEEPROWS && MODE == DFF_MODE_LANGEVIN && l == 0 && !full0) resbuf[rrow * LH + cl] = ni[i];
-                    else if (hoistA && l == 0) resbuf[rrow * LH + cl] = nxx[i];
-                    else resbuf[rrow * LH + cl] = d1[i] * (1.0f - g1) + dz * (ro[4][i] - ro[5][i]);
+                    if (KEEPROWS && MODE == DFF_MODE_LANGEVIN && l == 0 && !full0) resbuf[rs_o + LPR * i] = ni[i];
+                    else if (hoistA && l == 0) resbuf[rs_o + LPR * i] = nxx[i];
+                    else resbuf[rs_o + LPR * i] = d1[i] * (1.0f - g1) + dz * (ro[4][i] - ro[5][i]);
                 }
                 a_store_row(rrow, sub, dav, invE, true);   // (scale and inverse -> rsc: the attention backward block's waves)
                 (void)invE;
@@ -2481,7 +2528,7 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                         float nva[HC];
                         keep_get(l, KL{}, nva);
 #pragma unroll
-                        for (int i = 0; i < HC; ++i) n_store(rrow, sub + LPR * i, nva[i]);
+                        for (int i = 0; i < HC; ++i) n_put(i, nva[i]);
                     }
                 } else if constexpr (FOLD) {   // ... re-derived from the stashed node inputs, as the forward pass made them
                     float mean1, rstd1;
@@ -2489,7 +2536,7 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
 #pragma unroll
                     for (int i = 0; i < HC; ++i) {
                         const int cl = sub + LPR * i;
-                        n_store(rrow, cl, (ni[i] - mean1) * rstd1 * lw.ln1_g[cl] + lw.ln1_b[cl]);
+                        n_put(i, (ni[i] - mean1) * rstd1 * lw.ln1_g[cl] + lw.ln1_b[cl]);
                     }
                 }
                 // stage F operands: nodes_in stays in ro[1]; LN1 gamma -> ro[2]  (KEEPROWS: + gate-2 weights of layer l - 1 for its stage D)
@@ -2710,21 +2757,36 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                             if (nt < 4) acc_a[nt < 4 ? nt : 0] += acc;
                             else dxr += acc;
                         });
-                        // dQ_ext^T = K_ext^T dS^T: A = K_ext[j = 4 kk + r][16 nt + m], B = this lane's dS[r]
+                        // dQ_ext^T = K_ext^T dS^T, as O^T above: the 64 regular columns on the fp16 pipe -- dS^T of lane (i, kg) scaled by row i's
+                        // dattn scale (a power of two; the back-projection wants its A rows in exactly those units) and split --, the
+                        // extension tile (du) on the fp32 pipe in true units
                         f32x4 dq[5];
                         {
                             typedef const volatile lfloat* vlp;
-                            float bv[5][4];
+                            float bvx[4];
 #pragma unroll
-                            for (int nt = 0; nt < 5; ++nt)
+                            for (int r = 0; r < 4; ++r) bvx[r] = *(vlp)(Kx + (4 * quad + r) * XLD + 64 + col);
+                            f16x4 kh[4], kl[4];
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) bv[nt][r] = *(vlp)(Kx + (4 * quad + r) * XLD + 16 * nt + col);
+                            for (int nt = 0; nt < 4; ++nt) nt_load(nt, lane, kh[nt], kl[nt]);
+                            const float si_ = rsc[min(col, RLA - 1)];
+                            f16x4 sh, sl2;
+                            {
+                                unsigned h0, l0, h1, l1;
+                                split2h(dS[0] * si_, dS[1] * si_, h0, l0); split2h(dS[2] * si_, dS[3] * si_, h1, l1);
+                                sh = __builtin_bit_cast(f16x4, (u32x2){h0, h1}); sl2 = __builtin_bit_cast(f16x4, (u32x2){l0, l1});
+                            }
 #pragma unroll
-                            for (int nt = 0; nt < 5; ++nt) dq[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            for (int nt = 0; nt < 4; ++nt) {
+                                f32x4 cs = {0.f, 0.f, 0.f, 0.f}, cb = {0.f, 0.f, 0.f, 0.f};
+                                cs = __builtin_amdgcn_mfma_f32_16x16x16f16(kl[nt], sh, cs, 0, 0, 0);
+                                cs = __builtin_amdgcn_mfma_f32_16x16x16f16(kh[nt], sl2, cs, 0, 0, 0);
+                                cb = __builtin_amdgcn_mfma_f32_16x16x16f16(kh[nt], sh, cb, 0, 0, 0);
+                                dq[nt] = cb + cs * DFF_F16_LINV;   // (rows in the units of their dattn scale)
+                            }
+                            dq[4] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                                for (int nt = 0; nt < 5; ++nt) dq[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[nt][r], dS[r], dq[nt], 0, 0, 0);
+                            for (int r = 0; r < 4; ++r) dq[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(bvx[r], dS[r], dq[4], 0, 0, 0);
                         }
                         *(lf32x4*)(Gx + lroT + 64 + 4 * quad) = dq[4];   // du: the back-projection's fp32 k-step reads it (r_i is spent)
                         // dK_ext = dS^T Q_ext: k = n, likewise; extension columns -> dx_j
@@ -2735,7 +2797,7 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                         pf.tick(17); DFF_MARK(17);
                         const f32x4 (&dq4)[4] = *reinterpret_cast<const f32x4 (*)[4]>(&dq[0]);
                         stallR_run<U_GX, NKT, E, true>(sring, acc_a, dq4, sqa, lane, Gx + col * XLD + 64 + quad, qkvt_ext(lw, wave, lane),
-                                                       DFF_HEADS * 13 * 256, rsc);
+                                                       DFF_HEADS * 13 * 256, rsc, true);
                         pf.tick(18); DFF_MARK(18);
 #pragma unroll
                         for (int nt = 0; nt < E; ++nt) c_store_offs(mypart, mro, 16 * nt, acc_a[nt], lane);
@@ -2901,14 +2963,14 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                     float dyg[HC], xh[HC], ps[HC], ao[HC], ni[HC];
                     rows_of(l, ao, ni, nullptr, 0);
                     if constexpr (PAIR) { for (int i = 0; i < HC; ++i) ps[i] = psx[i]; } else
-                    psum_all(ps, rrow * LH + sub);
+                    psum_all(ps, rs_o);
                     float mean, rstd;
                     if constexpr (KEEPROWS) { mean = gate_get(l, std::integral_constant<int, 2>{}); rstd = gate_get(l, std::integral_constant<int, 3>{}); }
                     else ln_stats_row(ni, mean, rstd);
                     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                     for (int i = 0; i < HC; ++i) {
-                        const int o = rrow * LH + sub + LPR * i;
+                        const int o = rs_o + LPR * i;
                         xh[i] = (ni[i] - mean) * rstd;
                         dyg[i] = ps[i] * ro[2][i];
                         s1 += dyg[i];
@@ -2921,13 +2983,13 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                         // ro[6..8], prefetched by stage E); then its stage E operands: LN2 gamma -> ro[2], g1 (3) -> ro[3..5]
                         float dnv[HC];
 #pragma unroll
-                        for (int i = 0; i < HC; ++i) dnv[i] = resbuf[rrow * LH + sub + LPR * i] + rstd * (dyg[i] - s1 - xh[i] * s2);
+                        for (int i = 0; i < HC; ++i) dnv[i] = resbuf[rs_o + LPR * i] + rstd * (dyg[i] - s1 - xh[i] * s2);
                         stage_D(l - 1, dnv, std::integral_constant<int, 6>{}, rrow, sub);
                         ro_load(2, m.layer[l - 1].ln2_g, sub);
                         ro_load3(3, m.layer[l - 1].g1, sub);
                     } else {
 #pragma unroll
-                    for (int i = 0; i < HC; ++i) resbuf[rrow * LH + sub + LPR * i] += rstd * (dyg[i] - s1 - xh[i] * s2);
+                    for (int i = 0; i < HC; ++i) resbuf[rs_o + LPR * i] += rstd * (dyg[i] - s1 - xh[i] * s2);
                     if (l > 0) {   // stage D operands of layer l-1
                         const DffLayerDev& lp = m.layer[l - 1];
                         const gfloat* const sp = stash + (size_t)(l - 1) * sl.layer_stride;
@@ -2949,7 +3011,7 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                     float nva[HC];
                     keep_get(0, KL{}, nva);
 #pragma unroll
-                    for (int i = 0; i < HC; ++i) n_store(rrow, sub + LPR * i, nva[i]);
+                    for (int i = 0; i < HC; ++i) n_put(i, nva[i]);
                 }
             }
         }
@@ -2989,7 +3051,7 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
 #pragma unroll
                     for (int i = 0; i < HC; ++i) {
                         const int cl = sub + LPR * i;
-                        const float dn = resbuf[rrow * LH + cl];
+                        const float dn = resbuf[rs_o + LPR * i];
 #pragma unroll
                         for (int c3 = 0; c3 < 3; ++c3) f3[c3] += dn * m.WnT[(N + c3) * H + cl];
                     }
