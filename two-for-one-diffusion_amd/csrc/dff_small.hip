@@ -1391,13 +1391,18 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
             kp2[A][i] = k == 2 ? x[i] : kp2[A][i];
         }
     };
-    auto keep_get = [&](int k, auto ai, float (&x)[HC]) {
+    // Reads select by LANE masks: written as `k == 0 ? .. : ..` on the (wave-uniform) layer index the compiler turns every read into
+    // scalar compare-and-branch chains -- half a dozen taken branches per kept value in the stages every wave waits for; a copy of the
+    // index the compiler cannot see through (once per stage: `lsel`) makes them two v_cndmask each.
+    struct LSel { bool z, o; };
+    auto lsel = [](int k) { int kv = k; asm volatile("" : "+v"(kv)); return LSel{kv == 0, kv == 1}; };
+    auto keep_get = [&](const LSel k, auto ai, float (&x)[HC]) {
         constexpr int A = decltype(ai)::value;
 #pragma unroll
-        for (int i = 0; i < HC; ++i) x[i] = k == 0 ? kp0[A][i] : k == 1 ? kp1[A][i] : kp2[A][i];
+        for (int i = 0; i < HC; ++i) x[i] = k.z ? kp0[A][i] : (k.o ? kp1[A][i] : kp2[A][i]);
     };
     // attn_out / nodes_in / ff of layer l for a backward row stage: this thread's kept registers, or the prefetched ro[]
-    auto rows_of = [&](int l, float (&ao)[HC], float (&ni)[HC], float (*fv)[HC], int ffslot) {
+    auto rows_of = [&](const LSel l, float (&ao)[HC], float (&ni)[HC], float (*fv)[HC], int ffslot) {
 #pragma unroll
         for (int i = 0; i < HC; ++i) { ao[i] = ro[0][i]; ni[i] = ro[1][i]; if (fv) (*fv)[i] = ro[ffslot][i]; }
         if constexpr (KEEPROWS) {
@@ -1422,9 +1427,9 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
             kg2[q] = (k == 2 && which == q) ? g : kg2[q];
         }
     };
-    auto gate_get = [&](int k, auto wi) {
+    auto gate_get = [&](const LSel k, auto wi) {
         constexpr int Q = decltype(wi)::value;
-        return k == 0 ? kg0[Q] : k == 1 ? kg1[Q] : kg2[Q];
+        return k.z ? kg0[Q] : (k.o ? kg1[Q] : kg2[Q]);
     };
     // KEEPROWS: row stage D of layer ld (gate-2 backward: dn -> dff as the FFN-backward GEMM's input, dn1 partial -> resbuf)
     // on the kept rows and gate values.  It needs no partial sums, so it runs INSIDE the row stage that produces dn -- stage C
@@ -1433,8 +1438,9 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
     auto stage_D = [&](int ld, const float (&dn)[HC], auto wslot, int rrow, int sub) {
         constexpr int W = decltype(wslot)::value;
         float ao[HC], ni[HC], fv[HC], n1[HC];
-        keep_get(ld, KA{}, ao); keep_get(ld, KN{}, ni); keep_get(ld, KF{}, fv);
-        const float g1 = gate_get(ld, std::integral_constant<int, 0>{}), g2 = gate_get(ld, std::integral_constant<int, 1>{});
+        const LSel sd = lsel(ld);
+        keep_get(sd, KA{}, ao); keep_get(sd, KN{}, ni); keep_get(sd, KF{}, fv);
+        const float g1 = gate_get(sd, std::integral_constant<int, 0>{}), g2 = gate_get(sd, std::integral_constant<int, 1>{});
         float dg = 0.f;
 #pragma unroll
         for (int i = 0; i < HC; ++i) {
@@ -1697,8 +1703,8 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                     if (ract) {
                         float x[HC], nva[HC];
                         if (reuse0) {
-                            keep_get(0, KN{}, x);
-                            keep_get(0, KL{}, nva);
+                            keep_get(LSel{true, false}, KN{}, x);
+                            keep_get(LSel{true, false}, KL{}, nva);
                         } else {
 #pragma unroll
                             for (int i = 0; i < HC; ++i) x[i] = ld_ntg(sbq + sl.nodes_in + rrow * H + sub + LPR * i);
@@ -2334,7 +2340,7 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
             if constexpr (!KEEPROWS) { DFF_ROW_CONSTS
             if (ract) {
                 float n1[HC], dn[HC], ao[HC], ni[HC], fv[HC];
-                rows_of(l, ao, ni, &fv, 2);
+                rows_of(lsel(l), ao, ni, &fv, 2);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) dn[i] = resbuf[rs_o + LPR * i];
                 const float g1 = ro_gate(ao, ni, 3);
@@ -2472,7 +2478,8 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                         nxg[i] = lw.ln1_g[cl]; nxb[i] = lw.ln1_b[cl];
                     }
                 }
-                rows_of(l, ao, ni, nullptr, 0);
+                const LSel sl_ = lsel(l);
+                rows_of(sl_, ao, ni, nullptr, 0);
                 if constexpr (PAIR) { for (int i = 0; i < HC; ++i) ps[i] = psx[i]; } else
                 psum_all(ps, rs_o);
                 if constexpr (SPW && DFF_F16_ON(FOLD)) {   // the FFN backward chain ran in this row's scaled units
@@ -2481,13 +2488,13 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                 }
                 pf.tick(22); DFF_MARK(22);
                 float g1;
-                if constexpr (KEEPROWS) g1 = gate_get(l, std::integral_constant<int, 0>{});
+                if constexpr (KEEPROWS) g1 = gate_get(sl_, std::integral_constant<int, 0>{});
                 else g1 = ro_gate(ao, ni, 3);
                 pf.tick(23); DFF_MARK(23);
 #pragma unroll
                 for (int i = 0; i < HC; ++i) n1[i] = ao[i] * g1 + ni[i] * (1.0f - g1);
                 float mean, rstd;
-                if constexpr (KEEPROWS) { mean = gate_get(l, std::integral_constant<int, 4>{}); rstd = gate_get(l, std::integral_constant<int, 5>{}); }
+                if constexpr (KEEPROWS) { mean = gate_get(sl_, std::integral_constant<int, 4>{}); rstd = gate_get(sl_, std::integral_constant<int, 5>{}); }
                 else ln_stats_row(n1, mean, rstd);
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -2526,7 +2533,7 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                     // registers since the forward stage made them; the last layer's are still there
                     if (l < m.L - 1) {
                         float nva[HC];
-                        keep_get(l, KL{}, nva);
+                        keep_get(sl_, KL{}, nva);
 #pragma unroll
                         for (int i = 0; i < HC; ++i) n_put(i, nva[i]);
                     }
@@ -2961,11 +2968,12 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                 if constexpr (PAIR) pair_rows(psx, rrow, sub, ract, tq_);
                 if (ract) {
                     float dyg[HC], xh[HC], ps[HC], ao[HC], ni[HC];
-                    rows_of(l, ao, ni, nullptr, 0);
+                    const LSel sl_ = lsel(l);
+                    rows_of(sl_, ao, ni, nullptr, 0);
                     if constexpr (PAIR) { for (int i = 0; i < HC; ++i) ps[i] = psx[i]; } else
                     psum_all(ps, rs_o);
                     float mean, rstd;
-                    if constexpr (KEEPROWS) { mean = gate_get(l, std::integral_constant<int, 2>{}); rstd = gate_get(l, std::integral_constant<int, 3>{}); }
+                    if constexpr (KEEPROWS) { mean = gate_get(sl_, std::integral_constant<int, 2>{}); rstd = gate_get(sl_, std::integral_constant<int, 3>{}); }
                     else ln_stats_row(ni, mean, rstd);
                     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -3009,7 +3017,7 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                 DFF_ROW_CONSTS
                 if (ract) {
                     float nva[HC];
-                    keep_get(0, KL{}, nva);
+                    keep_get(LSel{true, false}, KL{}, nva);
 #pragma unroll
                     for (int i = 0; i < HC; ++i) n_put(i, nva[i]);
                 }
