@@ -1066,11 +1066,13 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
 #pragma unroll
             for (int i = 0; i < HC_; ++i) pv[w][i] = sm[LL::wreg + w * LL::WREG + MPO + o0 + LPR_ * i];
         __builtin_amdgcn_sched_barrier(0);
+        // (one v_add_f32 per term, spelled out: left to itself the compiler packs the two columns into v_pk_add_f32 and pays a
+        // v_mov per operand to line the pairs up -- 24 instructions for 14 additions, in the stages every wave waits for)
 #pragma unroll
         for (int i = 0; i < HC_; ++i) {
-            float t = 0.f;
+            float t = pv[0][i];
 #pragma unroll
-            for (int w = 0; w < NWR; ++w) t += pv[w][i];
+            for (int w = 1; w < NWR; ++w) asm("v_add_f32 %0, %1, %2" : "=v"(t) : "v"(t), "v"(pv[w][i]));
             out[i] = t;
         }
     };
@@ -1313,10 +1315,20 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
         float sc = 1.0f;
         inv = 1.0f;
         if constexpr (SPW && DFF_F16_ON(FOLD)) {
-            float mx = 0.f;
+            // the row maximum of |v| as an UNSIGNED-INTEGER maximum of the bit patterns (non-negative floats order like their bits): one
+            // v_max_u32 per reduction step where fmaxf costs three (it canonicalises both inputs); only the exponent is used
+            unsigned um = 0u;
 #pragma unroll
-            for (int i = 0; i < HC; ++i) mx = fmaxf(mx, fabsf(v[i]));
-            pow2_scale(rmaxf(mx), sc, inv);
+            for (int i = 0; i < HC; ++i) um = max(um, __float_as_uint(v[i]) & 0x7fffffffu);
+            if constexpr (LPR == 32) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(um, um, false, false);
+                um = max(sw[0], sw[1]);
+            }
+            um = max(um, (unsigned)__builtin_amdgcn_update_dpp(0, (int)um, 0xB1, 0xF, 0xF, true));
+            um = max(um, (unsigned)__builtin_amdgcn_update_dpp(0, (int)um, 0x4E, 0xF, 0xF, true));
+            um = max(um, (unsigned)__builtin_amdgcn_update_dpp(0, (int)um, 0x141, 0xF, 0xF, true));
+            um = max(um, (unsigned)__builtin_amdgcn_update_dpp(0, (int)um, 0x140, 0xF, 0xF, true));
+            pow2_scale(__uint_as_float(um), sc, inv);
             if (publish && sub == 0) { rsc[rrow] = sc; rsc[16 + rrow] = inv; }
         }
 #pragma unroll
