@@ -832,6 +832,21 @@ DEVI unsigned head_dma_entry(int sl, int RA) {
     const int row = r / (DFF_PLD / 4), c4 = r - row * (DFF_PLD / 4);
     return 0x80000000u | (unsigned)(row * 16 + 4 * min(c4, 3));
 }
+// QROWS > 0: only the q_ext rows are wanted (no P tile: the caller keeps it in LDS) and they are the first QROWS 16-byte slots of the
+// table -- ceil(QROWS / 64) instructions, no source select per lane (the general form below issued ~90 instructions for the same four
+// loads at the top of a row stage every wave waits for)
+template <int QROWS>
+DEVI void head_dma_q(const lu32* tab, const lfloat* Qx, const gfloat* sqkv, int lane) {
+    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)Qx);
+    constexpr int NI = (QROWS + 63) / 64;
+    unsigned e[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) e[k] = tab[64 * k + lane];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        if (64 * k + 63 < QROWS || lane < QROWS - 64 * k) lds_dma16(base + 1024u * k, sqkv + e[k]);
+    }
+}
 template <int NI>
 DEVI void head_dma(const lu32* tab, const lfloat* Qx /* wave-uniform; the regions the table describes start here */, const gfloat* sqkv, const gfloat* sp, int lane) {
     const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)Qx);
@@ -1006,6 +1021,11 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
     constexpr bool RELAY = NW == 8 && H == 64;
     constexpr bool KEEP_LAST = RELAY && !GEN;   // (the GEN variants re-derive their x-dependent extension columns on reload)
     constexpr bool HDMA = RELAY && !GEN;        // stash -> head buffers by LDS-DMA, requested a row stage ahead (head_dma)
+    // ... of a head's rows WITHOUT its P tile (layer 0 from the table / the stash): the FOLD layout has only q' rows to fetch
+    auto dma_nop = [=](const gfloat* sqkv, int lane) {
+        if constexpr (FOLD) head_dma_q<LL::RLA * (LL::XLD / 4)>(dmatab, Qx, sqkv, lane);
+        else head_dma<LL::DMA_N>(dmatab, Qx, sqkv, nullptr, lane);
+    };
     // FOLD has no K / V regions, and the layer BEFORE the last one keeps its q' and P in LDS too: copied to Qsave | Psave
     // after its forward attention, copied back before its backward one -- with the layer-0 table and KEEP_LAST no q' / P of
     // a 3-layer model ever goes through the stash in the sampling loops.
@@ -1623,7 +1643,7 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
             const int lane = lane_id();
             if (cached0_) {
                 sring_prefetch<SDR, KO, E>(sring, ss_wox(m.layer[0], wave), lane);
-                if constexpr (HDMA) head_dma<LL::DMA_N>(dmatab, Qx, l0e_ + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, lane);
+                if constexpr (HDMA) dma_nop(l0e_ + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, lane);
             } else sring_prefetch<SDR, KQ, E>(sring, ss_qkv(m.layer[0], wave), lane);
         }
     };
@@ -2465,9 +2485,11 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
             pf.tick(7); DFF_MARK(7);
             // first head of this layer's attention backward: start the stash read (hidden by row stage E)
             if constexpr (HDMA) {
-                if (!(KEEP_LAST && l == m.L - 1 && l > 0) && !(KEEP2 && l == m.L - 2 && l > 0 && MODE != DFF_MODE_SCORE))
-                    head_dma<LL::DMA_N>(dmatab, Qx, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW,
-                                        KEEP2 && l == 0 && m.L > 2 && MODE != DFF_MODE_SCORE && rows <= 10 ? nullptr : sb + sl.P + (size_t)wave * 256, lane_id());
+                if (!(KEEP_LAST && l == m.L - 1 && l > 0) && !(KEEP2 && l == m.L - 2 && l > 0 && MODE != DFF_MODE_SCORE)) {
+                    if (KEEP2 && l == 0 && m.L > 2 && MODE != DFF_MODE_SCORE && rows <= 10)   // (its P tile is in LDS: p0_copy)
+                        dma_nop(sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, lane_id());
+                    else head_dma<LL::DMA_N>(dmatab, Qx, sbq + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, sb + sl.P + (size_t)wave * 256, lane_id());
+                }
             }
             if constexpr (HPW == 2) {
                 const int lane = lane_id();
@@ -2828,7 +2850,7 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                         if constexpr (EARLY) {
                             early_done = true;
                             if constexpr (HDMA) {
-                                if (nxt && c0n) head_dma<LL::DMA_N>(dmatab, Qx, l0n + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, lane);
+                                if (nxt && c0n) dma_nop(l0n + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, lane);
                             }
                         }
                     }
@@ -2944,7 +2966,7 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                         // (now dead) Q region
                         early_done = true;
                         if constexpr (HDMA) {
-                            if (nxt && c0n) head_dma<LL::DMA_N>(dmatab, Qx, l0n + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, nullptr, lane);
+                            if (nxt && c0n) dma_nop(l0n + sl.qkv + (size_t)wave * (RA + 1) * DFF_QKVW, lane);
                         }
                     }
                 }
