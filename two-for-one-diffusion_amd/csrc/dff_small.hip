@@ -1300,12 +1300,19 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
     const bool xi_pre = DFF_XI_PRE && MODE != DFF_MODE_SCORE && !a.noise && rows * LPR <= (NWR - 1) * 64;
     static_assert(H % LPR == 0, "row layout");
     // (DFF_XI_STAGE: the row stage of layer 0 in whose shadow the idle wave draws -- 0: A, 1: B, 2: C)
+    // (the seed through an opaque copy: the ten round keys derived from it are otherwise computed once per kernel, spilled to VGPR
+    // lanes -- twenty SGPRs the register file does not have -- and read back with a v_readlane + wait state each, per draw)
+    auto seed_now = [&]() {
+        unsigned lo = (unsigned)a.seed, hi = (unsigned)(a.seed >> 32);
+        asm volatile("" : "+s"(lo), "+s"(hi));
+        return ((uint64_t)hi << 32) | lo;
+    };
     auto draw_xi = [&](int t_int_, int step_) {
         if (xi_pre && rwave == NWR - 1) {
             const int ln = lane_id();
             if (ln < rows * 4 && (ln & 3) < 3) {
                 const int row = ln >> 2, g = row / N;
-                xib[ln] = philox_normal(a.seed, a.item_offset + (size_t)b0 + g,
+                xib[ln] = philox_normal(seed_now(), a.item_offset + (size_t)b0 + g,
                                         MODE == DFF_MODE_DDPM ? (uint64_t)t_int_ : a.step_offset + step_, row - g * N, ln & 3);
             }
         }
@@ -1611,24 +1618,38 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
         pcij = (unsigned)i0 | ((unsigned)(ln_ - 10 * i0) << 4) | ((unsigned)(i1 & 15) << 8) | ((unsigned)((ln_ + 64 - 10 * i1) & 15) << 12) |
                (ln_ + 64 < 100 ? 1u << 16 : 0u);
     }
+    // sum of the first N of 16 column values in bead order (0 + v0 + v1 + ...), by EARLY EXIT: written as `i < N ? v[i] : 0` the
+    // sixteen conditions are sixteen lane masks (32 SGPRs, with the sixteen row clamps min(i, N - 1) of the loads in front of
+    // them 48) that the compiler computes once per kernel, spills to VGPR lanes and reads back one v_readlane at a time
+    // in the update stage of every step -- where wave 0 works alone in front of the whole workgroup.  The loads are not
+    // clamped either: rows past the protein's are read (inside the LDS allocation) and never added.
+    auto colsum16 = [&](const float (&v)[16], float off) {
+        int n_ = N;
+        asm volatile("" : "+s"(n_));
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (i >= n_) break;
+            asm volatile("" : "+v"(sacc));   // (keeps the exit a scalar branch)
+            sacc += v[i] - off;
+        }
+        return sacc;
+    };
     auto centre = [&]() {
         const int tq = tid_id();
         if (tq < rows * 4) {
             const int cc = tq & 3, pb0 = ((tq >> 2) / N) * N;
             float v[16];
+            const lfloat* const xcol = xst + pb0 * 4 + cc;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = xst[(pb0 + min(i, N - 1)) * 4 + cc];
+            for (int i = 0; i < 16; ++i) v[i] = xcol[4 * i];
             const float own = xst[tq];
-            float s1 = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s1 += i < N ? v[i] : 0.f;
+            const float s1 = colsum16(v, 0.f);
             const float m1 = s1 / (float)N;
             const float xc = own - m1;
             float xn_in = xc;
             if (MODE == DFF_MODE_LANGEVIN) {
-                float s2 = 0.f;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) s2 += i < N ? v[i] - m1 : 0.f;
+                const float s2 = colsum16(v, m1);
                 xn_in = xc - s2 / (float)N;
                 xcb[tq] = xc;
             }
@@ -3076,7 +3097,7 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
             const int row = tq >> 2, cc = tq & 3, g = row / N, i = row - g * N;
             const size_t item = (size_t)b0 + g;
             if (a.noise) xib[tq] = a.noise[(((size_t)step * a.B + item) * N + i) * 3 + cc];
-            else xib[tq] = philox_normal(a.seed, a.item_offset + item, MODE == DFF_MODE_DDPM ? (uint64_t)t_int : a.step_offset + step, i, cc);
+            else xib[tq] = philox_normal(seed_now(), a.item_offset + item, MODE == DFF_MODE_DDPM ? (uint64_t)t_int : a.step_offset + step, i, cc);
         }
         // Everything the update reads was written by wave 0 itself just above (dxs, supplied noise: LDS operations of one wave
         // complete in order) or before the barrier that ended the backward sweep (the waves' partials, the pre-drawn normals): no
@@ -3160,17 +3181,21 @@ __global__ __launch_bounds__((PAIR ? 4 : NW) * 64) void dff_small_kernel(const D
                 const float sig = ((t_int == 0) ? 0.f : 1.f) * expf(0.5f * sch_lv);
                 const float invn = (float)N;
                 float ev[16], zv[16], xv[16];
+                const int o0 = pb0 * 4 + cc;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int o = (pb0 + min(i, N - 1)) * 4 + cc;
-                    ev[i] = -dxs[o]; zv[i] = xib[o]; xv[i] = xst[o];
+                for (int i = 0; i < 16; ++i) {   // (unclamped: rows past the protein's are never summed, see colsum16)
+                    ev[i] = -dxs[o0 + 4 * i]; zv[i] = xib[o0 + 4 * i]; xv[i] = xst[o0 + 4 * i];
                 }
                 float e_own = -dxs[tq], z_own = xib[tq];
                 const float x_own = xst[tq];
+                // (four dependent means over 80 live values: here the early-exit form spills; the conditions are taken per lane
+                // against N in a VECTOR register instead -- one v_cmp each, still no kernel-lifetime lane masks)
+                int nv_ = N;
+                asm volatile("" : "+v"(nv_));
                 auto colmean = [&](const float (&v)[16]) {
                     float sacc = 0.f;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) sacc += i < N ? v[i] : 0.f;
+                    for (int i = 0; i < 16; ++i) sacc += i < nv_ ? v[i] : 0.f;
                     return sacc / invn;
                 };
                 const float me = colmean(ev), mz = colmean(zv);
