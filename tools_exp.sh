@@ -28,7 +28,7 @@ if [ "$cmd" = build ]; then
 elif [ "$cmd" = buildk ]; then   # the <= 64-row kernel TU instead (e.g. flags: -DDFF_FAST_BUILD -DDFF_ONLY="VAR_SPW(128,3,1)")
     name=$1; flags=$2
     d=build/exp/$name; mkdir -p $d
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-result $flags -c $SRC/dff_kernels.hip -o $d/dff_kernels.o &
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-result ${DFF_KERNELS_SCHED--mllvm -disable-machine-licm} $flags -c $SRC/dff_kernels.hip -o $d/dff_kernels.o &
     host=build/obj/dff_host.o
     case "$flags" in *DFF_PROF=1*)   # the host half refuses dff_debug_profile unless it was built with the stage ticks too
         hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-result -DDFF_PROF=1 -c $SRC/dff_host.hip -o $d/dff_host.o; host=$d/dff_host.o;; esac
@@ -41,7 +41,7 @@ elif [ "$cmd" = buildall ]; then   # EVERY translation unit with the flags (e.g.
     d=build/exp/$name; mkdir -p $d
     printf '#define DFF_BUILD_FLAGS "%s"\n' "$(printf '%s' "$flags" | sed 's/[\\"]/\\&/g')" > $d/dff_build_info.h
     C="hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-result $flags"
-    $C -c $SRC/dff_kernels.hip -o $d/dff_kernels.o &
+    $C ${DFF_KERNELS_SCHED--mllvm -disable-machine-licm} -c $SRC/dff_kernels.hip -o $d/dff_kernels.o &
     for k in 0 1 2; do $C -DDFF_SMALL_MODE=$k ${DFF_SMALL_SCHED--mllvm -amdgpu-sched-strategy=max-ilp -mllvm -amdgpu-use-amdgpu-trackers} -c $SRC/dff_small.hip -o $d/dff_small_m$k.o & done
     $C -DDFF_SRC_SHA=exp-$name -include $d/dff_build_info.h -c $SRC/dff_host.hip -o $d/dff_host.o &
     wait

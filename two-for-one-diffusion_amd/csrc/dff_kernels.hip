@@ -1,4 +1,5 @@
 // dff_kernels.hip -- the MI355X (gfx950 / CDNA4) device code of the denoising-force-field sampler.
+// (build.sh compiles this translation unit with -mllvm -disable-machine-licm: see there.)
 //
 // ONE persistent kernel runs the whole hot path for a group of proteins per workgroup:
 //
