@@ -16,14 +16,16 @@ GUARD, GUARD_FP32, STEP_TOL = 2.0, 2.5, 5e-6   # tests/test_gpu_parity.py: the s
 rel = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))  # noqa: E731
 
 
-def run(n_cases, seed, log=print):
-    """Returns the number of cases outside the bars (each case is logged as one line)."""
+def run(n_cases, seed, log=print, only=None, hook=None):
+    """Returns the number of cases outside the bars (each case is logged as one line).  `only`: run these case numbers of the
+    sequence (the others just consume their random draws); `hook(case, tag, model, params, x, t, sub, f, flags, cons, L)`: called
+    with a case's inputs and forces (tests/gen_outliers.py)."""
     rng = np.random.default_rng(seed)
     env = {k: os.environ.get(k) for k in ("DFF_SPLIT_BF16", "DFF_FOLD_KV")}
     bad = 0
     try:
         for case in range(n_cases):
-            bad += not _case(case, rng, log)
+            bad += not _case(case, rng, log, only, hook)
     finally:
         for k, v in env.items():
             if v is None: os.environ.pop(k, None)
@@ -31,7 +33,7 @@ def run(n_cases, seed, log=print):
     return bad
 
 
-def _case(case, rng, log):
+def _case(case, rng, log, only=None, hook=None):
     H = int(rng.choice([64, 96, 128]))
     N = int(rng.integers(2, (61 if H == 128 else 32) + 1))
     L = int(rng.integers(1, 5))
@@ -49,6 +51,11 @@ def _case(case, rng, log):
     params = synth.synth_gnn_params(N, H, L, seed=int(rng.integers(1, 1 << 30)), decoder_scale=dec, decoder_out=1 if cons else 3, node_in=N + 1 + 3 * ab, edge_in=(3 * intr + dist) or 1)
     tag = dict(case=case, H=H, N=N, L=L, B=B, dec=float("%.2g" % dec), xs=float("%.2g" % xs), G=G, split=int(split), fold=int(os.environ["DFF_FOLD_KV"]), flags="%d%d%d" % flags, cons=int(cons))
     fl = tuple(bool(v) for v in flags)
+    if only is not None and case not in only:   # (the same draws as a case that runs)
+        rng.uniform(0.0, 1.0, B)
+        if B > 12: rng.choice(B, 8, replace=False)
+        if shipped and cons: rng.integers(1, 60)
+        return True
     try:
         model = GraphTransformer(N, H, device="cuda:0", n_layers=L, use_intrinsic_coords=fl[0], use_abs_coords=fl[2], use_distances=fl[1],
                                  conservative=cons, state_dict=params)
@@ -62,6 +69,7 @@ def _case(case, rng, log):
         r64ref = twin.score(twin.to_torch(params, torch.float64), xs_.double(), ts_.double(), L, conservative=cons, flags=fl).numpy()
         r32 = rel(twin.score(twin.to_torch(params), xs_, ts_, L, conservative=cons, flags=fl).numpy(), r64ref)
         r = rel(f[sub], r64ref)
+        if hook is not None: hook(case, tag, model, params, x, t, sub, f, fl, cons, L)
         # (other branches: the tests' 2e-5 at unit coordinates; distance features at |x| ~ 10 sigma are ill-conditioned in float32 --
         # the reference's own float32 run is then 1e-4 from its float64 one -- so the bar follows that distance there)
         # other input branches: the hot path's bar up to 1.5 sigma; beyond, distance features make the INPUT ill-conditioned -- the
