@@ -69,6 +69,16 @@ def _case(case, rng, log, only=None, hook=None):
         r64ref = twin.score(twin.to_torch(params, torch.float64), xs_.double(), ts_.double(), L, conservative=cons, flags=fl).numpy()
         r32 = rel(twin.score(twin.to_torch(params), xs_, ts_, L, conservative=cons, flags=fl).numpy(), r64ref)
         r = rel(f[sub], r64ref)
+        if not shipped and xs > 1.5 and r > 2.5 * max(r32, 4e-7):
+            # Distance features far from the origin: single trajectories there are float32-UNSTABLE in the reference itself -- its own
+            # float32 run lands 3e-3 from its float64 one on one host CPU and 1.1e-1 on another (profiles/r06/gen_outliers*.txt; a
+            # 2^-22 relative change of x moves the float64 forces by 3e-3) -- so one float32 run is no yardstick.  Take the
+            # reference's float32 band instead: the worst of its runs at x and at the neighbouring float32 inputs (one ulp either way,
+            # forces compared with the float64 run at x).
+            for direction in (np.inf, -np.inf):
+                xn = torch.from_numpy(np.nextafter(x[sub], np.float32(direction)).astype(np.float32))
+                r32 = max(r32, rel(twin.score(twin.to_torch(params), xn, ts_, L, conservative=cons, flags=fl).numpy(), r64ref))
+            tag.update(band=1)
         if hook is not None: hook(case, tag, model, params, x, t, sub, f, fl, cons, L)
         # (other branches: the tests' 2e-5 at unit coordinates; distance features at |x| ~ 10 sigma are ill-conditioned in float32 --
         # the reference's own float32 run is then 1e-4 from its float64 one -- so the bar follows that distance there)

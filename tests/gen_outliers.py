@@ -31,6 +31,9 @@ def hook(case, tag, model, params, x, t, sub, f, fl, cons, L):
     m32 = -ns32["backward"](fw32, xc.astype(np.float32), st32)
     e64, st64 = kg.forward(fw64, xc.astype(np.float64), t[sub].astype(np.float64))
     m64 = -kg.backward(fw64, xc.astype(np.float64), st64)
+    if os.environ.get("GEN_OUTLIERS_DUMP"):   # the case's inputs for CPU-side analysis
+        np.savez(os.path.join(os.environ["GEN_OUTLIERS_DUMP"], f"case{case}.npz"), x=x[sub], t=t[sub], flags=np.array(fl), L=L, N=N, H=tag["H"],
+                 **{"p_" + k: v for k, v in params.items()})
     print(f"case {case} {tag}: whole sample set: kernel {rel(f[sub], r64):.3e}  twin f32 {rel(r32, r64):.3e}  numpy-f32 factorised {rel(m32, r64):.3e}"
           f"  (fp64 factorised vs twin f64 {rel(m64, r64):.1e})  |F|max {np.abs(r64).max():.3e}")
     for k, b in enumerate(sub):
