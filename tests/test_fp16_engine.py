@@ -14,6 +14,8 @@ a dot product (tests/test_gpu_parity.py, tests/fuzz_shapes.py: synthetic uniform
   engine; the pairwise-distance histograms of the two ensembles (the library's own dff_pwd_hist) are no
   further apart -- Jensen-Shannon, evaluate/evaluators.py:251-270 -- than two seeds of ONE engine, and both thermostats
   hold equipartition (dynamics/langevin_cgnet.py:538-542).
+* `test_engines_agree_statistically_iid`: the same comparison for the other sampler of the hot path -- reverse-DDPM chains
+  (models/ddpm.py:195-254) over the last 300 noise levels, 4096 chains per engine and seed.
 """
 import numpy as np
 import pytest
@@ -155,4 +157,51 @@ def test_engines_agree_statistically(dff, cfg, steps, monkeypatch, tmp_path):
           + " ".join(f"{v:.3e}" for v in cross) + " KE/expected=" + " ".join(f"{runs[k][1]:.4f}" for k in runs))
     # two engines are two samples of one ensemble: no further apart than two seeds of one engine (each JS is an estimate from
     # 256 x 60 correlated frames: a quarter of slack)
+    assert max(cross) <= 1.25 * max(same), (cross, same)
+
+
+@pytest.mark.parametrize("cfg", ["chignolin", "villin"])
+def test_engines_agree_statistically_iid(dff, cfg, monkeypatch, tmp_path):
+    """The reverse-DDPM sampler (models/ddpm.py:195-254, in-kernel Philox noise) on either engine: 4096 chains per run over the last
+    300 noise levels (a random-weight network is no denoiser: from t = T its chains run into the +-1000 clamp, from t = 300 they stay
+    O(1)); the pairwise-distance histograms are no further apart between the engines than between two seeds of one."""
+    from dff_amd.ddpm import GaussianDiffusion
+    from dff_amd.evaluate import PwdEvaluator
+    from dff_amd.score import GraphTransformer
+    _, N, H, L = synth.SHIPPED_CONFIGS[cfg]
+    B, rounds, t0 = 256, 16, 300
+    params = synth.synth_gnn_params(N, H, L, decoder_scale=1e-2)
+    inits = []
+    for r in range(rounds):
+        x = torch.from_numpy(synth.normal((B, N, 3), 300 + r, 5).astype(np.float32))
+        inits.append(x - x.mean(1, keepdim=True))
+    runs = {}
+    for split, seed in ((True, 11), (True, 22), (False, 11), (False, 22)):
+        monkeypatch.setenv("DFF_SPLIT_BF16", "1" if split else "0")
+        model = GraphTransformer(N, H, device="cuda:0", n_layers=L, use_intrinsic_coords=True, use_abs_coords=False,
+                                 use_distances=False, conservative=True, state_dict=params)
+        diff = GaussianDiffusion(model, num_atoms=N, timesteps=1000, norm_factor=NORM_STD[cfg])
+        outs = []
+        for r in range(rounds):
+            diff.seed(1000 * seed + r)
+            outs.append(diff.p_sample_loop_from(inits[r], t0, 0).cpu() * NORM_STD[cfg])
+        out = torch.cat(outs)
+        kname = model.native.last_launch()[0]
+        assert ("split_f16" in kname) == split, kname
+        assert out.shape == (B * rounds, N, 3) and torch.isfinite(out).all() and model.native.status() == 0
+        assert float(out.abs().max()) < 50.0 * NORM_STD[cfg] and not diff.last_clamped
+        assert float(out.mean(1).abs().max()) < 1e-3 * NORM_STD[cfg]          # centred chains (models/ddpm.py:251-252)
+        runs[(split, seed)] = out.contiguous()
+    assert not torch.equal(runs[(True, 11)], runs[(True, 22)])                 # (the seed reaches the kernel's Philox key)
+    js = {}
+    for a, b in (((True, 11), (True, 22)), ((False, 11), (False, 22)), ((True, 11), (False, 11)), ((True, 22), (False, 22)),
+                 ((True, 11), (False, 22))):
+        ev = PwdEvaluator(runs[a], mol_name=cfg, offset=3, saved_ref=str(tmp_path / f"iid_ref_{a[0]}_{a[1]}.pickle"))
+        js[(a, b)] = float(ev.eval(runs[b]))
+    same = [js[((True, 11), (True, 22))], js[((False, 11), (False, 22))]]
+    cross = [js[((True, 11), (False, 11))], js[((True, 22), (False, 22))], js[((True, 11), (False, 22))]]
+    print(f"{cfg} iid: JS(two seeds, split_f16)={same[0]:.3e} JS(two seeds, fp32 MFMA)={same[1]:.3e} JS(split_f16 vs fp32 MFMA)="
+          + " ".join(f"{v:.3e}" for v in cross))
+    # same seed, two engines: the same draws, so the ensembles nearly coincide; different seeds: the sampling noise of 4096 chains
+    # either way -- no pair of engines further apart than two seeds of one (a quarter of slack)
     assert max(cross) <= 1.25 * max(same), (cross, same)
